@@ -1,0 +1,97 @@
+/* svx.h -- C ABI of libsvx.so, the MI355X (gfx950) hot path of SVision.
+ *
+ * The reference (xjtu-omics/SVision v1.4) is pure Python and has no FFI layer;
+ * each entry point below replaces one Python hot loop and is bound from the
+ * Python host with ctypes (svision_amd/_lib.py; INTEGRATION.md shows the stub a
+ * reference maintainer would add).  Conventions:
+ *   - every pointer named d_* is a DEVICE pointer owned by the caller
+ *     (e.g. a torch tensor's data_ptr()); nothing is allocated or freed inside;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all
+ *     work is enqueued asynchronously on it, no host synchronisation inside;
+ *   - return value: 0 on success, a negative SVX_E* code otherwise; never throws;
+ *   - re-entrant; one process per GPU.
+ */
+#ifndef SVX_H
+#define SVX_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVX_VERSION 100            /* 0.1.0 */
+
+#define SVX_OK            0
+#define SVX_EINVAL       (-1)      /* bad argument (null pointer, bad layout...) */
+#define SVX_ECAPACITY    (-2)      /* caller-provided output capacity too small */
+#define SVX_ELAUNCH      (-3)      /* HIP reported a launch error */
+
+#define SVX_IMG           227      /* similarity image is 227 x 227 x 3 */
+#define SVX_LAYOUT_NHWC   0        /* [n][227][227][3]  (reference batch layout) */
+#define SVX_LAYOUT_NCHW   1        /* [n][3][227][227]  (planar, for the CNN)    */
+
+#define SVX_GAP_INS       1
+#define SVX_GAP_DEL       2
+
+/* One long CIGAR gap (I or D with length >= min_sv), 24 bytes.
+ * Replaces the entries of `all_long_gaps` built at
+ * reference src/collection/analyze_reads.py:828-853. */
+typedef struct SvxGap {
+    uint32_t aln;        /* alignment index in the batch                       */
+    uint32_t op;         /* index of the op inside that alignment's CIGAR      */
+    int32_t  read_pos;   /* readPos before the op (leading clips included)     */
+    int32_t  ref_pos;    /* refPos before the op                               */
+    int32_t  len;        /* op length                                          */
+    uint32_t kind;       /* SVX_GAP_INS / SVX_GAP_DEL                          */
+} SvxGap;
+
+int         svx_version(void);
+const char* svx_strerror(int code);
+
+/* Bytes of device scratch svx_cigar_scan needs for n_aln alignments. */
+size_t svx_cigar_scan_ws_bytes(uint32_t n_aln);
+
+/* Per-alignment CIGAR / segment scan.
+ * Replaces the Python loop of analyze_inside_align
+ * (reference src/collection/analyze_reads.py:828-853) and the pysam-derived
+ * reference_end / query_alignment_start / query_alignment_end
+ * (src/collection/analyze_reads.py:650-667) for a whole batch of alignments.
+ *
+ *   d_cigar     packed BAM CIGAR words (len << 4 | op) of all alignments, concatenated
+ *   d_cig_off   [n_aln + 1] word offsets into d_cigar (CSR)
+ *   d_ref_start [n_aln] 0-based reference start of each alignment
+ *   min_sv      options.min_sv_size
+ *   d_gaps      [gaps_cap] out: long gaps sorted by (aln, op)
+ *   d_gap_off   [n_aln + 1] out: CSR offsets into d_gaps per alignment
+ *               (d_gap_off[n_aln] = total number of long gaps, even when it
+ *               exceeds gaps_cap; gaps beyond gaps_cap are not written)
+ *   d_stats     [n_aln][4] out, may be NULL: ref_span (M,D,N,=,X),
+ *               lead_clip (leading S/H), trail_clip (trailing S/H),
+ *               query_len (M,I,S,H,=,X)
+ *   d_ws        scratch of svx_cigar_scan_ws_bytes(n_aln) bytes
+ * H is treated as S (the reference rewrites H to S, collect_signatures.py:91);
+ * N advances the read position only (analyze_reads.py:831-832). */
+int svx_cigar_scan(const uint32_t* d_cigar, const uint64_t* d_cig_off,
+                   const int32_t* d_ref_start, uint32_t n_aln, int32_t min_sv,
+                   SvxGap* d_gaps, uint64_t gaps_cap, uint32_t* d_gap_off,
+                   int32_t* d_stats, void* d_ws, void* stream);
+
+/* Similarity-image rasteriser (+ mean subtraction, + layout).
+ * Replaces BatchGenerator.next_batch's per-image loop
+ * (reference src/network/create_batch.py:103-152) and PlotSingleImg.plot
+ * (src/segmentplot/plot_segment.py:33-68, incl. cv2.line) for n images.
+ *
+ *   d_records  [n][12] int32: seg1 x_start,x_end,y_start,y_end,forward(0/1),
+ *              seg2 idem, read_len, ref_len  (TSV columns 1..12)
+ *   d_out      float32 [n][227][227][3] (NHWC) or [n][3][227][227] (NCHW):
+ *              255 - mean[c] on line pixels, -mean[c] elsewhere
+ *   mean       host pointer to 3 floats (reference: 104, 117, 124) */
+int svx_rasterize(const int32_t* d_records, uint32_t n, float* d_out, int layout,
+                  const float* mean, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVX_H */

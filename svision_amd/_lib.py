@@ -1,0 +1,61 @@
+"""ctypes binding of libsvx.so (C ABI declared in include/svx.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` /
+``make -C svision_amd/csrc``.  Loading fails loudly when it is missing: the
+product has no CPU or PyTorch fallback for these ops.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsvx.so")
+
+SVX_OK = 0
+SVX_EINVAL = -1
+SVX_ECAPACITY = -2
+SVX_ELAUNCH = -3
+LAYOUT_NHWC = 0
+LAYOUT_NCHW = 1
+IMG = 227
+GAP_INS = 1
+GAP_DEL = 2
+
+# every symbol include/svx.h declares: name -> (restype, argtypes)
+_vp, _u32, _i32, _u64, _sz = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int32, ctypes.c_uint64, ctypes.c_size_t
+SYMBOLS = {
+    "svx_version": (ctypes.c_int, []),
+    "svx_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "svx_cigar_scan_ws_bytes": (_sz, [_u32]),
+    "svx_cigar_scan": (ctypes.c_int, [_vp, _vp, _vp, _u32, _i32, _vp, _u64, _vp, _vp, _vp, _vp]),
+    "svx_rasterize": (ctypes.c_int, [_vp, _u32, _vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float), _vp]),
+}
+
+
+class SvxError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Return the loaded library, binding all prototypes on first use."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SvxError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C svision_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(code, what):
+    if code != SVX_OK:
+        msg = load().svx_strerror(code).decode()
+        raise SvxError(f"{what}: {msg} ({code})")

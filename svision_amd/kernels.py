@@ -1,0 +1,93 @@
+"""Device ops of the hot path: thin wrappers that hand torch-owned device
+buffers to the C ABI of libsvx.so on the current HIP stream.
+
+PyTorch is used here only for device memory and streams.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+GAP_DTYPE = np.dtype([("aln", "<u4"), ("op", "<u4"), ("read_pos", "<i4"),
+                      ("ref_pos", "<i4"), ("len", "<i4"), ("kind", "<u4")])
+MEAN = (104.0, 117.0, 124.0)   # reference src/network/create_batch.py:13
+
+
+def _stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _require_cuda(t, name):
+    if not t.is_cuda:
+        raise _lib.SvxError(f"{name} must be a device tensor (got {t.device}); the hot path has no CPU fallback")
+    if not t.is_contiguous():
+        raise _lib.SvxError(f"{name} must be contiguous")
+
+
+def rasterize(records, layout="NCHW", mean=MEAN, out=None):
+    """records: int32 device tensor [n,12] -> float32 [n,3,227,227] (NCHW) or
+    [n,227,227,3] (NHWC), mean-subtracted.  See include/svx.h svx_rasterize."""
+    lib = _lib.load()
+    _require_cuda(records, "records")
+    if records.dtype != torch.int32 or records.dim() != 2 or records.shape[1] != 12:
+        raise _lib.SvxError("records must be int32 [n,12]")
+    n = records.shape[0]
+    lay = {"NHWC": _lib.LAYOUT_NHWC, "NCHW": _lib.LAYOUT_NCHW}[layout]
+    shape = (n, _lib.IMG, _lib.IMG, 3) if lay == _lib.LAYOUT_NHWC else (n, 3, _lib.IMG, _lib.IMG)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=records.device)
+    else:
+        _require_cuda(out, "out")
+        if out.dtype != torch.float32 or out.numel() != n * 3 * _lib.IMG * _lib.IMG:
+            raise _lib.SvxError("out has the wrong dtype/size")
+    m = (ctypes.c_float * 3)(*mean)
+    rc = lib.svx_rasterize(records.data_ptr(), n, out.data_ptr(), lay, m, _stream_ptr(records.device))
+    _lib.check(rc, "svx_rasterize")
+    return out
+
+
+class CigarScanResult:
+    """Device-side result of :func:`cigar_scan`."""
+
+    def __init__(self, gaps, gap_off, stats, n_aln, cap):
+        self.gaps, self.gap_off, self.stats, self.n_aln, self.cap = gaps, gap_off, stats, n_aln, cap
+
+    def total(self):
+        return int(self.gap_off[self.n_aln].item())
+
+    def to_host(self):
+        """(gaps structured array sorted by (aln, op), gap_off uint32[n+1], stats int32[n,4])."""
+        off = self.gap_off.cpu().numpy().view(np.uint32)
+        total = int(off[self.n_aln])
+        if total > self.cap:
+            raise _lib.SvxError(f"cigar_scan: {total} long gaps exceed the capacity {self.cap}")
+        raw = self.gaps[: total * 6].cpu().numpy()
+        gaps = raw.view(GAP_DTYPE) if total else np.empty(0, GAP_DTYPE)
+        return gaps, off, self.stats.cpu().numpy()
+
+
+def cigar_scan(cigar, cig_off, ref_start, min_sv, gaps_cap=None):
+    """cigar: int32/uint32 device tensor of packed BAM CIGAR words; cig_off: int64 [n+1];
+    ref_start: int32 [n].  See include/svx.h svx_cigar_scan."""
+    lib = _lib.load()
+    for t, nm in ((cigar, "cigar"), (cig_off, "cig_off"), (ref_start, "ref_start")):
+        _require_cuda(t, nm)
+    if cigar.dtype not in (torch.int32, torch.uint32) or cig_off.dtype != torch.int64 or ref_start.dtype != torch.int32:
+        raise _lib.SvxError("cigar must be (u)int32, cig_off int64, ref_start int32")
+    n = ref_start.numel()
+    if cig_off.numel() != n + 1:
+        raise _lib.SvxError("cig_off must have n_aln + 1 entries")
+    dev = cigar.device
+    if gaps_cap is None:
+        gaps_cap = max(1024, 4 * n)
+    gaps = torch.empty(gaps_cap * 6, dtype=torch.int32, device=dev)
+    gap_off = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    stats = torch.empty((n, 4), dtype=torch.int32, device=dev)
+    ws = torch.empty(max(1, lib.svx_cigar_scan_ws_bytes(n)), dtype=torch.uint8, device=dev)
+    rc = lib.svx_cigar_scan(cigar.data_ptr(), cig_off.data_ptr(), ref_start.data_ptr(), n, int(min_sv),
+                            gaps.data_ptr(), gaps_cap, gap_off.data_ptr(), stats.data_ptr(), ws.data_ptr(),
+                            _stream_ptr(dev))
+    _lib.check(rc, "svx_cigar_scan")
+    return CigarScanResult(gaps, gap_off, stats, n, gaps_cap)

@@ -1,0 +1,100 @@
+"""AlexNet classifier of the similarity images, on PyTorch-ROCm (fp32).
+
+Mirrors the TF1 graph of the reference (src/network/alexnet.py:26-58, layer
+helpers :100-170): conv1 11x11/4 VALID 3->96, pool, LRN; conv2 5x5 SAME g=2,
+pool, LRN; conv3/4/5 3x3 SAME (g=1,2,2), pool; fc6/fc7 (ReLU), fc8 -> 5 logits
+(DEL, INS, INV, DUP, tDUP).  Dropout is the identity at inference
+(predict.py:22,210).  Parameters keep the checkpoint's names and layouts
+(``convN/weights`` HWIO, ``fcN/weights`` [in,out]) at the ``-m`` boundary and are
+re-laid out once for the device:
+
+* conv HWIO -> OIHW (grouped conv = split of input channels and of the output
+  axis, identical to ``groups=2``);
+* fc6 rows permuted from the reference's NHWC flatten ((h*6+w)*256+c) to NCHW;
+* TF LRN (alpha not divided by the window) == torch LRN with alpha*5.
+
+The dense contractions (conv via MIOpen, fc via hipBLASLt) are the only MFMA
+users; everything feeding them comes from the hand-written HIP rasteriser.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+CLASSES = ("DEL", "INS", "INV", "DUP", "tDUP")
+
+# name, kernel, cin/groups, cout, stride, pad, groups
+_CONVS = (
+    ("conv1", 11, 3, 96, 4, 0, 1),
+    ("conv2", 5, 48, 256, 1, 2, 2),
+    ("conv3", 3, 256, 384, 1, 1, 1),
+    ("conv4", 3, 192, 384, 1, 1, 2),
+    ("conv5", 3, 192, 256, 1, 1, 2),
+)
+_FCS = (("fc6", 9216, 4096), ("fc7", 4096, 4096), ("fc8", 4096, 5))
+
+
+def checkpoint_shapes():
+    """Tensor names/shapes the reference graph restores by name (predict.py:183-184)."""
+    shapes = {}
+    for name, k, cin, cout, _s, _p, _g in _CONVS:
+        shapes[f"{name}/weights"] = (k, k, cin, cout)
+        shapes[f"{name}/biases"] = (cout,)
+    for name, nin, nout in _FCS:
+        shapes[f"{name}/weights"] = (nin, nout)
+        shapes[f"{name}/biases"] = (nout,)
+    return shapes
+
+
+class AlexNet(torch.nn.Module):
+    """Inference-only AlexNet holding device-layout parameters."""
+
+    def __init__(self, params, device="cuda", channels_last=False):
+        super().__init__()
+        want = checkpoint_shapes()
+        missing = [k for k in want if k not in params]
+        if missing:
+            raise KeyError(f"checkpoint lacks tensors {missing}")   # TF raises NotFoundError
+        self.channels_last = channels_last
+        for name, _k, _cin, _cout, _s, _p, _g in _CONVS:
+            w = np.asarray(params[f"{name}/weights"], np.float32)
+            if tuple(w.shape) != want[f"{name}/weights"]:
+                raise ValueError(f"{name}/weights has shape {w.shape}, expected {want[f'{name}/weights']}")
+            wt = torch.from_numpy(np.ascontiguousarray(w.transpose(3, 2, 0, 1)))          # HWIO -> OIHW
+            if channels_last:
+                wt = wt.contiguous(memory_format=torch.channels_last)
+            self.register_buffer(f"{name}_w", wt.to(device))
+            self.register_buffer(f"{name}_b", torch.from_numpy(np.asarray(params[f"{name}/biases"], np.float32).copy()).to(device))
+        for name, nin, nout in _FCS:
+            w = np.asarray(params[f"{name}/weights"], np.float32)
+            if tuple(w.shape) != (nin, nout):
+                raise ValueError(f"{name}/weights has shape {w.shape}, expected {(nin, nout)}")
+            if name == "fc6":
+                # rows (h,w,c) -> (c,h,w): our activations are flattened NCHW
+                w = w.reshape(6, 6, 256, nout).transpose(2, 0, 1, 3).reshape(nin, nout)
+            # store [out,in] for F.linear
+            self.register_buffer(f"{name}_w", torch.from_numpy(np.ascontiguousarray(w.T)).to(device))
+            self.register_buffer(f"{name}_b", torch.from_numpy(np.asarray(params[f"{name}/biases"], np.float32).copy()).to(device))
+
+    @torch.no_grad()
+    def forward(self, x):
+        """x: float32 [B,3,227,227] (mean-subtracted, as produced by the rasteriser) -> logits [B,5]."""
+        if self.channels_last:
+            x = x.contiguous(memory_format=torch.channels_last)
+        for name, _k, _cin, _cout, stride, pad, groups in _CONVS:
+            x = F.relu_(F.conv2d(x, getattr(self, f"{name}_w"), getattr(self, f"{name}_b"),
+                                 stride=stride, padding=pad, groups=groups))
+            if name in ("conv1", "conv2"):
+                x = F.max_pool2d(x, 3, 2)
+                x = F.local_response_norm(x, size=5, alpha=2e-05 * 5, beta=0.75, k=1.0)
+            elif name == "conv5":
+                x = F.max_pool2d(x, 3, 2)
+        x = x.reshape(x.shape[0], 9216) if not self.channels_last else x.contiguous().reshape(x.shape[0], 9216)
+        x = F.relu_(F.linear(x, self.fc6_w, self.fc6_b))
+        x = F.relu_(F.linear(x, self.fc7_w, self.fc7_b))
+        return F.linear(x, self.fc8_w, self.fc8_b)
+
+    @torch.no_grad()
+    def predict(self, x):
+        """(logits, argmax, softmax) -- the three fetches of predict.py:209."""
+        logits = self.forward(x)
+        return logits, torch.argmax(logits, dim=1), torch.softmax(logits, dim=1)

@@ -1,0 +1,22 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    """The C oracle (oracle/libsvx_oracle.so), built on demand with gcc."""
+    import subprocess
+    from oracle import cbind
+    if not os.path.exists(cbind.LIB_PATH):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    return cbind.load()

@@ -1,0 +1,27 @@
+"""CPU test: libsvx.so loads and exports every symbol include/svx.h declares (no compute)."""
+import os
+import re
+
+from svision_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_header_symbols():
+    header = open(os.path.join(ROOT, "include", "svx.h")).read()
+    declared = set(re.findall(r"\b(svx_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(_lib.SYMBOLS), (declared, set(_lib.SYMBOLS))
+    lib = _lib.load()
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.svx_version() == 100
+    assert lib.svx_strerror(0) == b"ok" and b"capacity" in lib.svx_strerror(-2)
+    assert lib.svx_cigar_scan_ws_bytes(0) >= 0 and lib.svx_cigar_scan_ws_bytes(10_000_000) > 40_000_000
+
+
+def test_device_ops_refuse_cpu_tensors():
+    import pytest
+    import torch
+    from svision_amd import kernels
+    with pytest.raises(_lib.SvxError):
+        kernels.rasterize(torch.zeros((1, 12), dtype=torch.int32))

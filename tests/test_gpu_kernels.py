@@ -1,0 +1,112 @@
+"""GPU parity tests (-m gpu): HIP kernels through the C ABI vs the oracle, bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cigar_ref, encode_ref
+from svision_amd import kernels
+from tests import datagen
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t.to(DEV) if dtype is None else t.to(DEV, dtype)
+
+
+@pytest.mark.parametrize("layout", ["NHWC", "NCHW"])
+@pytest.mark.parametrize("n", [1, 3, 64, 257])
+def test_rasterize_matches_oracle(oracle_lib, layout, n):
+    from oracle import cbind
+    rec = datagen.random_records(n, seed=100 + n)
+    got = kernels.rasterize(_dev(rec), layout=layout).cpu().numpy()
+    want = cbind.rasterize(rec, layout)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
+
+
+def test_rasterize_python_oracle_and_pad_record():
+    rec = np.concatenate([datagen.random_records(40, seed=7), np.asarray([encode_ref.PAD_RECORD], np.int32)])
+    got = kernels.rasterize(_dev(rec), layout="NHWC").cpu().numpy()
+    assert np.array_equal(got, encode_ref.encode_records(rec))
+
+
+def test_rasterize_large_batch_properties(oracle_lib):
+    """Full-size batch (4096 images = 2.5 GB): spot-check images against the oracle and
+    check size-independent properties (value set, ch1 subset of ch0, ch2 subset of ch0)."""
+    from oracle import cbind
+    n = 4096
+    rec = datagen.random_records(n, seed=5)
+    out = kernels.rasterize(_dev(rec), layout="NCHW")
+    m = torch.tensor(kernels.MEAN, device=DEV).view(1, 3, 1, 1)
+    mask = out + m
+    assert torch.all((mask == 0) | (mask == 255))
+    on = mask > 0
+    assert torch.all(on[:, 0] | ~on[:, 1]) and torch.all(on[:, 0] | ~on[:, 2])
+    colcnt = on[:, 0].sum(dim=1, keepdim=True)            # [n,1,227]
+    assert torch.equal(on[:, 1], on[:, 0] & (colcnt >= 2))
+    idx = np.arange(0, n, 97)
+    assert np.array_equal(out[idx].cpu().numpy(), cbind.rasterize(rec[idx], "NCHW"))
+
+
+def test_rasterize_empty():
+    out = kernels.rasterize(torch.empty((0, 12), dtype=torch.int32, device=DEV))
+    assert out.shape == (0, 3, 227, 227)
+
+
+@pytest.mark.parametrize("n_aln,mean_ops,rate", [(1, 5, 0.5), (64, 30, 0.2), (5000, 300, 0.01), (300, 5000, 0.002)])
+def test_cigar_scan_matches_oracle(oracle_lib, n_aln, mean_ops, rate):
+    from oracle import cbind
+    cigar, off, ref_start = datagen.random_cigars(n_aln, seed=n_aln, mean_ops=mean_ops, long_gap_rate=rate)
+    res = kernels.cigar_scan(_dev(cigar.view(np.int32)), _dev(off.astype(np.int64)), _dev(ref_start), 50)
+    gaps, gap_off, stats = res.to_host()
+    o_gaps, o_off, o_stats = cbind.cigar_scan(cigar, off, ref_start, 50)
+    assert np.array_equal(gap_off, o_off)
+    assert np.array_equal(stats, o_stats)
+    assert gaps.tobytes() == o_gaps.tobytes()
+
+
+def test_cigar_scan_ragged_and_empty(oracle_lib):
+    from oracle import cbind
+    # empty batch
+    res = kernels.cigar_scan(torch.empty(0, dtype=torch.int32, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV),
+                             torch.empty(0, dtype=torch.int32, device=DEV), 50)
+    assert res.total() == 0
+    # alignments with empty CIGARs in the middle, all-clip CIGARs, one very long CIGAR
+    texts = ["", "10S", "5H10S", "100S2000M300I1500M200D1500M50S", "", "60I", "60D", "49I49D50I50D", "3H7S100M2N5P60I8S2H"]
+    ops = [cigar_ref.parse_cigar(t) for t in texts]
+    big = [(7, 10), (1, 55), (8, 1), (2, 70)] * 20000
+    ops.append(big)
+    words = [cigar_ref.pack_cigar(o) for o in ops]
+    off = np.zeros(len(ops) + 1, np.uint64)
+    off[1:] = np.cumsum([len(w) for w in words])
+    cigar = np.asarray([w for ws in words for w in ws], np.uint32)
+    ref_start = np.arange(len(ops), dtype=np.int32) * 1000 + 7
+    res = kernels.cigar_scan(_dev(cigar.view(np.int32)), _dev(off.astype(np.int64)), _dev(ref_start), 50)
+    gaps, gap_off, stats = res.to_host()
+    o_gaps, o_off, o_stats = cbind.cigar_scan(cigar, off, ref_start, 50)
+    assert np.array_equal(gap_off, o_off) and np.array_equal(stats, o_stats) and gaps.tobytes() == o_gaps.tobytes()
+    assert int(gap_off[-1]) == 2 + 1 + 1 + 2 + 1 + 40000
+    # capacity overflow is reported, not silently truncated
+    small = kernels.cigar_scan(_dev(cigar.view(np.int32)), _dev(off.astype(np.int64)), _dev(ref_start), 50, gaps_cap=16)
+    assert small.total() == int(gap_off[-1])
+    with pytest.raises(Exception):
+        small.to_host()
+
+
+def test_alexnet_matches_numpy_oracle():
+    from oracle import alexnet_ref
+    from svision_amd.network.alexnet import AlexNet
+    params = alexnet_ref.random_params(seed=3)
+    rec = datagen.random_records(6, seed=21, hostile=False)
+    x = encode_ref.encode_records(rec)
+    o_logits, o_cls, o_prob = alexnet_ref.predict(params, x)
+    for cl in (False, True):
+        net = AlexNet(params, device=DEV, channels_last=cl)
+        img = kernels.rasterize(_dev(rec), layout="NCHW")
+        logits, cls, prob = net.predict(img)
+        # north_star tolerance: CNN softmax within 1e-3 (fp32)
+        assert np.abs(prob.cpu().numpy() - o_prob).max() < 1e-3
+        assert np.allclose(logits.cpu().numpy(), o_logits, rtol=1e-3, atol=1e-3 * np.abs(o_logits).max())
