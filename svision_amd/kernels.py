@@ -80,8 +80,9 @@ def cigar_scan(cigar, cig_off, ref_start, min_sv, gaps_cap=None):
     if cig_off.numel() != n + 1:
         raise _lib.SvxError("cig_off must have n_aln + 1 entries")
     dev = cigar.device
-    if gaps_cap is None:
-        gaps_cap = max(1024, 4 * n)
+    auto = gaps_cap is None
+    if auto:
+        gaps_cap = max(1024, n // 2)
     gaps = torch.empty(gaps_cap * 6, dtype=torch.int32, device=dev)
     gap_off = torch.empty(n + 1, dtype=torch.int32, device=dev)
     stats = torch.empty((n, 4), dtype=torch.int32, device=dev)
@@ -90,4 +91,7 @@ def cigar_scan(cigar, cig_off, ref_start, min_sv, gaps_cap=None):
                             gaps.data_ptr(), gaps_cap, gap_off.data_ptr(), stats.data_ptr(), ws.data_ptr(),
                             _stream_ptr(dev))
     _lib.check(rc, "svx_cigar_scan")
-    return CigarScanResult(gaps, gap_off, stats, n, gaps_cap)
+    res = CigarScanResult(gaps, gap_off, stats, n, gaps_cap)
+    if auto and res.total() > gaps_cap:       # d_gap_off[n] holds the full count: rerun with the exact capacity
+        return cigar_scan(cigar, cig_off, ref_start, min_sv, gaps_cap=res.total())
+    return res
