@@ -1,0 +1,298 @@
+"""Per-read alignment analysis: split-read segments, in-CIGAR long gaps, gap typing.
+
+Host-side mirror of the reference's ``src/collection/analyze_reads.py``:
+``analyze_between_aligns`` :619-801, ``analyze_inside_align`` :804-970 (its CIGAR
+walk :828-853 runs on the GPU -- ``svx_cigar_scan`` -- and only the handful of
+long gaps per alignment reach this module), ``analyze_gap`` :155-615,
+``trim_segs`` :82-152, ``shift_left`` :12-39, ``cal_overlap_ratio`` :49-80.
+The ``--hash`` re-aligner branches (:731-790, :898-929) are not part of the
+default path and are not implemented here.
+"""
+from .classes import Seg, Signature, by_read_pos
+
+
+def shift_left(ref_seq, ref_start, target_start, target_end):
+    """Left-align the interval [target_start, target_end) inside ``ref_seq`` (which
+    starts at ``ref_start``) while the base before it equals its last base (:12-39)."""
+    rel_s = target_start - ref_start
+    rel_e = target_end - ref_start
+    n = len(ref_seq)
+    if rel_s >= n or rel_e >= n:
+        return target_start, target_end
+    k = 0
+    while target_start - ref_start > 0 and ref_seq[rel_s - k - 1] == ref_seq[rel_e - k]:
+        k += 1
+        target_start -= 1
+        target_end -= 1
+    return target_start, target_end
+
+
+def cal_overlap_ratio(base, target, left_most, right_most):
+    """Fraction of ``base``'s reference span covered by ``target`` (:49-80)."""
+    if base is target:
+        return 0
+    if base.ref_start < left_most or base.ref_end > right_most:
+        return 1.0
+    span = base.ref_end - base.ref_start
+    if base.ref_start >= target.ref_start and base.ref_end <= target.ref_end:
+        return 1.0
+    if base.ref_end >= target.ref_end > base.ref_start and target.ref_start < base.ref_start:
+        return (target.ref_end - base.ref_start) / span
+    if base.ref_end < target.ref_start < base.ref_start and target.ref_end > base.ref_end:
+        return (base.ref_end - target.ref_start) / span
+    return 0
+
+
+def trim_segs(segs, first, last):
+    """Clamp / extend segments to +-2 x gap around the breakpoint, in place (:82-152)."""
+    gap = max(last.q_start - first.q_end, last.ref_start - first.ref_end)
+    left_most = first.ref_end - gap * 2
+    right_most = last.ref_start + gap * 2
+    for seg in segs:
+        if seg is first:
+            if seg.ref_start < left_most:
+                seg.q_start += left_most - seg.ref_start
+                seg.ref_start = left_most
+            elif seg.ref_start > left_most:
+                grow = seg.ref_start - left_most
+                seg.ref_start = left_most
+                seg.q_end += grow
+                for other in segs:
+                    if other is not first:
+                        other.q_start += grow
+                        other.q_end += grow
+        elif seg is last:
+            if seg.ref_end > right_most:
+                seg.q_end -= seg.ref_end - right_most
+                seg.ref_end = right_most
+            elif seg.ref_end < right_most:
+                seg.q_end += right_most - seg.ref_end
+                seg.ref_end = right_most
+        else:
+            length = seg.q_end - seg.q_start
+            if seg.ref_start < left_most:
+                seg.ref_start = left_most
+                seg.ref_end = left_most + length
+            if seg.ref_end > right_most:
+                seg.ref_end = right_most
+                seg.ref_start = right_most - length
+
+
+def _signature(chrom, qname, sig_type, first_bkp, segs, helpers, trim_first, trim_last, mechanism="None",
+               extend_end=0):
+    """Shared tail of every analyze_gap branch: breakpoints of the helper segments in read
+    order, extreme coordinates, trim, Signature."""
+    bkps = [first_bkp]
+    for seg in segs:
+        if any(seg is h for h in helpers):
+            bkps.append([seg.ref_start, seg.ref_end, seg.ref_end - seg.ref_start])
+    left = min(b[0] for b in bkps)
+    right = max(b[1] for b in bkps)
+    trim_segs(segs, trim_first, trim_last)
+    return Signature(chrom, left, right + extend_end, sig_type, qname, segs, bkps, mechanism)
+
+
+def _gap_bkp(anchor_end, next_start, length_if_open, length_if_closed=1):
+    """[[start, end, len]] of the main breakpoint: closed (next starts at/before the anchor
+    end) -> one-base interval."""
+    if next_start <= anchor_end:
+        return [anchor_end, anchor_end + 1, length_if_closed]
+    return [anchor_end, next_start, length_if_open]
+
+
+def analyze_gap(cur, nxt, chrom_of, fetch_ref, options, qname, help_segs=()):
+    """Type the junction between two major segments ``cur`` -> ``nxt`` of one read, with the
+    segments lying between them on the read as helpers (:155-615).  Returns a Signature or
+    None.  ``cur``/``nxt`` are private copies; helper segments are mutated in place, as in
+    the reference."""
+    if cur.ref_id != nxt.ref_id:
+        return None
+    helpers = list(help_segs)
+    covered = list(helpers)
+    chrom = chrom_of(cur.ref_id)
+    min_sv, max_sv = options.min_sv_size, options.max_sv_size
+
+    if cur.is_reverse == nxt.is_reverse:
+        lo = min(cur.ref_start, cur.ref_end, nxt.ref_start, nxt.ref_end)
+        hi = max(cur.ref_start, cur.ref_end, nxt.ref_start, nxt.ref_end)
+        ref_seq = None
+        for seg in helpers:                                   # :184-193 forward helpers are left-shifted
+            if not seg.is_reverse:
+                if ref_seq is None:
+                    ref_seq = fetch_ref(chrom, lo, hi)
+                seg.ref_start, seg.ref_end = shift_left(ref_seq, lo, seg.ref_start, seg.ref_end)
+        d_read = nxt.q_start - cur.q_end
+        d_ref = nxt.ref_start - cur.ref_end
+
+        if d_ref >= -min_sv:
+            diff = d_read - d_ref
+            if diff >= min_sv:                                # INS :207-246
+                covered += [cur, nxt]
+                segs = sorted(covered, key=by_read_pos)
+                bkp = _gap_bkp(cur.ref_end, nxt.ref_start, abs(d_read), abs(d_read) + abs(d_ref))
+                return _signature(chrom, qname, "sigGap", bkp, segs, helpers, cur, nxt,
+                                  extend_end=diff if not helpers else 0)
+            if -max_sv <= diff <= -min_sv:                    # DEL :248-315
+                if ref_seq is None:
+                    ref_seq = fetch_ref(chrom, lo, hi)
+                s, e = shift_left(ref_seq, lo, cur.ref_end, nxt.ref_start)
+                cur.ref_end = s + 1
+                nxt.ref_start = e
+                covered += [cur, nxt]
+                segs = sorted(covered, key=by_read_pos)
+                bkp = _gap_bkp(cur.ref_end, nxt.ref_start, nxt.ref_start - cur.ref_end)
+                if helpers:
+                    mechanism = "None"
+                elif d_read > 10:
+                    mechanism = "MMBIR+%d" % d_read
+                elif d_read >= -2:
+                    mechanism = ("NHEJ+%d" if d_read >= 0 else "NHEJ%d") % d_read
+                elif d_read >= -20:
+                    mechanism = "AltEJ%d" % d_read
+                else:
+                    mechanism = "NAHR%d" % d_read
+                return _signature(chrom, qname, "sigGap", bkp, segs, helpers, cur, nxt, mechanism)
+            # neither: only a junction bridged by helper segments is reported (INV-like) :317-352
+            if helpers:
+                covered += [cur, nxt]
+                segs = sorted(covered, key=by_read_pos)
+                bkp = _gap_bkp(cur.ref_end, nxt.ref_start, nxt.ref_start - cur.ref_end)
+                sig = _signature(chrom, qname, "sigGap", bkp, segs, helpers, cur, nxt)
+                if nxt.ref_start - cur.ref_end > 0:
+                    return sig
+            return None
+
+        # reference overlap beyond min_sv: duplication :355-424
+        dup_len = abs(d_ref)
+        dup = Seg(nxt.q_start, nxt.q_start + dup_len, nxt.ref_start, nxt.ref_start + dup_len,
+                  cur.ref_id, cur.is_reverse, qual=cur.qual)
+        rest = Seg(nxt.q_start + dup_len + 1, nxt.q_end, nxt.ref_start + dup_len + 1, nxt.ref_end,
+                   cur.ref_id, cur.is_reverse, qual=cur.qual)
+        if rest.q_end < rest.q_start:
+            rest.q_end = dup.q_end + dup_len
+            rest.ref_end = dup.ref_end + dup_len
+        covered += [cur, dup, rest]
+        segs = sorted(covered, key=by_read_pos)
+        blen = abs(d_read) + abs(d_ref)
+        bkp = _gap_bkp(cur.ref_end, rest.ref_start, blen, blen)
+        return _signature(chrom, qname, "sigDup", bkp, segs, helpers + [dup], cur, rest)
+
+    # opposite strands: only when nothing lies between them; a forward stand-in segment is
+    # synthesised so that the pair can be drawn :427-615
+    covered += [cur, nxt]
+    if helpers:
+        return None
+    if not cur.is_reverse:                                    # forward then reverse
+        new_len = cur.q_end - cur.q_start
+        if nxt.ref_end <= cur.ref_end:
+            added = Seg(nxt.q_end, nxt.q_end + new_len, cur.ref_end, cur.ref_end + new_len,
+                        cur.ref_id, cur.is_reverse, qual=cur.qual)
+        else:
+            fixed = max(nxt.ref_end - cur.ref_end, nxt.q_end - cur.q_end)
+            added = Seg(cur.q_end + fixed, cur.q_end + fixed + new_len, nxt.ref_end, nxt.ref_end + new_len,
+                        cur.ref_id, cur.is_reverse, qual=cur.qual)
+        covered.append(added)
+        segs = sorted(covered, key=by_read_pos)
+        bkp = _gap_bkp(cur.ref_end, added.ref_start, added.ref_start - cur.ref_end)
+        return _signature(chrom, qname, "sigUncovered", bkp, segs, [nxt], cur, added)
+    # reverse then forward
+    new_len = nxt.q_end - nxt.q_start
+    if cur.ref_start >= nxt.ref_start:
+        added = Seg(0, new_len, nxt.ref_start - new_len, nxt.ref_start - 1, cur.ref_id, nxt.is_reverse, qual=cur.qual)
+        shift = new_len
+    else:
+        fixed = max(nxt.ref_start - cur.ref_start, nxt.q_start - cur.q_start)
+        added = Seg(0, new_len, nxt.ref_start - fixed - new_len, nxt.ref_start - fixed - 1,
+                    cur.ref_id, nxt.is_reverse, qual=cur.qual)
+        shift = new_len + abs((nxt.ref_start - cur.ref_start) - (nxt.q_start - cur.q_start))
+    for seg in covered:
+        seg.q_start += shift
+        seg.q_end += shift
+    covered.append(added)
+    segs = sorted(covered, key=by_read_pos)
+    # added.ref_end < nxt.ref_start always, so the reference's malformed closed-gap list (:545,593) is unreachable
+    assert nxt.ref_start > added.ref_end
+    bkp = [added.ref_end, nxt.ref_start, nxt.ref_start - added.ref_end]
+    return _signature(chrom, qname, "sigUncovered", bkp, segs, [cur], added, nxt)
+
+
+def analyze_between_aligns(primary, supplementary, table, options):
+    """Primary + supplementary alignments of one read -> (major, minor) segments (:619-801).
+
+    ``primary``/``supplementary`` are record indices into ``table`` (an AlignmentTable with the
+    device scan attached).  Query coordinates are expressed on the primary's strand."""
+    if not options.contig and len(supplementary) > 4:
+        return [], []
+    flag, pos = table.flag, table.pos
+    p_rev = bool(flag[primary] & 0x10)
+    qlen = int(table.l_seq[primary])                       # supplementary records inherit the primary's SEQ
+    majors, minors, same_strand = [], [], []
+    for a in [primary] + list(supplementary):
+        a_rev = bool(flag[a] & 0x10)
+        lead, trail = int(table.lead_clip[a]), int(table.trail_clip[a])
+        if a_rev != p_rev:
+            q_start, q_end = trail, qlen - lead              # qlen - query_alignment_end, qlen - query_alignment_start
+        else:
+            q_start, q_end = lead, qlen - trail
+        r0 = int(pos[a])
+        seg = Seg(q_start, q_end, r0, r0 + int(table.ref_span[a]), int(table.tid[a]), a_rev != p_rev,
+                  bool(flag[a] & 0x800), qual=int(table.mapq[a]), aln=int(a))
+        if seg.is_reverse:
+            seg.type = "other"
+            minors.append(seg)
+        else:
+            same_strand.append(seg)
+    if len(same_strand) == 1:
+        same_strand[0].type = "main"
+        return same_strand, minors
+    ordered = sorted(same_strand, key=by_read_pos)
+    left_most = min(s.ref_start for s in ordered)
+    right_most = max(s.ref_end for s in ordered)
+    last = len(ordered) - 1
+    for i, base in enumerate(ordered):
+        covered = False
+        if 0 < i < last:
+            for target in ordered:
+                if cal_overlap_ratio(base, target, left_most, right_most) >= 0.8:
+                    covered = True
+                    break
+        if covered:
+            base.type = "other"
+            minors.append(base)
+        else:
+            base.type = "main"
+            majors.append(base)
+    return majors, minors
+
+
+def analyze_inside_align(seg, gaps):
+    """Split one major segment at its long CIGAR gaps (:857-948).  ``gaps`` are this
+    alignment's SvxGap records (kind, ref_pos, len in op order) from the device scan;
+    returns the new major segments, or None when the alignment holds no long gap."""
+    if len(gaps) == 0:
+        return None
+    out = []
+    vrp = seg.q_start
+
+    def piece(q0, q1, r0, r1):
+        out.append(Seg(q0, q1, r0, r1, seg.ref_id, False, seg.is_supplementary, "main", seg.qual, seg.aln))
+
+    first_ref = int(gaps[0]["ref_pos"])
+    m = first_ref - seg.ref_start
+    piece(vrp, vrp + m, seg.ref_start, first_ref - 1)
+    vrp += m
+    prev_end = None
+    for g in gaps:
+        kind, ref_pos, length = int(g["kind"]), int(g["ref_pos"]), int(g["len"])
+        if prev_end is not None:
+            m = ref_pos - prev_end
+            piece(vrp + 1, vrp + m + 1, prev_end, ref_pos)
+            vrp += m
+        if kind == 1:
+            vrp += length
+            prev_end = ref_pos
+        else:
+            prev_end = ref_pos + length
+    m = seg.ref_end - prev_end
+    piece(vrp + 1, vrp + m + 1, prev_end, seg.ref_end)
+    return out

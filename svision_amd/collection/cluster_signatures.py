@@ -1,0 +1,77 @@
+"""Partition + hierarchical clustering of signatures into candidate SV sites.
+
+Host-side mirror of the reference's ``src/collection/cluster_signatures.py``:
+``signature_partition`` :51-66, ``cluster_partitions`` :68-130,
+``span_position_distance`` :132-141.  The O(n^2) Python-callback ``pdist`` of the
+reference is replaced by the same IEEE-double arithmetic evaluated with NumPy on
+the condensed index pairs; the condensed matrix then goes through the very same
+SciPy ``linkage(method="average")`` / ``fcluster(criterion="distance")`` calls,
+so merge order, labels and therefore site coordinates are unchanged.
+"""
+import logging
+
+import numpy as np
+from scipy.cluster.hierarchy import fcluster, linkage
+
+from .classes import Cluster
+
+
+def partition_and_cluster(signatures, chrom, sample, options):
+    partitions = signature_partition(signatures, options)
+    return cluster_partitions(partitions, chrom, sample, options)
+
+
+def signature_partition(signatures, options):
+    """Greedy split of the key-sorted signatures (:51-66).  A partition is only closed
+    once it holds MORE than min_support signatures, and only such partitions are kept."""
+    ordered = sorted(signatures, key=lambda s: s.get_key())
+    partitions, cur = [], []
+    for sig in ordered:
+        if len(cur) > options.min_support and cur[-1].position_distance_to(sig) > options.patition_max_distance:
+            partitions.append(cur)
+            cur = []
+        cur.append(sig)
+    if len(cur) > options.min_support:
+        partitions.append(cur)
+    return partitions
+
+
+def span_position_distance_condensed(starts, ends, normalizer=1000):
+    """Condensed pairwise matrix of span_position_distance (:132-141) in pdist order."""
+    n = len(starts)
+    i, j = np.triu_indices(n, k=1)
+    s = np.asarray(starts, np.float64)
+    e = np.asarray(ends, np.float64)
+    span = e - s
+    centre = np.floor_divide(s + e, 2)
+    pos = np.minimum(np.minimum(np.abs(s[i] - s[j]), np.abs(e[i] - e[j])), np.abs(centre[i] - centre[j])) / normalizer
+    with np.errstate(invalid="ignore", divide="ignore"):
+        spd = np.abs(span[i] - span[j]) / np.maximum(span[i], span[j])
+    return pos + spd
+
+
+def cluster_partitions(partitions, chrom, sample, options):
+    clusters = []
+    for part in partitions:
+        if len(part) > 100000:                                # :80-85
+            logging.warning("Partition size large than 100,000, ranging from %s:%d-%d", chrom, part[0].tstart, part[-1].tstart)
+            continue
+        if len(part) == 1:
+            groups = [part]
+        else:
+            y = span_position_distance_condensed([s.tstart for s in part], [s.tend for s in part])
+            z = linkage(y, method="average")
+            labels = fcluster(z, options.cluster_max_distance, criterion="distance")
+            groups = [[] for _ in range(int(labels.max()))]
+            for sig, lab in zip(part, labels):
+                groups[lab - 1].append(sig)
+        for sigs in groups:
+            cl = Cluster(sigs)
+            if cl.abandon == 0:
+                clusters.append(cl)
+    if clusters:                                              # coverage: one vectorised pass (classes.py:165-170)
+        tid = sample.table.get_tid(clusters[0].contig)
+        cov = sample.table.count_overlaps(tid, [int(c.cstart) for c in clusters], [int(c.cend) for c in clusters])
+        for c, v in zip(clusters, cov):
+            c.coverage = int(v)
+    return sorted(clusters, key=lambda c: (c.contig, (c.cstart + c.cend) / 2))

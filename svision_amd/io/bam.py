@@ -1,0 +1,302 @@
+"""Own BGZF/BAM/FASTA codec (no pysam/htslib in this image or on the GPU box).
+
+Replaces, for the hot path, what the reference obtains from pysam
+(SURVEY 8(a')): ``AlignmentFile.fetch`` (run_collection.py:23-26,
+classes.py:165-170, genotype.py:22-26), header checks (SVision:141-157),
+``FastaFile.fetch`` (analyze_reads.py:42-46).  Records are decoded straight
+into a structure-of-arrays :class:`AlignmentTable` whose packed CIGAR words are
+uploaded to HBM once and scanned by ``svx_cigar_scan``; per-record Python
+objects are never built.
+
+Follows the SAM/BAM specification (SAMv1 section 4): BGZF blocks are gzip members with a
+``BC`` extra field; BAM records are little-endian.  CIGARs longer than 65535
+ops (``CG`` tag) are not supported yet.
+"""
+import struct
+import zlib
+
+import numpy as np
+
+_BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+_MAX_BLOCK = 0xFF00
+
+FLAG_REVERSE = 0x10
+FLAG_UNMAPPED = 0x4
+FLAG_SECONDARY = 0x100
+FLAG_SUPPLEMENTARY = 0x800
+
+
+def bgzf_decompress(data):
+    """Concatenated BGZF blocks -> decompressed bytes."""
+    out = []
+    pos, n = 0, len(data)
+    while pos < n:
+        if data[pos:pos + 4] != b"\x1f\x8b\x08\x04":
+            raise ValueError("not a BGZF block at offset %d" % pos)
+        xlen = struct.unpack_from("<H", data, pos + 10)[0]
+        bsize = None
+        p, end = pos + 12, pos + 12 + xlen
+        while p < end:
+            si1, si2, slen = data[p], data[p + 1], struct.unpack_from("<H", data, p + 2)[0]
+            if si1 == 66 and si2 == 67:
+                bsize = struct.unpack_from("<H", data, p + 4)[0]
+            p += 4 + slen
+        if bsize is None:
+            raise ValueError("BGZF block without BC field")
+        cdata = data[pos + 12 + xlen: pos + bsize + 1 - 8]
+        out.append(zlib.decompress(cdata, -15))
+        pos += bsize + 1
+    return b"".join(out)
+
+
+def bgzf_compress(data, level=1):
+    """bytes -> BGZF blocks (+ EOF marker)."""
+    out = []
+    for i in range(0, len(data), _MAX_BLOCK):
+        chunk = data[i:i + _MAX_BLOCK]
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        cdata = co.compress(chunk) + co.flush()
+        bsize = len(cdata) + 25
+        out.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize)
+                   + cdata + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+    out.append(_BGZF_EOF)
+    return b"".join(out)
+
+
+class AlignmentTable:
+    """Structure-of-arrays view of a coordinate-sorted set of BAM records.
+
+    tid, pos (int32), flag (uint16), mapq (uint8), l_seq (int32; 0 when SEQ is '*'),
+    name_id (int32, first-occurrence order of QNAME), cigar (uint32 packed words),
+    cig_off (int64 CSR, n+1).  ``ref_span``/``lead_clip``/``trail_clip`` are filled by
+    the device CIGAR scan (:meth:`attach_scan`).
+    """
+
+    def __init__(self, references, lengths, tid, pos, flag, mapq, l_seq, name_id, names, cigar, cig_off, header_text=""):
+        self.references = list(references)
+        self.lengths = list(lengths)
+        self.tid = np.ascontiguousarray(tid, np.int32)
+        self.pos = np.ascontiguousarray(pos, np.int32)
+        self.flag = np.ascontiguousarray(flag, np.uint16)
+        self.mapq = np.ascontiguousarray(mapq, np.uint8)
+        self.l_seq = np.ascontiguousarray(l_seq, np.int32)
+        self.name_id = np.ascontiguousarray(name_id, np.int32)
+        self.names = names
+        self.cigar = np.ascontiguousarray(cigar, np.uint32)
+        self.cig_off = np.ascontiguousarray(cig_off, np.int64)
+        self.header_text = header_text
+        self.ref_span = None
+        self.lead_clip = None
+        self.trail_clip = None
+        self._tid_bounds = None
+
+    def __len__(self):
+        return int(self.tid.size)
+
+    @property
+    def sort_order(self):
+        for line in self.header_text.split("\n"):
+            if line.startswith("@HD"):
+                for f in line.split("\t")[1:]:
+                    if f.startswith("SO:"):
+                        return f[3:]
+        return None
+
+    def get_tid(self, name):
+        try:
+            return self.references.index(name)
+        except ValueError:
+            return -1
+
+    def attach_scan(self, stats):
+        """stats: int32 [n,4] from svx_cigar_scan (ref_span, lead_clip, trail_clip, query_len)."""
+        self.ref_span = np.ascontiguousarray(stats[:, 0])
+        self.lead_clip = np.ascontiguousarray(stats[:, 1])
+        self.trail_clip = np.ascontiguousarray(stats[:, 2])
+
+    def ref_end(self):
+        """htslib bam_endpos: pos + reference span, or pos + 1 for spanless/unmapped records."""
+        span = np.where((self.ref_span > 0) & ((self.flag & FLAG_UNMAPPED) == 0), self.ref_span, 1)
+        return self.pos.astype(np.int64) + span
+
+    def _bounds(self):
+        if self._tid_bounds is None:
+            nref = len(self.references)
+            # records are sorted by (tid, pos) with unmapped-without-position (tid -1) last
+            key = np.where(self.tid < 0, nref, self.tid)
+            self._tid_bounds = np.searchsorted(key, np.arange(nref + 1), side="left")
+            self._run_max_end = {}
+        return self._tid_bounds
+
+    def fetch(self, tid, start, end):
+        """Indices (file order) of records overlapping the half-open interval
+        [start, end) on reference ``tid`` -- pysam ``fetch(contig, start, end)``."""
+        b = self._bounds()
+        lo, hi = int(b[tid]), int(b[tid + 1])
+        if lo == hi:
+            return np.empty(0, np.int64)
+        pos = self.pos[lo:hi]
+        stop = lo + int(np.searchsorted(pos, end, side="left"))      # pos < end
+        idx = np.arange(lo, stop, dtype=np.int64)
+        return idx[self.ref_end()[lo:stop] > start]
+
+    def count_overlaps(self, tid, starts, ends):
+        """Vectorised number of records overlapping each [start, end): the per-cluster
+        coverage the reference gets by re-opening the BAM (classes.py:165-170)."""
+        b = self._bounds()
+        lo, hi = int(b[tid]), int(b[tid + 1])
+        pos = self.pos[lo:hi]
+        rend = np.sort(self.ref_end()[lo:hi])
+        starts = np.asarray(starts, np.int64)
+        ends = np.asarray(ends, np.int64)
+        n_pos_lt_end = np.searchsorted(pos, ends, side="left")
+        n_end_le_start = np.searchsorted(rend, starts, side="right")
+        # overlap <=> pos < end and ref_end > start; records with ref_end <= start all have pos < end (end >= start)
+        return np.where(ends >= starts, n_pos_lt_end - n_end_le_start, 0)
+
+
+def read_bam(path):
+    """Decode a whole BAM file into an :class:`AlignmentTable`."""
+    with open(path, "rb") as f:
+        raw = bgzf_decompress(f.read())
+    if raw[:4] != b"BAM\x01":
+        raise ValueError("%s is not a BAM file" % path)
+    l_text = struct.unpack_from("<i", raw, 4)[0]
+    text = raw[8:8 + l_text].split(b"\x00")[0].decode()
+    p = 8 + l_text
+    n_ref = struct.unpack_from("<i", raw, p)[0]
+    p += 4
+    refs, lens = [], []
+    for _ in range(n_ref):
+        l_name = struct.unpack_from("<i", raw, p)[0]
+        refs.append(raw[p + 4:p + 4 + l_name - 1].decode())
+        lens.append(struct.unpack_from("<i", raw, p + 4 + l_name)[0])
+        p += 8 + l_name
+    # pass 1: record offsets
+    offs = []
+    n = len(raw)
+    unpack_i = struct.Struct("<i").unpack_from
+    while p < n:
+        offs.append(p)
+        p += 4 + unpack_i(raw, p)[0]
+    buf = np.frombuffer(raw, np.uint8)
+    offs = np.asarray(offs, np.int64)
+    nrec = offs.size
+
+    def field(off, dtype, width):
+        idx = offs[:, None] + (off + np.arange(width))[None, :]
+        return buf[idx].copy().view(dtype).reshape(-1)
+
+    tid = field(4, "<i4", 4)
+    pos = field(8, "<i4", 4)
+    l_name = field(12, "u1", 1).astype(np.int64)
+    mapq = field(13, "u1", 1)
+    n_cig = field(16, "<u2", 2).astype(np.int64)
+    flag = field(18, "<u2", 2)
+    l_seq = field(20, "<i4", 4)
+    cig_off = np.zeros(nrec + 1, np.int64)
+    cig_off[1:] = np.cumsum(n_cig)
+    cig_start = offs + 36 + l_name
+    # gather CIGAR words: flat byte index of every word
+    total = int(cig_off[-1])
+    rec_of_word = np.repeat(np.arange(nrec), n_cig)
+    word_in_rec = np.arange(total) - cig_off[rec_of_word]
+    byte0 = cig_start[rec_of_word] + 4 * word_in_rec
+    cigar = buf[(byte0[:, None] + np.arange(4)[None, :])].copy().view("<u4").reshape(-1) if total else np.empty(0, np.uint32)
+    names, name_ids, seen = [], np.empty(nrec, np.int32), {}
+    for i in range(nrec):
+        o = int(offs[i]) + 36
+        nm = raw[o:o + int(l_name[i]) - 1]
+        j = seen.get(nm)
+        if j is None:
+            j = len(names)
+            seen[nm] = j
+            names.append(nm.decode())
+        name_ids[i] = j
+    return AlignmentTable(refs, lens, tid, pos, flag, mapq, l_seq, name_ids, names, cigar, cig_off, text)
+
+
+def _reg2bin(beg, end):
+    end -= 1
+    for shift, base in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        if beg >> shift == end >> shift:
+            return base + (beg >> shift)
+    return 0
+
+
+def write_bam(path, table, with_seq=True, level=1):
+    """Encode an :class:`AlignmentTable` as a coordinate-sorted BAM (SEQ = N's for
+    records with l_seq > 0, '*' otherwise; QUAL 0xFF; no tags)."""
+    text = table.header_text or ("@HD\tVN:1.6\tSO:coordinate\n" + "".join(
+        "@SQ\tSN:%s\tLN:%d\n" % (r, l) for r, l in zip(table.references, table.lengths)))
+    parts = [b"BAM\x01", struct.pack("<i", len(text)), text.encode(), struct.pack("<i", len(table.references))]
+    for r, l in zip(table.references, table.lengths):
+        parts.append(struct.pack("<i", len(r) + 1) + r.encode() + b"\x00" + struct.pack("<i", l))
+    span_ops = np.array([1, 0, 1, 1, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0], np.int64)
+    for i in range(len(table)):
+        cw = table.cigar[table.cig_off[i]:table.cig_off[i + 1]]
+        span = int(((cw >> 4).astype(np.int64) * span_ops[cw & 15]).sum())
+        name = table.names[table.name_id[i]].encode() + b"\x00"
+        l_seq = int(table.l_seq[i]) if with_seq else 0
+        pos = int(table.pos[i])
+        body = struct.pack("<iiBBHHHIiii", int(table.tid[i]), pos, len(name), int(table.mapq[i]),
+                           _reg2bin(pos, pos + max(span, 1)), cw.size, int(table.flag[i]), l_seq, -1, -1, 0)
+        body += name + cw.astype("<u4").tobytes() + b"\xff" * ((l_seq + 1) // 2) + b"\xff" * l_seq
+        parts.append(struct.pack("<i", len(body)) + body)
+    with open(path, "wb") as f:
+        f.write(bgzf_compress(b"".join(parts), level))
+
+
+class Fasta:
+    """In-memory FASTA with pysam.FastaFile's ``references`` / ``fetch`` / ``get_reference_length``."""
+
+    def __init__(self, path=None, sequences=None):
+        self.references = []
+        self._seq = {}
+        if sequences is not None:
+            for name, seq in sequences.items():
+                self.references.append(name)
+                self._seq[name] = seq if isinstance(seq, (bytes, bytearray)) else str(seq).encode()
+        elif path is not None:
+            name, chunks = None, []
+            with open(path, "rb") as f:
+                for line in f:
+                    if line.startswith(b">"):
+                        if name is not None:
+                            self._seq[name] = b"".join(chunks)
+                        name = line[1:].split()[0].decode()
+                        self.references.append(name)
+                        chunks = []
+                    else:
+                        chunks.append(line.strip())
+            if name is not None:
+                self._seq[name] = b"".join(chunks)
+
+    def get_reference_length(self, name):
+        return len(self._seq[name])
+
+    def fetch(self, name, start, end):
+        """0-based half-open; clipped to the contig like htslib faidx."""
+        seq = self._seq[name]
+        start = max(0, int(start))
+        end = min(len(seq), int(end))
+        return seq[start:end].decode() if end > start else ""
+
+    def fetch_bytes(self, name, start, end):
+        seq = self._seq[name]
+        return seq[max(0, int(start)):max(0, min(len(seq), int(end)))]
+
+
+def write_fasta(path, sequences, width=60):
+    with open(path, "wb") as f:
+        for name, seq in sequences.items():
+            seq = seq if isinstance(seq, (bytes, bytearray)) else str(seq).encode()
+            f.write(b">" + name.encode() + b"\n")
+            for i in range(0, len(seq), width):
+                f.write(seq[i:i + width] + b"\n")
+    with open(path + ".fai", "w") as f:
+        off = 0
+        for name, seq in sequences.items():
+            off += len(name) + 2
+            f.write("%s\t%d\t%d\t%d\t%d\n" % (name, len(seq), off, width, width + 1))
+            off += len(seq) + (len(seq) + width - 1) // width

@@ -1,0 +1,78 @@
+"""A sequenced sample resident on the device: the decoded BAM as a structure of arrays,
+its packed CIGAR words in HBM, and the result of the device CIGAR scan.
+
+This is the object the reference's ``sample_path`` argument stands for
+(run_collection.py:15-26 re-opens the BAM in every worker; here the file is decoded
+once per process, uploaded once, and every alignment's long gaps / reference span /
+clip lengths come from one ``svx_cigar_scan`` launch sequence).
+"""
+import numpy as np
+
+from .io.bam import Fasta, read_bam
+
+_CACHE = {}
+
+
+class Sample:
+    def __init__(self, table, fasta, gaps, gap_off, stats, min_sv, device_buffers=None):
+        self.table = table
+        self.fasta = fasta
+        self.gaps = gaps
+        self.gap_off = np.asarray(gap_off).astype(np.int64)
+        self.min_sv = min_sv
+        self.device_buffers = device_buffers
+        table.attach_scan(np.asarray(stats))
+
+    # -- construction -----------------------------------------------------------------
+    @classmethod
+    def from_table(cls, table, fasta, min_sv, device="cuda"):
+        """Upload the packed CIGARs and run the device scan (the product path)."""
+        import torch
+        from . import kernels
+        dev = torch.device(device)
+        d_cigar = torch.from_numpy(table.cigar.view(np.int32)).to(dev)
+        d_off = torch.from_numpy(table.cig_off).to(dev)
+        d_pos = torch.from_numpy(table.pos).to(dev)
+        res = kernels.cigar_scan(d_cigar, d_off, d_pos, min_sv)
+        gaps, gap_off, stats = res.to_host()
+        return cls(table, fasta, gaps, gap_off, stats, min_sv, device_buffers=(d_cigar, d_off, d_pos, res))
+
+    @classmethod
+    def with_scan(cls, table, fasta, min_sv, scan):
+        """Attach an externally computed scan (tests inject the oracle's here)."""
+        gaps, gap_off, stats = scan
+        return cls(table, fasta, gaps, gap_off, stats, min_sv)
+
+    @classmethod
+    def open(cls, bam_path, genome_path, min_sv, device="cuda"):
+        key = (bam_path, genome_path, int(min_sv), str(device))
+        if key not in _CACHE:
+            _CACHE[key] = cls.from_table(read_bam(bam_path), Fasta(genome_path), min_sv, device)
+        return _CACHE[key]
+
+    # -- accessors used by the collection step ----------------------------------------
+    def gaps_of(self, aln):
+        return self.gaps[self.gap_off[aln]:self.gap_off[aln + 1]]
+
+    def chrom_of(self, tid):
+        return self.table.references[tid]
+
+    def fetch_ref(self, chrom, start, end):
+        """pysam FastaFile.fetch semantics (analyze_reads.py:42-46); bytes for cheap indexing."""
+        if start < 0 or end < start:
+            raise ValueError("invalid coordinates: start (%d) > stop (%d)" % (start, end))
+        return self.fasta.fetch_bytes(chrom, start, end)
+
+
+def register(path, sample):
+    """Make ``run_detect(options, path, ...)`` resolve to an already prepared Sample."""
+    _CACHE[("registered", path)] = sample
+
+
+def resolve(sample_or_path, options):
+    if isinstance(sample_or_path, Sample):
+        return sample_or_path
+    reg = _CACHE.get(("registered", sample_or_path))
+    if reg is not None:
+        return reg
+    return Sample.open(sample_or_path, options.genome, options.min_sv_size)
