@@ -108,6 +108,13 @@ class AlignmentTable:
         except ValueError:
             return -1
 
+    def ids_of(self, names):
+        """name_id values of the given QNAMEs (unknown names are ignored)."""
+        if getattr(self, "_name_index", None) is None:
+            self._name_index = {nm: i for i, nm in enumerate(self.names)}
+        idx = self._name_index
+        return np.fromiter((idx[n] for n in names if n in idx), np.int64)
+
     def attach_scan(self, stats):
         """stats: int32 [n,4] from svx_cigar_scan (ref_span, lead_clip, trail_clip, query_len)."""
         self.ref_span = np.ascontiguousarray(stats[:, 0])

@@ -1,0 +1,121 @@
+"""CNN prediction over one chromosome's segment TSV, per-site vote, VCF body output.
+
+Mirror of the reference's ``Predict`` (src/network/predict.py:14-303): same constructor,
+``run(out_path_prefix, options)`` writes ``{prefix}.vcf`` and ``{prefix}.score.txt``.  The
+TF1 session (:165-210) is replaced by the PyTorch-ROCm AlexNet fed directly by the HIP
+rasteriser; the ``-m`` checkpoint prefix is read with :mod:`tf_checkpoint`.
+"""
+import logging
+
+import numpy as np
+
+from .create_batch import BatchGenerator
+from .output import write_results_to_vcf
+
+_TYPE_NAMES = {"0": "DEL", "1": "INS", "2": "INV", "3": "DUP", "4": "tDUP"}
+_MODEL_CACHE = {}
+
+
+def load_classifier(model_path, device="cuda"):
+    """-> callable(images NCHW device tensor) -> (logits, argmax, softmax) numpy arrays."""
+    import torch
+    from .alexnet import AlexNet
+    from .tf_checkpoint import read_checkpoint
+    key = (model_path, str(device))
+    if key not in _MODEL_CACHE:
+        _MODEL_CACHE[key] = AlexNet(read_checkpoint(model_path), device=device)
+    net = _MODEL_CACHE[key]
+
+    def classify(images):
+        logits, cls, prob = net.predict(images)
+        packed = torch.cat([logits, prob, cls.to(logits.dtype).unsqueeze(1)], dim=1).cpu().numpy()   # one D2H copy
+        return packed[:, :5], packed[:, 10].astype(np.int64), packed[:, 5:10]
+    return classify
+
+
+class Predict:
+    def __init__(self, chrom, segments_out_file):
+        self.segments_out_file = segments_out_file
+        self.chrom = chrom
+        self.dropout_rate = 1.
+        self.num_classes = 5
+
+    def get_region_potential_svtypes(self, reads_dict):
+        """Group a site's reads by their set of predicted classes and average breakpoints (:87-145).
+        reads_dict: {read_id: {class: [start, end, len]}} -> [(type string, [read ids], [[s,e,len],...])]"""
+        stats = {}
+        for read_id, infos in reads_dict.items():
+            key = "".join(str(c) for c in sorted(infos.keys()))
+            bkps = [infos[int(ch)] for ch in key]
+            if key not in stats:
+                stats[key] = [[read_id], bkps]
+                continue
+            old = stats[key][1]
+            n = len(stats[key][0])
+            stats[key][1] = [[int((b[0] + o[0] * n) / (n + 1)), int((b[1] + o[1] * n) / (n + 1)), int((b[2] + o[2] * n) / (n + 1))]
+                             for b, o in zip(bkps, old)]
+            stats[key][0].append(read_id)
+        ranked = sorted(stats.items(), key=lambda kv: len(kv[1][0]), reverse=True)
+        return [("+".join(_TYPE_NAMES.get(ch, "") for ch in key), reads, bkps) for key, (reads, bkps) in ranked]
+
+    def run(self, out_path_prefix, options, classifier=None, sample=None):
+        from .. import sample as _sample
+        if sample is None:
+            sample = _sample.resolve(options.bam_path, options)
+        batch_size = options.batch_size
+        gen = BatchGenerator(self.segments_out_file, shuffle=False, nb_classes=self.num_classes, batch_size=batch_size,
+                             layout="NCHW")
+        if classifier is None:
+            classifier = load_classifier(options.model_path)
+        n_batches = np.floor(gen.data_size / batch_size).astype(np.int16)        # predict.py:175 (int16, as upstream)
+        if int(n_batches) * batch_size != gen.data_size:
+            logging.warning("batch count wrapped in int16 (%d images): tail images are skipped, as upstream", gen.data_size)
+        with open(out_path_prefix + ".score.txt", "w") as score_out, open(out_path_prefix + ".vcf", "w") as vcf_out:
+            site = _SiteState()
+            logging.info("Predicting " + self.chrom)
+            for _ in range(n_batches):
+                if getattr(classifier, "needs_images", True):
+                    images, labels = gen.next_batch(batch_size)
+                else:                                                        # predictions injected by a test
+                    images, labels = None, gen.next_labels(batch_size)
+                _logits, classes, probs = classifier(images)
+                for i, label in enumerate(labels):
+                    if "complement" in label:
+                        continue
+                    f = label.split("svision")
+                    read_num, region, read_name = f[0], f[1], f[2]
+                    cls = int(classes[i])
+                    if f[7] == "True" and cls == 2:                           # :229-231 forward pairs cannot be INV
+                        continue
+                    if region != site.region:
+                        if site.region != "":
+                            self._flush(site, vcf_out, score_out, options, sample)
+                        site = _SiteState(region)
+                    rid = read_num.replace("m", "")
+                    site.read_names[rid] = read_name
+                    site.sig_types.append(f[3])
+                    site.predict_scores.append(round(probs[i][cls], 2))
+                    site.sig_scores[rid] = f[6]
+                    site.mechanisms[rid] = f[8]
+                    if "m" not in read_num and cls in (0, 1):                 # :278-280 only main x main pairs call INS/DEL
+                        continue
+                    site.reads.setdefault(rid, {})[cls] = [int(f[4]), int(f[5]), int(f[9])]
+            self._flush(site, vcf_out, score_out, options, sample)
+
+    def _flush(self, site, vcf_out, score_out, options, sample):
+        write_results_to_vcf(vcf_out, score_out, self.get_region_potential_svtypes(site.reads), site.region,
+                             site.read_names, site.sig_types, site.sig_scores, site.predict_scores, site.mechanisms,
+                             options, sample)
+
+
+class _SiteState:
+    """Everything predict.py accumulates between two region changes (:186-203, :240-246)."""
+
+    def __init__(self, region=""):
+        self.region = region
+        self.reads = {}
+        self.read_names = {}
+        self.sig_scores = {}
+        self.mechanisms = {}
+        self.sig_types = []
+        self.predict_scores = []

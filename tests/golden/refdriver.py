@@ -171,6 +171,11 @@ class FastaFile:
         return len(self._seqs[chrom])
 
 
+class _Shape(list):
+    def as_list(self):
+        return list(self)
+
+
 class _Anything:
     """Permissive stub: any attribute is a callable returning another stub."""
 
@@ -183,11 +188,20 @@ class _Anything:
     def __enter__(self):
         return self
 
+    def __rsub__(self, other):
+        return _Anything()
+
+    def __hash__(self):
+        return id(self)
+
+    def __iter__(self):                      # tf.split(...) results are zipped pairwise
+        return iter([_Anything(), _Anything()])
+
     def __exit__(self, *a):
         return False
 
     def get_shape(self):
-        return [1, 1, 1, 3]
+        return _Shape([1, 1, 1, 4])
 
     def as_list(self):
         return [1]
@@ -225,7 +239,11 @@ def install_stubs():
     tfm.float32 = "float32"
     bs4 = types.ModuleType("bs4")
     bs4.BeautifulSoup = object
-    sys.modules.update({"pysam": pysam, "cv2": cv2, "tensorflow": tfm, "bs4": bs4})
+    bs4.__path__ = []
+    bs4_element = types.ModuleType("bs4.element")
+    bs4_element.NavigableString = str
+    bs4.element = bs4_element
+    sys.modules.update({"pysam": pysam, "cv2": cv2, "tensorflow": tfm, "bs4": bs4, "bs4.element": bs4_element})
     if REF_ROOT not in sys.path:
         sys.path.insert(0, REF_ROOT)
     import warnings
