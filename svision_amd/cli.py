@@ -1,0 +1,234 @@
+"""The ``SVision`` command line on MI355X: same arguments, same outputs.
+
+Mirror of the reference driver (``/root/reference/SVision``): argument surface :27-106,
+input checks :141-157, window tasking :164-234 (including the ``-c chr:a-b`` quirk that
+windows restart at 0), Step 1 collection :259-294, Step 2 prediction :296-328, score range +
+merge :331-339, cleanup :370-372.  The two process pools are replaced by one process per
+GPU (chromosomes sharded across ranks when launched under torchrun, see dist.py).
+"""
+import argparse
+import datetime
+import logging
+import os
+import shutil
+import sys
+from time import localtime, strftime
+
+import numpy as np
+
+from . import __version__, dist as sdist
+from .io.bam import Fasta, read_bam
+
+REFERENCE_VERSION = "1.4"      # ##source line of the VCF the reference writes (src/version.py)
+
+
+def parse_arguments(arguments=None):
+    p = argparse.ArgumentParser(formatter_class=argparse.RawDescriptionHelpFormatter,
+                                description="SVision (MI355X hot path %s)\n\nShort Usage: SVision [parameters] -o <output path> "
+                                            "-b <input bam path> -g <reference> -m <model path>" % __version__)
+    g = p.add_argument_group("Input/Output parameters")
+    g.add_argument("-o", dest="out_path", type=os.path.abspath, required=True, help="Absolute path to output")
+    g.add_argument("-b", dest="bam_path", type=os.path.abspath, required=True, help="Absolute path to bam file")
+    g.add_argument("-m", dest="model_path", type=os.path.abspath, required=True, help="Absolute path to CNN predict model")
+    g.add_argument("-g", dest="genome", type=os.path.abspath, required=True, help="Absolute path to your reference genome")
+    g.add_argument("-n", dest="sample", type=str, required=True, help="Name of the BAM sample name")
+    g = p.add_argument_group("Optional parameters")
+    g.add_argument("-t", dest="thread_num", type=int, default=1, help="Thread numbers (default: %(default)s)")
+    g.add_argument("-s", dest="min_support", type=int, default=5, help="Minimum support read number required for SV calling (default: %(default)s)")
+    g.add_argument("-c", dest="chrom", type=str, default=None, help="Specific region (chr1:xxx-xxx) or chromosome (chr1) to detect")
+    g.add_argument("--hash", action="store_true", default=False, help="Activate local realignment for unmapped sequences (default: %(default)s)")
+    g.add_argument("--qname", action="store_true", default=False, help="Report support names for each events (default: %(default)s)")
+    g.add_argument("--graph", action="store_true", default=False, help="Report graph for events (default: %(default)s)")
+    g.add_argument("--contig", action="store_true", default=False, help="Activate contig mode (default: %(default)s)")
+    g.add_argument("--debug", action="store_true", default=False, help="Activate debug mode and keep intermedia outputs (default: %(default)s)")
+    g = p.add_argument_group("Collect parameters")
+    g.add_argument("--min_mapq", type=int, default=10, help="Minimum mapping quality of reads to consider (default: %(default)s)")
+    g.add_argument("--min_sv_size", type=int, default=50, help="Minimum SV size to detect (default: %(default)s)")
+    g.add_argument("--max_sv_size", type=int, default=1000000, help="Maximum SV size to detect (default: %(default)s)")
+    g.add_argument("--window_size", type=int, default=10000000, help="The sliding window size in segment collection (default: %(default)s)")
+    g = p.add_argument_group("Cluster parameters")
+    g.add_argument("--patition_max_distance", type=int, default=5000, help="Maximum distance to partition signatures (default: %(default)s)")
+    g.add_argument("--cluster_max_distance", type=float, default=0.3, help="Clustering maximum distance for a partition (default: %(default)s)")
+    g = p.add_argument_group("Predict parameters")
+    g.add_argument("--batch_size", type=int, default=128, help="Batch size for the CNN prediction model (default: %(default)s)")
+    g = p.add_argument_group("Genotype parameters")
+    g.add_argument("--min_gt_depth", type=int, default=4, help="Minimum reads required for genotyping (default: %(default)s)")
+    g.add_argument("--homo_thresh", type=float, default=0.8, help="Minimum variant allele frequency to be called as homozygous (default: %(default)s)")
+    g.add_argument("--hete_thresh", type=float, default=0.2, help="Minimum variant allele frequency to be called as heterozygous (default: %(default)s)")
+    g = p.add_argument_group("Hash table parameters")
+    g.add_argument("--k_size", type=int, default=10, help="Size of kmer (default: %(default)s)")
+    g.add_argument("--min_accept", type=int, default=50, help="Minimum match length for realignment (default: %(default)s)")
+    g.add_argument("--max_hash_len", type=int, default=1000, help="Maximum length of unmapped sequence length for realignment (default: %(default)s)")
+    return p.parse_args(sys.argv[1:] if arguments is None else arguments)
+
+
+def build_tasks(options, references, lengths, fasta_refs):
+    """{chrom: [[start, end], ...]} in BAM-header order (SVision:164-234)."""
+    length_of = dict(zip(references, lengths))
+    window = options.window_size
+    tasks = {}
+    if options.chrom is None:
+        for chrom in references:
+            n = length_of[chrom]
+            if chrom not in fasta_refs:
+                continue
+            if options.contig:
+                window = n
+            if n < window:
+                tasks.setdefault(chrom, []).append([0, n])
+                continue
+            pos = 0
+            for _ in range(int(n / window)):
+                tasks.setdefault(chrom, []).append([pos, pos + window])
+                pos += window
+            if pos < n:
+                tasks.setdefault(chrom, []).append([pos, n])
+        return tasks
+    chrom = options.chrom
+    if chrom in fasta_refs:
+        start, end = 0, length_of[chrom]
+    else:
+        cords = chrom.split(":")[1]
+        chrom, start, end = chrom.split(":")[0], int(cords.split("-")[0]), int(cords.split("-")[1])
+    tasks[chrom] = []
+    region_length = end - start + 1
+    if region_length < window:
+        tasks[chrom].append([start, end])
+    else:
+        pos = 0                                           # upstream restarts at 0, not at `start`
+        for _ in range(int(region_length / window)):
+            tasks[chrom].append([pos, pos + window])
+            pos += window
+        if pos < region_length:
+            tasks[chrom].append([pos, region_length])
+    return tasks
+
+
+def run(options, sample=None, classifier=None):
+    """Whole pipeline; returns the merged VCF path (rank 0) or None."""
+    from . import sample as _sample
+    from .collection import run_collection
+    from .network.output import cal_scores_max_min, merge_split_vcfs
+    from .network.predict import Predict
+
+    rank, ws = sdist.init_from_env()
+    if options.hash or options.graph:
+        raise SystemExit("--hash and --graph are outside the MI355X hot path of this build (SURVEY 8(f) next steps)")
+    work_dir = options.out_path
+    os.makedirs(work_dir, exist_ok=True)
+    fmt = logging.Formatter("%(asctime)s [%(levelname)-7.7s]  %(message)s")
+    root = logging.getLogger()
+    root.setLevel(logging.INFO)
+    fh = logging.FileHandler("%s/SVision_%s%s.log" % (work_dir, strftime("%y%m%d_%H%M%S", localtime()),
+                                                     "" if ws == 1 else ".rank%d" % rank), mode="w")
+    fh.setFormatter(fmt)
+    root.addHandler(fh)
+    logging.info("******************** Start SVision, version %s (svision_amd %s) ********************", REFERENCE_VERSION, __version__)
+    logging.info("CMD: %s", " ".join(sys.argv))
+    logging.info("WORKDIR DIR: %s", os.path.abspath(work_dir))
+    logging.info("CNN MODEL: %s", os.path.abspath(options.model_path))
+    logging.info("INPUT BAM: %s", os.path.abspath(options.bam_path))
+
+    if sample is None:
+        table = read_bam(options.bam_path)
+        if table.sort_order != "coordinate":
+            logging.error("This is not a coordinate sorted BAM file")
+            raise SystemExit(1)
+        fasta = Fasta(options.genome)
+        if options.contig:
+            options.min_support = 1
+        sample = _sample.Sample.from_table(table, fasta, options.min_sv_size)
+    elif options.contig:
+        options.min_support = 1
+    _sample.register(options.bam_path, sample)
+    table, fasta = sample.table, sample.fasta
+
+    tasks = build_tasks(options, table.references, table.lengths, fasta.references)
+    if len(tasks) == 0:
+        logging.error("No mapped reads in the BAM, please check your reference input!")
+        raise SystemExit(1)
+    chroms = list(tasks.keys())
+    length_of = dict(zip(table.references, table.lengths))
+    mine = sdist.shard_chromosomes(chroms, [length_of.get(c, 1) for c in chroms], ws)[rank]
+
+    seg_dir = os.path.join(work_dir, "segments")
+    pred_dir = os.path.join(work_dir, "predict_results")
+    os.makedirs(seg_dir, exist_ok=True)
+    os.makedirs(pred_dir, exist_ok=True)
+    t0 = datetime.datetime.now()
+    logging.info("\n****************** Step1 Image coding and segmentation ******************")
+    for chrom in mine:
+        parts = []
+        for part, (start, end) in enumerate(tasks[chrom]):
+            err = run_collection.run_detect(options, options.bam_path, chrom, part, start, end)
+            if err is not None:
+                logging.error("%s:%s-%s %s", chrom, start, end, err)      # upstream drops this string silently
+            parts.append(os.path.join(seg_dir, "%s.segments.%d.bed" % (chrom, part)))
+        with open(os.path.join(seg_dir, chrom + ".segments.all.bed"), "w") as out:   # `cat parts > all.bed`
+            for p in parts:
+                if os.path.exists(p):
+                    with open(p) as f:
+                        shutil.copyfileobj(f, out)
+    t1 = datetime.datetime.now()
+    logging.info("[Coding finished]: Collect segment signatures, Cost time: %s", (t1 - t0).seconds)
+
+    logging.info("\n****************** Step2 CNN prediction ******************")
+    for chrom in mine:
+        prefix = os.path.join(pred_dir, "%s.predict.s%s" % (chrom, options.min_support))
+        try:
+            Predict(chrom, os.path.join(seg_dir, chrom + ".segments.all.bed")).run(prefix, options, classifier=classifier, sample=sample)
+        except Exception as e:                                # upstream: error string, silently dropped
+            logging.error("predict %s failed: %r", chrom, e)
+            raise
+    t2 = datetime.datetime.now()
+    logging.info("[Prediction finished]: Predicting types, Cost time: %s", (t2 - t1).seconds)
+
+    # ---- the single cross-shard exchange: score range + record gather ----
+    local_scores = cal_scores_max_min(pred_dir) if ws == 1 else _scores_of(pred_dir, mine, options)
+    max_score, min_score = sdist.exchange_score_range(local_scores)
+    if max_score is None:
+        print("Empty output in the score file!!! Program exit")
+        raise SystemExit(0)
+    merged_path = os.path.join(options.out_path, "%s.svision.s%s.vcf" % (options.sample, options.min_support))
+    if ws > 1:
+        bodies = {}
+        for chrom in mine:
+            with open(os.path.join(pred_dir, "%s.predict.s%s.vcf" % (chrom, options.min_support))) as f:
+                bodies[chrom] = f.read()
+        bodies = sdist.gather_texts(bodies, dst=0)
+        if rank == 0:
+            for chrom, text in bodies.items():
+                with open(os.path.join(pred_dir, "%s.predict.s%s.vcf" % (chrom, options.min_support)), "w") as f:
+                    f.write(text)
+    if rank == 0:
+        options.source_version = REFERENCE_VERSION
+        merge_split_vcfs(pred_dir, merged_path, max_score, min_score, chroms, options, fasta=fasta)
+        logging.info("[All steps finished] Total Cost time: %ss", (datetime.datetime.now() - t0).seconds)
+    if ws > 1:
+        import torch.distributed as tdist
+        tdist.barrier()
+    if not options.debug and rank == 0:
+        shutil.rmtree(seg_dir, ignore_errors=True)
+        shutil.rmtree(pred_dir, ignore_errors=True)
+    root.removeHandler(fh)
+    fh.close()
+    return merged_path if rank == 0 else None
+
+
+def _scores_of(pred_dir, chroms, options):
+    """Scores of this rank's chromosomes only (a shared out_path may hold other ranks' files)."""
+    scores = []
+    for chrom in chroms:
+        path = os.path.join(pred_dir, "%s.predict.s%s.score.txt" % (chrom, options.min_support))
+        if os.path.exists(path):
+            with open(path) as f:
+                scores += [float(l.strip()) for l in f if l.strip() != "0"]
+    return scores
+
+
+def main(arguments=None):
+    run(parse_arguments(arguments))
+
+
+if __name__ == "__main__":
+    main()

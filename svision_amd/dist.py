@@ -1,0 +1,96 @@
+"""Multi-GPU layout of the hot path: one process per GPU, chromosomes sharded across ranks,
+one exchange at the end.
+
+The collection and prediction of a chromosome never look at another chromosome
+(SVision:264-278, :318-319), so ranks work on disjoint chromosome sets with no data-path
+collective.  The only cross-shard dependency of the whole pipeline is the global score
+min/max used to rescale QUAL (output.py:336-338) plus the concatenation of the per-chromosome
+VCF bodies in task order (output.py:305-331): one all_reduce(MIN) + all_reduce(MAX) on a
+scalar and one gather of packed records to rank 0, over RCCL/xGMI (backend "nccl") on GPUs
+or gloo on CPU (tests).
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def init_from_env():
+    """Initialise the process group when launched under torchrun (RANK/WORLD_SIZE set)."""
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    if ws > 1 and not dist.is_initialized():
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(backend)
+    return world()
+
+
+def _comm_device():
+    if dist.is_initialized() and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def shard_chromosomes(chroms, weights, n_ranks):
+    """Longest-processing-time-first assignment of chromosomes to ranks.
+    -> list (per rank) of chromosome names, each in the original task order."""
+    load = [0.0] * n_ranks
+    owner = {}
+    for name, w in sorted(zip(chroms, weights), key=lambda t: -t[1]):
+        r = min(range(n_ranks), key=lambda k: (load[k], k))
+        owner[name] = r
+        load[r] += w
+    return [[c for c in chroms if owner[c] == r] for r in range(n_ranks)]
+
+
+def exchange_score_range(local_scores):
+    """Global (max, min) of the per-record scores; (None, None) when no rank has any."""
+    rank, ws = world()
+    has = len(local_scores) > 0
+    mx = float(np.max(local_scores)) if has else -np.inf
+    mn = float(np.min(local_scores)) if has else np.inf
+    if ws > 1:
+        dev = _comm_device()
+        t_max = torch.tensor([mx], dtype=torch.float64, device=dev)
+        t_min = torch.tensor([mn], dtype=torch.float64, device=dev)
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t_min, op=dist.ReduceOp.MIN)
+        mx, mn = float(t_max.item()), float(t_min.item())
+    if mx == -np.inf:
+        return None, None
+    return np.float64(mx), np.float64(mn)
+
+
+def gather_texts(texts, dst=0):
+    """{key: str} on every rank -> merged dict on rank ``dst`` (None elsewhere).
+    Packed as bytes: all_gather of sizes, then one padded all_gather of the payloads."""
+    rank, ws = world()
+    if ws == 1:
+        return dict(texts)
+    import json
+    payload = json.dumps(texts).encode()
+    dev = _comm_device()
+    size = torch.tensor([len(payload)], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(ws)]
+    dist.all_gather(sizes, size)
+    cap = int(max(int(s.item()) for s in sizes))
+    buf = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    if payload:
+        buf[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(dev)
+    out = [torch.zeros(cap, dtype=torch.uint8, device=dev) for _ in range(ws)] if rank == dst else None
+    dist.gather(buf, out, dst=dst)
+    if rank != dst:
+        return None
+    merged = {}
+    for r in range(ws):
+        n = int(sizes[r].item())
+        merged.update(json.loads(bytes(out[r][:n].cpu().numpy().tobytes()).decode()))
+    return merged
