@@ -198,7 +198,7 @@ def write_checkpoint(prefix, tensors, crc_tensors=False):
     off = 0
     with open("%s.data-00000-of-00001" % prefix, "wb") as f:
         for name in names:
-            arr = np.ascontiguousarray(tensors[name], np.float32)
+            arr = np.asarray(tensors[name], dtype=np.float32, order="C")
             raw = arr.tobytes()
             f.write(raw)
             shape = b"".join(_proto_field(2, 2, (lambda d: _put_varint(len(d)) + d)(_proto_field(1, 0, _put_varint(int(s)))))

@@ -1,0 +1,79 @@
+"""GPU twins of the pipeline tests (-m gpu): the device scan feeds the collection step, the HIP
+rasteriser feeds the PyTorch-ROCm AlexNet restored from a TF checkpoint prefix."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from svision_amd import cli
+from svision_amd.network import tf_checkpoint as ck
+from svision_amd.network.alexnet import AlexNet
+from svision_amd.network.create_batch import BatchGenerator
+from svision_amd.network.predict import load_classifier
+from tests import helpers
+from tests.test_cli_e2e import ChromInjected, _case, make_options
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cli_with_device_scan_reproduces_reference_vcf(tmp_path):
+    case = _case()
+    sample = helpers.golden_sample(50, device="cuda:0")
+    merged = cli.run(make_options(str(tmp_path), case), sample=sample, classifier=ChromInjected(case, case["chrom_order"]))
+    assert open(merged).read() == case["merged_vcf"]
+
+
+@pytest.fixture(scope="module")
+def checkpoint(tmp_path_factory):
+    from oracle import alexnet_ref
+    params = alexnet_ref.random_params(seed=7)
+    prefix = str(tmp_path_factory.mktemp("ckpt") / "svision-cnn-model.ckpt")
+    ck.write_checkpoint(prefix, params)
+    return prefix, params
+
+
+def test_classifier_from_checkpoint_matches_cpu_checker(checkpoint, tmp_path):
+    """north_star tolerance: softmax within 1e-3 (fp32) of the CPU fp32 restatement, same classes."""
+    from oracle import encode_ref
+    prefix, params = checkpoint
+    case = _case()
+    bed = tmp_path / "chrB.bed"
+    bed.write_text(case["chroms"]["chrB"]["tsv"])
+    gen = BatchGenerator(str(bed), nb_classes=5, batch_size=64, layout="NCHW")
+    classify = load_classifier(prefix, device="cuda:0")
+    checker = AlexNet(params, device="cpu")                       # plain PyTorch fp32 on the host
+    for _ in range(gen.data_size // 64):
+        lo = gen.pointer
+        images, _labels = gen.next_batch(64)
+        _logits, cls, prob = classify(images)
+        want_img = encode_ref.encode_records(gen.records[lo:lo + 64])            # oracle rasteriser
+        assert np.array_equal(images.cpu().numpy(), want_img.transpose(0, 3, 1, 2))
+        _l, wcls, wprob = checker.predict(torch.from_numpy(np.ascontiguousarray(want_img.transpose(0, 3, 1, 2))))
+        assert np.abs(prob - wprob.numpy()).max() < 1e-3
+        sure = np.sort(wprob.numpy(), axis=1)[:, -1] - np.sort(wprob.numpy(), axis=1)[:, -2] > 2e-3
+        assert np.array_equal(cls[sure], wcls.numpy()[sure])
+
+
+def test_full_cli_on_device(checkpoint, tmp_path):
+    """BAM file + FASTA + checkpoint prefix on disk -> VCF, everything on the device path."""
+    from svision_amd.io import bam
+    prefix, _params = checkpoint
+    fasta = helpers.load_golden_fasta()
+    fa = str(tmp_path / "genome.fa")
+    bam.write_fasta(fa, {n: fasta._seq[n] for n in fasta.references})
+    out = str(tmp_path / "out")
+    opts = cli.parse_arguments(["-o", out, "-b", os.path.join(helpers.GOLDEN, "collect_small.bam"), "-m", prefix, "-g", fa,
+                                "-n", "HGtest", "-s", "3", "--window_size", "150000", "--batch_size", "64", "--debug"])
+    merged = cli.run(opts)
+    body = [l for l in open(merged).read().splitlines() if not l.startswith("#")]
+    assert len(body) > 10
+    case = _case()
+    for chrom in case["chrom_order"]:                            # the encode side is independent of the CNN
+        got = open(os.path.join(out, "segments", chrom + ".segments.all.bed")).read()
+        assert got == case["chroms"][chrom]["tsv"]
+    # every record sits on a candidate site of the TSV
+    sites = {tuple(l.split("\t")[0].split("+")[:3]) for c in case["chrom_order"] for l in case["chroms"][c]["tsv"].splitlines()}
+    for l in body:
+        f = l.split("\t")
+        assert (f[0], f[1], f[7].split(";")[0][4:]) in sites

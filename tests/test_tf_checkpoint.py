@@ -1,0 +1,54 @@
+"""-m boundary: TF1 V2 checkpoint (tensor bundle) reader, validated by round trip through the
+own writer (real SVision weights are not available offline)."""
+import numpy as np
+import pytest
+
+from svision_amd.network import tf_checkpoint as ck
+from svision_amd.network.alexnet import AlexNet, checkpoint_shapes
+
+
+def test_roundtrip_with_extra_variables(tmp_path):
+    rng = np.random.default_rng(0)
+    tensors = {k: rng.standard_normal(s).astype(np.float32) for k, s in
+               {"conv1/weights": (11, 11, 3, 96), "conv1/biases": (96,), "fc8/weights": (4096, 5), "fc8/biases": (5,),
+                "fc8/weights/Adam": (4096, 5), "beta1_power": ()}.items()}
+    prefix = str(tmp_path / "model.ckpt")
+    ck.write_checkpoint(prefix, tensors, crc_tensors=True)
+    idx = ck.read_index(prefix)
+    assert idx[""]["num_shards"] == 1
+    assert idx["conv1/weights"]["shape"] == (11, 11, 3, 96) and idx["beta1_power"]["shape"] == ()
+    got = ck.read_checkpoint(prefix)
+    assert set(got) == set(tensors)
+    for k in tensors:
+        assert np.array_equal(got[k], tensors[k])
+    only = ck.read_checkpoint(prefix, names=["fc8/weights", "fc8/biases"])
+    assert set(only) == {"fc8/weights", "fc8/biases"}
+    with pytest.raises(KeyError):
+        ck.read_checkpoint(prefix, names=["fc7/weights"])
+
+
+def test_missing_prefix_and_bad_magic(tmp_path):
+    with pytest.raises(FileNotFoundError):
+        ck.read_checkpoint(str(tmp_path / "nope.ckpt"))
+    p = tmp_path / "bad.ckpt.index"
+    p.write_bytes(b"\x00" * 64)
+    with pytest.raises(ValueError):
+        ck.read_index(str(tmp_path / "bad.ckpt"))
+
+
+def test_crc32c_known_answer():
+    # RFC 3720 test vector: 32 bytes of zeros -> 0x8A9136AA ; "123456789" -> 0xE3069283
+    assert ck._crc32c(b"\x00" * 32) == 0x8A9136AA
+    assert ck._crc32c(b"123456789") == 0xE3069283
+
+
+def test_alexnet_requires_all_tensors():
+    shapes = checkpoint_shapes()
+    params = {k: np.zeros(s, np.float32) for k, s in shapes.items()}
+    del params["fc7/biases"]
+    with pytest.raises(KeyError):
+        AlexNet(params, device="cpu")
+    params["fc7/biases"] = np.zeros(4096, np.float32)
+    params["conv2/weights"] = np.zeros((5, 5, 96, 256), np.float32)      # ungrouped shape is wrong
+    with pytest.raises(ValueError):
+        AlexNet(params, device="cpu")
