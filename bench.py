@@ -1,14 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- candidate SV sites/sec (encode+CNN) on N MI355X of one node.
 
-A *step* is one pass of the hot path over one batch of synthetic input that is
-already resident in HBM: CIGAR/segment scan of the alignments behind the batch,
-rasterisation of B candidate similarity images, AlexNet forward + argmax/softmax.
-Workload: BASELINE.json configs[1] stand-in ("HiFi chr21, 1xMI355X, batch=64
-candidate images"), synthetic (no real BAM ships with the reference).
+Workload (BASELINE.json configs[1] stand-in, synthetic: the reference ships no BAM):
+a chr21-sized contig (46,709,983 bp), HiFi reads N(15 kb, 2 kb) at 30x with planted
+SVs; its alignments are decoded to packed arrays and resident in HBM before the timed
+region.  A *step* is one collection window of the reference driver (10 Mb, SVision:88)
+through the whole hot path:
 
-Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline`
-(dominant kernel) and `cpu_baseline` (oracle port timed on this box, N=1 only).
+  device  CIGAR/segment scan of the window's alignments        (svx_cigar_scan)
+  host    reads -> signatures -> clusters -> segment pairs      (parity-tested mirror of src/collection)
+  device  similarity-image rasterisation + AlexNet fp32, batches of 64 candidate images
+  host    per-site vote -> VCF body lines + scores
+
+value = candidate sites (distinct regions of the segment TSV) per second, whole job.
+With N>1 every rank owns its own chromosome-sized shard (weak scaling, no data-path
+collective; one score-range all_reduce + one record gather at the end, inside the timed
+region).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -22,13 +29,17 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from svision_amd import kernels  # noqa: E402
+from svision_amd import dist as sdist, kernels, synth  # noqa: E402
+from svision_amd.io import bam  # noqa: E402
 from svision_amd.network.alexnet import AlexNet, checkpoint_shapes  # noqa: E402
+from svision_amd.pipeline import HotPath  # noqa: E402
+from svision_amd.sample import Sample  # noqa: E402
 
 IMG_BYTES = 227 * 227 * 3 * 4 + 48            # 618,348 B written + 48 B read per image
 CNN_FLOP = 1_440_662_592                      # FLOP per image
 HBM_PEAK = 8.0e12                             # MI355X_MICROARCH.md: HBM3E 8 TB/s
-F32_MFMA_PEAK = 157.3e12                      # MI355X_MICROARCH.md: FP32 matrix peak
+F32_MFMA_PEAK = 157.3e12                      # MI355X_MICROARCH.md: FP32 matrix peak (f32-in MFMA)
+CHR21 = 46_709_983
 
 
 def random_weights(seed=0):
@@ -43,60 +54,68 @@ def random_weights(seed=0):
     return p
 
 
-def make_workload(batch, aln_per_image, seed):
-    """Synthetic HiFi-like batch: `batch` segment-pair records + the CIGARs of the
-    alignments behind them (15 kb reads, ~0.1-0.3 % error -> a few hundred ops each)."""
-    from tests import datagen
-    rec = datagen.random_records(batch, seed=seed, hostile=False)
-    cigar, off, ref_start = datagen.random_cigars(batch * aln_per_image, seed=seed + 1, mean_ops=300, long_gap_rate=0.003)
-    return rec, cigar, off, ref_start
+def options_ns(batch):
+    import types
+    return types.SimpleNamespace(
+        out_path=None, bam_path="<resident>", model_path=None, genome=None, sample="bench", thread_num=1, min_support=5,
+        chrom=None, hash=False, qname=False, graph=False, contig=False, debug=False, min_mapq=10, min_sv_size=50,
+        max_sv_size=1000000, window_size=10000000, patition_max_distance=5000, cluster_max_distance=0.3,
+        batch_size=batch, min_gt_depth=4, homo_thresh=0.8, hete_thresh=0.2, k_size=10, min_accept=50, max_hash_len=1000)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="candidate images per CNN batch (BASELINE configs[1])")
-    ap.add_argument("--aln-per-image", type=int, default=9, help="alignments scanned per candidate image (chr21 30x: ~9e4 reads / ~1e4 images)")
-    ap.add_argument("--images-per-site", type=float, default=20.0, help="images per candidate site (SURVEY 8a cfg2 estimate: 1e4 images / 500 sites)")
+    ap.add_argument("--contig-len", type=int, default=CHR21)
+    ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
+    rank, world = sdist.init_from_env()
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    B = args.batch
-    # each rank owns its own shard of candidate sites (weak scaling: fixed work per GPU, no data-path collective)
-    rec, cigar, off, ref_start = make_workload(B, args.aln_per_image, seed=1000 + rank)
-    d_rec = torch.from_numpy(rec).to(dev)
-    d_cigar = torch.from_numpy(cigar.view(np.int32)).to(dev)
-    d_off = torch.from_numpy(off.astype(np.int64)).to(dev)
-    d_ref = torch.from_numpy(ref_start).to(dev)
+    # ---- untimed set-up: synthetic sample -> packed arrays -> HBM ----
+    cfg = synth.SimConfig(contigs=[("chr21", args.contig_len)], coverage=args.coverage, seed=1 + rank)
+    table, genome, _svs = synth.simulate(cfg)
+    opts = options_ns(args.batch)
+    sample = Sample.from_table(table, bam.Fasta(sequences=genome), opts.min_sv_size, device=dev)
     net = AlexNet(random_weights(0), device=dev)
-    img = torch.empty((B, 3, 227, 227), dtype=torch.float32, device=dev)
+    hot = HotPath(sample, opts, net, device=dev)
+    windows = []
+    pos = 0
+    while pos < args.contig_len:
+        windows.append(("chr21", pos, min(args.contig_len, pos + opts.window_size)))
+        pos += opts.window_size
 
-    gaps_cap = max(1024, ref_start.size)
-    ev = {k: [] for k in ("scan", "raster", "cnn")}
+    ev = {"raster": [], "cnn": [], "scan": []}
+    orig_launch = hot.launch
 
-    def step(record):
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if record else None
-        if record: e[0].record()
-        scan = kernels.cigar_scan(d_cigar, d_off, d_ref, 50, gaps_cap=gaps_cap)
-        if record: e[1].record()
-        kernels.rasterize(d_rec, layout="NCHW", out=img)
-        if record: e[2].record()
-        logits, cls, prob = net.predict(img)
-        if record:
-            e[3].record()
-            ev["scan"].append((e[0], e[1])); ev["raster"].append((e[1], e[2])); ev["cnn"].append((e[2], e[3]))
-        return scan, cls, prob
+    def timed_launch(res):          # HIP events on the stream the kernels are launched on (torch's current stream)
+        n = res.n_images
+        if n == 0:
+            return res
+        b = hot.batch
+        pad = (-n) % b
+        from svision_amd.pipeline import _PAD_REC
+        recs = np.asarray([ln.record() for ln in res.lines] + [_PAD_REC] * pad, np.int32)
+        d_rec = torch.from_numpy(recs).to(dev, non_blocking=True)
+        outs = []
+        for lo in range(0, n + pad, b):
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            e[0].record()
+            img = kernels.rasterize(d_rec[lo:lo + b], layout="NCHW")
+            e[1].record()
+            logits, cls, prob = net.predict(img)
+            e[2].record()
+            ev["raster"].append((e[0], e[1])); ev["cnn"].append((e[1], e[2]))
+            outs.append(torch.cat([prob, cls.to(prob.dtype).unsqueeze(1)], dim=1))
+        res.packed = torch.cat(outs, dim=0)
+        return res
 
     def sync_all():
         if world > 1:
@@ -104,29 +123,42 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(False)
+    def run(n_steps, record):
+        hot.launch = timed_launch if record else orig_launch
+        seq = [windows[i % len(windows)] for i in range(n_steps)]
+        sites = images = records = 0
+        scores = []
+        for res in hot.run_windows(seq):
+            sites += res.n_sites; images += res.n_images; records += res.n_records
+            scores += [float(s) for s in res.scores.split()]
+        return sites, images, records, scores
+
+    run(args.warmup, False)
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step(True)
+    sites, images, records, scores = run(args.steps, True)
+    # the single cross-shard exchange of the job: score range + record gather (dist.py)
+    sdist.exchange_score_range(scores)
+    sdist.gather_texts({"rank%d" % rank: "%d records" % records})
     sync_all()
     dt = time.perf_counter() - t0
+
+    totals = torch.tensor([sites, images, dt], dtype=torch.float64, device=dev)
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        tmax = totals.clone()
+        dist.all_reduce(totals, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax[2].item())
+    tot_sites, tot_images = float(totals[0].item()), float(totals[1].item())
 
-    ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
-    images = B * args.steps * world
-    sites = images / args.images_per_site
-    n_ops = int(cigar.size)
-    raster_bytes = IMG_BYTES * B
-    cnn_flop = CNN_FLOP * B
+    ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) if v else float("nan") for k, v in ev.items()}
+    B = args.batch
+    cnn_tflops = CNN_FLOP * B / (ms["cnn"] * 1e-3) / 1e12
+    raster_gbs = IMG_BYTES * B / (ms["raster"] * 1e-3) / 1e9
     line = {
         "metric": "candidate SV sites/sec (encode+CNN)",
-        "value": sites / dt,
+        "value": tot_sites / dt,
         "unit": "sites/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -137,20 +169,24 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "cfg2 stand-in: HiFi chr21-like, batch=%d candidate images/step, %d alignments scanned/step, CNN fp32" % (B, B * args.aln_per_image),
-                   "batch": B, "images_per_site": args.images_per_site, "images_per_s": images / dt,
-                   "cigar_ops_per_step": n_ops, "parallelism": "sites sharded per GPU, no data-path collective"},
-        "roofline": {"kernel": "AlexNet forward (MIOpen/hipBLASLt fp32)", "bound": "mfma", "achieved": cnn_flop / (ms["cnn"] * 1e-3) / 1e12,
-                     "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": cnn_flop / (ms["cnn"] * 1e-3) / F32_MFMA_PEAK, "traffic": None},
+        "config": {"workload": "cfg2 stand-in: synthetic HiFi chr21 (%d bp, N(15kb,2kb) reads, %gx), step = one 10 Mb window, "
+                               "CNN batch = %d candidate images, fp32" % (args.contig_len, args.coverage, B),
+                   "batch": B, "alignments": len(table), "cigar_ops": int(table.cigar.size), "windows": len(windows),
+                   "sites_per_step": sites / args.steps, "images_per_site": images / max(sites, 1),
+                   "images_per_s": tot_images / dt, "parallelism": "one process per GPU, chromosome-sized shard per rank, "
+                   "no data-path collective (score-range all_reduce + record gather once)"},
+        "roofline": {"kernel": "AlexNet forward, batch %d (MIOpen conv + hipBLASLt fc, fp32)" % B, "bound": "mfma",
+                     "achieved": cnn_tflops, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
+                     "frac": cnn_tflops * 1e12 / F32_MFMA_PEAK, "traffic": None, "ms": ms["cnn"]},
         "roofline_kernels": {
-            "raster_kernel": {"bound": "hbm", "achieved": raster_bytes / (ms["raster"] * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                              "frac": raster_bytes / (ms["raster"] * 1e-3) / HBM_PEAK, "ms": ms["raster"], "traffic": None},
-            "cigar_scan": {"bound": "hbm", "achieved": (4 * n_ops + 32 * ref_start.size) / (ms["scan"] * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
-                           "unit": "GB/s", "frac": (4 * n_ops + 32 * ref_start.size) / (ms["scan"] * 1e-3) / HBM_PEAK, "ms": ms["scan"], "traffic": None},
+            "raster_kernel": {"bound": "hbm", "achieved": raster_gbs, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                              "frac": raster_gbs * 1e9 / HBM_PEAK, "ms": ms["raster"], "traffic": None,
+                              "note": "one launch per CNN batch (%d images, %.1f MB): launch-latency dominated; see the "
+                                      "large-batch microbenchmark in profiles/ for the streaming rate" % (B, IMG_BYTES * B / 1e6)},
         },
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(rec, cigar, off, ref_start, args)
+        line["cpu_baseline"] = cpu_baseline(sample, opts, windows[0], net)
     if rank == 0:
         print(json.dumps(line))
     if world > 1:
@@ -158,27 +194,54 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(rec, cigar, off, ref_start, args):
-    """The oracle port (C restatement of scan + rasteriser, torch-CPU fp32 AlexNet with
-    the reference's batch of 128 -> here the same batch as the GPU leg) timed on this
-    box's host cores on a bounded sample of the same workload."""
+def cpu_baseline(sample, opts, window, gpu_net):
+    """The oracle port of the same step on this box's host cores: C restatement of the scan and of
+    the rasteriser (single thread), plain PyTorch CPU fp32 AlexNet (the reference runs CPU
+    TensorFlow), the same host collection / vote code; timed on a bounded sample (one window's
+    collection, the first sites' images)."""
+    import io
     from oracle import cbind
+    from svision_amd.collection.output_clusters import collect_pair_lines
+    from svision_amd.collection.run_collection import detect_window
+    from svision_amd.network.predict import Predict, SiteVoter
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    params = {}
     net = AlexNet(random_weights(0), device="cpu")
-    B = rec.shape[0]
-    reps, t_total = 0, 0.0
-    t_budget = 15.0
-    while t_total < t_budget and reps < 50:
+    table = sample.table
+    chrom, start, end = window
+    t0 = time.perf_counter()
+    cbind.cigar_scan(table.cigar, table.cig_off.astype(np.uint64), table.pos, opts.min_sv_size)
+    t_scan = (time.perf_counter() - t0) * (end - start) / max(table.lengths[0], 1)
+    t0 = time.perf_counter()
+    _sigs, clusters = detect_window(opts, sample, chrom, start, end)
+    lines = collect_pair_lines(clusters, opts)
+    t_collect = time.perf_counter() - t0
+    n_sites_window = len({ln.region for ln in lines})
+    # bounded sample: the first sites' images, up to ~20 s of CNN time
+    B = 128                                           # reference default batch (SVision:88)
+    recs = np.asarray([ln.record() for ln in lines], np.int32)
+    done, t_enc_cnn, outs = 0, 0.0, []
+    while done < len(lines) and t_enc_cnn < 20.0:
         t0 = time.perf_counter()
-        cbind.cigar_scan(cigar, off, ref_start, 50)
-        x = cbind.rasterize(rec, "NCHW")
-        net.predict(torch.from_numpy(x))
-        t_total += time.perf_counter() - t0
-        reps += 1
-    sites = reps * B / args.images_per_site
-    return {"value": sites / t_total, "unit": "sites/s", "cores": cores, "kind": "port",
-            "sample": "%d steps of the same %d-image batch (C oracle scan+raster single thread, torch CPU fp32 AlexNet on %d threads)" % (reps, B, cores)}
+        x = cbind.rasterize(recs[done:done + B], "NCHW")
+        _l, cls, prob = net.predict(torch.from_numpy(x))
+        t_enc_cnn += time.perf_counter() - t0
+        outs.append((cls.numpy(), prob.numpy()))
+        done = min(len(lines), done + B)
+    t0 = time.perf_counter()
+    voter = SiteVoter(Predict(chrom, None), io.StringIO(), io.StringIO(), opts, sample)
+    voter.feed_batch([ln.label() for ln in lines[:done]], np.concatenate([o[0] for o in outs]), np.concatenate([o[1] for o in outs]))
+    voter.finish()
+    t_vote = time.perf_counter() - t0
+    frac = done / max(len(lines), 1)
+    sites = n_sites_window * frac
+    total = (t_scan + t_collect) * frac + t_enc_cnn + t_vote
+    return {"value": sites / total, "unit": "sites/s", "cores": threads, "kind": "port",
+            "sample": "first %d of %d images (%.1f sites) of window %s:%d-%d: C oracle scan+rasteriser (1 thread), torch CPU fp32 "
+                      "AlexNet batch %d on %d threads, same host collection/vote code; %.1f s CPU" %
+                      (done, len(lines), sites, chrom, start, end, B, threads, total)}
 
 
 if __name__ == "__main__":

@@ -51,6 +51,11 @@ class PairLine:
         """12 ints: TSV columns 1..12 (svx_rasterize input)."""
         return self.seg1.fields() + self.seg2.fields() + (self.read_len, self.ref_len)
 
+    def label(self):
+        """The label string BatchGenerator derives from the TSV line (create_batch.py:45-49)."""
+        return "svision".join([self.tag, self.region, self.qname, self.sig_type, str(self.bkp[0]), str(self.bkp[1]),
+                               str(self.score), self.forward, self.mechanism, str(self.bkp[2])])
+
     def text(self):
         return "\t".join([self.region, self.seg1.toString(), self.seg2.toString(), str(self.read_len), str(self.ref_len),
                           self.tag, str(self.sub), self.qname, self.sig_type, str(self.bkp[0]), str(self.bkp[1]),

@@ -71,7 +71,7 @@ class Predict:
         if int(n_batches) * batch_size != gen.data_size:
             logging.warning("batch count wrapped in int16 (%d images): tail images are skipped, as upstream", gen.data_size)
         with open(out_path_prefix + ".score.txt", "w") as score_out, open(out_path_prefix + ".vcf", "w") as vcf_out:
-            site = _SiteState()
+            voter = SiteVoter(self, vcf_out, score_out, options, sample)
             logging.info("Predicting " + self.chrom)
             for _ in range(n_batches):
                 if getattr(classifier, "needs_images", True):
@@ -79,33 +79,54 @@ class Predict:
                 else:                                                        # predictions injected by a test
                     images, labels = None, gen.next_labels(batch_size)
                 _logits, classes, probs = classifier(images)
-                for i, label in enumerate(labels):
-                    if "complement" in label:
-                        continue
-                    f = label.split("svision")
-                    read_num, region, read_name = f[0], f[1], f[2]
-                    cls = int(classes[i])
-                    if f[7] == "True" and cls == 2:                           # :229-231 forward pairs cannot be INV
-                        continue
-                    if region != site.region:
-                        if site.region != "":
-                            self._flush(site, vcf_out, score_out, options, sample)
-                        site = _SiteState(region)
-                    rid = read_num.replace("m", "")
-                    site.read_names[rid] = read_name
-                    site.sig_types.append(f[3])
-                    site.predict_scores.append(round(probs[i][cls], 2))
-                    site.sig_scores[rid] = f[6]
-                    site.mechanisms[rid] = f[8]
-                    if "m" not in read_num and cls in (0, 1):                 # :278-280 only main x main pairs call INS/DEL
-                        continue
-                    site.reads.setdefault(rid, {})[cls] = [int(f[4]), int(f[5]), int(f[9])]
-            self._flush(site, vcf_out, score_out, options, sample)
+                voter.feed_batch(labels, classes, probs)
+            voter.finish()
 
-    def _flush(self, site, vcf_out, score_out, options, sample):
-        write_results_to_vcf(vcf_out, score_out, self.get_region_potential_svtypes(site.reads), site.region,
-                             site.read_names, site.sig_types, site.sig_scores, site.predict_scores, site.mechanisms,
-                             options, sample)
+
+class SiteVoter:
+    """The per-image bookkeeping of predict.py:213-300: consumes (label, class, softmax row) in
+    TSV order, groups by region, and emits one site through write_results_to_vcf at every
+    region change and at the end."""
+
+    def __init__(self, predictor, vcf_out, score_out, options, sample):
+        self.predictor, self.vcf_out, self.score_out = predictor, vcf_out, score_out
+        self.options, self.sample = options, sample
+        self.site = _SiteState()
+        self.n_sites = 0
+
+    def feed_batch(self, labels, classes, probs):
+        site = self.site
+        for i, label in enumerate(labels):
+            if "complement" in label:
+                continue
+            f = label.split("svision")
+            read_num, region, read_name = f[0], f[1], f[2]
+            cls = int(classes[i])
+            if f[7] == "True" and cls == 2:                           # :229-231 forward pairs cannot be INV
+                continue
+            if region != site.region:
+                if site.region != "":
+                    self._flush(site)
+                site = self.site = _SiteState(region)
+            rid = read_num.replace("m", "")
+            site.read_names[rid] = read_name
+            site.sig_types.append(f[3])
+            site.predict_scores.append(round(probs[i][cls], 2))
+            site.sig_scores[rid] = f[6]
+            site.mechanisms[rid] = f[8]
+            if "m" not in read_num and cls in (0, 1):                 # :278-280 only main x main pairs call INS/DEL
+                continue
+            site.reads.setdefault(rid, {})[cls] = [int(f[4]), int(f[5]), int(f[9])]
+
+    def finish(self):
+        self._flush(self.site)
+        self.site = _SiteState()
+
+    def _flush(self, site):
+        self.n_sites += 1 if site.region != "" else 0
+        write_results_to_vcf(self.vcf_out, self.score_out, self.predictor.get_region_potential_svtypes(site.reads),
+                             site.region, site.read_names, site.sig_types, site.sig_scores, site.predict_scores,
+                             site.mechanisms, self.options, self.sample)
 
 
 class _SiteState:

@@ -50,6 +50,31 @@ class Sample:
             _CACHE[key] = cls.from_table(read_bam(bam_path), Fasta(genome_path), min_sv, device)
         return _CACHE[key]
 
+    def rescan_window(self, chrom, start, end):
+        """Re-run the device scan for the block of rows whose start lies in [start, end) of
+        ``chrom`` and refresh the host copies (streaming use: each window's rows are scanned
+        when the window is processed).  Rows form a partition of the table over windows."""
+        import torch
+        from . import kernels
+        table = self.table
+        b = table._bounds()
+        tid = table.get_tid(chrom)
+        lo = int(b[tid]) + int(np.searchsorted(table.pos[b[tid]:b[tid + 1]], start, side="left"))
+        hi = int(b[tid]) + int(np.searchsorted(table.pos[b[tid]:b[tid + 1]], end, side="left"))
+        if hi <= lo:
+            return 0
+        d_cigar, d_off, d_pos, _ = self.device_buffers
+        cap = int(self.gap_off[hi] - self.gap_off[lo])
+        res = kernels.cigar_scan(d_cigar, d_off[lo:hi + 1], d_pos[lo:hi], self.min_sv, gaps_cap=max(cap, 16))
+        gaps, gap_off, stats = res.to_host()
+        if int(gap_off[-1]) != cap or not np.array_equal(gap_off.astype(np.int64) + self.gap_off[lo], self.gap_off[lo:hi + 1]):
+            raise RuntimeError("window rescan disagrees with the resident scan")
+        gaps = gaps.copy()
+        gaps["aln"] += lo
+        self.gaps[self.gap_off[lo]:self.gap_off[hi]] = gaps
+        table.ref_span[lo:hi], table.lead_clip[lo:hi], table.trail_clip[lo:hi] = stats[:, 0], stats[:, 1], stats[:, 2]
+        return hi - lo
+
     # -- accessors used by the collection step ----------------------------------------
     def gaps_of(self, aln):
         return self.gaps[self.gap_off[aln]:self.gap_off[aln + 1]]
