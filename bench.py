@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 from svision_amd import dist as sdist, kernels, synth  # noqa: E402
 from svision_amd.io import bam  # noqa: E402
 from svision_amd.network.alexnet import AlexNet, checkpoint_shapes  # noqa: E402
-from svision_amd.pipeline import HotPath  # noqa: E402
+from svision_amd.pipeline import PooledHotPath  # noqa: E402
 from svision_amd.sample import Sample  # noqa: E402
 
 IMG_BYTES = 227 * 227 * 3 * 4 + 48            # 618,348 B written + 48 B read per image
@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="candidate images per CNN batch (BASELINE configs[1])")
     ap.add_argument("--contig-len", type=int, default=CHR21)
     ap.add_argument("--coverage", type=float, default=30.0)
+    ap.add_argument("--workers", type=int, default=8, help="helper processes for the Python host glue (collection, vote)")
+    ap.add_argument("--streams", type=int, default=2, help="HIP streams the per-batch graphs are replayed on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -85,37 +87,12 @@ def main():
     opts = options_ns(args.batch)
     sample = Sample.from_table(table, bam.Fasta(sequences=genome), opts.min_sv_size, device=dev)
     net = AlexNet(random_weights(0), device=dev)
-    hot = HotPath(sample, opts, net, device=dev)
+    hot = PooledHotPath(sample, opts, net, device=dev, n_workers=args.workers, n_streams=args.streams)
     windows = []
     pos = 0
     while pos < args.contig_len:
         windows.append(("chr21", pos, min(args.contig_len, pos + opts.window_size)))
         pos += opts.window_size
-
-    ev = {"raster": [], "cnn": [], "scan": []}
-    orig_launch = hot.launch
-
-    def timed_launch(res):          # HIP events on the stream the kernels are launched on (torch's current stream)
-        n = res.n_images
-        if n == 0:
-            return res
-        b = hot.batch
-        pad = (-n) % b
-        from svision_amd.pipeline import _PAD_REC
-        recs = np.asarray([ln.record() for ln in res.lines] + [_PAD_REC] * pad, np.int32)
-        d_rec = torch.from_numpy(recs).to(dev, non_blocking=True)
-        outs = []
-        for lo in range(0, n + pad, b):
-            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-            e[0].record()
-            img = kernels.rasterize(d_rec[lo:lo + b], layout="NCHW")
-            e[1].record()
-            logits, cls, prob = net.predict(img)
-            e[2].record()
-            ev["raster"].append((e[0], e[1])); ev["cnn"].append((e[1], e[2]))
-            outs.append(torch.cat([prob, cls.to(prob.dtype).unsqueeze(1)], dim=1))
-        res.packed = torch.cat(outs, dim=0)
-        return res
 
     def sync_all():
         if world > 1:
@@ -123,20 +100,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(n_steps, record):
-        hot.launch = timed_launch if record else orig_launch
+    def run(n_steps):
         seq = [windows[i % len(windows)] for i in range(n_steps)]
         sites = images = records = 0
         scores = []
+        hot.device_events.clear()
         for res in hot.run_windows(seq):
             sites += res.n_sites; images += res.n_images; records += res.n_records
             scores += [float(s) for s in res.scores.split()]
         return sites, images, records, scores
 
-    run(args.warmup, False)
+    run(args.warmup)
     sync_all()
     t0 = time.perf_counter()
-    sites, images, records, scores = run(args.steps, True)
+    sites, images, records, scores = run(args.steps)
     # the single cross-shard exchange of the job: score range + record gather (dist.py)
     sdist.exchange_score_range(scores)
     sdist.gather_texts({"rank%d" % rank: "%d records" % records})
@@ -152,10 +129,12 @@ def main():
         dt = float(tmax[2].item())
     tot_sites, tot_images = float(totals[0].item()), float(totals[1].item())
 
-    ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) if v else float("nan") for k, v in ev.items()}
     B = args.batch
-    cnn_tflops = CNN_FLOP * B / (ms["cnn"] * 1e-3) / 1e12
-    raster_gbs = IMG_BYTES * B / (ms["raster"] * 1e-3) / 1e9
+    dev_ms = sum(e0.elapsed_time(e1) for e0, e1, _n in hot.device_events)
+    dev_images = sum(n for _e0, _e1, n in hot.device_events)
+    hot.close()
+    cnn_tflops = CNN_FLOP * dev_images / (dev_ms * 1e-3) / 1e12
+    ms_batch = dev_ms / max(dev_images / B, 1)
     line = {
         "metric": "candidate SV sites/sec (encode+CNN)",
         "value": tot_sites / dt,
@@ -173,17 +152,13 @@ def main():
                                "CNN batch = %d candidate images, fp32" % (args.contig_len, args.coverage, B),
                    "batch": B, "alignments": len(table), "cigar_ops": int(table.cigar.size), "windows": len(windows),
                    "sites_per_step": sites / args.steps, "images_per_site": images / max(sites, 1),
-                   "images_per_s": tot_images / dt, "parallelism": "one process per GPU, chromosome-sized shard per rank, "
+                   "images_per_s": tot_images / dt, "host_workers": args.workers, "streams": args.streams, "parallelism": "one process per GPU, chromosome-sized shard per rank, "
                    "no data-path collective (score-range all_reduce + record gather once)"},
-        "roofline": {"kernel": "AlexNet forward, batch %d (MIOpen conv + hipBLASLt fc, fp32)" % B, "bound": "mfma",
+        "roofline": {"kernel": "device stage per batch of %d images: raster_kernel + AlexNet forward fp32 (MIOpen conv, hipBLASLt fc), "
+                               "graph replays on %d streams" % (B, args.streams), "bound": "mfma",
                      "achieved": cnn_tflops, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
-                     "frac": cnn_tflops * 1e12 / F32_MFMA_PEAK, "traffic": None, "ms": ms["cnn"]},
-        "roofline_kernels": {
-            "raster_kernel": {"bound": "hbm", "achieved": raster_gbs, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                              "frac": raster_gbs * 1e9 / HBM_PEAK, "ms": ms["raster"], "traffic": None,
-                              "note": "one launch per CNN batch (%d images, %.1f MB): launch-latency dominated; see the "
-                                      "large-batch microbenchmark in profiles/ for the streaming rate" % (B, IMG_BYTES * B / 1e6)},
-        },
+                     "frac": cnn_tflops * 1e12 / F32_MFMA_PEAK, "traffic": None, "ms_per_batch": ms_batch,
+                     "device_busy_frac": dev_ms * 1e-3 / dt},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(sample, opts, windows[0], net)

@@ -120,11 +120,15 @@ class AlignmentTable:
         self.ref_span = np.ascontiguousarray(stats[:, 0])
         self.lead_clip = np.ascontiguousarray(stats[:, 1])
         self.trail_clip = np.ascontiguousarray(stats[:, 2])
+        self._ref_end = None
 
     def ref_end(self):
         """htslib bam_endpos: pos + reference span, or pos + 1 for spanless/unmapped records."""
-        span = np.where((self.ref_span > 0) & ((self.flag & FLAG_UNMAPPED) == 0), self.ref_span, 1)
-        return self.pos.astype(np.int64) + span
+        if getattr(self, "_ref_end", None) is None:
+            span = np.where((self.ref_span > 0) & ((self.flag & FLAG_UNMAPPED) == 0), self.ref_span, 1)
+            self._ref_end = self.pos.astype(np.int64) + span
+            self._ref_end_sorted = {}
+        return self._ref_end
 
     def _bounds(self):
         if self._tid_bounds is None:
@@ -153,7 +157,10 @@ class AlignmentTable:
         b = self._bounds()
         lo, hi = int(b[tid]), int(b[tid + 1])
         pos = self.pos[lo:hi]
-        rend = np.sort(self.ref_end()[lo:hi])
+        rend_all = self.ref_end()
+        if tid not in self._ref_end_sorted:
+            self._ref_end_sorted[tid] = np.sort(rend_all[lo:hi])
+        rend = self._ref_end_sorted[tid]
         starts = np.asarray(starts, np.int64)
         ends = np.asarray(ends, np.int64)
         n_pos_lt_end = np.searchsorted(pos, ends, side="left")

@@ -1,5 +1,6 @@
 """In-memory streaming form of the hot path: one collection window at a time, no
-intermediate files, host work of window k+1 overlapped with the device work of window k.
+intermediate files; the host stages run in helper processes while the GPU-owning process
+only feeds the device.
 
 Same stages and the same (parity-tested) functions as the file-based driver (cli.py):
 
@@ -8,10 +9,15 @@ Same stages and the same (parity-tested) functions as the file-based driver (cli
   device  svx_rasterize + AlexNet, batches of `batch_size` images     (create_batch.py:88, predict.py:206-210)
   host    per-site vote -> VCF body lines + scores                    (predict.py:213-300, output.py:469)
 
-Used by bench.py (throughput) and available to embedders; the CLI keeps the reference's
-on-disk TSV boundary.
+The reference fans windows out to a ``multiprocessing.Pool`` (SVision:261-281); here the pool
+workers keep only the Python glue (collection + vote) and hand packed int32 records to the one
+process that owns the GPU.  The device stage replays a captured HIP graph per batch (rasterise
+-> AlexNet -> pack) on a few streams, so the owner process spends microseconds per batch.
 """
+import collections
 import io
+import multiprocessing as mp
+import multiprocessing.connection as mpc
 
 import numpy as np
 import torch
@@ -26,64 +32,137 @@ _PAD_REC = parse_data_fields(PAD_DATA.split("_"))
 
 
 class WindowResult:
-    __slots__ = ("chrom", "start", "end", "lines", "n_images", "packed", "vcf", "scores", "n_sites", "n_records")
+    __slots__ = ("chrom", "start", "end", "lines", "n_images", "packed", "vcf", "scores", "n_sites", "n_records",
+                 "records", "done_event", "t_device")
+
+
+def _collect_lines(sample, options, chrom, start, end):
+    _sigs, clusters = detect_window(options, sample, chrom, start, end)
+    return collect_pair_lines(clusters, options)
+
+
+def _vote(sample, options, chrom, lines, classes, probs):
+    vcf, score = io.StringIO(), io.StringIO()
+    n_sites = 0
+    if lines:
+        voter = SiteVoter(Predict(chrom, None), vcf, score, options, sample)
+        voter.feed_batch([ln.label() for ln in lines], classes, probs)
+        voter.finish()
+        n_sites = voter.n_sites
+    return vcf.getvalue(), score.getvalue(), n_sites
+
+
+class DeviceStage:
+    """records [n,12] -> (softmax[5], class) per image, in batches of ``batch`` images, each batch a
+    replay of one captured graph: svx_rasterize -> AlexNet forward -> softmax/argmax -> pack."""
+
+    def __init__(self, net, batch, device, n_streams=2, use_graph=True):
+        self.net, self.batch, self.device = net, batch, torch.device(device)
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
+        self.use_graph = use_graph
+        self.slots = []
+        for s in self.streams:
+            rec = torch.zeros((batch, 12), dtype=torch.int32, device=self.device)
+            rec[:] = torch.tensor(_PAD_REC, dtype=torch.int32, device=self.device)
+            img = torch.empty((batch, 3, 227, 227), dtype=torch.float32, device=self.device)
+            out = torch.empty((batch, 6), dtype=torch.float32, device=self.device)
+            graph = None
+            with torch.cuda.stream(s):
+                for _ in range(2):                           # warm MIOpen / hipBLASLt before capture
+                    self._body(rec, img, out)
+            s.synchronize()
+            if use_graph:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=s):
+                    self._body(rec, img, out)
+            self.slots.append((rec, img, out, graph))
+
+    def _body(self, rec, img, out):
+        kernels.rasterize(rec, layout="NCHW", out=img)
+        _logits, cls, prob = self.net.predict(img)
+        out[:, :5] = prob
+        out[:, 5] = cls.to(torch.float32)
+
+    def run(self, d_rec, out):
+        """d_rec: int32 [n_padded,12] on the device (n_padded % batch == 0); out: float32 [n_padded,6].
+        Enqueues everything asynchronously; the caller's current stream waits for the side streams."""
+        main = torch.cuda.current_stream(self.device)
+        used = set()
+        b = self.batch
+        for i, lo in enumerate(range(0, d_rec.shape[0], b)):
+            k = i % len(self.streams)
+            s = self.streams[k]
+            rec, img, o, graph = self.slots[k]
+            if k not in used:
+                s.wait_stream(main)
+                used.add(k)
+            with torch.cuda.stream(s):
+                rec.copy_(d_rec[lo:lo + b], non_blocking=True)
+                if graph is not None:
+                    graph.replay()
+                else:
+                    self._body(rec, img, o)
+                out[lo:lo + b].copy_(o, non_blocking=True)
+        for k in used:
+            main.wait_stream(self.streams[k])
+        return out
 
 
 class HotPath:
-    def __init__(self, sample, options, net, device="cuda"):
+    """Single-process form: collect -> device -> vote, with the device work of window k overlapped
+    with the host collection of window k+1."""
+
+    def __init__(self, sample, options, net, device="cuda", n_streams=2, use_graph=True):
         self.sample, self.options, self.net = sample, options, net
         self.device = torch.device(device)
         self.batch = options.batch_size
+        self.stage = DeviceStage(net, self.batch, self.device, n_streams, use_graph)
+        self.device_events = []          # (start, end, n_images_padded) per window, on the launch stream
 
-    # ---- stage 1+2: device scan of the window's rows + host collection ---------------------
     def collect(self, chrom, start, end, rescan=True):
         res = WindowResult()
         res.chrom, res.start, res.end = chrom, start, end
         if rescan:
             self.sample.rescan_window(chrom, start, end)
-        _sigs, clusters = detect_window(self.options, self.sample, chrom, start, end)
-        res.lines = collect_pair_lines(clusters, self.options)
+        res.lines = _collect_lines(self.sample, self.options, chrom, start, end)
         res.n_images = len(res.lines)
+        res.records = np.asarray([ln.record() for ln in res.lines], np.int32).reshape(-1, 12)
         res.packed = None
         return res
 
-    # ---- stage 3: encode + CNN, enqueued asynchronously on the current stream -----------------
     def launch(self, res):
+        """Enqueue encode + CNN for the window's records; returns immediately."""
         n = res.n_images
+        res.t_device = None
         if n == 0:
             return res
-        b = self.batch
-        pad = (-n) % b
-        recs = np.asarray([ln.record() for ln in res.lines] + [_PAD_REC] * pad, np.int32)
-        d_rec = torch.from_numpy(recs).to(self.device, non_blocking=True)
-        outs = []
-        for lo in range(0, n + pad, b):
-            img = kernels.rasterize(d_rec[lo:lo + b], layout="NCHW")
-            logits, cls, prob = self.net.predict(img)
-            outs.append(torch.cat([prob, cls.to(prob.dtype).unsqueeze(1)], dim=1))
-        res.packed = torch.cat(outs, dim=0)
+        pad = (-n) % self.batch
+        recs = np.concatenate([res.records, np.tile(np.asarray(_PAD_REC, np.int32), (pad, 1))]) if pad else res.records
+        d_rec = torch.from_numpy(np.ascontiguousarray(recs)).to(self.device, non_blocking=True)
+        out = torch.empty((n + pad, 6), dtype=torch.float32, device=self.device)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.stage.run(d_rec, out)
+        e1.record()
+        res.packed, res.done_event, res.t_device = out, e1, (e0, e1)
+        self.device_events.append((e0, e1, n + pad))
         return res
 
-    # ---- stage 4: one D2H copy, per-site vote, VCF body lines -----------------------------------
-    def finish(self, res):
-        vcf, score = io.StringIO(), io.StringIO()
-        res.n_sites = 0
-        if res.n_images:
-            packed = res.packed.cpu().numpy()
-            probs, classes = packed[:, :5], packed[:, 5].astype(np.int64)
-            voter = SiteVoter(Predict(res.chrom, None), vcf, score, self.options, self.sample)
-            labels = [ln.label() for ln in res.lines]
-            voter.feed_batch(labels, classes[:len(labels)], probs[:len(labels)])
-            voter.finish()
-            res.n_sites = voter.n_sites
-        res.vcf, res.scores = vcf.getvalue(), score.getvalue()
-        res.n_records = res.vcf.count("\n")
+    def fetch_predictions(self, res):
+        if res.n_images == 0:
+            return np.empty(0, np.int64), np.empty((0, 5), np.float32)
+        packed = res.packed.cpu().numpy()[:res.n_images]
         res.packed = None
+        return packed[:, 5].astype(np.int64), packed[:, :5]
+
+    def finish(self, res):
+        classes, probs = self.fetch_predictions(res)
+        res.vcf, res.scores, res.n_sites = _vote(self.sample, self.options, res.chrom, res.lines, classes, probs)
+        res.n_records = res.vcf.count("\n")
         return res
 
     def run_windows(self, windows):
-        """Software pipeline over [(chrom, start, end)]: the CNN of window k runs on the device
-        while the host collects window k+1.  Yields WindowResults in order."""
         prev = None
         for chrom, start, end in windows:
             cur = self.collect(chrom, start, end)
@@ -92,3 +171,106 @@ class HotPath:
             prev = self.launch(cur)
         if prev is not None:
             yield self.finish(prev)
+
+
+# --------------------------------------------------------------------------------------------------
+# Multi-process host: helper processes run collection and vote; the owner process runs the device.
+_POOL_STATE = {}
+
+
+def _worker_main(conn):
+    """Helper process: never touches the GPU.  Protocol on the duplex pipe:
+       owner -> ("win", wid, chrom, start, end)   helper -> ("rec", wid, records int32[n,12])
+       owner -> ("pred", wid, classes, probs)      helper -> ("done", wid, vcf, scores, n_sites, n_images)
+       owner -> ("stop",)"""
+    sample, options = _POOL_STATE["sample"], _POOL_STATE["options"]
+    held = {}
+    while True:
+        msg = conn.recv()
+        if msg[0] == "stop":
+            return
+        if msg[0] == "win":
+            _t, wid, chrom, start, end = msg
+            lines = _collect_lines(sample, options, chrom, start, end)
+            held[wid] = (chrom, lines)
+            recs = np.asarray([ln.record() for ln in lines], np.int32).reshape(-1, 12)
+            conn.send(("rec", wid, recs))
+        elif msg[0] == "pred":
+            _t, wid, classes, probs = msg
+            chrom, lines = held.pop(wid)
+            vcf, scores, n_sites = _vote(sample, options, chrom, lines, classes, probs)
+            conn.send(("done", wid, vcf, scores, n_sites, len(lines)))
+
+
+class PooledHotPath(HotPath):
+    """Owner process = device feeder; ``n_workers`` forked helpers do the Python glue."""
+
+    def __init__(self, sample, options, net, device="cuda", n_workers=8, n_streams=2, use_graph=True, max_inflight=3):
+        super().__init__(sample, options, net, device, n_streams, use_graph)
+        _POOL_STATE["sample"], _POOL_STATE["options"] = sample, options
+        ctx = mp.get_context("fork")                         # helpers inherit the resident host arrays copy-on-write
+        self.conns, self.procs = [], []
+        for _ in range(n_workers):
+            a, b = ctx.Pipe(duplex=True)
+            p = ctx.Process(target=_worker_main, args=(b,), daemon=True)
+            p.start()
+            b.close()
+            self.conns.append(a)
+            self.procs.append(p)
+        self.max_inflight = max_inflight
+
+    def close(self):
+        for c in self.conns:
+            try:
+                c.send(("stop",))
+            except (BrokenPipeError, OSError):
+                pass
+        for p in self.procs:
+            p.join(timeout=5)
+        self.conns, self.procs = [], []
+
+    def run_windows(self, windows, rescan=True):
+        """Yields WindowResults (completion order).  Each helper holds one window at a time."""
+        windows = list(windows)
+        nxt = 0
+        idle = list(range(len(self.conns)))
+        busy = {}                     # conn index -> wid
+        ready = collections.deque()   # (conn index, WindowResult with records) waiting for the device
+        inflight = collections.deque()  # (conn index, WindowResult) enqueued on the device
+        remaining = len(windows)
+        while remaining:
+            while idle and nxt < len(windows):
+                ci = idle.pop()
+                chrom, start, end = windows[nxt]
+                if rescan:
+                    self.sample.rescan_window(chrom, start, end)      # device scan of the window's block
+                self.conns[ci].send(("win", nxt, chrom, start, end))
+                busy[ci] = nxt
+                nxt += 1
+            while ready and len(inflight) < self.max_inflight:
+                ci, res = ready.popleft()
+                inflight.append((ci, self.launch(res)))
+            while inflight and (inflight[0][1].n_images == 0 or inflight[0][1].done_event.query()):
+                ci, res = inflight.popleft()
+                classes, probs = self.fetch_predictions(res)
+                self.conns[ci].send(("pred", busy[ci], classes, probs))
+            waiting = [self.conns[ci] for ci in busy]
+            for c in mpc.wait(waiting, timeout=0.0005 if inflight else 0.05):
+                ci = self.conns.index(c)
+                msg = c.recv()
+                if msg[0] == "rec":
+                    res = WindowResult()
+                    res.chrom, res.start, res.end = windows[msg[1]]
+                    res.records, res.n_images, res.lines, res.packed = msg[2], int(msg[2].shape[0]), None, None
+                    res.t_device = None
+                    ready.append((ci, res))
+                else:
+                    _t, wid, vcf, scores, n_sites, n_images = msg
+                    res = WindowResult()
+                    res.chrom, res.start, res.end = windows[wid]
+                    res.vcf, res.scores, res.n_sites, res.n_images = vcf, scores, n_sites, n_images
+                    res.n_records = vcf.count("\n")
+                    del busy[ci]
+                    idle.append(ci)
+                    remaining -= 1
+                    yield res

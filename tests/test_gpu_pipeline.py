@@ -77,3 +77,27 @@ def test_full_cli_on_device(checkpoint, tmp_path):
     for l in body:
         f = l.split("\t")
         assert (f[0], f[1], f[7].split(";")[0][4:]) in sites
+
+
+def test_streaming_pipelines_agree(checkpoint):
+    """Single-process eager, graph-replay multi-stream, and the pooled (helper processes) pipelines
+    produce the same per-window VCF bodies and scores."""
+    from svision_amd.pipeline import HotPath, PooledHotPath
+    from svision_amd.network.tf_checkpoint import read_checkpoint
+    prefix, _ = checkpoint
+    net = AlexNet(read_checkpoint(prefix), device="cuda:0")
+    windows = [("chrA", 0, 150_000), ("chrA", 150_000, 300_000), ("chrA", 300_000, 420_000), ("chrB", 0, 150_000), ("chrB", 150_000, 200_000)]
+    outs = []
+    for kind in ("eager", "graph", "pool"):
+        sample = helpers.golden_sample(50, device="cuda:0")
+        opts = helpers.default_options(min_support=3, batch_size=64, bam_path="<resident>")
+        if kind == "pool":
+            hp = PooledHotPath(sample, opts, net, device="cuda:0", n_workers=3, n_streams=2)
+        else:
+            hp = HotPath(sample, opts, net, device="cuda:0", n_streams=1 if kind == "eager" else 3, use_graph=kind != "eager")
+        got = {(r.chrom, r.start): (r.vcf, r.scores, r.n_sites, r.n_images) for r in hp.run_windows(windows)}
+        if kind == "pool":
+            hp.close()
+        outs.append(got)
+    assert outs[0] == outs[1] == outs[2]
+    assert sum(v[3] for v in outs[0].values()) == 704 and sum(v[2] for v in outs[0].values()) > 20
