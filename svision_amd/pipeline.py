@@ -48,7 +48,8 @@ def _vote(sample, options, chrom, lines, classes, probs):
         voter = SiteVoter(Predict(chrom, None), vcf, score, options, sample)
         voter.feed_batch([ln.label() for ln in lines], classes, probs)
         voter.finish()
-        n_sites = voter.n_sites
+        # candidate sites = distinct region keys of the segment TSV, whatever the CNN says
+        n_sites = len({ln.region for ln in lines})
     return vcf.getvalue(), score.getvalue(), n_sites
 
 

@@ -100,4 +100,4 @@ def test_streaming_pipelines_agree(checkpoint):
             hp.close()
         outs.append(got)
     assert outs[0] == outs[1] == outs[2]
-    assert sum(v[3] for v in outs[0].values()) == 704 and sum(v[2] for v in outs[0].values()) > 20
+    assert sum(v[3] for v in outs[0].values()) == 610 and sum(v[2] for v in outs[0].values()) > 20
