@@ -91,6 +91,18 @@ int svx_cigar_scan(const uint32_t* d_cigar, const uint64_t* d_cig_off,
 int svx_rasterize(const int32_t* d_records, uint32_t n, float* d_out, int layout,
                   const float* mean, void* stream);
 
+/* Fused conv epilogue: bias add + ReLU + 3x3/2 VALID max-pool (+ TF local response
+ * normalisation across channels when lrn != 0), NCHW float32.
+ * Replaces the elementwise chain between two convolutions of the reference graph:
+ * tf.nn.bias_add + relu (src/network/alexnet.py:132-135), max_pool (:158-161), lrn (:164-166)
+ * as composed at alexnet.py:29-31, :34-36, :45-46.
+ *   d_x   [n][channels][height][width]  raw convolution output (no bias)
+ *   d_y   [n][channels][(height-3)/2+1][(width-3)/2+1]
+ *   LRN:  y = p / (k + alpha * sum_{|j-c| <= radius} p_j^2)^beta   (alpha NOT divided by the window) */
+int svx_bias_relu_pool_lrn(const float* d_x, const float* d_bias, float* d_y, uint32_t n, uint32_t channels,
+                           uint32_t height, uint32_t width, int lrn, uint32_t radius, float alpha, float beta,
+                           float k, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

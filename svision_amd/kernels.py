@@ -95,3 +95,19 @@ def cigar_scan(cigar, cig_off, ref_start, min_sv, gaps_cap=None):
     if auto and res.total() > gaps_cap:       # d_gap_off[n] holds the full count: rerun with the exact capacity
         return cigar_scan(cigar, cig_off, ref_start, min_sv, gaps_cap=res.total())
     return res
+
+
+def bias_relu_pool_lrn(x, bias, lrn=True, radius=2, alpha=2e-05, beta=0.75, k=1.0):
+    """x: float32 [n,C,H,W] raw conv output -> relu(x+bias) -> max-pool 3x3/2 -> (LRN) as one kernel.
+    See include/svx.h svx_bias_relu_pool_lrn."""
+    lib = _lib.load()
+    _require_cuda(x, "x")
+    _require_cuda(bias, "bias")
+    if x.dtype != torch.float32 or x.dim() != 4 or bias.dtype != torch.float32 or bias.numel() != x.shape[1]:
+        raise _lib.SvxError("x must be float32 [n,C,H,W] and bias float32 [C]")
+    n, c, h, w = x.shape
+    y = torch.empty((n, c, (h - 3) // 2 + 1, (w - 3) // 2 + 1), dtype=torch.float32, device=x.device)
+    rc = lib.svx_bias_relu_pool_lrn(x.data_ptr(), bias.data_ptr(), y.data_ptr(), n, c, h, w, 1 if lrn else 0, radius,
+                                    alpha, beta, k, _stream_ptr(x.device))
+    _lib.check(rc, "svx_bias_relu_pool_lrn")
+    return y

@@ -48,8 +48,10 @@ def checkpoint_shapes():
 class AlexNet(torch.nn.Module):
     """Inference-only AlexNet holding device-layout parameters."""
 
-    def __init__(self, params, device="cuda", channels_last=False):
+    def __init__(self, params, device="cuda", channels_last=False, fused=None):
         super().__init__()
+        # fused: conv epilogues (bias+relu+pool+LRN) as one hand-written HIP kernel; default on the GPU
+        self.fused = (torch.device(device).type == "cuda" and not channels_last) if fused is None else fused
         want = checkpoint_shapes()
         missing = [k for k in want if k not in params]
         if missing:
@@ -81,6 +83,11 @@ class AlexNet(torch.nn.Module):
         if self.channels_last:
             x = x.contiguous(memory_format=torch.channels_last)
         for name, _k, _cin, _cout, stride, pad, groups in _CONVS:
+            if self.fused and name in ("conv1", "conv2", "conv5"):
+                from .. import kernels
+                x = F.conv2d(x, getattr(self, f"{name}_w"), None, stride=stride, padding=pad, groups=groups)
+                x = kernels.bias_relu_pool_lrn(x, getattr(self, f"{name}_b"), lrn=name != "conv5")
+                continue
             x = F.relu_(F.conv2d(x, getattr(self, f"{name}_w"), getattr(self, f"{name}_b"),
                                  stride=stride, padding=pad, groups=groups))
             if name in ("conv1", "conv2"):

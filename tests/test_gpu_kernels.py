@@ -110,3 +110,20 @@ def test_alexnet_matches_numpy_oracle():
         # north_star tolerance: CNN softmax within 1e-3 (fp32)
         assert np.abs(prob.cpu().numpy() - o_prob).max() < 1e-3
         assert np.allclose(logits.cpu().numpy(), o_logits, rtol=1e-3, atol=1e-3 * np.abs(o_logits).max())
+
+
+@pytest.mark.parametrize("shape,lrn", [((3, 96, 55, 55), True), ((2, 256, 27, 27), True), ((4, 256, 13, 13), False), ((1, 7, 9, 11), True)])
+def test_bias_relu_pool_lrn_matches_numpy_oracle(shape, lrn):
+    """fp32 op: tolerance 1e-5 relative vs the NumPy restatement of relu(x+b) -> max_pool -> tf LRN."""
+    from oracle import alexnet_ref
+    rng = np.random.default_rng(shape[1])
+    x = (rng.standard_normal(shape) * 30).astype(np.float32)
+    b = rng.standard_normal(shape[1]).astype(np.float32)
+    got = kernels.bias_relu_pool_lrn(_dev(x), _dev(b), lrn=lrn).cpu().numpy()
+    nhwc = np.maximum(x.transpose(0, 2, 3, 1) + b, 0)
+    want = alexnet_ref._max_pool_3x3s2_valid(np.ascontiguousarray(nhwc))
+    if lrn:
+        want = alexnet_ref._lrn(np.ascontiguousarray(want))
+    want = want.transpose(0, 3, 1, 2)
+    assert got.shape == want.shape
+    assert np.allclose(got, want, rtol=1e-5, atol=1e-6)
