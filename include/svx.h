@@ -91,6 +91,18 @@ int svx_cigar_scan(const uint32_t* d_cigar, const uint64_t* d_cig_off,
 int svx_rasterize(const int32_t* d_records, uint32_t n, float* d_out, int layout,
                   const float* mean, void* stream);
 
+/* Encode + first CNN layer without materialising the image ("sparse conv1").
+ * Replaces, for n segment pairs, BatchGenerator.next_batch + PlotSingleImg.plot (as svx_rasterize)
+ * AND conv1 -> relu -> pool1 -> norm1 of the reference graph (src/network/alexnet.py:29-31):
+ * the image is 255 on a few hundred line pixels and 0 elsewhere, so the 11x11/4 VALID convolution
+ * of the mean-subtracted image is base[k] + 255 * (sum of the weight rows of the set pixels).
+ *   d_records [n][12] int32 as for svx_rasterize
+ *   d_w1      conv1/weights in checkpoint layout HWIO [11][11][3][96], 16-B aligned
+ *   d_base    [96]: biases[k] - sum_{ky,kx,ch} mean[ch] * w[ky][kx][ch][k], 16-B aligned
+ *   d_y       float32 [n][96][27][27] (NCHW) = norm1 output */
+int svx_encode_conv1(const int32_t* d_records, uint32_t n, const float* d_w1, const float* d_base, float* d_y,
+                     int lrn, uint32_t radius, float alpha, float beta, float k, void* stream);
+
 /* Fused conv epilogue: bias add + ReLU + 3x3/2 VALID max-pool (+ TF local response
  * normalisation across channels when lrn != 0), NCHW float32.
  * Replaces the elementwise chain between two convolutions of the reference graph:

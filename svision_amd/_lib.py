@@ -28,6 +28,8 @@ SYMBOLS = {
     "svx_cigar_scan_ws_bytes": (_sz, [_u32]),
     "svx_cigar_scan": (ctypes.c_int, [_vp, _vp, _vp, _u32, _i32, _vp, _u64, _vp, _vp, _vp, _vp]),
     "svx_rasterize": (ctypes.c_int, [_vp, _u32, _vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float), _vp]),
+    "svx_encode_conv1": (ctypes.c_int, [_vp, _u32, _vp, _vp, _vp, ctypes.c_int, _u32, ctypes.c_float, ctypes.c_float,
+                                        ctypes.c_float, _vp]),
     "svx_bias_relu_pool_lrn": (ctypes.c_int, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, ctypes.c_int, _u32,
                                               ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),
 }

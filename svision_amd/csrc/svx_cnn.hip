@@ -8,9 +8,7 @@
 // row of one image for ALL channels, keeps the pooled values in LDS, and applies the
 // cross-channel normalisation from there.  HBM traffic = conv output read once (+ halo
 // rows through L2) and the 4x smaller pooled tensor written once.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include "../../include/svx.h"
+#include "svx_raster_common.hpp"
 
 namespace {
 
@@ -50,7 +48,105 @@ void bias_relu_pool_lrn_kernel(const float* __restrict__ x, const float* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Encode + first layer in one kernel.  The similarity image is 0/255 on <= 3 thin lines and 0
+// elsewhere, so conv1 (11x11 stride 4 VALID, 3 -> 96) of the mean-subtracted image is
+//     base[k] + 255 * sum_{set pixels (ch,r,c) in the window} w[r-4oy][c-4ox][ch][k],
+//     base[k] = bias[k] - sum_{ky,kx,ch} mean[ch] * w[ky][kx][ch][k]      (VALID: position independent)
+// i.e. a few dozen 96-wide weight rows per output position instead of 363.  The 227x227x3 fp32
+// image (618 KB) is never materialised: the bit planes are drawn in LDS (same code as
+// svx_rasterize), each lane owns (one pooled pixel, 8 output channels), walks the 3x3 conv
+// positions under it, extracts the 11-bit window masks from the bit planes and accumulates the
+// weight rows of the set taps (checkpoint layout HWIO = [tap][96 channels], 32 B per lane,
+// L2 resident).  ReLU, max-pool and the cross-channel LRN follow from LDS.
+constexpr int C1 = 96, C1_GROUPS = 12, P1 = 27, ENC_BLOCK = 384;   // conv1 output is 55x55, pooled 27x27
+
+__device__ inline unsigned window_mask(const unsigned* row_words, int c0)
+{
+    const int w = c0 >> 5, sh = c0 & 31;
+    unsigned m = row_words[w] >> sh;
+    if (sh > 21) m |= row_words[w + 1] << (32 - sh);
+    return m & 0x7FFu;
+}
+
+__global__ __launch_bounds__(ENC_BLOCK)
+void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __restrict__ w1, const float* __restrict__ base,
+                         float* __restrict__ y, int lrn, int radius, float alpha, float beta, float kk)
+{
+    using namespace svx_raster;
+    __shared__ unsigned bits[3 * PLANE_WORDS];
+    __shared__ unsigned colcnt[IMG];
+    __shared__ unsigned colmask[ROW_WORDS];
+    __shared__ float pooled[P1 * C1];                 // [ox][k]
+
+    const int img = blockIdx.x / P1;
+    const int oyp = blockIdx.x - img * P1;
+    draw_planes<ENC_BLOCK>(records + (size_t)img * 12, bits, colcnt, colmask);
+
+    const int tid = threadIdx.x;
+    if (tid < P1 * C1_GROUPS) {
+        const int oxp = tid / C1_GROUPS, g = tid - oxp * C1_GROUPS;
+        const float4 b0 = reinterpret_cast<const float4*>(base)[2 * g];
+        const float4 b1 = reinterpret_cast<const float4*>(base)[2 * g + 1];
+        float best[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) best[j] = 0.0f;          // relu folded in: max(0, .)
+        for (int dy = 0; dy < 3; ++dy) {
+            const int oy = 2 * oyp + dy;
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ox = 2 * oxp + dx;
+                float acc[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                for (int ky = 0; ky < 11; ++ky) {
+                    const int r = 4 * oy + ky;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        unsigned m = window_mask(bits + ch * PLANE_WORDS + r * ROW_WORDS, 4 * ox);
+                        while (m) {
+                            const int kx = __ffs(m) - 1;
+                            m &= m - 1;
+                            const float4* wp = reinterpret_cast<const float4*>(w1 + ((ky * 11 + kx) * 3 + ch) * C1) + 2 * g;
+                            const float4 u0 = wp[0], u1 = wp[1];
+                            acc[0] = fmaf(255.0f, u0.x, acc[0]); acc[1] = fmaf(255.0f, u0.y, acc[1]);
+                            acc[2] = fmaf(255.0f, u0.z, acc[2]); acc[3] = fmaf(255.0f, u0.w, acc[3]);
+                            acc[4] = fmaf(255.0f, u1.x, acc[4]); acc[5] = fmaf(255.0f, u1.y, acc[5]);
+                            acc[6] = fmaf(255.0f, u1.z, acc[6]); acc[7] = fmaf(255.0f, u1.w, acc[7]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) best[j] = fmaxf(best[j], acc[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pooled[oxp * C1 + 8 * g + j] = best[j];
+    }
+    __syncthreads();
+    float* yb = y + (size_t)img * C1 * P1 * P1 + (size_t)oyp * P1;
+    for (int idx = tid; idx < C1 * P1; idx += ENC_BLOCK) {
+        const int k = idx / P1, ox = idx - k * P1;            // consecutive lanes -> consecutive ox (coalesced rows)
+        float v = pooled[ox * C1 + k];
+        if (lrn) {
+            float s = 0.0f;
+            const int lo = max(0, k - radius), hi = min(C1 - 1, k + radius);
+            for (int j = lo; j <= hi; ++j) { const float q = pooled[ox * C1 + j]; s += q * q; }
+            v = v / powf(kk + alpha * s, beta);
+        }
+        yb[(size_t)k * P1 * P1 + ox] = v;
+    }
+}
+
 }  // namespace
+
+extern "C" int svx_encode_conv1(const int32_t* d_records, uint32_t n, const float* d_w1, const float* d_base, float* d_y,
+                                int lrn, uint32_t radius, float alpha, float beta, float k, void* stream)
+{
+    if (n == 0) return SVX_OK;
+    if (!d_records || !d_w1 || !d_base || !d_y) return SVX_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(d_w1) & 15u) || (reinterpret_cast<uintptr_t>(d_base) & 15u)) return SVX_EINVAL;
+    hipLaunchKernelGGL(encode_conv1_kernel, dim3(n * P1), dim3(ENC_BLOCK), 0, static_cast<hipStream_t>(stream),
+                       d_records, d_w1, d_base, d_y, lrn, (int)radius, alpha, beta, k);
+    return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
+}
 
 extern "C" int svx_bias_relu_pool_lrn(const float* d_x, const float* d_bias, float* d_y, uint32_t n, uint32_t channels,
                                       uint32_t height, uint32_t width, int lrn, uint32_t radius, float alpha, float beta,

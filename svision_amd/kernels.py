@@ -111,3 +111,21 @@ def bias_relu_pool_lrn(x, bias, lrn=True, radius=2, alpha=2e-05, beta=0.75, k=1.
                                     alpha, beta, k, _stream_ptr(x.device))
     _lib.check(rc, "svx_bias_relu_pool_lrn")
     return y
+
+
+def encode_conv1(records, w1_hwio, base, lrn=True, radius=2, alpha=2e-05, beta=0.75, k=1.0):
+    """records int32 [n,12] -> float32 [n,96,27,27]: rasterise + conv1 + relu + pool1 + norm1 in one
+    kernel, exploiting the sparsity of the similarity image.  See include/svx.h svx_encode_conv1."""
+    lib = _lib.load()
+    for t, nm in ((records, "records"), (w1_hwio, "w1"), (base, "base")):
+        _require_cuda(t, nm)
+    if records.dtype != torch.int32 or records.dim() != 2 or records.shape[1] != 12:
+        raise _lib.SvxError("records must be int32 [n,12]")
+    if tuple(w1_hwio.shape) != (11, 11, 3, 96) or w1_hwio.dtype != torch.float32 or base.numel() != 96:
+        raise _lib.SvxError("w1 must be float32 HWIO [11,11,3,96] and base float32 [96]")
+    n = records.shape[0]
+    y = torch.empty((n, 96, 27, 27), dtype=torch.float32, device=records.device)
+    rc = lib.svx_encode_conv1(records.data_ptr(), n, w1_hwio.data_ptr(), base.data_ptr(), y.data_ptr(), 1 if lrn else 0,
+                              radius, alpha, beta, k, _stream_ptr(records.device))
+    _lib.check(rc, "svx_encode_conv1")
+    return y

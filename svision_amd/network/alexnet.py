@@ -48,7 +48,7 @@ def checkpoint_shapes():
 class AlexNet(torch.nn.Module):
     """Inference-only AlexNet holding device-layout parameters."""
 
-    def __init__(self, params, device="cuda", channels_last=False, fused=None):
+    def __init__(self, params, device="cuda", channels_last=False, fused=None, mean=(104.0, 117.0, 124.0)):
         super().__init__()
         # fused: conv epilogues (bias+relu+pool+LRN) as one hand-written HIP kernel; default on the GPU
         self.fused = (torch.device(device).type == "cuda" and not channels_last) if fused is None else fused
@@ -66,6 +66,12 @@ class AlexNet(torch.nn.Module):
                 wt = wt.contiguous(memory_format=torch.channels_last)
             self.register_buffer(f"{name}_w", wt.to(device))
             self.register_buffer(f"{name}_b", torch.from_numpy(np.asarray(params[f"{name}/biases"], np.float32).copy()).to(device))
+        # sparse first layer (svx_encode_conv1): checkpoint-layout weights + the constant response of
+        # the all-background image, base[k] = bias[k] - sum mean[ch] * w[..., ch, k] (float64 on the host)
+        w1 = np.asarray(params["conv1/weights"], np.float64)
+        base = np.asarray(params["conv1/biases"], np.float64) - np.einsum("hwck,c->k", w1, np.asarray(mean, np.float64))
+        self.register_buffer("conv1_hwio", torch.from_numpy(np.ascontiguousarray(params["conv1/weights"], np.float32)).to(device))
+        self.register_buffer("conv1_base", torch.from_numpy(base.astype(np.float32)).to(device))
         for name, nin, nout in _FCS:
             w = np.asarray(params[f"{name}/weights"], np.float32)
             if tuple(w.shape) != (nin, nout):
@@ -78,11 +84,27 @@ class AlexNet(torch.nn.Module):
             self.register_buffer(f"{name}_b", torch.from_numpy(np.asarray(params[f"{name}/biases"], np.float32).copy()).to(device))
 
     @torch.no_grad()
+    def forward_records(self, records):
+        """records: int32 device tensor [B,12] (TSV columns 1..12) -> logits [B,5].  The image is never
+        materialised: rasterisation + conv1 + relu + pool1 + norm1 run as one sparse HIP kernel."""
+        from .. import kernels
+        x = kernels.encode_conv1(records, self.conv1_hwio, self.conv1_base)
+        return self._tail(x, first=1)
+
+    @torch.no_grad()
+    def predict_records(self, records):
+        logits = self.forward_records(records)
+        return logits, torch.argmax(logits, dim=1), torch.softmax(logits, dim=1)
+
+    @torch.no_grad()
     def forward(self, x):
         """x: float32 [B,3,227,227] (mean-subtracted, as produced by the rasteriser) -> logits [B,5]."""
         if self.channels_last:
             x = x.contiguous(memory_format=torch.channels_last)
-        for name, _k, _cin, _cout, stride, pad, groups in _CONVS:
+        return self._tail(x, first=0)
+
+    def _tail(self, x, first):
+        for name, _k, _cin, _cout, stride, pad, groups in _CONVS[first:]:
             if self.fused and name in ("conv1", "conv2", "conv5"):
                 from .. import kernels
                 x = F.conv2d(x, getattr(self, f"{name}_w"), None, stride=stride, padding=pad, groups=groups)

@@ -57,8 +57,9 @@ class DeviceStage:
     """records [n,12] -> (softmax[5], class) per image, in batches of ``batch`` images, each batch a
     replay of one captured graph: svx_rasterize -> AlexNet forward -> softmax/argmax -> pack."""
 
-    def __init__(self, net, batch, device, n_streams=2, use_graph=True):
+    def __init__(self, net, batch, device, n_streams=2, use_graph=True, sparse_first_layer=True):
         self.net, self.batch, self.device = net, batch, torch.device(device)
+        self.sparse_first_layer = sparse_first_layer
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
         self.use_graph = use_graph
         self.slots = []
@@ -79,8 +80,11 @@ class DeviceStage:
             self.slots.append((rec, img, out, graph))
 
     def _body(self, rec, img, out):
-        kernels.rasterize(rec, layout="NCHW", out=img)
-        _logits, cls, prob = self.net.predict(img)
+        if self.sparse_first_layer:
+            _logits, cls, prob = self.net.predict_records(rec)      # svx_encode_conv1: no image tensor
+        else:
+            kernels.rasterize(rec, layout="NCHW", out=img)
+            _logits, cls, prob = self.net.predict(img)
         out[:, :5] = prob
         out[:, 5] = cls.to(torch.float32)
 

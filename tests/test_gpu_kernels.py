@@ -127,3 +127,22 @@ def test_bias_relu_pool_lrn_matches_numpy_oracle(shape, lrn):
     want = want.transpose(0, 3, 1, 2)
     assert got.shape == want.shape
     assert np.allclose(got, want, rtol=1e-5, atol=1e-6)
+
+
+def test_encode_conv1_matches_dense_path():
+    """Sparse rasterise+conv1+relu+pool+LRN vs the dense path (rasterise -> NumPy oracle layers):
+    fp32, 1e-4 relative on the layer output; end to end softmax within 1e-3 of the NumPy AlexNet."""
+    from oracle import alexnet_ref
+    from svision_amd.network.alexnet import AlexNet
+    params = alexnet_ref.random_params(seed=11)
+    rec = np.concatenate([datagen.random_records(24, seed=33), np.asarray([encode_ref.PAD_RECORD], np.int32)])
+    net = AlexNet(params, device=DEV)
+    got = kernels.encode_conv1(_dev(rec), net.conv1_hwio, net.conv1_base).cpu().numpy()
+    x = encode_ref.encode_records(rec)
+    a = alexnet_ref._conv_layer(x, params["conv1/weights"], params["conv1/biases"], 4, "VALID", 1)
+    want = alexnet_ref._lrn(np.ascontiguousarray(alexnet_ref._max_pool_3x3s2_valid(a))).transpose(0, 3, 1, 2)
+    assert got.shape == want.shape == (25, 96, 27, 27)
+    assert np.allclose(got, want, rtol=1e-4, atol=1e-4)
+    _l, cls, prob = net.predict_records(_dev(rec))
+    _ol, o_cls, o_prob = alexnet_ref.predict(params, x)
+    assert np.abs(prob.cpu().numpy() - o_prob).max() < 1e-3

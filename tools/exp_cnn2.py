@@ -18,13 +18,15 @@ p = random_weights(0)
 B = 64
 rec = torch.from_numpy(datagen.random_records(B*16, seed=1, hostile=False)).to(dev)
 img = kernels.rasterize(rec[:B], layout="NCHW")
-for fused in (False, True):
+for fused in (True,):
     net = AlexNet(p, device=dev, fused=fused)
     print(f"fused={fused} eager 1 stream: {timeit(lambda: net.predict(img)):.3f} ms/batch", flush=True)
     ref = AlexNet(p, device=dev, fused=False).predict(img)[2]
     print("  max |softmax diff| vs torch ops:", float((net.predict(img)[2]-ref).abs().max()))
-    for ns in (1, 2, 3, 4):
-        st = DeviceStage(net, B, dev, n_streams=ns)
+    print(f"  eager predict_records: {timeit(lambda: net.predict_records(rec[:B])):.3f} ms/batch")
+    print("  max |softmax diff| sparse vs dense:", float((net.predict_records(rec[:B])[2]-ref).abs().max()))
+    for ns, sp in ((1, False), (1, True), (2, True), (3, True), (4, True)):
+        st = DeviceStage(net, B, dev, n_streams=ns, sparse_first_layer=sp)
         out = torch.empty((B*16, 6), device=dev)
         ms = timeit(lambda: st.run(rec, out), n=10, warm=2) / 16
-        print(f"  graph x{ns} streams: {ms:.3f} ms/batch -> {1.4407*B/ms/1e3:.1f} TFLOP/s", flush=True)
+        print(f"  graph x{ns} streams sparse={sp}: {ms:.3f} ms/batch -> {1.4407*B/ms:.1f} TFLOP/s", flush=True)
