@@ -9,6 +9,7 @@ from svision_amd.network.alexnet import AlexNet
 from svision_amd.pipeline import DeviceStage
 from tests import datagen
 dev = torch.device("cuda:0")
+torch.backends.cudnn.benchmark = os.environ.get("TORCH_BENCH", "0") == "1"
 def timeit(fn, n=30, warm=5):
     for _ in range(warm): fn()
     torch.cuda.synchronize(); t=time.perf_counter()
