@@ -78,12 +78,22 @@ void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __res
     __shared__ unsigned colcnt[IMG];
     __shared__ unsigned colmask[ROW_WORDS];
     __shared__ float pooled[P1 * C1];                 // [ox][k]
+    __shared__ unsigned rowany[3][ROW_WORDS];         // per conv row of this strip: OR of its 11 image rows x 3 planes
 
     const int img = blockIdx.x / P1;
     const int oyp = blockIdx.x - img * P1;
     draw_planes<ENC_BLOCK>(records + (size_t)img * 12, bits, colcnt, colmask);
 
     const int tid = threadIdx.x;
+    if (tid < 3 * ROW_WORDS) {
+        const int dy = tid / ROW_WORDS, w = tid - dy * ROW_WORDS;
+        const int r0 = 4 * (2 * oyp + dy);
+        unsigned any = 0;
+        for (int ky = 0; ky < 11; ++ky)
+            any |= bits[(r0 + ky) * ROW_WORDS + w] | bits[2 * PLANE_WORDS + (r0 + ky) * ROW_WORDS + w];   // plane 1 is a subset of plane 0
+        rowany[dy][w] = any;
+    }
+    __syncthreads();
     if (tid < P1 * C1_GROUPS) {
         const int oxp = tid / C1_GROUPS, g = tid - oxp * C1_GROUPS;
         const float4 b0 = reinterpret_cast<const float4*>(base)[2 * g];
@@ -96,7 +106,8 @@ void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __res
             for (int dx = 0; dx < 3; ++dx) {
                 const int ox = 2 * oxp + dx;
                 float acc[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-                for (int ky = 0; ky < 11; ++ky) {
+                const bool touched = window_mask(rowany[dy], 4 * ox) != 0;      // ~90 % of the windows are empty
+                for (int ky = 0; touched && ky < 11; ++ky) {
                     const int r = 4 * oy + ky;
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch) {

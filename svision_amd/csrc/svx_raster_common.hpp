@@ -112,14 +112,14 @@ __device__ inline void draw_planes(const int32_t* __restrict__ r, unsigned* bits
     for (int i = tid; i < IMG; i += BLOCK_T) colcnt[i] = 0;
     if (tid < ROW_WORDS) colmask[tid] = 0;
 
-    // every lane derives the (wave-uniform) line set-ups itself: 12 ints, a few doubles
-    const int read_len = r[10], ref_len = r[11];
-    double ratio = (double)(read_len > ref_len ? read_len : ref_len) / 227.0;
-    if (ratio < 1) ratio = 1;
-    Line lines[2];
-    int rev[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    // two lanes derive the two line set-ups (fp64 scaling + clipLine) and publish them through LDS
+    __shared__ Line sh_lines[2];
+    __shared__ int sh_rev[2];
+    if (tid < 2) {
+        const int s = tid;
+        const int read_len = r[10], ref_len = r[11];
+        double ratio = (double)(read_len > ref_len ? read_len : ref_len) / 227.0;
+        if (ratio < 1) ratio = 1;
         const int xs = r[s * 5 + 0], ys = r[s * 5 + 2];
         const long long len = (long long)r[s * 5 + 3] - (long long)ys;
         const int fwd = r[s * 5 + 4] != 0;
@@ -127,10 +127,12 @@ __device__ inline void draw_planes(const int32_t* __restrict__ r, unsigned* bits
         const long long ye = (long long)ys + (len - 1);
         const long long cs = scale_coord(ys, ratio), rs = scale_coord(xs, ratio);
         const long long ce = (long long)((double)ye / ratio), re = (long long)((double)xe / ratio);
-        rev[s] = !fwd;
-        lines[s] = fwd ? setup_line(cs, rs, ce, re) : setup_line(ce, re, cs, rs);
+        sh_rev[s] = !fwd;
+        sh_lines[s] = fwd ? setup_line(cs, rs, ce, re) : setup_line(ce, re, cs, rs);
     }
     __syncthreads();
+    Line lines[2] = {sh_lines[0], sh_lines[1]};
+    const int rev[2] = {sh_rev[0], sh_rev[1]};
 
     // draw: one lane per Bresenham step (<= 227 per line)
 #pragma unroll
