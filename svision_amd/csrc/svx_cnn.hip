@@ -59,7 +59,7 @@ void bias_relu_pool_lrn_kernel(const float* __restrict__ x, const float* __restr
 // positions under it, extracts the 11-bit window masks from the bit planes and accumulates the
 // weight rows of the set taps (checkpoint layout HWIO = [tap][96 channels], 32 B per lane,
 // L2 resident).  ReLU, max-pool and the cross-channel LRN follow from LDS.
-constexpr int C1 = 96, C1_GROUPS = 12, P1 = 27, ENC_BLOCK = 384;   // conv1 output is 55x55, pooled 27x27
+constexpr int C1 = 96, C1_GROUPS = 12, P1 = 27, ENC_BLOCK = 384, TAPQ = 16;   // conv1 output is 55x55, pooled 27x27
 
 __device__ inline unsigned window_mask(const unsigned* row_words, int c0)
 {
@@ -78,6 +78,7 @@ void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __res
     __shared__ unsigned colcnt[IMG];
     __shared__ unsigned colmask[ROW_WORDS];
     __shared__ float pooled[P1 * C1];                 // [ox][k]
+    __shared__ unsigned short tapq[TAPQ * ENC_BLOCK];  // per-lane queue of pending tap indices, [slot][lane]
     __shared__ unsigned rowany[3][ROW_WORDS];         // per conv row of this strip: OR of its 11 image rows x 3 planes
 
     const int img = blockIdx.x / P1;
@@ -107,6 +108,32 @@ void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __res
                 const int ox = 2 * oxp + dx;
                 float acc[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
                 const bool touched = window_mask(rowany[dy], 4 * ox) != 0;      // ~90 % of the windows are empty
+                // Set taps are queued (LDS, [slot][lane]: conflict free) and consumed four at a time so that
+                // eight 16-B weight loads are in flight per lane instead of one dependent L2 round trip per tap;
+                // accumulation order stays the tap order (deterministic).
+                int qn = 0;
+                auto flush = [&]() {
+                    for (int i = 0; i < qn; i += 4) {
+                        float4 u[4][2];
+                        float sc[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const bool ok = i + j < qn;
+                            const int tap = ok ? (int)tapq[(i + j) * ENC_BLOCK + tid] : 0;
+                            const float4* wp = reinterpret_cast<const float4*>(w1 + tap * C1) + 2 * g;
+                            u[j][0] = wp[0]; u[j][1] = wp[1];
+                            sc[j] = ok ? 255.0f : 0.0f;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            acc[0] = fmaf(sc[j], u[j][0].x, acc[0]); acc[1] = fmaf(sc[j], u[j][0].y, acc[1]);
+                            acc[2] = fmaf(sc[j], u[j][0].z, acc[2]); acc[3] = fmaf(sc[j], u[j][0].w, acc[3]);
+                            acc[4] = fmaf(sc[j], u[j][1].x, acc[4]); acc[5] = fmaf(sc[j], u[j][1].y, acc[5]);
+                            acc[6] = fmaf(sc[j], u[j][1].z, acc[6]); acc[7] = fmaf(sc[j], u[j][1].w, acc[7]);
+                        }
+                    }
+                    qn = 0;
+                };
                 for (int ky = 0; touched && ky < 11; ++ky) {
                     const int r = 4 * oy + ky;
 #pragma unroll
@@ -115,15 +142,12 @@ void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __res
                         while (m) {
                             const int kx = __ffs(m) - 1;
                             m &= m - 1;
-                            const float4* wp = reinterpret_cast<const float4*>(w1 + ((ky * 11 + kx) * 3 + ch) * C1) + 2 * g;
-                            const float4 u0 = wp[0], u1 = wp[1];
-                            acc[0] = fmaf(255.0f, u0.x, acc[0]); acc[1] = fmaf(255.0f, u0.y, acc[1]);
-                            acc[2] = fmaf(255.0f, u0.z, acc[2]); acc[3] = fmaf(255.0f, u0.w, acc[3]);
-                            acc[4] = fmaf(255.0f, u1.x, acc[4]); acc[5] = fmaf(255.0f, u1.y, acc[5]);
-                            acc[6] = fmaf(255.0f, u1.z, acc[6]); acc[7] = fmaf(255.0f, u1.w, acc[7]);
+                            tapq[qn * ENC_BLOCK + tid] = (unsigned short)((ky * 11 + kx) * 3 + ch);
+                            if (++qn == TAPQ) flush();
                         }
                     }
                 }
+                flush();
 #pragma unroll
                 for (int j = 0; j < 8; ++j) best[j] = fmaxf(best[j], acc[j]);
             }
