@@ -9,10 +9,19 @@
 // cross-channel normalisation from there.  HBM traffic = conv output read once (+ halo
 // rows through L2) and the 4x smaller pooled tensor written once.
 #include "svx_raster_common.hpp"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int BLOCK = 256;
+
+// v / (k + alpha*s)^beta.  The reference network uses beta = 0.75: x^-0.75 = rsqrt(x) * rsqrt(sqrt(x)),
+// three hardware ops (a few ulp) instead of a ~100-instruction powf.
+__device__ inline float lrn_scale(float v, float x, float beta)
+{
+    if (beta == 0.75f) return v * __frsqrt_rn(x) * __frsqrt_rn(__fsqrt_rn(x));
+    return v / powf(x, beta);
+}
 
 // relu(max(window) + bias) == max(relu(x + bias)) : + and relu are monotonic.
 __global__ __launch_bounds__(BLOCK)
@@ -42,7 +51,7 @@ void bias_relu_pool_lrn_kernel(const float* __restrict__ x, const float* __restr
             float s = 0.0f;
             const int lo = max(0, c - radius), hi = min(C - 1, c + radius);
             for (int j = lo; j <= hi; ++j) { const float q = pooled[j * OW + ox]; s += q * q; }
-            v = v / powf(k + alpha * s, beta);
+            v = lrn_scale(v, k + alpha * s, beta);
         }
         yb[(size_t)c * OH * OW + ox] = v;
     }
@@ -59,7 +68,7 @@ void bias_relu_pool_lrn_kernel(const float* __restrict__ x, const float* __restr
 // positions under it, extracts the 11-bit window masks from the bit planes and accumulates the
 // weight rows of the set taps (checkpoint layout HWIO = [tap][96 channels], 32 B per lane,
 // L2 resident).  ReLU, max-pool and the cross-channel LRN follow from LDS.
-constexpr int C1 = 96, C1_GROUPS = 12, P1 = 27, ENC_BLOCK = 384, TAPQ = 16;   // conv1 output is 55x55, pooled 27x27
+constexpr int C1 = 96, C1_GROUPS = 12, P1 = 27, ENC_BLOCK = 384, C1P = C1 + 1;   // conv1 output is 55x55, pooled 27x27
 
 __device__ inline unsigned window_mask(const unsigned* row_words, int c0)
 {
@@ -71,19 +80,19 @@ __device__ inline unsigned window_mask(const unsigned* row_words, int c0)
 
 __global__ __launch_bounds__(ENC_BLOCK)
 void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __restrict__ w1, const float* __restrict__ base,
-                         float* __restrict__ y, int lrn, int radius, float alpha, float beta, float kk)
+                         float* __restrict__ y, int lrn, int radius, float alpha, float beta, float kk, int dbg)
 {
     using namespace svx_raster;
     __shared__ unsigned bits[3 * PLANE_WORDS];
     __shared__ unsigned colcnt[IMG];
     __shared__ unsigned colmask[ROW_WORDS];
-    __shared__ float pooled[P1 * C1];                 // [ox][k]
-    __shared__ unsigned short tapq[TAPQ * ENC_BLOCK];  // per-lane queue of pending tap indices, [slot][lane]
-    __shared__ unsigned rowany[3][ROW_WORDS];         // per conv row of this strip: OR of its 11 image rows x 3 planes
+    __shared__ unsigned pooled_bits[P1 * C1P];        // [ox][k] pooled activations as float bit patterns (row padded: no bank conflicts)
+    __shared__ unsigned rowany[3][ROW_WORDS];
+    __shared__ int has_empty[P1];         // per conv row of this strip: OR of its 11 image rows x 3 planes
 
     const int img = blockIdx.x / P1;
     const int oyp = blockIdx.x - img * P1;
-    draw_planes<ENC_BLOCK>(records + (size_t)img * 12, bits, colcnt, colmask);
+    if (!(dbg & 4)) draw_planes<ENC_BLOCK>(records + (size_t)img * 12, bits, colcnt, colmask);
 
     const int tid = threadIdx.x;
     if (tid < 3 * ROW_WORDS) {
@@ -95,76 +104,65 @@ void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __res
         rowany[dy][w] = any;
     }
     __syncthreads();
-    if (tid < P1 * C1_GROUPS) {
-        const int oxp = tid / C1_GROUPS, g = tid - oxp * C1_GROUPS;
+    if (tid < P1) {                                   // does this pooled pixel see at least one empty window?
+        bool any_empty = false;
+        for (int win = 0; win < 9; ++win)
+            any_empty |= window_mask(rowany[win / 3], 4 * (2 * tid + win % 3)) == 0;
+        has_empty[tid] = any_empty ? 1 : 0;
+    }
+    __syncthreads();
+    for (int i = tid; i < P1 * C1; i += ENC_BLOCK) {  // empty windows all respond relu(base[k]); relu floor otherwise
+        const int ox = i / C1, k = i - ox * C1;
+        pooled_bits[ox * C1P + k] = has_empty[ox] ? __float_as_uint(fmaxf(base[k], 0.0f)) : 0u;
+    }
+    __syncthreads();
+    // One lane per (pooled pixel, conv window under it, 8-channel group): 27 x 9 x 12 items.  ~90 % of the
+    // windows are empty (constant response base[k]); a touched window walks its 33 row masks and adds the
+    // weight rows of its set taps.  Max-pool = integer atomic max on the (non-negative) float bit patterns:
+    // exact and order independent.
+    for (int item = tid; item < P1 * 9 * C1_GROUPS; item += ENC_BLOCK) {
+        const int g = item % C1_GROUPS, pw = item / C1_GROUPS;
+        const int oxp = pw / 9, win = pw - oxp * 9;
+        const int dy = win / 3, dx = win - dy * 3;
+        const int oy = 2 * oyp + dy, ox = 2 * oxp + dx;
+        if ((dbg & 1) || window_mask(rowany[dy], 4 * ox) == 0) continue;
         const float4 b0 = reinterpret_cast<const float4*>(base)[2 * g];
         const float4 b1 = reinterpret_cast<const float4*>(base)[2 * g + 1];
-        float best[8];
+        float acc[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        {
+            for (int ky = 0; ky < 11; ++ky) {
+                const int r = 4 * oy + ky;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) best[j] = 0.0f;          // relu folded in: max(0, .)
-        for (int dy = 0; dy < 3; ++dy) {
-            const int oy = 2 * oyp + dy;
-            for (int dx = 0; dx < 3; ++dx) {
-                const int ox = 2 * oxp + dx;
-                float acc[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-                const bool touched = window_mask(rowany[dy], 4 * ox) != 0;      // ~90 % of the windows are empty
-                // Set taps are queued (LDS, [slot][lane]: conflict free) and consumed four at a time so that
-                // eight 16-B weight loads are in flight per lane instead of one dependent L2 round trip per tap;
-                // accumulation order stays the tap order (deterministic).
-                int qn = 0;
-                auto flush = [&]() {
-                    for (int i = 0; i < qn; i += 4) {
-                        float4 u[4][2];
-                        float sc[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const bool ok = i + j < qn;
-                            const int tap = ok ? (int)tapq[(i + j) * ENC_BLOCK + tid] : 0;
-                            const float4* wp = reinterpret_cast<const float4*>(w1 + tap * C1) + 2 * g;
-                            u[j][0] = wp[0]; u[j][1] = wp[1];
-                            sc[j] = ok ? 255.0f : 0.0f;
-                        }
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            acc[0] = fmaf(sc[j], u[j][0].x, acc[0]); acc[1] = fmaf(sc[j], u[j][0].y, acc[1]);
-                            acc[2] = fmaf(sc[j], u[j][0].z, acc[2]); acc[3] = fmaf(sc[j], u[j][0].w, acc[3]);
-                            acc[4] = fmaf(sc[j], u[j][1].x, acc[4]); acc[5] = fmaf(sc[j], u[j][1].y, acc[5]);
-                            acc[6] = fmaf(sc[j], u[j][1].z, acc[6]); acc[7] = fmaf(sc[j], u[j][1].w, acc[7]);
-                        }
-                    }
-                    qn = 0;
-                };
-                for (int ky = 0; touched && ky < 11; ++ky) {
-                    const int r = 4 * oy + ky;
-#pragma unroll
-                    for (int ch = 0; ch < 3; ++ch) {
-                        unsigned m = window_mask(bits + ch * PLANE_WORDS + r * ROW_WORDS, 4 * ox);
-                        while (m) {
-                            const int kx = __ffs(m) - 1;
-                            m &= m - 1;
-                            tapq[qn * ENC_BLOCK + tid] = (unsigned short)((ky * 11 + kx) * 3 + ch);
-                            if (++qn == TAPQ) flush();
-                        }
+                for (int ch = 0; ch < 3; ++ch) {
+                    unsigned m = window_mask(bits + ch * PLANE_WORDS + r * ROW_WORDS, 4 * ox);
+                    while (m) {
+                        const int kx = __ffs(m) - 1;
+                        m &= m - 1;
+                        const float4* wp = reinterpret_cast<const float4*>(w1 + ((ky * 11 + kx) * 3 + ch) * C1) + 2 * g;
+                        const float4 u0 = wp[0], u1 = wp[1];
+                        acc[0] = fmaf(255.0f, u0.x, acc[0]); acc[1] = fmaf(255.0f, u0.y, acc[1]);
+                        acc[2] = fmaf(255.0f, u0.z, acc[2]); acc[3] = fmaf(255.0f, u0.w, acc[3]);
+                        acc[4] = fmaf(255.0f, u1.x, acc[4]); acc[5] = fmaf(255.0f, u1.y, acc[5]);
+                        acc[6] = fmaf(255.0f, u1.z, acc[6]); acc[7] = fmaf(255.0f, u1.w, acc[7]);
                     }
                 }
-                flush();
-#pragma unroll
-                for (int j = 0; j < 8; ++j) best[j] = fmaxf(best[j], acc[j]);
             }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pooled[oxp * C1 + 8 * g + j] = best[j];
+        for (int j = 0; j < 8; ++j)
+            if (acc[j] > 0.0f) atomicMax(&pooled_bits[oxp * C1P + 8 * g + j], __float_as_uint(acc[j]));
     }
     __syncthreads();
+    const float* pooled = reinterpret_cast<const float*>(pooled_bits);
     float* yb = y + (size_t)img * C1 * P1 * P1 + (size_t)oyp * P1;
     for (int idx = tid; idx < C1 * P1; idx += ENC_BLOCK) {
         const int k = idx / P1, ox = idx - k * P1;            // consecutive lanes -> consecutive ox (coalesced rows)
-        float v = pooled[ox * C1 + k];
+        float v = pooled[ox * C1P + k];
         if (lrn) {
             float s = 0.0f;
             const int lo = max(0, k - radius), hi = min(C1 - 1, k + radius);
-            for (int j = lo; j <= hi; ++j) { const float q = pooled[ox * C1 + j]; s += q * q; }
-            v = v / powf(kk + alpha * s, beta);
+            for (int j = lo; j <= hi; ++j) { const float q = pooled[ox * C1P + j]; s += q * q; }
+            v = lrn_scale(v, kk + alpha * s, beta);
         }
         yb[(size_t)k * P1 * P1 + ox] = v;
     }
@@ -178,8 +176,9 @@ extern "C" int svx_encode_conv1(const int32_t* d_records, uint32_t n, const floa
     if (n == 0) return SVX_OK;
     if (!d_records || !d_w1 || !d_base || !d_y) return SVX_EINVAL;
     if ((reinterpret_cast<uintptr_t>(d_w1) & 15u) || (reinterpret_cast<uintptr_t>(d_base) & 15u)) return SVX_EINVAL;
+    static const int dbg = getenv("SVX_ENC_DEBUG") ? atoi(getenv("SVX_ENC_DEBUG")) : 0;
     hipLaunchKernelGGL(encode_conv1_kernel, dim3(n * P1), dim3(ENC_BLOCK), 0, static_cast<hipStream_t>(stream),
-                       d_records, d_w1, d_base, d_y, lrn, (int)radius, alpha, beta, k);
+                       d_records, d_w1, d_base, d_y, (dbg & 2) ? 0 : lrn, (int)radius, alpha, beta, k, dbg);
     return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
 }
 
