@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--contig-len", type=int, default=CHR21)
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--workers", type=int, default=8, help="helper processes for the Python host glue (collection, vote)")
-    ap.add_argument("--streams", type=int, default=2, help="HIP streams the per-batch graphs are replayed on")
+    ap.add_argument("--streams", type=int, default=3, help="HIP streams the per-batch graphs are replayed on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -159,6 +159,7 @@ def main():
                      "achieved": cnn_tflops, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                      "frac": cnn_tflops * 1e12 / F32_MFMA_PEAK, "traffic": None, "ms_per_batch": ms_batch,
                      "device_busy_frac": dev_ms * 1e-3 / dt},
+        "roofline_kernels": kernel_calibration(sample, net, dev, B),
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(sample, opts, windows[0], net)
@@ -167,6 +168,48 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def kernel_calibration(sample, net, dev, B, reps=20):
+    """Live per-kernel timings of the hand-written kernels (HIP events on the launch stream, eager,
+    outside the timed region) at the sizes the pipeline uses them."""
+    from tests import datagen
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    out = {}
+    rec = torch.from_numpy(datagen.random_records(B, seed=7, hostile=False)).to(dev)
+    img = torch.empty((B, 3, 227, 227), dtype=torch.float32, device=dev)
+    t = timed(lambda: kernels.rasterize(rec, layout="NCHW", out=img))
+    out["raster_kernel"] = {"bound": "hbm", "launch": "%d images" % B, "us": t * 1e6, "achieved": IMG_BYTES * B / t / 1e9,
+                            "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": IMG_BYTES * B / t / HBM_PEAK,
+                            "note": "dense image path (BatchGenerator API); the pipeline uses encode_conv1 instead"}
+    t = timed(lambda: kernels.encode_conv1(rec, net.conv1_hwio, net.conv1_base))
+    out["encode_conv1_kernel"] = {"bound": "latency", "launch": "%d images" % B, "us": t * 1e6,
+                                  "note": "rasterise + sparse conv1 + relu + pool + LRN; replaces %.1f MB of image traffic and "
+                                          "13.5 GFLOP of dense conv1 per batch" % (IMG_BYTES * B / 1e6)}
+    table = sample.table
+    d_cigar, d_off, d_pos, _ = sample.device_buffers
+    n = len(table)
+    cap = max(1024, int(sample.gap_off[-1]) + 16)
+    t = timed(lambda: kernels.cigar_scan(d_cigar, d_off, d_pos, sample.min_sv, gaps_cap=cap))
+    alg = 4 * int(table.cigar.size) + 32 * n + 24 * int(sample.gap_off[-1])
+    out["cigar_scan (5 kernels)"] = {"bound": "hbm", "launch": "%d alignments, %d ops" % (n, table.cigar.size), "us": t * 1e6,
+                                     "achieved": alg / t / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / t / HBM_PEAK}
+    t = timed(lambda: net.predict_records(rec))
+    out["device_stage_eager_1_stream"] = {"bound": "mfma", "launch": "%d images" % B, "us": t * 1e6,
+                                          "achieved": CNN_FLOP * B / t / 1e12, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
+                                          "frac": CNN_FLOP * B / t / F32_MFMA_PEAK}
+    return out
 
 
 def cpu_baseline(sample, opts, window, gpu_net):

@@ -115,6 +115,11 @@ int svx_bias_relu_pool_lrn(const float* d_x, const float* d_bias, float* d_y, ui
                            uint32_t height, uint32_t width, int lrn, uint32_t radius, float alpha, float beta,
                            float k, void* stream);
 
+/* In-place bias add + ReLU on an NCHW float32 tensor [n][channels][plane] (plane = H*W >= 4):
+ * tf.nn.bias_add + tf.nn.relu of the layers without pooling (conv3, conv4;
+ * src/network/alexnet.py:39,42 via :132-135). d_x must be 16-B aligned. */
+int svx_bias_relu(float* d_x, const float* d_bias, uint32_t n, uint32_t channels, uint32_t plane, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

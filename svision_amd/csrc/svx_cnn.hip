@@ -182,6 +182,44 @@ extern "C" int svx_encode_conv1(const int32_t* d_records, uint32_t n, const floa
     return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
 }
 
+namespace {
+// In-place relu(x + bias[c]) on an NCHW tensor: one 16-B load + store per lane (conv3 / conv4 epilogue,
+// src/network/alexnet.py:132-135).  plane = H*W elements per (image, channel).
+__global__ __launch_bounds__(BLOCK)
+void bias_relu_kernel(float* __restrict__ x, const float* __restrict__ bias, int channels, int plane, long long total)
+{
+    const long long stride = (long long)gridDim.x * BLOCK * 4;
+    for (long long e = ((long long)blockIdx.x * BLOCK + threadIdx.x) * 4; e < total; e += stride) {
+        if (e + 3 < total) {
+            float4 v = *reinterpret_cast<float4*>(x + e);
+            const long long p = e / plane;
+            const int c0 = (int)(p % channels);
+            const int rem = plane - (int)(e - p * plane);              // elements left in this plane
+            const float b0 = bias[c0], b1 = bias[c0 + 1 < channels ? c0 + 1 : 0];
+            v.x = fmaxf(v.x + b0, 0.0f);
+            v.y = fmaxf(v.y + (rem > 1 ? b0 : b1), 0.0f);
+            v.z = fmaxf(v.z + (rem > 2 ? b0 : b1), 0.0f);
+            v.w = fmaxf(v.w + (rem > 3 ? b0 : b1), 0.0f);
+            *reinterpret_cast<float4*>(x + e) = v;
+        } else {
+            for (long long q = e; q < total; ++q) x[q] = fmaxf(x[q] + bias[(q / plane) % channels], 0.0f);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int svx_bias_relu(float* d_x, const float* d_bias, uint32_t n, uint32_t channels, uint32_t plane, void* stream)
+{
+    const long long total = (long long)n * channels * plane;
+    if (total == 0) return SVX_OK;
+    if (!d_x || !d_bias || plane < 4 || (reinterpret_cast<uintptr_t>(d_x) & 15u)) return SVX_EINVAL;
+    long long blocks = (total / 4 + BLOCK - 1) / BLOCK;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(bias_relu_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, static_cast<hipStream_t>(stream),
+                       d_x, d_bias, (int)channels, (int)plane, total);
+    return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
+}
+
 extern "C" int svx_bias_relu_pool_lrn(const float* d_x, const float* d_bias, float* d_y, uint32_t n, uint32_t channels,
                                       uint32_t height, uint32_t width, int lrn, uint32_t radius, float alpha, float beta,
                                       float k, void* stream)

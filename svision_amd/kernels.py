@@ -129,3 +129,16 @@ def encode_conv1(records, w1_hwio, base, lrn=True, radius=2, alpha=2e-05, beta=0
                               radius, alpha, beta, k, _stream_ptr(records.device))
     _lib.check(rc, "svx_encode_conv1")
     return y
+
+
+def bias_relu_(x, bias):
+    """In-place relu(x + bias[c]) on a float32 NCHW device tensor.  See include/svx.h svx_bias_relu."""
+    lib = _lib.load()
+    _require_cuda(x, "x")
+    _require_cuda(bias, "bias")
+    if x.dtype != torch.float32 or x.dim() != 4 or bias.numel() != x.shape[1]:
+        raise _lib.SvxError("x must be float32 [n,C,H,W] and bias float32 [C]")
+    n, c, h, w = x.shape
+    rc = lib.svx_bias_relu(x.data_ptr(), bias.data_ptr(), n, c, h * w, _stream_ptr(x.device))
+    _lib.check(rc, "svx_bias_relu")
+    return x

@@ -116,6 +116,11 @@ class AlexNet(torch.nn.Module):
                 x = F.conv2d(x, getattr(self, f"{name}_w"), None, stride=stride, padding=pad, groups=groups)
                 x = kernels.bias_relu_pool_lrn(x, getattr(self, f"{name}_b"), lrn=name != "conv5")
                 continue
+            if self.fused:
+                from .. import kernels
+                x = F.conv2d(x, getattr(self, f"{name}_w"), None, stride=stride, padding=pad, groups=groups)
+                x = kernels.bias_relu_(x, getattr(self, f"{name}_b"))
+                continue
             x = F.relu_(F.conv2d(x, getattr(self, f"{name}_w"), getattr(self, f"{name}_b"),
                                  stride=stride, padding=pad, groups=groups))
             if name in ("conv1", "conv2"):

@@ -146,3 +146,13 @@ def test_encode_conv1_matches_dense_path():
     _l, cls, prob = net.predict_records(_dev(rec))
     _ol, o_cls, o_prob = alexnet_ref.predict(params, x)
     assert np.abs(prob.cpu().numpy() - o_prob).max() < 1e-3
+
+
+@pytest.mark.parametrize("shape", [(3, 384, 13, 13), (2, 5, 2, 3), (1, 7, 1, 5)])
+def test_bias_relu_inplace(shape):
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(shape).astype(np.float32)
+    b = rng.standard_normal(shape[1]).astype(np.float32)
+    t = _dev(x)
+    kernels.bias_relu_(t, _dev(b))
+    assert np.array_equal(t.cpu().numpy(), np.maximum(x + b[None, :, None, None], 0))
