@@ -32,10 +32,40 @@ __device__ inline float elem_value(const unsigned* bits, int e, int layout, floa
     return ((w >> (c & 31)) & 1u) ? 255.0f - mean : -mean;
 }
 
+// Four consecutive output floats starting at element e (e + 3 inside the image).  The planar layout reads
+// one bit-plane word for the whole group; groups that straddle an image row, and the interleaved NHWC
+// layout (measured slower with a grouped form), use the per-element form.
+template <int LAYOUT>
+__device__ inline float4 elem_group(const unsigned* bits, int e, float m0, float m1, float m2)
+{
+    float4 v;
+    if (LAYOUT == SVX_LAYOUT_NCHW) {
+        const int ch = e / PLANE_ELEMS, pix = e - ch * PLANE_ELEMS;
+        const int r = pix / IMG, c = pix - r * IMG;
+        if (c + 3 < IMG) {
+            const unsigned* row = bits + ch * PLANE_WORDS + r * ROW_WORDS;
+            const int w0 = c >> 5, sh = c & 31;
+            unsigned b = row[w0] >> sh;
+            if (sh > 28) b |= row[w0 + 1] << (32 - sh);
+            const float mean = ch == 0 ? m0 : (ch == 1 ? m1 : m2);
+            const float lo = -mean, hi = 255.0f - mean;
+            v.x = (b & 1u) ? hi : lo; v.y = (b & 2u) ? hi : lo; v.z = (b & 4u) ? hi : lo; v.w = (b & 8u) ? hi : lo;
+            return v;
+        }
+    }
+    v.x = elem_value(bits, e + 0, LAYOUT, m0, m1, m2);
+    v.y = elem_value(bits, e + 1, LAYOUT, m0, m1, m2);
+    v.z = elem_value(bits, e + 2, LAYOUT, m0, m1, m2);
+    v.w = elem_value(bits, e + 3, LAYOUT, m0, m1, m2);
+    return v;
+}
+
+template <int LAYOUT>
 __global__ __launch_bounds__(BLOCK)
 void raster_kernel(const int32_t* __restrict__ records, uint32_t n, float* __restrict__ out,
-                   int layout, int strips, float m0, float m1, float m2)
+                   int strips, float m0, float m1, float m2)
 {
+    constexpr int layout = LAYOUT;
     // plane 0: all segments, plane 1: columns with >= 2 hits, plane 2: reverse segments
     __shared__ unsigned bits[3 * PLANE_WORDS];
     __shared__ unsigned colcnt[IMG];
@@ -67,13 +97,7 @@ void raster_kernel(const int32_t* __restrict__ records, uint32_t n, float* __res
     if (tid < e_hi - tail_beg) gout[tail_beg + tid] = elem_value(bits, tail_beg + tid, layout, m0, m1, m2);
     float4* out4 = reinterpret_cast<float4*>(out);
     for (long long q = q_lo + tid; q < q_hi; q += BLOCK) {
-        const int e = (int)(q * 4 - base);
-        float4 v;
-        v.x = elem_value(bits, e + 0, layout, m0, m1, m2);
-        v.y = elem_value(bits, e + 1, layout, m0, m1, m2);
-        v.z = elem_value(bits, e + 2, layout, m0, m1, m2);
-        v.w = elem_value(bits, e + 3, layout, m0, m1, m2);
-        out4[q] = v;
+        out4[q] = elem_group<LAYOUT>(bits, (int)(q * 4 - base), m0, m1, m2);
     }
 }
 
@@ -91,7 +115,11 @@ extern "C" int svx_rasterize(const int32_t* d_records, uint32_t n, float* d_out,
     int strips = 1;
     while (strips < 16 && (uint64_t)n * strips < 2048) strips *= 2;
     dim3 grid(n * strips), block(BLOCK);
-    hipLaunchKernelGGL(raster_kernel, grid, block, 0, static_cast<hipStream_t>(stream),
-                       d_records, n, d_out, layout, strips, mean[0], mean[1], mean[2]);
+    if (layout == SVX_LAYOUT_NCHW)
+        hipLaunchKernelGGL(raster_kernel<SVX_LAYOUT_NCHW>, grid, block, 0, static_cast<hipStream_t>(stream),
+                           d_records, n, d_out, strips, mean[0], mean[1], mean[2]);
+    else
+        hipLaunchKernelGGL(raster_kernel<SVX_LAYOUT_NHWC>, grid, block, 0, static_cast<hipStream_t>(stream),
+                           d_records, n, d_out, strips, mean[0], mean[1], mean[2]);
     return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
 }
