@@ -120,6 +120,19 @@ int svx_bias_relu_pool_lrn(const float* d_x, const float* d_bias, float* d_y, ui
  * src/network/alexnet.py:39,42 via :132-135). d_x must be 16-B aligned. */
 int svx_bias_relu(float* d_x, const float* d_bias, uint32_t n, uint32_t channels, uint32_t plane, void* stream);
 
+/* fp32 implicit-GEMM convolution on the matrix cores (v_mfma_f32_32x32x2_f32): stride 1, SAME padding,
+ * square kernel 3 or 5, optional channel groups, optional fused bias + ReLU.
+ * Replaces tf.nn.conv2d (+ split/concat for groups, + bias_add + relu) of the reference layers conv2..conv5
+ * (src/network/alexnet.py:34,39,42,45 via :109-135).
+ *   d_in      float32 [n][cin][height][width]  (NCHW)
+ *   d_w_hwio  float32 [ksize][ksize][cin/groups][cout]  -- the checkpoint layout, 16-B aligned
+ *   d_bias    float32 [cout] or NULL (raw convolution output, e.g. in front of svx_bias_relu_pool_lrn)
+ *   d_out     float32 [n][cout][height][width]
+ * Requires (cin/groups) % 16 == 0 and (cout/groups) % 64 == 0. */
+int svx_conv2d_same(const float* d_in, const float* d_w_hwio, const float* d_bias, float* d_out, uint32_t n,
+                    uint32_t cin, uint32_t cout, uint32_t height, uint32_t width, uint32_t ksize,
+                    uint32_t groups, int relu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,152 @@
+// svx_conv.hip -- fp32 implicit-GEMM convolution on the gfx950 matrix cores (MI355X).
+//
+// The dense contractions of the reference CNN after the first layer: tf.nn.conv2d, stride 1, SAME
+// padding, optional 2-way channel groups (src/network/alexnet.py:34,39,42,45 via :109-129), with the
+// bias + ReLU of :132-135 fused in the epilogue.  NCHW activations, weights in the checkpoint's own
+// HWIO layout [kh][kw][Cin/groups][Cout] (the group split is a slice of the last axis, exactly as
+// tf.split(axis=3) does it).
+//
+// GEMM view per group:   D[n][m] = sum_k  Wt[n][k] * X[k][m]
+//   n = output channel in the group, m = (image, y, x) output pixel, k = (ky, kx, c).
+// Rows of D are channels and columns are pixels so that each MFMA accumulator register holds 32
+// consecutive pixels of one channel plane: coalesced 128-B stores into NCHW.
+//
+// Tiling: 256 threads = 4 waves compute a 64 (n) x 128 (m) tile; each wave owns 32 x 64 (two
+// v_mfma_f32_32x32x2_f32 accumulators, 32 VGPRs).  K is walked in slices of 16 that never straddle a
+// filter tap (Cin/groups is a multiple of 16), so the padding test is one predicate per slice and the
+// eight activation loads of a lane are a constant stride apart.  Both operands are staged in LDS as
+// [k][n] / [k][m] (unit stride across lanes: no bank conflicts on write or on the ds_read_b32 fragment
+// reads), double buffered, with the global loads of slice k+1 in flight under the MFMAs of slice k and
+// one barrier per slice.  fp32 MFMA issues every 64 cycles, so 24 KB of LDS traffic per slice is far
+// below the LDS rate; the kernel is matrix-pipe bound.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/svx.h"
+
+namespace {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int BN = 64, BM = 128, BK = 16, THREADS = 256;
+
+template <int KS>
+__global__ __launch_bounds__(THREADS, 2)
+void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
+                       float* __restrict__ out, int nimg, int Cin, int Cout, int H, int W, int groups, int relu)
+{
+    constexpr int P = KS / 2;
+    __shared__ float Ws[2][BK][BN];
+    __shared__ float Xs[2][BK][BM];
+
+    const int CinG = Cin / groups, CoutG = Cout / groups;
+    const int n_tiles = CoutG / BN;
+    const int g = blockIdx.y / n_tiles;
+    const int n0 = (blockIdx.y - g * n_tiles) * BN;
+    const int m0 = blockIdx.x * BM;
+    const int HW = H * W;
+    const long long Mtot = (long long)nimg * HW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave & 1, wm = wave >> 1;
+
+    // activation loader: one output pixel (column m) and k rows xk0, xk0+2, ..., xk0+14 per lane
+    const int xm = tid & (BM - 1), xk0 = tid >> 7;
+    const long long m = (long long)m0 + xm;
+    const bool m_ok = m < Mtot;
+    const int b = m_ok ? (int)(m / HW) : 0;
+    const int pix = m_ok ? (int)(m - (long long)b * HW) : 0;
+    const int y = pix / W, x = pix - y * W;
+    const float* in_b = in + ((size_t)b * Cin + (size_t)g * CinG + xk0) * HW;
+    // weight loader: k row wk, four consecutive output channels
+    const int wk = tid >> 4, wn4 = (tid & 15) * 4;
+    const float* w_b = w + (size_t)g * CoutG + n0 + wn4;
+
+    const int cblocks = CinG / BK;
+    const int nk = KS * KS * cblocks;
+
+    v16f acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
+
+    float xr[8];
+    float4 wr;
+    int ky = 0, kx = 0, cb = 0;           // decomposition of the slice being LOADED
+
+    auto load_slice = [&]() {
+        const int yy = y + ky - P, xx = x + kx - P;
+        const bool ok = m_ok && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+        const float* p = in_b + (size_t)(cb * BK) * HW + yy * W + xx;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xr[i] = ok ? p[(size_t)(2 * i) * HW] : 0.0f;
+        wr = *reinterpret_cast<const float4*>(w_b + ((size_t)((ky * KS + kx) * CinG + cb * BK + wk)) * Cout);
+        if (++cb == cblocks) { cb = 0; if (++kx == KS) { kx = 0; ++ky; } }
+    };
+    auto store_slice = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) Xs[buf][xk0 + 2 * i][xm] = xr[i];
+        *reinterpret_cast<float4*>(&Ws[buf][wk][wn4]) = wr;
+    };
+
+    load_slice();
+    store_slice(0);
+    __syncthreads();
+
+    const int fk = lane >> 5, fj = lane & 31;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) load_slice();                       // global loads of the next slice fly under the MFMAs below
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            const float a = Ws[buf][2 * kk + fk][wn * 32 + fj];
+            const float b0 = Xs[buf][2 * kk + fk][wm * 64 + fj];
+            const float b1 = Xs[buf][2 * kk + fk][wm * 64 + 32 + fj];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+        }
+        if (more) store_slice(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: D[row = channel][col = pixel]; lane holds col = lane & 31, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const long long mm = (long long)m0 + wm * 64 + t * 32 + fj;
+        if (mm >= Mtot) continue;
+        const int bb = (int)(mm / HW);
+        const int pp = (int)(mm - (long long)bb * HW);
+        float* o = out + ((size_t)bb * Cout + (size_t)g * CoutG + n0 + wn * 32 + 4 * fk) * HW + pp;
+        const v16f& acc = t == 0 ? acc0 : acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int nl = (r & 3) + 8 * (r >> 2);
+            float v = acc[r];
+            if (bias) v += bias[g * CoutG + n0 + wn * 32 + 4 * fk + nl];
+            if (relu) v = fmaxf(v, 0.0f);
+            o[(size_t)nl * HW] = v;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int svx_conv2d_same(const float* d_in, const float* d_w_hwio, const float* d_bias, float* d_out, uint32_t n,
+                               uint32_t cin, uint32_t cout, uint32_t height, uint32_t width, uint32_t ksize,
+                               uint32_t groups, int relu, void* stream)
+{
+    if (n == 0) return SVX_OK;
+    if (!d_in || !d_w_hwio || !d_out || groups == 0 || cin % groups || cout % groups) return SVX_EINVAL;
+    const uint32_t cin_g = cin / groups, cout_g = cout / groups;
+    if (cin_g % BK || cout_g % BN || (ksize != 3 && ksize != 5)) return SVX_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(d_w_hwio) & 15u) || (cout % 4)) return SVX_EINVAL;
+    const long long mtot = (long long)n * height * width;
+    dim3 grid((unsigned)((mtot + BM - 1) / BM), groups * (cout_g / BN)), block(THREADS);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (ksize == 3)
+        hipLaunchKernelGGL(conv_igemm_kernel<3>, grid, block, 0, st, d_in, d_w_hwio, d_bias, d_out, (int)n, (int)cin, (int)cout,
+                           (int)height, (int)width, (int)groups, relu);
+    else
+        hipLaunchKernelGGL(conv_igemm_kernel<5>, grid, block, 0, st, d_in, d_w_hwio, d_bias, d_out, (int)n, (int)cin, (int)cout,
+                           (int)height, (int)width, (int)groups, relu);
+    return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
+}

@@ -142,3 +142,25 @@ def bias_relu_(x, bias):
     rc = lib.svx_bias_relu(x.data_ptr(), bias.data_ptr(), n, c, h * w, _stream_ptr(x.device))
     _lib.check(rc, "svx_bias_relu")
     return x
+
+
+def conv2d_same(x, w_hwio, bias=None, groups=1, relu=False):
+    """x float32 [n,Cin,H,W], w_hwio float32 [k,k,Cin/groups,Cout] (checkpoint layout) -> [n,Cout,H,W]:
+    stride-1 SAME convolution on the fp32 matrix cores, optional fused bias + ReLU.
+    See include/svx.h svx_conv2d_same."""
+    lib = _lib.load()
+    _require_cuda(x, "x")
+    _require_cuda(w_hwio, "w_hwio")
+    if x.dtype != torch.float32 or x.dim() != 4 or w_hwio.dtype != torch.float32 or w_hwio.dim() != 4:
+        raise _lib.SvxError("x must be float32 NCHW and w float32 HWIO")
+    n, cin, h, w = x.shape
+    k, k2, cin_g, cout = w_hwio.shape
+    if k != k2 or cin_g * groups != cin:
+        raise _lib.SvxError("weight shape %s does not match input %s with %d groups" % (tuple(w_hwio.shape), tuple(x.shape), groups))
+    if bias is not None:
+        _require_cuda(bias, "bias")
+    y = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
+    rc = lib.svx_conv2d_same(x.data_ptr(), w_hwio.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                             n, cin, cout, h, w, k, groups, 1 if relu else 0, _stream_ptr(x.device))
+    _lib.check(rc, "svx_conv2d_same")
+    return y

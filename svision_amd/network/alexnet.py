@@ -54,8 +54,11 @@ def checkpoint_shapes():
 class AlexNet(torch.nn.Module):
     """Inference-only AlexNet holding device-layout parameters."""
 
-    def __init__(self, params, device="cuda", channels_last=False, fused=None, mean=(104.0, 117.0, 124.0)):
+    def __init__(self, params, device="cuda", channels_last=False, fused=None, mean=(104.0, 117.0, 124.0), own_conv=()):
         super().__init__()
+        # own_conv: layer names whose convolution runs on the hand-written MFMA implicit-GEMM kernel
+        # (svx_conv2d_same) instead of MIOpen
+        self.own_conv = tuple(own_conv)
         # fused: conv epilogues (bias+relu+pool+LRN) as one hand-written HIP kernel; default on the GPU
         self.fused = (torch.device(device).type == "cuda" and not channels_last) if fused is None else fused
         want = checkpoint_shapes()
@@ -72,6 +75,8 @@ class AlexNet(torch.nn.Module):
                 wt = wt.contiguous(memory_format=torch.channels_last)
             self.register_buffer(f"{name}_w", wt.to(device))
             self.register_buffer(f"{name}_b", torch.from_numpy(np.asarray(params[f"{name}/biases"], np.float32).copy()).to(device))
+        for name in ("conv2", "conv3", "conv4", "conv5"):          # checkpoint-layout weights for svx_conv2d_same
+            self.register_buffer(f"{name}_hwio", torch.from_numpy(np.ascontiguousarray(params[f"{name}/weights"], np.float32)).to(device))
         # sparse first layer (svx_encode_conv1): checkpoint-layout weights + the constant response of
         # the all-background image, base[k] = bias[k] - sum mean[ch] * w[..., ch, k] (float64 on the host)
         w1 = np.asarray(params["conv1/weights"], np.float64)
@@ -111,6 +116,14 @@ class AlexNet(torch.nn.Module):
 
     def _tail(self, x, first):
         for name, _k, _cin, _cout, stride, pad, groups in _CONVS[first:]:
+            if name in self.own_conv:
+                from .. import kernels
+                if name in ("conv2", "conv5"):
+                    x = kernels.conv2d_same(x, getattr(self, f"{name}_hwio"), None, groups=groups)
+                    x = kernels.bias_relu_pool_lrn(x, getattr(self, f"{name}_b"), lrn=name != "conv5")
+                else:
+                    x = kernels.conv2d_same(x, getattr(self, f"{name}_hwio"), getattr(self, f"{name}_b"), groups=groups, relu=True)
+                continue
             if self.fused and name in ("conv1", "conv2", "conv5"):
                 from .. import kernels
                 x = F.conv2d(x, getattr(self, f"{name}_w"), None, stride=stride, padding=pad, groups=groups)

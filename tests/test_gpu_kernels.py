@@ -156,3 +156,23 @@ def test_bias_relu_inplace(shape):
     t = _dev(x)
     kernels.bias_relu_(t, _dev(b))
     assert np.array_equal(t.cpu().numpy(), np.maximum(x + b[None, :, None, None], 0))
+
+
+@pytest.mark.parametrize("n,cin,cout,hw,k,groups", [(3, 96, 256, 27, 5, 2), (5, 256, 384, 13, 3, 1), (2, 384, 384, 13, 3, 2),
+                                                     (64, 384, 256, 13, 3, 2), (1, 16, 64, 5, 3, 1)])
+def test_conv2d_same_matches_torch_fp32(n, cin, cout, hw, k, groups):
+    """fp32 MFMA implicit GEMM vs a plain PyTorch fp32 conv of the same op (tolerance 2e-4 of the output scale)."""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(cin + cout)
+    x = rng.standard_normal((n, cin, hw, hw)).astype(np.float32)
+    w = (rng.standard_normal((k, k, cin // groups, cout)) / np.sqrt(k * k * cin // groups)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    xt, wt, bt = _dev(x), _dev(w), _dev(b)
+    want = F.conv2d(xt.double(), wt.permute(3, 2, 0, 1).contiguous().double(), bt.double(), 1, k // 2, 1, groups)
+    got = kernels.conv2d_same(xt, wt, bt, groups=groups, relu=False)
+    scale = float(want.abs().max())
+    assert float((got.double() - want).abs().max()) < 2e-4 * scale
+    got_raw = kernels.conv2d_same(xt, wt, None, groups=groups, relu=False)
+    assert float((got_raw.double() + bt.double().view(1, -1, 1, 1) - want).abs().max()) < 2e-4 * scale
+    got_relu = kernels.conv2d_same(xt, wt, bt, groups=groups, relu=True)
+    assert float((got_relu.double() - want.clamp_min(0)).abs().max()) < 2e-4 * scale
