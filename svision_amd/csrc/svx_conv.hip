@@ -96,14 +96,23 @@ void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w
         const int buf = kt & 1;
         const bool more = kt + 1 < nk;
         if (more) load_slice();                       // global loads of the next slice fly under the MFMAs below
+        // all 24 fragment reads of the slice are issued before the first MFMA (the scheduler barriers keep the
+        // compiler from sinking each read next to its use): only the first reads' LDS latency is exposed per slice,
+        // the rest lands under the 16 back-to-back matrix instructions
+        float fa[BK / 2], fb0[BK / 2], fb1[BK / 2];
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
-            const float a = Ws[buf][2 * kk + fk][wn * 32 + fj];
-            const float b0 = Xs[buf][2 * kk + fk][wm * 64 + fj];
-            const float b1 = Xs[buf][2 * kk + fk][wm * 64 + 32 + fj];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+            fa[kk] = Ws[buf][2 * kk + fk][wn * 32 + fj];
+            fb0[kk] = Xs[buf][2 * kk + fk][wm * 64 + fj];
+            fb1[kk] = Xs[buf][2 * kk + fk][wm * 64 + 32 + fj];
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk], fb0[kk], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk], fb1[kk], acc1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         if (more) store_slice(buf ^ 1);
         __syncthreads();
     }
