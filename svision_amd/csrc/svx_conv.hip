@@ -49,17 +49,21 @@ void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave & 1, wm = wave >> 1;
 
-    // activation loader: one output pixel (column m) and k rows xk0, xk0+2, ..., xk0+14 per lane
+    // activation loader: one output pixel (column m) and k rows xk0, xk0+2, ..., xk0+14 per lane.  Addresses are
+    // (uniform row base in SGPRs) + (one 32-bit lane offset): no per-load address arithmetic.
     const int xm = tid & (BM - 1), xk0 = tid >> 7;
     const long long m = (long long)m0 + xm;
     const bool m_ok = m < Mtot;
     const int b = m_ok ? (int)(m / HW) : 0;
     const int pix = m_ok ? (int)(m - (long long)b * HW) : 0;
     const int y = pix / W, x = pix - y * W;
-    const float* in_b = in + ((size_t)b * Cin + (size_t)g * CinG + xk0) * HW;
+    const unsigned tbase = (unsigned)((b * Cin + g * CinG + xk0) * HW);
+    const char* rowp[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rowp[i] = reinterpret_cast<const char*>(in + (size_t)(2 * i) * HW);
     // weight loader: k row wk, four consecutive output channels
     const int wk = tid >> 4, wn4 = (tid & 15) * 4;
-    const float* w_b = w + (size_t)g * CoutG + n0 + wn4;
+    const unsigned wconst = (unsigned)(wk * Cout + g * CoutG + n0 + wn4);
 
     const int cblocks = CinG / BK;
     const int nk = KS * KS * cblocks;
@@ -70,20 +74,25 @@ void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w
 
     float xr[8];
     float4 wr;
-    int ky = 0, kx = 0, cb = 0;           // decomposition of the slice being LOADED
+    bool xr_ok = false;
+    int ky = 0, kx = 0, cb = 0;           // decomposition of the slice being LOADED (all wave-uniform)
 
+    // branch-free: out-of-image taps load from a clamped (valid) address and are zeroed by a select at LDS-store
+    // time, so the loads can be issued ahead of the matrix instructions and nothing waits on them before those
     auto load_slice = [&]() {
         const int yy = y + ky - P, xx = x + kx - P;
-        const bool ok = m_ok && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-        const float* p = in_b + (size_t)(cb * BK) * HW + yy * W + xx;
+        xr_ok = m_ok && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+        const int yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1);
+        const unsigned ob = (tbase + (unsigned)(yc * W + xc) + (unsigned)(cb * BK * HW)) * 4u;   // byte offset < 4 GB
 #pragma unroll
-        for (int i = 0; i < 8; ++i) xr[i] = ok ? p[(size_t)(2 * i) * HW] : 0.0f;
-        wr = *reinterpret_cast<const float4*>(w_b + ((size_t)((ky * KS + kx) * CinG + cb * BK + wk)) * Cout);
+        for (int i = 0; i < 8; ++i) xr[i] = *reinterpret_cast<const float*>(rowp[i] + ob);
+        const char* wrow = reinterpret_cast<const char*>(w + (size_t)((ky * KS + kx) * CinG + cb * BK) * Cout);   // uniform
+        wr = *reinterpret_cast<const float4*>(wrow + wconst * 4u);
         if (++cb == cblocks) { cb = 0; if (++kx == KS) { kx = 0; ++ky; } }
     };
     auto store_slice = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) Xs[buf][xk0 + 2 * i][xm] = xr[i];
+        for (int i = 0; i < 8; ++i) Xs[buf][xk0 + 2 * i][xm] = xr_ok ? xr[i] : 0.0f;
         *reinterpret_cast<float4*>(&Ws[buf][wk][wn4]) = wr;
     };
 
@@ -92,13 +101,10 @@ void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w
     __syncthreads();
 
     const int fk = lane >> 5, fj = lane & 31;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) load_slice();                       // global loads of the next slice fly under the MFMAs below
-        // all 24 fragment reads of the slice are issued before the first MFMA (the scheduler barriers keep the
-        // compiler from sinking each read next to its use): only the first reads' LDS latency is exposed per slice,
-        // the rest lands under the 16 back-to-back matrix instructions
+    // One slice: 24 fragment reads up front, then 16 MFMAs with the next slice's global loads and address
+    // arithmetic interleaved between them (an MFMA occupies the matrix pipe for 64 cycles but issues in 4, so
+    // a wave's own memory work hides under its own matrix work), then the LDS stores and one barrier.
+    auto compute_slice = [&](int buf, bool prefetch) {
         float fa[BK / 2], fb0[BK / 2], fb1[BK / 2];
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
@@ -106,16 +112,20 @@ void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w
             fb0[kk] = Xs[buf][2 * kk + fk][wm * 64 + fj];
             fb1[kk] = Xs[buf][2 * kk + fk][wm * 64 + 32 + fj];
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if (prefetch) load_slice();
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk], fb0[kk], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk], fb1[kk], acc1, 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) store_slice(buf ^ 1);
+    };
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        const int buf = kt & 1;
+        compute_slice(buf, true);
+        store_slice(buf ^ 1);
         __syncthreads();
     }
+    compute_slice((nk - 1) & 1, false);
 
     // epilogue: D[row = channel][col = pixel]; lane holds col = lane & 31, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 #pragma unroll
