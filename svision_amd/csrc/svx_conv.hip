@@ -27,9 +27,9 @@ namespace {
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-constexpr int BN = 64, BM = 128, BK = 16, THREADS = 256;
+constexpr int BN = 64, BM = 128, THREADS = 256;
 
-template <int KS>
+template <int KS, int BK>
 __global__ __launch_bounds__(THREADS, 2)
 void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
                        float* __restrict__ out, int nimg, int Cin, int Cout, int H, int W, int groups, int relu)
@@ -58,9 +58,10 @@ void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w
     const int pix = m_ok ? (int)(m - (long long)b * HW) : 0;
     const int y = pix / W, x = pix - y * W;
     const unsigned tbase = (unsigned)((b * Cin + g * CinG + xk0) * HW);
-    const char* rowp[8];
+    constexpr int XR = BK / 2, WR = BK / 16;       // activation rows / weight float4s per lane and slice
+    const char* rowp[XR];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) rowp[i] = reinterpret_cast<const char*>(in + (size_t)(2 * i) * HW);
+    for (int i = 0; i < XR; ++i) rowp[i] = reinterpret_cast<const char*>(in + (size_t)(2 * i) * HW);
     // weight loader: k row wk, four consecutive output channels
     const int wk = tid >> 4, wn4 = (tid & 15) * 4;
     const unsigned wconst = (unsigned)(wk * Cout + g * CoutG + n0 + wn4);
@@ -72,8 +73,8 @@ void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
 
-    float xr[8];
-    float4 wr;
+    float xr[XR];
+    float4 wr[WR];
     bool xr_ok = false;
     int ky = 0, kx = 0, cb = 0;           // decomposition of the slice being LOADED (all wave-uniform)
 
@@ -85,15 +86,17 @@ void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w
         const int yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1);
         const unsigned ob = (tbase + (unsigned)(yc * W + xc) + (unsigned)(cb * BK * HW)) * 4u;   // byte offset < 4 GB
 #pragma unroll
-        for (int i = 0; i < 8; ++i) xr[i] = *reinterpret_cast<const float*>(rowp[i] + ob);
+        for (int i = 0; i < XR; ++i) xr[i] = *reinterpret_cast<const float*>(rowp[i] + ob);
         const char* wrow = reinterpret_cast<const char*>(w + (size_t)((ky * KS + kx) * CinG + cb * BK) * Cout);   // uniform
-        wr = *reinterpret_cast<const float4*>(wrow + wconst * 4u);
+#pragma unroll
+        for (int j = 0; j < WR; ++j) wr[j] = *reinterpret_cast<const float4*>(wrow + (wconst + (unsigned)(16 * j * Cout)) * 4u);
         if (++cb == cblocks) { cb = 0; if (++kx == KS) { kx = 0; ++ky; } }
     };
     auto store_slice = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) Xs[buf][xk0 + 2 * i][xm] = xr_ok ? xr[i] : 0.0f;
-        *reinterpret_cast<float4*>(&Ws[buf][wk][wn4]) = wr;
+        for (int i = 0; i < XR; ++i) Xs[buf][xk0 + 2 * i][xm] = xr_ok ? xr[i] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < WR; ++j) *reinterpret_cast<float4*>(&Ws[buf][wk + 16 * j][wn4]) = wr[j];
     };
 
     load_slice();
@@ -156,16 +159,16 @@ extern "C" int svx_conv2d_same(const float* d_in, const float* d_w_hwio, const f
     if (n == 0) return SVX_OK;
     if (!d_in || !d_w_hwio || !d_out || groups == 0 || cin % groups || cout % groups) return SVX_EINVAL;
     const uint32_t cin_g = cin / groups, cout_g = cout / groups;
-    if (cin_g % BK || cout_g % BN || (ksize != 3 && ksize != 5)) return SVX_EINVAL;
+    if (cin_g % 16 || cout_g % BN || (ksize != 3 && ksize != 5)) return SVX_EINVAL;
     if ((reinterpret_cast<uintptr_t>(d_w_hwio) & 15u) || (cout % 4)) return SVX_EINVAL;
     const long long mtot = (long long)n * height * width;
     dim3 grid((unsigned)((mtot + BM - 1) / BM), groups * (cout_g / BN)), block(THREADS);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (ksize == 3)
-        hipLaunchKernelGGL(conv_igemm_kernel<3>, grid, block, 0, st, d_in, d_w_hwio, d_bias, d_out, (int)n, (int)cin, (int)cout,
-                           (int)height, (int)width, (int)groups, relu);
-    else
-        hipLaunchKernelGGL(conv_igemm_kernel<5>, grid, block, 0, st, d_in, d_w_hwio, d_bias, d_out, (int)n, (int)cin, (int)cout,
-                           (int)height, (int)width, (int)groups, relu);
+#define SVX_LAUNCH_CONV(KS_, BK_) hipLaunchKernelGGL((conv_igemm_kernel<KS_, BK_>), grid, block, 0, st, d_in, d_w_hwio, d_bias, \
+        d_out, (int)n, (int)cin, (int)cout, (int)height, (int)width, (int)groups, relu)
+    const bool k32 = false;   // 32-deep slices measured slower on MI355X (144 VGPRs, spills): kept for experiments only
+    if (ksize == 3) { if (k32) SVX_LAUNCH_CONV(3, 32); else SVX_LAUNCH_CONV(3, 16); }
+    else            { if (k32) SVX_LAUNCH_CONV(5, 32); else SVX_LAUNCH_CONV(5, 16); }
+#undef SVX_LAUNCH_CONV
     return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
 }
