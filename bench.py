@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--workers", type=int, default=8, help="helper processes for the Python host glue (collection, vote)")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the per-batch graphs are replayed on")
+    ap.add_argument("--inflight", type=int, default=3, help="windows enqueued on the device at once")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -87,7 +88,7 @@ def main():
     opts = options_ns(args.batch)
     sample = Sample.from_table(table, bam.Fasta(sequences=genome), opts.min_sv_size, device=dev)
     net = AlexNet(random_weights(0), device=dev)
-    hot = PooledHotPath(sample, opts, net, device=dev, n_workers=args.workers, n_streams=args.streams)
+    hot = PooledHotPath(sample, opts, net, device=dev, n_workers=args.workers, n_streams=args.streams, max_inflight=args.inflight)
     windows = []
     pos = 0
     while pos < args.contig_len:
