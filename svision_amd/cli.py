@@ -112,8 +112,8 @@ def run(options, sample=None, classifier=None):
     from .network.predict import Predict
 
     rank, ws = sdist.init_from_env()
-    if options.hash or options.graph:
-        raise SystemExit("--hash and --graph are outside the MI355X hot path of this build (SURVEY 8(f) next steps)")
+    if options.graph:
+        raise SystemExit("--graph (GFA output) is outside the MI355X hot path of this build (SURVEY 8(f))")
     work_dir = options.out_path
     os.makedirs(work_dir, exist_ok=True)
     fmt = logging.Formatter("%(asctime)s [%(levelname)-7.7s]  %(message)s")
@@ -130,7 +130,7 @@ def run(options, sample=None, classifier=None):
     logging.info("INPUT BAM: %s", os.path.abspath(options.bam_path))
 
     if sample is None:
-        table = read_bam(options.bam_path)
+        table = read_bam(options.bam_path, with_seq=bool(options.hash))
         if table.sort_order != "coordinate":
             logging.error("This is not a coordinate sorted BAM file")
             raise SystemExit(1)

@@ -5,9 +5,10 @@ Host-side mirror of the reference's ``src/collection/analyze_reads.py``:
 walk :828-853 runs on the GPU -- ``svx_cigar_scan`` -- and only the handful of
 long gaps per alignment reach this module), ``analyze_gap`` :155-615,
 ``trim_segs`` :82-152, ``shift_left`` :12-39, ``cal_overlap_ratio`` :49-80.
-The ``--hash`` re-aligner branches (:731-790, :898-929) are not part of the
-default path and are not implemented here.
+The ``--hash`` branches (:731-790, :898-929) re-align unmapped / inserted read pieces with
+the k-mer aligner of :mod:`svision_amd.segmentplot` and add the hits as helper segments.
 """
+from ..segmentplot.run_hash_lineplot import hashplot_unmapped
 from .classes import Seg, Signature, by_read_pos
 
 
@@ -216,7 +217,22 @@ def analyze_gap(cur, nxt, chrom_of, fetch_ref, options, qname, help_segs=()):
     return _signature(chrom, qname, "sigUncovered", bkp, segs, [cur], added, nxt)
 
 
-def analyze_between_aligns(primary, supplementary, table, options):
+def _hash_hits_to_segs(hits, read_offset, ref_offset, like, read_seq):
+    """Aligner hits (piece / window coordinates) -> helper segments in read / reference coordinates
+    (:757-773, :910-929)."""
+    out = []
+    for h in hits:
+        fwd = h.forward()
+        q0 = (h.xStart() if fwd else h.xEnd()) + read_offset
+        q1 = (h.xEnd() if fwd else h.xStart()) + read_offset
+        seg = Seg(q0, q1, h.yStart() + ref_offset, h.yEnd() + ref_offset, like.ref_id, not fwd,
+                  like.is_supplementary, "other", like.qual, -1)
+        seg.read_seq = read_seq
+        out.append(seg)
+    return out
+
+
+def analyze_between_aligns(primary, supplementary, table, options, sample=None):
     """Primary + supplementary alignments of one read -> (major, minor) segments (:619-801).
 
     ``primary``/``supplementary`` are record indices into ``table`` (an AlignmentTable with the
@@ -227,6 +243,7 @@ def analyze_between_aligns(primary, supplementary, table, options):
     p_rev = bool(flag[primary] & 0x10)
     qlen = int(table.l_seq[primary])                       # supplementary records inherit the primary's SEQ
     majors, minors, same_strand = [], [], []
+    whole_seq = table.query_sequence(primary) if options.hash else None
     for a in [primary] + list(supplementary):
         a_rev = bool(flag[a] & 0x10)
         lead, trail = int(table.lead_clip[a]), int(table.trail_clip[a])
@@ -237,6 +254,8 @@ def analyze_between_aligns(primary, supplementary, table, options):
         r0 = int(pos[a])
         seg = Seg(q_start, q_end, r0, r0 + int(table.ref_span[a]), int(table.tid[a]), a_rev != p_rev,
                   bool(flag[a] & 0x800), qual=int(table.mapq[a]), aln=int(a))
+        if options.hash:
+            seg.read_seq = whole_seq[q_start:q_end]           # :667 (TypeError on SEQ '*', as upstream)
         if seg.is_reverse:
             seg.type = "other"
             minors.append(seg)
@@ -244,7 +263,7 @@ def analyze_between_aligns(primary, supplementary, table, options):
             same_strand.append(seg)
     if len(same_strand) == 1:
         same_strand[0].type = "main"
-        return same_strand, minors
+        return same_strand, minors                            # (:685-691 returns before the --hash block)
     ordered = sorted(same_strand, key=by_read_pos)
     left_most = min(s.ref_start for s in ordered)
     right_most = max(s.ref_end for s in ordered)
@@ -262,15 +281,45 @@ def analyze_between_aligns(primary, supplementary, table, options):
         else:
             base.type = "main"
             majors.append(base)
+    if options.hash:
+        _hash_between(majors, minors, options, sample)
     return majors, minors
 
 
-def analyze_inside_align(seg, gaps):
+def _hash_between(majors, minors, options, sample):
+    """--hash: re-align the unmapped read piece between two adjacent main segments (:731-790).
+    Upstream indexes the sorted segment list with the loop counter rather than with the main
+    segment's own position (:744-745) and slices the segment's own bases with whole-read
+    coordinates (:761-763); both are kept."""
+    ordered = sorted(majors + minors, key=by_read_pos)
+    main_idx = [i for i, s in enumerate(ordered) if s.type == "main"]
+    for i in range(len(main_idx) - 1):
+        if main_idx[i + 1] - main_idx[i] != 1:
+            continue
+        cur, nxt = ordered[i], ordered[i + 1]
+        d_read = nxt.q_start - cur.q_end
+        if d_read < options.min_sv_size:
+            continue
+        d_ref = nxt.ref_start - cur.ref_end
+        if not (d_ref >= -options.min_sv_size and abs(d_read - d_ref) >= options.min_sv_size):
+            continue
+        read_start, read_end = cur.q_end, nxt.q_start
+        piece = cur.read_seq[read_start:read_end]
+        ref_start = min(cur.ref_start, nxt.ref_start)
+        ref_end = max(cur.ref_end, nxt.ref_end)
+        ref_seq = sample.fetch_ref_str(sample.chrom_of(cur.ref_id), ref_start, ref_end)
+        if len(piece) < options.max_hash_len:
+            _m, hits = hashplot_unmapped(ref_seq, piece, options.k_size, options.min_accept)
+            minors.extend(_hash_hits_to_segs(hits, read_start, ref_start, cur, piece))
+
+
+def analyze_inside_align(seg, gaps, options=None, sample=None):
     """Split one major segment at its long CIGAR gaps (:857-948).  ``gaps`` are this
-    alignment's SvxGap records (kind, ref_pos, len in op order) from the device scan;
-    returns the new major segments, or None when the alignment holds no long gap."""
+    alignment's SvxGap records (kind, read_pos, ref_pos, len in op order) from the device scan;
+    returns (new major segments, helper segments from --hash) or (None, None) when the alignment
+    holds no long gap."""
     if len(gaps) == 0:
-        return None
+        return None, None
     out = []
     vrp = seg.q_start
 
@@ -295,4 +344,18 @@ def analyze_inside_align(seg, gaps):
             prev_end = ref_pos + length
     m = seg.ref_end - prev_end
     piece(vrp + 1, vrp + m + 1, prev_end, seg.ref_end)
-    return out
+    helpers = []
+    if options is not None and options.hash:                   # :898-929 re-align every long insertion
+        ref_seq = None
+        for g in gaps:
+            if int(g["kind"]) != 1:
+                continue
+            read_pos, length = int(g["read_pos"]), int(g["len"])
+            ins = seg.read_seq[read_pos - seg.q_start:read_pos + length - seg.q_start]
+            if ref_seq is None or True:                        # upstream re-fetches per insertion (same span)
+                ref_seq = sample.fetch_ref_str(sample.chrom_of(seg.ref_id), seg.ref_start, seg.ref_end)
+            if len(ins) < options.max_hash_len:
+                _m, hits = hashplot_unmapped(ref_seq, ins, options.k_size, options.min_accept)
+                hs = _hash_hits_to_segs(hits, read_pos, seg.ref_start, seg, "")
+                helpers.extend(hs)
+    return out, helpers

@@ -13,7 +13,7 @@ comparison is used.
 class Seg:
     """One aligned piece of a read in read/reference coordinates."""
     __slots__ = ("q_start", "q_end", "ref_start", "ref_end", "ref_id", "is_reverse",
-                 "is_supplementary", "type", "qual", "aln")
+                 "is_supplementary", "type", "qual", "aln", "read_seq")
 
     def __init__(self, q_start, q_end, ref_start, ref_end, ref_id, is_reverse,
                  is_supplementary=False, type=None, qual=0, aln=-1):
@@ -25,10 +25,13 @@ class Seg:
         self.type = type
         self.qual = qual
         self.aln = aln            # index of the source alignment in the AlignmentTable (-1: synthetic)
+        self.read_seq = None      # bases of this piece of the read (--hash only)
 
     def copy(self):
-        return Seg(self.q_start, self.q_end, self.ref_start, self.ref_end, self.ref_id, self.is_reverse,
-                   self.is_supplementary, self.type, self.qual, self.aln)
+        c = Seg(self.q_start, self.q_end, self.ref_start, self.ref_end, self.ref_id, self.is_reverse,
+                self.is_supplementary, self.type, self.qual, self.aln)
+        c.read_seq = self.read_seq
+        return c
 
     def __repr__(self):
         return "Seg(q=%d-%d ref=%d-%d rev=%s %s)" % (self.q_start, self.q_end, self.ref_start, self.ref_end,

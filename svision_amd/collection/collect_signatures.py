@@ -65,14 +65,15 @@ def analyze_alignments(rows, sample, options, part_num=0):
             # SEQ '*' on the primary: the reference slices None (analyze_reads.py:667) and the window fails
             raise TypeError("'NoneType' object is not subscriptable")
         qname = table.names[int(uniq[rid])]
-        majors, minors = analyze_between_aligns(primary, supp, table, options)
+        majors, minors = analyze_between_aligns(primary, supp, table, options, sample)
         segs = list(minors)
         for seg in majors:                                    # :201-216
-            pieces = analyze_inside_align(seg, sample.gaps_of(seg.aln))
+            pieces, helpers = analyze_inside_align(seg, sample.gaps_of(seg.aln), options, sample)
             if pieces is None:
                 segs.append(seg)
             else:
                 segs.extend(pieces)
+                segs.extend(helpers)
         segs.sort(key=by_read_pos)
         n = len(segs)
         if n < 2:

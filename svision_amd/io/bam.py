@@ -20,6 +20,12 @@ import numpy as np
 _BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
 _MAX_BLOCK = 0xFF00
 
+_SEQ_LUT = np.frombuffer(b"=ACMGRSVTWYHKDBN", np.uint8)
+_SEQ_CODE = np.zeros(256, np.uint8) + 15
+for _i, _c in enumerate(b"=ACMGRSVTWYHKDBN"):
+    _SEQ_CODE[_c] = _i
+    _SEQ_CODE[ord(chr(_c).lower())] = _i
+
 FLAG_REVERSE = 0x10
 FLAG_UNMAPPED = 0x4
 FLAG_SECONDARY = 0x100
@@ -72,7 +78,8 @@ class AlignmentTable:
     the device CIGAR scan (:meth:`attach_scan`).
     """
 
-    def __init__(self, references, lengths, tid, pos, flag, mapq, l_seq, name_id, names, cigar, cig_off, header_text=""):
+    def __init__(self, references, lengths, tid, pos, flag, mapq, l_seq, name_id, names, cigar, cig_off, header_text="",
+                 seq_packed=None, seq_off=None):
         self.references = list(references)
         self.lengths = list(lengths)
         self.tid = np.ascontiguousarray(tid, np.int32)
@@ -85,6 +92,9 @@ class AlignmentTable:
         self.cigar = np.ascontiguousarray(cigar, np.uint32)
         self.cig_off = np.ascontiguousarray(cig_off, np.int64)
         self.header_text = header_text
+        # optional read bases (needed by --hash only): BAM 4-bit codes, two per byte, record i at byte seq_off[i]
+        self.seq_packed = seq_packed
+        self.seq_off = seq_off
         self.ref_span = None
         self.lead_clip = None
         self.trail_clip = None
@@ -107,6 +117,18 @@ class AlignmentTable:
             return self.references.index(name)
         except ValueError:
             return -1
+
+    def query_sequence(self, i):
+        """SEQ of record i as stored in the BAM (str), or None when absent ('*') -- pysam's query_sequence."""
+        n = int(self.l_seq[i])
+        if n == 0 or self.seq_packed is None:
+            return None
+        o = int(self.seq_off[i])
+        raw = np.frombuffer(self.seq_packed, np.uint8, (n + 1) // 2, o)
+        codes = np.empty(2 * raw.size, np.uint8)
+        codes[0::2] = raw >> 4
+        codes[1::2] = raw & 15
+        return _SEQ_LUT[codes[:n]].tobytes().decode()
 
     def ids_of(self, names):
         """name_id values of the given QNAMEs (unknown names are ignored)."""
@@ -169,8 +191,8 @@ class AlignmentTable:
         return np.where(ends >= starts, n_pos_lt_end - n_end_le_start, 0)
 
 
-def read_bam(path):
-    """Decode a whole BAM file into an :class:`AlignmentTable`."""
+def read_bam(path, with_seq=False):
+    """Decode a whole BAM file into an :class:`AlignmentTable` (``with_seq``: keep the read bases)."""
     with open(path, "rb") as f:
         raw = bgzf_decompress(f.read())
     if raw[:4] != b"BAM\x01":
@@ -227,7 +249,11 @@ def read_bam(path):
             seen[nm] = j
             names.append(nm.decode())
         name_ids[i] = j
-    return AlignmentTable(refs, lens, tid, pos, flag, mapq, l_seq, name_ids, names, cigar, cig_off, text)
+    seq_packed = seq_off = None
+    if with_seq:
+        seq_packed = raw                                   # 4-bit SEQ is used in place from the decompressed file
+        seq_off = cig_start + 4 * n_cig
+    return AlignmentTable(refs, lens, tid, pos, flag, mapq, l_seq, name_ids, names, cigar, cig_off, text, seq_packed, seq_off)
 
 
 def _reg2bin(beg, end):
@@ -255,10 +281,23 @@ def write_bam(path, table, with_seq=True, level=1):
         pos = int(table.pos[i])
         body = struct.pack("<iiBBHHHIiii", int(table.tid[i]), pos, len(name), int(table.mapq[i]),
                            _reg2bin(pos, pos + max(span, 1)), cw.size, int(table.flag[i]), l_seq, -1, -1, 0)
-        body += name + cw.astype("<u4").tobytes() + b"\xff" * ((l_seq + 1) // 2) + b"\xff" * l_seq
+        if l_seq and table.seq_packed is not None:
+            o = int(table.seq_off[i])
+            seq_bytes = bytes(table.seq_packed[o:o + (l_seq + 1) // 2])
+        else:
+            seq_bytes = b"\xff" * ((l_seq + 1) // 2)       # N's
+        body += name + cw.astype("<u4").tobytes() + seq_bytes + b"\xff" * l_seq
         parts.append(struct.pack("<i", len(body)) + body)
     with open(path, "wb") as f:
         f.write(bgzf_compress(b"".join(parts), level))
+
+
+def pack_sequence(seq):
+    """ASCII bases -> BAM 4-bit packed bytes."""
+    codes = _SEQ_CODE[np.frombuffer(seq if isinstance(seq, (bytes, bytearray)) else seq.encode(), np.uint8)]
+    if codes.size % 2:
+        codes = np.concatenate([codes, np.zeros(1, np.uint8)])
+    return ((codes[0::2] << 4) | codes[1::2]).astype(np.uint8).tobytes()
 
 
 class Fasta:

@@ -44,10 +44,10 @@ class Sample:
         return cls(table, fasta, gaps, gap_off, stats, min_sv)
 
     @classmethod
-    def open(cls, bam_path, genome_path, min_sv, device="cuda"):
-        key = (bam_path, genome_path, int(min_sv), str(device))
+    def open(cls, bam_path, genome_path, min_sv, device="cuda", with_seq=False):
+        key = (bam_path, genome_path, int(min_sv), str(device), bool(with_seq))
         if key not in _CACHE:
-            _CACHE[key] = cls.from_table(read_bam(bam_path), Fasta(genome_path), min_sv, device)
+            _CACHE[key] = cls.from_table(read_bam(bam_path, with_seq=with_seq), Fasta(genome_path), min_sv, device)
         return _CACHE[key]
 
     def rescan_window(self, chrom, start, end):
@@ -89,6 +89,12 @@ class Sample:
         return self.fasta.fetch_bytes(chrom, start, end)
 
 
+    def _fetch_ref_str(self, chrom, start, end):
+        return self.fetch_ref(chrom, start, end).decode()
+
+    fetch_ref_str = _fetch_ref_str
+
+
 def register(path, sample):
     """Make ``run_detect(options, path, ...)`` resolve to an already prepared Sample."""
     _CACHE[("registered", path)] = sample
@@ -100,4 +106,4 @@ def resolve(sample_or_path, options):
     reg = _CACHE.get(("registered", sample_or_path))
     if reg is not None:
         return reg
-    return Sample.open(sample_or_path, options.genome, options.min_sv_size)
+    return Sample.open(sample_or_path, options.genome, options.min_sv_size, with_seq=bool(options.hash))

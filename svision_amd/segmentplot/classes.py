@@ -12,6 +12,10 @@ class Segment:
         self._xEnd = x_start + (length - 1) if forward else x_start - (length - 1)
         self._yEnd = y_start + (length - 1)
 
+    def setxEnd(self, v): self._xEnd = v
+    def setyEnd(self, v): self._yEnd = v
+    def setLength(self, v): self._length = v
+
     def xStart(self): return self._xStart
     def yStart(self): return self._yStart
     def xEnd(self): return self._xEnd

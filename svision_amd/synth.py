@@ -59,6 +59,8 @@ def plant_svs(cfg):
             sv = {"type": kind, "pos": pos, "len": size, "src": -1, "gt": gt}
             if kind == "dDUP":
                 sv["src"] = pos - int(rng.integers(3 * size + 2_000, 3 * size + 12_000))
+            elif kind in ("cINS", "rcINS"):        # insertion whose bases are a (reverse-complemented) nearby copy
+                sv["src"] = pos - size - int(rng.integers(0, 1_500))
             svs.append(sv)
             pos += 3 * size + cfg.sv_min_gap + int(rng.exponential(cfg.sv_spacing))
         out[name] = svs
@@ -83,6 +85,8 @@ def _haplotype_pieces(length, svs, hap):
             pieces.append((c, p + n, 1, 0)); pieces.append((p, p + n, 1, 0)); c = p + n
         elif t == "dDUP":
             pieces.append((c, p, 1, 0)); pieces.append((sv["src"], sv["src"] + n, 1, 0)); c = p
+        elif t in ("cINS", "rcINS"):
+            pieces.append((c, p, 1, 0)); pieces.append((sv["src"], sv["src"] + n, 1 if t == "cINS" else -1, 2)); c = p
         elif t == "DELINV":
             d = n // 2
             pieces.append((c, p, 1, 0)); pieces.append((p + d, p + d + n, -1, 0)); c = p + d + n
@@ -119,12 +123,42 @@ def _noisy_block(rng, n, err_rate):
     return ops, lens, read_len
 
 
-def simulate(cfg, with_genome=True):
-    """-> (AlignmentTable, genome dict or None, svs dict)."""
+_COMP = np.zeros(256, np.uint8)
+for _a, _b in zip(b"ACGTN", b"TGCAN"):
+    _COMP[_a] = _b
+
+
+def _revcomp(arr):
+    return _COMP[arr[::-1]]
+
+
+def _block_bases(rng, ref_bases, ops, lens):
+    """Read bases (reference order) of one aligned block given its noisy CIGAR."""
+    out = []
+    r = 0
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    for op, n in zip(ops.tolist(), lens.tolist()):
+        if op == 7:                                   # =
+            out.append(ref_bases[r:r + n]); r += n
+        elif op == 8:                                 # X: any other base
+            sub = ref_bases[r:r + n].copy()
+            for j in range(n):
+                sub[j] = acgt[(int(np.searchsorted(acgt, sub[j])) + int(rng.integers(1, 4))) % 4]
+            out.append(sub); r += n
+        elif op == 1:                                 # I
+            out.append(acgt[rng.integers(0, 4, n)])
+        elif op == 2:                                 # D
+            r += n
+    return np.concatenate(out) if out else np.empty(0, np.uint8)
+
+
+def simulate(cfg, with_genome=True, with_seq=False):
+    """-> (AlignmentTable, genome dict or None, svs dict).  ``with_seq``: also synthesise the read bases
+    (primary records carry SEQ, as minimap2 writes them; needed for --hash only)."""
     rng = np.random.default_rng(cfg.seed + 2)
     svs = plant_svs(cfg)
-    genome = make_genome(cfg) if with_genome else None
-    recs = []          # (tid, pos, flag, mapq, l_seq, name_id, ops, lens)
+    genome = make_genome(cfg) if (with_genome or with_seq) else None
+    recs = []          # (tid, pos, flag, mapq, l_seq, name_id, ops, lens[, seq])
     names = []
     for tid, (cname, clen) in enumerate(cfg.contigs):
         for hap in (0, 1):
@@ -149,7 +183,9 @@ def simulate(cfg, with_genome=True):
                     s, e = max(a, d0), min(b, d1)
                     if e <= s:
                         continue
-                    if novel:
+                    if novel == 2:             # unaligned insertion carrying a copy of ref[lo:hi] (strand sign)
+                        blocks.append(("N", e - s, lo + (s - d0) if strand > 0 else hi - (e - d0), strand))
+                    elif novel:
                         blocks.append(("N", e - s))
                     elif strand > 0:
                         blocks.append(("M", lo + (s - d0), lo + (e - d0), 1))
@@ -157,7 +193,8 @@ def simulate(cfg, with_genome=True):
                         blocks.append(("M", hi - (e - d0), hi - (s - d0), -1))
                 name_id = len(names)
                 names.append("%s_h%d_r%d" % (cname, hap, r))
-                _emit_read(rng, cfg, tid, blocks, bool(rev[r]), name_id, recs)
+                _emit_read(rng, cfg, tid, blocks, bool(rev[r]), name_id, recs,
+                           np.frombuffer(genome[cname], np.uint8) if with_seq else None)
     recs.sort(key=lambda t: (t[0], t[1]))
     n = len(recs)
     tid = np.fromiter((t[0] for t in recs), np.int32, n)
@@ -183,19 +220,42 @@ def simulate(cfg, with_genome=True):
         nid[i] = remap[j]
     refs = [c for c, _ in cfg.contigs]
     lens_c = [l for _, l in cfg.contigs]
-    return AlignmentTable(refs, lens_c, tid, pos, flag, mapq, l_seq, nid, new_names, cigar, cig_off), genome, svs
+    seq_packed = seq_off = None
+    if with_seq:
+        from .io.bam import pack_sequence
+        chunks, seq_off, o = [], np.zeros(n, np.int64), 0
+        for i, t in enumerate(recs):
+            seq_off[i] = o
+            if t[8] is not None:
+                pk = pack_sequence(t[8].tobytes())
+                chunks.append(pk)
+                o += len(pk)
+        seq_packed = b"".join(chunks)
+    return AlignmentTable(refs, lens_c, tid, pos, flag, mapq, l_seq, nid, new_names, cigar, cig_off,
+                          seq_packed=seq_packed, seq_off=seq_off), genome, svs
 
 
-def _emit_read(rng, cfg, tid, blocks, read_rev, name_id, recs):
+def _emit_read(rng, cfg, tid, blocks, read_rev, name_id, recs, ref_bases=None):
     """Group a read's blocks into alignments and append BAM-like records."""
     # 1. noisy CIGAR per aligned block, read extents
     items = []      # [kind, ref_lo, ref_hi, strand, ops, lens, read_len]
+    pieces = []     # read bases per block, in donor-forward read orientation
     for blk in blocks:
         if blk[0] == "N":
             items.append(["N", 0, 0, 0, None, None, blk[1]])
+            if ref_bases is not None:
+                if len(blk) == 4:              # copy insertion
+                    src = ref_bases[blk[2]:blk[2] + blk[1]]
+                    pieces.append(src.copy() if blk[3] > 0 else _revcomp(src))
+                else:
+                    pieces.append(np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, blk[1])])
         else:
             ops, lens, rl = _noisy_block(rng, blk[2] - blk[1], cfg.err_rate)
             items.append(["M", blk[1], blk[2], blk[3], ops, lens, rl])
+            if ref_bases is not None:
+                bases = _block_bases(rng, ref_bases[blk[1]:blk[2]], ops, lens)
+                pieces.append(bases if blk[3] > 0 else _revcomp(bases))
+    read_fwd = np.concatenate(pieces) if (ref_bases is not None and pieces) else None
     total = sum(it[6] for it in items)
     # 2. merge collinear forward blocks separated by small gaps into one alignment
     alns = []       # [q_lo, q_hi, strand, ref_lo, ops, lens]
@@ -241,4 +301,8 @@ def _emit_read(rng, cfg, tid, blocks, read_rev, name_id, recs):
         o = np.concatenate([np.asarray(pre[0], np.int64), ops, np.asarray(post[0], np.int64)])
         l = np.concatenate([np.asarray(pre[1], np.int64), lens, np.asarray(post[1], np.int64)])
         flag = (FLAG_REVERSE if bam_rev else 0) | (0 if k == primary else FLAG_SUPPLEMENTARY)
-        recs.append((tid, ref_lo, flag, 60, total if k == primary else 0, name_id, o, l))
+        seq = None
+        if read_fwd is not None and k == primary:
+            as_sequenced = _revcomp(read_fwd) if read_rev else read_fwd
+            seq = _revcomp(as_sequenced) if bam_rev else as_sequenced      # BAM stores SEQ on the reference strand
+        recs.append((tid, ref_lo, flag, 60, total if k == primary else 0, name_id, o, l, seq))

@@ -109,7 +109,8 @@ def _record_from_table(table, i):
     words = table.cigar[int(table.cig_off[i]):int(table.cig_off[i + 1])]
     a.cigarstring = "".join("%d%s" % (int(w) >> 4, cigar_ref.OPS[int(w) & 15]) for w in words) if len(words) else None
     l_seq = int(table.l_seq[i])
-    a.query_sequence = ("N" * l_seq) if l_seq > 0 else None
+    seq = table.query_sequence(i) if getattr(table, "seq_packed", None) is not None else None
+    a.query_sequence = seq if seq is not None else (("N" * l_seq) if l_seq > 0 else None)
     return a
 
 

@@ -61,7 +61,7 @@ def test_inside_align_fuzz(fx):
         arr = np.array([(0, g[0], g[2], g[3], g[4], g[1]) for g in gaps],
                        dtype=[("aln", "<u4"), ("op", "<u4"), ("read_pos", "<i4"), ("ref_pos", "<i4"), ("len", "<i4"), ("kind", "<u4")])
         seg = Seg(case["q_start"], 0, case["ref_start"], case["ref_end"], 0, False, False, "main", 60, 0)
-        got = ar.analyze_inside_align(seg, arr)
+        got, _helpers = ar.analyze_inside_align(seg, arr)
         exp = case["segs"]
         assert (got is None) == (exp is None)
         if got is not None:

@@ -101,3 +101,21 @@ def test_streaming_pipelines_agree(checkpoint):
         outs.append(got)
     assert outs[0] == outs[1] == outs[2]
     assert sum(v[3] for v in outs[0].values()) == 610 and sum(v[2] for v in outs[0].values()) > 20
+
+
+def test_cli_hash_mode_on_device(checkpoint, tmp_path):
+    """--hash end to end on the device path: BAM with read bases -> TSV identical to the reference's."""
+    import json
+    from svision_amd.io import bam
+    prefix, _params = checkpoint
+    fasta = helpers.load_golden_fasta("hash_collect.fa.gz")
+    fa = str(tmp_path / "genome.fa")
+    bam.write_fasta(fa, {n: fasta._seq[n] for n in fasta.references})
+    out = str(tmp_path / "out")
+    opts = cli.parse_arguments(["-o", out, "-b", os.path.join(helpers.GOLDEN, "hash_collect.bam"), "-m", prefix, "-g", fa,
+                                "-n", "HGhash", "-s", "3", "--hash", "--batch_size", "64", "--debug"])
+    merged = cli.run(opts)
+    with open(os.path.join(helpers.GOLDEN, "hash_collect.expected.json")) as f:
+        want = [w for w in json.load(f)["windows"] if w["hash"]][0]
+    assert open(os.path.join(out, "segments", "chrH.segments.all.bed")).read() == want["tsv"]
+    assert os.path.exists(merged)
