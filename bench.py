@@ -95,10 +95,12 @@ def main():
         windows.append(("chr21", pos, min(args.contig_len, pos + opts.window_size)))
         pos += opts.window_size
 
+    import torch.distributed as tdist
+    grouped = tdist.is_available() and tdist.is_initialized()
+
     def sync_all():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
+        if grouped:
+            tdist.barrier()
         torch.cuda.synchronize()
 
     def run(n_steps):
@@ -122,11 +124,10 @@ def main():
     dt = time.perf_counter() - t0
 
     totals = torch.tensor([sites, images, dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        import torch.distributed as dist
+    if grouped:
         tmax = totals.clone()
-        dist.all_reduce(totals, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tdist.all_reduce(totals, op=tdist.ReduceOp.SUM)
+        tdist.all_reduce(tmax, op=tdist.ReduceOp.MAX)
         dt = float(tmax[2].item())
     tot_sites, tot_images = float(totals[0].item()), float(totals[1].item())
 
@@ -166,9 +167,8 @@ def main():
         line["cpu_baseline"] = cpu_baseline(sample, opts, windows[0], net)
     if rank == 0:
         print(json.dumps(line))
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    if grouped:
+        tdist.destroy_process_group()
 
 
 def kernel_calibration(sample, net, dev, B, reps=20):

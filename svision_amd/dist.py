@@ -25,7 +25,9 @@ def world():
 def init_from_env():
     """Initialise the process group when launched under torchrun (RANK/WORLD_SIZE set)."""
     ws = int(os.environ.get("WORLD_SIZE", "1"))
-    if ws > 1 and not dist.is_initialized():
+    # SVX_FORCE_DIST=1 initialises the group even for a single rank (exercises the RCCL path on one GPU)
+    force = os.environ.get("SVX_FORCE_DIST") == "1" and "RANK" in os.environ
+    if (ws > 1 or force) and not dist.is_initialized():
         backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
@@ -57,7 +59,7 @@ def exchange_score_range(local_scores):
     has = len(local_scores) > 0
     mx = float(np.max(local_scores)) if has else -np.inf
     mn = float(np.min(local_scores)) if has else np.inf
-    if ws > 1:
+    if dist.is_available() and dist.is_initialized():
         dev = _comm_device()
         t_max = torch.tensor([mx], dtype=torch.float64, device=dev)
         t_min = torch.tensor([mn], dtype=torch.float64, device=dev)
@@ -73,7 +75,7 @@ def gather_texts(texts, dst=0):
     """{key: str} on every rank -> merged dict on rank ``dst`` (None elsewhere).
     Packed as bytes: all_gather of sizes, then one padded all_gather of the payloads."""
     rank, ws = world()
-    if ws == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return dict(texts)
     import json
     payload = json.dumps(texts).encode()
