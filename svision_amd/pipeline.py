@@ -260,7 +260,12 @@ class PooledHotPath(HotPath):
                 classes, probs = self.fetch_predictions(res)
                 self.conns[ci].send(("pred", busy[ci], classes, probs))
             waiting = [self.conns[ci] for ci in busy]
-            for c in mpc.wait(waiting, timeout=0.0005 if inflight else 0.05):
+            got = mpc.wait(waiting, timeout=0.0005 if inflight else 0.05)
+            if not got and not inflight and not ready:
+                dead = [ci for ci in busy if not self.procs[ci].is_alive()]
+                if dead:
+                    raise RuntimeError("host helper process %s died while holding window %s" % (dead, [busy[ci] for ci in dead]))
+            for c in got:
                 ci = self.conns.index(c)
                 msg = c.recv()
                 if msg[0] == "rec":
