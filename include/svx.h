@@ -115,6 +115,12 @@ int svx_bias_relu_pool_lrn(const float* d_x, const float* d_bias, float* d_y, ui
                            uint32_t height, uint32_t width, int lrn, uint32_t radius, float alpha, float beta,
                            float k, void* stream);
 
+/* fc8 + softmax + argmax in one launch: logits = x @ W^T + b (tf xw_plus_b, src/network/alexnet.py:58,148),
+ * tf.nn.softmax and tf.argmax as fetched at src/network/predict.py:209.
+ *   d_x [n][4096] fc7 activations, d_w [5][4096] (fc8/weights transposed), d_bias [5]
+ *   d_out [n][12] = softmax[5], class (as float), logits[5], 0 */
+int svx_fc8_softmax(const float* d_x, const float* d_w, const float* d_bias, float* d_out, uint32_t n, void* stream);
+
 /* In-place bias add + ReLU on an NCHW float32 tensor [n][channels][plane] (plane = H*W >= 4):
  * tf.nn.bias_add + tf.nn.relu of the layers without pooling (conv3, conv4;
  * src/network/alexnet.py:39,42 via :132-135). d_x must be 16-B aligned. */

@@ -220,6 +220,52 @@ extern "C" int svx_bias_relu(float* d_x, const float* d_bias, uint32_t n, uint32
     return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
 }
 
+namespace {
+// Last layer + outputs in one launch: logits = x @ W8^T + b8 (xw_plus_b, src/network/alexnet.py:58,148),
+// tf.nn.softmax and tf.argmax (first maximal index) as fetched at src/network/predict.py:209.  One
+// workgroup per image, one wave per class; packed row = [softmax x5, class, logits x5, pad].
+constexpr int FC8_IN = 4096, FC8_OUT = 5;
+__global__ __launch_bounds__(64 * FC8_OUT)
+void fc8_softmax_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                        float* __restrict__ out)
+{
+    __shared__ float logit[FC8_OUT];
+    const int img = blockIdx.x, cls = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float4* xv = reinterpret_cast<const float4*>(x + (size_t)img * FC8_IN);
+    const float4* wv = reinterpret_cast<const float4*>(w + (size_t)cls * FC8_IN);
+    float acc = 0.0f;
+#pragma unroll 4
+    for (int i = lane; i < FC8_IN / 4; i += 64) {
+        const float4 a = xv[i], b = wv[i];
+        acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) logit[cls] = acc + bias[cls];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = logit[0];
+        int best = 0;
+        for (int j = 1; j < FC8_OUT; ++j) if (logit[j] > m) { m = logit[j]; best = j; }
+        float e[FC8_OUT], s = 0.0f;
+        for (int j = 0; j < FC8_OUT; ++j) { e[j] = expf(logit[j] - m); s += e[j]; }
+        float* o = out + (size_t)img * 12;
+        for (int j = 0; j < FC8_OUT; ++j) { o[j] = e[j] / s; o[6 + j] = logit[j]; }
+        o[5] = (float)best;
+        o[11] = 0.0f;
+    }
+}
+}  // namespace
+
+extern "C" int svx_fc8_softmax(const float* d_x, const float* d_w, const float* d_bias, float* d_out, uint32_t n, void* stream)
+{
+    if (n == 0) return SVX_OK;
+    if (!d_x || !d_w || !d_bias || !d_out) return SVX_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(d_x) & 15u) || (reinterpret_cast<uintptr_t>(d_w) & 15u)) return SVX_EINVAL;
+    hipLaunchKernelGGL(fc8_softmax_kernel, dim3(n), dim3(64 * FC8_OUT), 0, static_cast<hipStream_t>(stream), d_x, d_w, d_bias, d_out);
+    return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
+}
+
 extern "C" int svx_bias_relu_pool_lrn(const float* d_x, const float* d_bias, float* d_y, uint32_t n, uint32_t channels,
                                       uint32_t height, uint32_t width, int lrn, uint32_t radius, float alpha, float beta,
                                       float k, void* stream)

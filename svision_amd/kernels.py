@@ -164,3 +164,19 @@ def conv2d_same(x, w_hwio, bias=None, groups=1, relu=False):
                              n, cin, cout, h, w, k, groups, 1 if relu else 0, _stream_ptr(x.device))
     _lib.check(rc, "svx_conv2d_same")
     return y
+
+
+def fc8_softmax(x, w_out_in, bias, out=None):
+    """x float32 [n,4096], w float32 [5,4096], bias [5] -> packed float32 [n,12] = softmax[5], class, logits[5], 0.
+    See include/svx.h svx_fc8_softmax."""
+    lib = _lib.load()
+    for t, nm in ((x, "x"), (w_out_in, "w"), (bias, "bias")):
+        _require_cuda(t, nm)
+    if x.dtype != torch.float32 or x.dim() != 2 or x.shape[1] != 4096 or tuple(w_out_in.shape) != (5, 4096):
+        raise _lib.SvxError("x must be float32 [n,4096] and w float32 [5,4096]")
+    n = x.shape[0]
+    if out is None:
+        out = torch.empty((n, 12), dtype=torch.float32, device=x.device)
+    rc = lib.svx_fc8_softmax(x.data_ptr(), w_out_in.data_ptr(), bias.data_ptr(), out.data_ptr(), n, _stream_ptr(x.device))
+    _lib.check(rc, "svx_fc8_softmax")
+    return out

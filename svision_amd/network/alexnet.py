@@ -116,7 +116,15 @@ class AlexNet(torch.nn.Module):
             x = x.contiguous(memory_format=torch.channels_last)
         return self._tail(x, first=0)
 
-    def _tail(self, x, first):
+    @torch.no_grad()
+    def predict_records_packed(self, records, out=None):
+        """records int32 [B,12] -> float32 [B,12] = softmax[5], class, logits[5], 0 (all hand-written kernels except fc6/fc7)."""
+        from .. import kernels
+        x = kernels.encode_conv1(records, self.conv1_hwio, self.conv1_base)
+        h7 = self._tail(x, first=1, upto_fc7=True)
+        return kernels.fc8_softmax(h7, self.fc8_w, self.fc8_b, out=out)
+
+    def _tail(self, x, first, upto_fc7=False):
         for name, _k, _cin, _cout, stride, pad, groups in _CONVS[first:]:
             if name in self.own_conv:
                 from .. import kernels
@@ -146,6 +154,8 @@ class AlexNet(torch.nn.Module):
         x = x.reshape(x.shape[0], 9216) if not self.channels_last else x.contiguous().reshape(x.shape[0], 9216)
         x = F.relu_(F.linear(x, self.fc6_w, self.fc6_b))
         x = F.relu_(F.linear(x, self.fc7_w, self.fc7_b))
+        if upto_fc7:
+            return x
         return F.linear(x, self.fc8_w, self.fc8_b)
 
     @torch.no_grad()

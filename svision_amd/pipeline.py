@@ -63,11 +63,13 @@ class DeviceStage:
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
         self.use_graph = use_graph
         self.slots = []
+        self.packed12 = {}
         for s in self.streams:
             rec = torch.zeros((batch, 12), dtype=torch.int32, device=self.device)
             rec[:] = torch.tensor(_PAD_REC, dtype=torch.int32, device=self.device)
             img = torch.empty((batch, 3, 227, 227), dtype=torch.float32, device=self.device)
             out = torch.empty((batch, 6), dtype=torch.float32, device=self.device)
+            self.packed12[id(out)] = torch.empty((batch, 12), dtype=torch.float32, device=self.device)
             graph = None
             with torch.cuda.stream(s):
                 for _ in range(2):                           # warm MIOpen / hipBLASLt before capture
@@ -81,7 +83,9 @@ class DeviceStage:
 
     def _body(self, rec, img, out):
         if self.sparse_first_layer:
-            _logits, cls, prob = self.net.predict_records(rec)      # svx_encode_conv1: no image tensor
+            self.net.predict_records_packed(rec, out=self.packed12[id(out)])   # softmax[5], class, logits[5]
+            out.copy_(self.packed12[id(out)][:, :6])
+            return
         else:
             kernels.rasterize(rec, layout="NCHW", out=img)
             _logits, cls, prob = self.net.predict(img)

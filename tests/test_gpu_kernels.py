@@ -176,3 +176,23 @@ def test_conv2d_same_matches_torch_fp32(n, cin, cout, hw, k, groups):
     assert float((got_raw.double() + bt.double().view(1, -1, 1, 1) - want).abs().max()) < 2e-4 * scale
     got_relu = kernels.conv2d_same(xt, wt, bt, groups=groups, relu=True)
     assert float((got_relu.double() - want.clamp_min(0)).abs().max()) < 2e-4 * scale
+
+
+def test_fc8_softmax_and_packed_predict():
+    from oracle import alexnet_ref
+    from svision_amd.network.alexnet import AlexNet
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((7, 4096)).astype(np.float32)
+    w = (rng.standard_normal((5, 4096)) * 0.03).astype(np.float32)
+    b = rng.standard_normal(5).astype(np.float32)
+    got = kernels.fc8_softmax(_dev(x), _dev(w), _dev(b)).cpu().numpy()
+    logits = x.astype(np.float64) @ w.T.astype(np.float64) + b
+    assert np.allclose(got[:, 6:11], logits, rtol=1e-5, atol=1e-5)
+    assert np.array_equal(got[:, 5].astype(int), logits.argmax(1))
+    assert np.allclose(got[:, :5], alexnet_ref.softmax(logits.astype(np.float32)), atol=1e-6)
+    params = alexnet_ref.random_params(seed=4)
+    net = AlexNet(params, device=DEV)
+    rec = _dev(datagen.random_records(9, seed=5, hostile=False))
+    packed = net.predict_records_packed(rec).cpu().numpy()
+    _l, cls, prob = net.predict_records(rec)
+    assert np.abs(packed[:, :5] - prob.cpu().numpy()).max() < 1e-5
