@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--workers", type=int, default=8, help="helper processes for the Python host glue (collection, vote)")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the per-batch graphs are replayed on")
-    ap.add_argument("--inflight", type=int, default=3, help="windows enqueued on the device at once")
+    ap.add_argument("--inflight", type=int, default=6, help="windows enqueued on the device at once")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
