@@ -9,7 +9,6 @@
 // cross-channel normalisation from there.  HBM traffic = conv output read once (+ halo
 // rows through L2) and the 4x smaller pooled tensor written once.
 #include "svx_raster_common.hpp"
-#include <stdlib.h>
 
 namespace {
 
@@ -80,7 +79,7 @@ __device__ inline unsigned window_mask(const unsigned* row_words, int c0)
 
 __global__ __launch_bounds__(ENC_BLOCK)
 void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __restrict__ w1, const float* __restrict__ base,
-                         float* __restrict__ y, int lrn, int radius, float alpha, float beta, float kk, int dbg)
+                         float* __restrict__ y, int lrn, int radius, float alpha, float beta, float kk)
 {
     using namespace svx_raster;
     __shared__ unsigned bits[3 * PLANE_WORDS];
@@ -92,7 +91,7 @@ void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __res
 
     const int img = blockIdx.x / P1;
     const int oyp = blockIdx.x - img * P1;
-    if (!(dbg & 4)) draw_planes<ENC_BLOCK>(records + (size_t)img * 12, bits, colcnt, colmask);
+    draw_planes<ENC_BLOCK>(records + (size_t)img * 12, bits, colcnt, colmask);
 
     const int tid = threadIdx.x;
     if (tid < 3 * ROW_WORDS) {
@@ -125,7 +124,7 @@ void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __res
         const int oxp = pw / 9, win = pw - oxp * 9;
         const int dy = win / 3, dx = win - dy * 3;
         const int oy = 2 * oyp + dy, ox = 2 * oxp + dx;
-        if ((dbg & 1) || window_mask(rowany[dy], 4 * ox) == 0) continue;
+        if (window_mask(rowany[dy], 4 * ox) == 0) continue;
         const float4 b0 = reinterpret_cast<const float4*>(base)[2 * g];
         const float4 b1 = reinterpret_cast<const float4*>(base)[2 * g + 1];
         float acc[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
@@ -176,9 +175,8 @@ extern "C" int svx_encode_conv1(const int32_t* d_records, uint32_t n, const floa
     if (n == 0) return SVX_OK;
     if (!d_records || !d_w1 || !d_base || !d_y) return SVX_EINVAL;
     if ((reinterpret_cast<uintptr_t>(d_w1) & 15u) || (reinterpret_cast<uintptr_t>(d_base) & 15u)) return SVX_EINVAL;
-    static const int dbg = getenv("SVX_ENC_DEBUG") ? atoi(getenv("SVX_ENC_DEBUG")) : 0;
     hipLaunchKernelGGL(encode_conv1_kernel, dim3(n * P1), dim3(ENC_BLOCK), 0, static_cast<hipStream_t>(stream),
-                       d_records, d_w1, d_base, d_y, (dbg & 2) ? 0 : lrn, (int)radius, alpha, beta, k, dbg);
+                       d_records, d_w1, d_base, d_y, lrn, (int)radius, alpha, beta, k);
     return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
 }
 

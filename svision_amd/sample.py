@@ -89,10 +89,9 @@ class Sample:
         return self.fasta.fetch_bytes(chrom, start, end)
 
 
-    def _fetch_ref_str(self, chrom, start, end):
+    def fetch_ref_str(self, chrom, start, end):
+        """The same as text (the --hash re-aligner works on str)."""
         return self.fetch_ref(chrom, start, end).decode()
-
-    fetch_ref_str = _fetch_ref_str
 
 
 def register(path, sample):
