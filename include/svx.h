@@ -139,6 +139,26 @@ int svx_conv2d_same(const float* d_in, const float* d_w_hwio, const float* d_bia
                     uint32_t cin, uint32_t cout, uint32_t height, uint32_t width, uint32_t ksize,
                     uint32_t groups, int relu, void* stream);
 
+/* ---- host side: native BGZF/BAM ingestion (no device work) -------------------------------------------
+ * Replaces the per-record pysam iteration of the reference (aln_file.fetch at
+ * src/collection/run_collection.py:23-26, field reads at src/collection/collect_signatures.py:128-155):
+ * block-parallel inflate, then all records scattered into caller-owned arrays.
+ *   svx_bam_open    -> opaque handle or NULL (svx_bam_error() tells why); threads <= 0: all cores (max 64)
+ *   svx_bam_sizes   -> sizes[8] = n_records, n_cigar_words, n_refs, n_names, names_bytes, header_bytes,
+ *                      ref_names_bytes, raw_bytes
+ *   svx_bam_export  -> fills tid/pos/flag/mapq/l_seq/name_id [n_records], cig_off [n_records+1], cigar
+ *                      [n_cigar_words], names / ref_names ('\n'-separated, first-occurrence order), header text,
+ *                      ref_lens [n_refs], and (if not NULL) seq_off = byte offset of each record's 4-bit SEQ
+ *                      inside the decompressed file exposed by svx_bam_raw() */
+void*          svx_bam_open(const char* path, int threads);
+const char*    svx_bam_error(void);
+void           svx_bam_sizes(void* handle, uint64_t* sizes);
+void           svx_bam_export(void* handle, int threads, int32_t* tid, int32_t* pos, uint16_t* flag, uint8_t* mapq,
+                              int32_t* l_seq, int32_t* name_id, int64_t* cig_off, uint32_t* cigar, char* names,
+                              char* header, char* ref_names, int32_t* ref_lens, int64_t* seq_off);
+const uint8_t* svx_bam_raw(void* handle);
+void           svx_bam_close(void* handle);
+
 #ifdef __cplusplus
 }
 #endif

@@ -191,8 +191,43 @@ class AlignmentTable:
         return np.where(ends >= starts, n_pos_lt_end - n_end_le_start, 0)
 
 
-def read_bam(path, with_seq=False):
-    """Decode a whole BAM file into an :class:`AlignmentTable` (``with_seq``: keep the read bases)."""
+def read_bam(path, with_seq=False, threads=0):
+    """Decode a whole BAM file into an :class:`AlignmentTable` with the native multi-threaded decoder of
+    libsvx.so (svx_bam_*); ``with_seq``: keep the 4-bit read bases (needed by --hash only)."""
+    import ctypes
+    from .. import _lib
+    lib = _lib.load()
+    h = lib.svx_bam_open(path.encode(), int(threads))
+    if not h:
+        msg = lib.svx_bam_error().decode()
+        raise ValueError("%s: %s" % (path, msg))
+    try:
+        sizes = np.zeros(8, np.uint64)
+        lib.svx_bam_sizes(h, sizes.ctypes.data)
+        n, nc, nref, _nn, nb, hb, rb, rawb = (int(v) for v in sizes)
+        tid, pos, l_seq, name_id = (np.empty(n, np.int32) for _ in range(4))
+        flag, mapq = np.empty(n, np.uint16), np.empty(n, np.uint8)
+        cig_off, cigar = np.empty(n + 1, np.int64), np.empty(nc, np.uint32)
+        names, header, ref_names = np.empty(nb, np.uint8), np.empty(hb, np.uint8), np.empty(rb, np.uint8)
+        ref_lens = np.empty(nref, np.int32)
+        seq_off = np.empty(n, np.int64) if with_seq else None
+        lib.svx_bam_export(h, int(threads), tid.ctypes.data, pos.ctypes.data, flag.ctypes.data, mapq.ctypes.data,
+                           l_seq.ctypes.data, name_id.ctypes.data, cig_off.ctypes.data, cigar.ctypes.data, names.ctypes.data,
+                           header.ctypes.data, ref_names.ctypes.data, ref_lens.ctypes.data,
+                           seq_off.ctypes.data if with_seq else None)
+        seq_packed = None
+        if with_seq:
+            seq_packed = ctypes.string_at(lib.svx_bam_raw(h), rawb)
+    finally:
+        lib.svx_bam_close(h)
+    name_list = names.tobytes().decode().split("\n")[:-1] if nb else []
+    refs = ref_names.tobytes().decode().split("\n")[:-1] if rb else []
+    return AlignmentTable(refs, [int(v) for v in ref_lens], tid, pos, flag, mapq, l_seq, name_id, name_list, cigar, cig_off,
+                          header.tobytes().decode(), seq_packed, seq_off)
+
+
+def read_bam_python(path, with_seq=False):
+    """Pure-Python decoder of the same format (zlib + NumPy); kept as the independent check of the native one."""
     with open(path, "rb") as f:
         raw = bgzf_decompress(f.read())
     if raw[:4] != b"BAM\x01":

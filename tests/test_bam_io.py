@@ -1,0 +1,74 @@
+"""Own BGZF/BAM/FASTA codec: native multi-threaded decoder (svx_bam_*) vs the pure-Python one, writer round trip,
+pysam-like fetch / coverage semantics, error paths."""
+import os
+
+import numpy as np
+import pytest
+
+from svision_amd import synth
+from svision_amd.io import bam
+from tests import helpers
+
+
+def _same(a, b):
+    for f in ("tid", "pos", "flag", "mapq", "l_seq", "name_id", "cigar", "cig_off"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    assert a.names == b.names and a.references == b.references and a.lengths == b.lengths
+    assert a.header_text == b.header_text
+
+
+@pytest.mark.parametrize("name,with_seq", [("collect_small.bam", False), ("hash_collect.bam", True), ("ont_small.bam", False)])
+def test_native_decoder_matches_python(name, with_seq):
+    path = os.path.join(helpers.GOLDEN, name)
+    a, b = bam.read_bam(path, with_seq=with_seq, threads=3), bam.read_bam_python(path, with_seq=with_seq)
+    _same(a, b)
+    assert a.sort_order == "coordinate"
+    if with_seq:
+        for i in range(0, len(a), 7):
+            assert a.query_sequence(i) == b.query_sequence(i)
+
+
+def test_write_read_roundtrip_and_fetch(tmp_path, oracle_lib):
+    cfg = synth.SimConfig(contigs=[("c1", 120_000), ("c2", 60_000)], coverage=6, read_len_mean=5000, read_len_sd=700,
+                          sv_spacing=9000, sv_min_gap=5000, sv_max=1200, seed=8)
+    table, genome, _ = synth.simulate(cfg, with_seq=True)
+    path = str(tmp_path / "x.bam")
+    bam.write_bam(path, table)
+    back = bam.read_bam(path, with_seq=True)
+    _same(table, back) if table.header_text else None
+    for f in ("tid", "pos", "flag", "mapq", "l_seq", "name_id", "cigar", "cig_off"):
+        assert np.array_equal(getattr(table, f), getattr(back, f))
+    assert [back.query_sequence(i) for i in range(len(back))] == [table.query_sequence(i) for i in range(len(table))]
+    # fetch / coverage vs a brute-force overlap test (pysam: records overlapping [start, end) in file order)
+    back.attach_scan(helpers.oracle_scan(back, 50)[2])
+    rend = back.ref_end()
+    for tid, s, e in ((0, 0, 120_000), (0, 30_000, 30_001), (0, 50_000, 50_000), (1, 10_000, 45_000), (1, 59_999, 70_000)):
+        want = [i for i in range(len(back)) if back.tid[i] == tid and back.pos[i] < e and rend[i] > s]
+        assert back.fetch(tid, s, e).tolist() == want
+        assert int(back.count_overlaps(tid, [s], [e])[0]) == len(want)
+    # FASTA round trip incl. .fai and clipped fetch
+    fa = str(tmp_path / "g.fa")
+    bam.write_fasta(fa, genome)
+    g = bam.Fasta(fa)
+    assert g.references == ["c1", "c2"] and g.get_reference_length("c2") == 60_000
+    assert g.fetch("c1", 119_990, 130_000) == genome["c1"][119_990:].decode()
+    assert g.fetch("c1", 500, 400) == ""
+    fai = open(fa + ".fai").read().split("\n")
+    assert fai[0].split("\t")[:2] == ["c1", "120000"]
+
+
+def test_decoder_error_paths(tmp_path):
+    with pytest.raises(ValueError):
+        bam.read_bam(str(tmp_path / "missing.bam"))
+    p = tmp_path / "junk.bam"
+    p.write_bytes(b"this is not a bam file at all")
+    with pytest.raises(ValueError):
+        bam.read_bam(str(p))
+    q = tmp_path / "notbam.bam"
+    q.write_bytes(bam.bgzf_compress(b"XYZ\x01" + b"\x00" * 64))
+    with pytest.raises(ValueError):
+        bam.read_bam(str(q))
+    empty = tmp_path / "empty.bam"
+    t = bam.AlignmentTable(["c"], [1000], [], [], [], [], [], [], [], [], [0])
+    bam.write_bam(str(empty), t)
+    assert len(bam.read_bam(str(empty))) == 0
