@@ -156,32 +156,35 @@ def run(options, sample=None, classifier=None):
     os.makedirs(seg_dir, exist_ok=True)
     os.makedirs(pred_dir, exist_ok=True)
     t0 = datetime.datetime.now()
-    logging.info("\n****************** Step1 Image coding and segmentation ******************")
-    for chrom in mine:
-        parts = []
-        for part, (start, end) in enumerate(tasks[chrom]):
-            err = run_collection.run_detect(options, options.bam_path, chrom, part, start, end)
-            if err is not None:
-                logging.error("%s:%s-%s %s", chrom, start, end, err)      # upstream drops this string silently
-            parts.append(os.path.join(seg_dir, "%s.segments.%d.bed" % (chrom, part)))
-        with open(os.path.join(seg_dir, chrom + ".segments.all.bed"), "w") as out:   # `cat parts > all.bed`
-            for p in parts:
-                if os.path.exists(p):
-                    with open(p) as f:
-                        shutil.copyfileobj(f, out)
-    t1 = datetime.datetime.now()
-    logging.info("[Coding finished]: Collect segment signatures, Cost time: %s", (t1 - t0).seconds)
+    if classifier is None:
+        # device path: Step 1 and Step 2 streamed window by window (collection of window k+1 on the host while the
+        # device classifies window k), one vote stream per chromosome in window order = the order of all.bed
+        _run_streaming(options, sample, tasks, mine, seg_dir, pred_dir)
+        t1 = t2 = datetime.datetime.now()
+        logging.info("[Coding + prediction finished]: streamed, Cost time: %s", (t2 - t0).seconds)
+    else:
+        logging.info("\n****************** Step1 Image coding and segmentation ******************")
+        for chrom in mine:
+            parts = []
+            for part, (start, end) in enumerate(tasks[chrom]):
+                err = run_collection.run_detect(options, options.bam_path, chrom, part, start, end)
+                if err is not None:
+                    logging.error("%s:%s-%s %s", chrom, start, end, err)      # upstream drops this string silently
+                parts.append(os.path.join(seg_dir, "%s.segments.%d.bed" % (chrom, part)))
+            with open(os.path.join(seg_dir, chrom + ".segments.all.bed"), "w") as out:   # `cat parts > all.bed`
+                for p in parts:
+                    if os.path.exists(p):
+                        with open(p) as f:
+                            shutil.copyfileobj(f, out)
+        t1 = datetime.datetime.now()
+        logging.info("[Coding finished]: Collect segment signatures, Cost time: %s", (t1 - t0).seconds)
 
-    logging.info("\n****************** Step2 CNN prediction ******************")
-    for chrom in mine:
-        prefix = os.path.join(pred_dir, "%s.predict.s%s" % (chrom, options.min_support))
-        try:
+        logging.info("\n****************** Step2 CNN prediction ******************")
+        for chrom in mine:
+            prefix = os.path.join(pred_dir, "%s.predict.s%s" % (chrom, options.min_support))
             Predict(chrom, os.path.join(seg_dir, chrom + ".segments.all.bed")).run(prefix, options, classifier=classifier, sample=sample)
-        except Exception as e:                                # upstream: error string, silently dropped
-            logging.error("predict %s failed: %r", chrom, e)
-            raise
-    t2 = datetime.datetime.now()
-    logging.info("[Prediction finished]: Predicting types, Cost time: %s", (t2 - t1).seconds)
+        t2 = datetime.datetime.now()
+        logging.info("[Prediction finished]: Predicting types, Cost time: %s", (t2 - t1).seconds)
 
     # ---- the single cross-shard exchange: score range + record gather ----
     local_scores = cal_scores_max_min(pred_dir) if ws == 1 else _scores_of(pred_dir, mine, options)
@@ -213,6 +216,47 @@ def run(options, sample=None, classifier=None):
     root.removeHandler(fh)
     fh.close()
     return merged_path if rank == 0 else None
+
+
+def _run_streaming(options, sample, tasks, chroms, seg_dir, pred_dir):
+    """Steps 1 + 2 without the TSV round trip: same functions, same order of lines, same vote semantics as
+    Predict.run over ``{chrom}.segments.all.bed`` (predict.py:206-300); the segment files are still written."""
+    import sys
+    import traceback
+    import numpy as np
+    from .network.predict import Predict, SiteVoter, load_network
+    from .pipeline import HotPath
+    net = load_network(options.model_path)
+    hot = HotPath(sample, options, net, n_streams=3)
+    for chrom in chroms:
+        prefix = os.path.join(pred_dir, "%s.predict.s%s" % (chrom, options.min_support))
+        with open(prefix + ".score.txt", "w") as score_out, open(prefix + ".vcf", "w") as vcf_out, \
+                open(os.path.join(seg_dir, chrom + ".segments.all.bed"), "w") as all_bed:
+            voter = SiteVoter(Predict(chrom, None), vcf_out, score_out, options, sample)
+            logging.info("Predicting " + chrom)
+
+            def feed(res):
+                classes, probs = hot.fetch_predictions(res)
+                voter.feed_batch([ln.label() for ln in res.lines], classes, probs)
+
+            prev = None
+            for part, (start, end) in enumerate(tasks[chrom]):
+                try:
+                    cur = hot.collect(chrom, start, end, rescan=False)
+                except Exception:                                 # run_collection.py:44-47: the window yields nothing
+                    _t, value, trace = sys.exc_info()
+                    logging.error("%s:%s-%s [ERROR]: %s. Locate At: %s", chrom, start, end, value, traceback.extract_tb(trace))
+                    cur = hot.empty(chrom, start, end)
+                text = "".join(ln.text() for ln in cur.lines)
+                with open(os.path.join(seg_dir, "%s.segments.%d.bed" % (chrom, part)), "w") as f:
+                    f.write(text)
+                all_bed.write(text)
+                if prev is not None:
+                    feed(prev)
+                prev = hot.launch(cur)
+            if prev is not None:
+                feed(prev)
+            voter.finish()
 
 
 def _scores_of(pred_dir, chroms, options):

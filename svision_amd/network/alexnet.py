@@ -78,12 +78,12 @@ class AlexNet(torch.nn.Module):
             self.register_buffer(f"{name}_w", wt.to(device))
             self.register_buffer(f"{name}_b", torch.from_numpy(np.asarray(params[f"{name}/biases"], np.float32).copy()).to(device))
         for name in ("conv2", "conv3", "conv4", "conv5"):          # checkpoint-layout weights for svx_conv2d_same
-            self.register_buffer(f"{name}_hwio", torch.from_numpy(np.ascontiguousarray(params[f"{name}/weights"], np.float32)).to(device))
+            self.register_buffer(f"{name}_hwio", torch.from_numpy(np.array(params[f"{name}/weights"], np.float32, copy=True)).to(device))
         # sparse first layer (svx_encode_conv1): checkpoint-layout weights + the constant response of
         # the all-background image, base[k] = bias[k] - sum mean[ch] * w[..., ch, k] (float64 on the host)
         w1 = np.asarray(params["conv1/weights"], np.float64)
         base = np.asarray(params["conv1/biases"], np.float64) - np.einsum("hwck,c->k", w1, np.asarray(mean, np.float64))
-        self.register_buffer("conv1_hwio", torch.from_numpy(np.ascontiguousarray(params["conv1/weights"], np.float32)).to(device))
+        self.register_buffer("conv1_hwio", torch.from_numpy(np.array(params["conv1/weights"], np.float32, copy=True)).to(device))
         self.register_buffer("conv1_base", torch.from_numpy(base.astype(np.float32)).to(device))
         for name, nin, nout in _FCS:
             w = np.asarray(params[f"{name}/weights"], np.float32)

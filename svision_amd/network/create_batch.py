@@ -64,6 +64,15 @@ class BatchGenerator:
     def reset_pointer(self):
         self.pointer = 0
 
+    def next_records(self, batch_size):
+        """-> (records int32 device tensor [B,12], labels): the packed form of the next batch, for the
+        classifier that fuses encoding and the first CNN layer (svx_encode_conv1)."""
+        if self._d_records is None:
+            self._d_records = torch.from_numpy(self.records).to(self.device)
+        lo = self.pointer
+        self.pointer += batch_size
+        return self._d_records[lo:lo + batch_size], self.labels[lo:lo + batch_size]
+
     def next_labels(self, batch_size):
         """Advance the pointer without rasterising (labels only)."""
         lo = self.pointer

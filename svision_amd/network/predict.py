@@ -16,21 +16,30 @@ _TYPE_NAMES = {"0": "DEL", "1": "INS", "2": "INV", "3": "DUP", "4": "tDUP"}
 _MODEL_CACHE = {}
 
 
-def load_classifier(model_path, device="cuda"):
-    """-> callable(images NCHW device tensor) -> (logits, argmax, softmax) numpy arrays."""
-    import torch
+def load_network(model_path, device="cuda"):
     from .alexnet import AlexNet
     from .tf_checkpoint import read_checkpoint
     key = (model_path, str(device))
     if key not in _MODEL_CACHE:
         _MODEL_CACHE[key] = AlexNet(read_checkpoint(model_path), device=device)
-    net = _MODEL_CACHE[key]
+    return _MODEL_CACHE[key]
 
-    def classify(images):
-        logits, cls, prob = net.predict(images)
-        packed = torch.cat([logits, prob, cls.to(logits.dtype).unsqueeze(1)], dim=1).cpu().numpy()   # one D2H copy
-        return packed[:, :5], packed[:, 10].astype(np.int64), packed[:, 5:10]
-    return classify
+
+class RecordClassifier:
+    """callable(records int32 device tensor [B,12]) -> (logits, argmax, softmax) numpy arrays.  Encoding is fused
+    into the first layer (svx_encode_conv1): the images of create_batch.py:103-152 are never materialised."""
+    from_records = True
+
+    def __init__(self, net):
+        self.net = net
+
+    def __call__(self, records):
+        packed = self.net.predict_records_packed(records).cpu().numpy()          # one D2H copy per batch
+        return packed[:, 6:11], packed[:, 5].astype(np.int64), packed[:, :5]
+
+
+def load_classifier(model_path, device="cuda"):
+    return RecordClassifier(load_network(model_path, device))
 
 
 class Predict:
@@ -74,7 +83,9 @@ class Predict:
             voter = SiteVoter(self, vcf_out, score_out, options, sample)
             logging.info("Predicting " + self.chrom)
             for _ in range(n_batches):
-                if getattr(classifier, "needs_images", True):
+                if getattr(classifier, "from_records", False):
+                    images, labels = gen.next_records(batch_size)
+                elif getattr(classifier, "needs_images", True):
                     images, labels = gen.next_batch(batch_size)
                 else:                                                        # predictions injected by a test
                     images, labels = None, gen.next_labels(batch_size)

@@ -139,6 +139,12 @@ class HotPath:
         res.packed = None
         return res
 
+    def empty(self, chrom, start, end):
+        res = WindowResult()
+        res.chrom, res.start, res.end, res.lines, res.n_images, res.packed = chrom, start, end, [], 0, None
+        res.records = np.empty((0, 12), np.int32)
+        return res
+
     def launch(self, res):
         """Enqueue encode + CNN for the window's records; returns immediately."""
         n = res.n_images

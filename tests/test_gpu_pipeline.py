@@ -41,12 +41,14 @@ def test_classifier_from_checkpoint_matches_cpu_checker(checkpoint, tmp_path):
     bed = tmp_path / "chrB.bed"
     bed.write_text(case["chroms"]["chrB"]["tsv"])
     gen = BatchGenerator(str(bed), nb_classes=5, batch_size=64, layout="NCHW")
-    classify = load_classifier(prefix, device="cuda:0")
+    classify = load_classifier(prefix, device="cuda:0")           # records -> (logits, class, softmax), sparse first layer
     checker = AlexNet(params, device="cpu")                       # plain PyTorch fp32 on the host
     for _ in range(gen.data_size // 64):
         lo = gen.pointer
-        images, _labels = gen.next_batch(64)
-        _logits, cls, prob = classify(images)
+        records, _labels = gen.next_records(64)
+        _logits, cls, prob = classify(records)
+        gen.pointer = lo
+        images, _labels = gen.next_batch(64)                      # the dense image path of the BatchGenerator API
         want_img = encode_ref.encode_records(gen.records[lo:lo + 64])            # oracle rasteriser
         assert np.array_equal(images.cpu().numpy(), want_img.transpose(0, 3, 1, 2))
         _l, wcls, wprob = checker.predict(torch.from_numpy(np.ascontiguousarray(want_img.transpose(0, 3, 1, 2))))
@@ -121,3 +123,28 @@ def test_cli_hash_mode_on_device(checkpoint, tmp_path):
     with open(os.path.join(helpers.GOLDEN, "hash_collect.expected.json")) as f:
         want = [w for w in json.load(f)["windows"] if w["hash"]][0]
     assert open(os.path.join(out, "segments", "chrH.segments.all.bed")).read() == want["tsv"]
+
+
+def test_streaming_cli_equals_file_based_cli(checkpoint, tmp_path):
+    """The device CLI (windows streamed, no TSV round trip) writes the same segment files, per-chromosome VCF bodies,
+    scores and merged VCF as the file-based flow (run_detect -> cat -> Predict.run) with the same network."""
+    from svision_amd.io import bam
+    from svision_amd.network.predict import load_classifier
+    prefix, _params = checkpoint
+    fasta = helpers.load_golden_fasta()
+    fa = str(tmp_path / "genome.fa")
+    bam.write_fasta(fa, {n: fasta._seq[n] for n in fasta.references})
+    outs = {}
+    for kind in ("stream", "files"):
+        out = str(tmp_path / kind)
+        opts = cli.parse_arguments(["-o", out, "-b", os.path.join(helpers.GOLDEN, "collect_small.bam"), "-m", prefix, "-g", fa,
+                                    "-n", "HGtest", "-s", "3", "--window_size", "150000", "--batch_size", "64", "--debug"])
+        merged = cli.run(opts, classifier=None if kind == "stream" else load_classifier(prefix, device="cuda:0"))
+        files = {"merged": open(merged).read()}
+        for sub in ("segments", "predict_results"):
+            for fn in sorted(os.listdir(os.path.join(out, sub))):
+                files[sub + "/" + fn] = open(os.path.join(out, sub, fn)).read()
+        outs[kind] = files
+    assert outs["stream"].keys() == outs["files"].keys()
+    for k in outs["stream"]:
+        assert outs["stream"][k] == outs["files"][k], k
