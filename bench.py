@@ -77,7 +77,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank, world = sdist.init_from_env()
+    # order matters for robustness: device scan (HIP only), then fork the host helpers, then bring up RCCL
+    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -89,6 +90,7 @@ def main():
     sample = Sample.from_table(table, bam.Fasta(sequences=genome), opts.min_sv_size, device=dev)
     net = AlexNet(random_weights(0), device=dev)
     hot = PooledHotPath(sample, opts, net, device=dev, n_workers=args.workers, n_streams=args.streams, max_inflight=args.inflight)
+    rank, world = sdist.init_from_env()
     windows = []
     pos = 0
     while pos < args.contig_len:

@@ -5,7 +5,7 @@
 // inflated block-parallel (BGZF blocks are independent gzip members; zlib raw inflate on a thread pool),
 // record offsets are chained once, and the fixed fields / CIGAR words / names / 4-bit sequences are
 // scattered in parallel into caller-owned arrays that go to the GPU unchanged (svx_cigar_scan input).
-// SAMv1 section 4 layouts; CIGARs with more than 65535 operations (CG tag) are not supported.
+// SAMv1 section 4 layouts, including CIGARs with more than 65535 operations (CG:B,I tag).
 #include <zlib.h>
 
 #include <algorithm>
@@ -30,6 +30,7 @@ struct Bam {
     std::vector<int32_t> ref_lens;
     std::vector<uint64_t> rec_off;         // offset of each record's block_size field
     std::vector<uint64_t> cig_off;         // CSR over CIGAR words, n_rec + 1
+    std::vector<uint64_t> cig_src;         // byte offset of each record's CIGAR words (record body or CG:B,I tag)
     std::vector<int32_t> name_id;
     std::vector<uint32_t> name_first;      // record index of the first occurrence of every distinct QNAME
     uint64_t names_bytes = 0;
@@ -38,6 +39,34 @@ struct Bam {
 
 inline uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
 inline uint16_t rd16(const uint8_t* p) { uint16_t v; memcpy(&v, p, 2); return v; }
+
+// CIGARs with more than 65535 operations live in the CG:B,I tag; the record then carries "<l_seq>S<ref_len>N"
+// (SAMv1 4.2.2).  Returns the byte offset of the tag's uint32 array and its length, or 0.
+uint64_t find_long_cigar(const std::vector<uint8_t>& r, uint64_t aux, uint64_t end, uint32_t* count)
+{
+    while (aux + 3 <= end) {
+        const uint8_t t0 = r[aux], t1 = r[aux + 1], ty = r[aux + 2];
+        uint64_t p = aux + 3;
+        switch (ty) {
+        case 'A': case 'c': case 'C': p += 1; break;
+        case 's': case 'S': p += 2; break;
+        case 'i': case 'I': case 'f': p += 4; break;
+        case 'Z': case 'H': while (p < end && r[p]) ++p; ++p; break;
+        case 'B': {
+            if (p + 5 > end) return 0;
+            const uint8_t sub = r[p];
+            const uint32_t n = rd32(&r[p + 1]);
+            const uint32_t width = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+            if (t0 == 'C' && t1 == 'G' && sub == 'I') { *count = n; return p + 5; }
+            p += 5 + (uint64_t)n * width;
+            break;
+        }
+        default: return 0;
+        }
+        aux = p;
+    }
+    return 0;
+}
 
 template <class F>
 void parallel_for(size_t n, int threads, F fn)
@@ -140,7 +169,19 @@ void* svx_bam_open(const char* path, int threads)
         b->rec_off.push_back(p);
         const uint8_t* rec = &r[p + 4];
         const uint32_t l_name = rec[8];
-        const uint32_t n_cig = rd16(rec + 12);
+        uint32_t n_cig = rd16(rec + 12);
+        uint64_t src = p + 4 + 32 + l_name;
+        if (n_cig == 2) {                                     // possible CG-tag placeholder
+            const uint32_t w0 = rd32(&r[src]), w1 = rd32(&r[src + 4]);
+            const uint32_t l_seq = rd32(rec + 16);
+            if ((w0 & 15) == 4 && (w0 >> 4) == l_seq && (w1 & 15) == 3) {
+                uint32_t cnt = 0;
+                const uint64_t aux = src + 8 + (l_seq + 1) / 2 + l_seq;
+                const uint64_t at = find_long_cigar(r, aux, p + 4 + bs, &cnt);
+                if (at) { src = at; n_cig = cnt; }
+            }
+        }
+        b->cig_src.push_back(src);
         b->cig_off.push_back(b->cig_off.back() + n_cig);
         std::string_view nm(reinterpret_cast<const char*>(rec + 32), l_name ? l_name - 1 : 0);
         auto it = seen.find(nm);
@@ -184,13 +225,14 @@ void svx_bam_export(void* h, int threads, int32_t* tid, int32_t* pos, uint16_t* 
             tid[i] = (int32_t)rd32(rec); pos[i] = (int32_t)rd32(rec + 4);
             const uint32_t l_name = rec[8];
             mapq[i] = rec[9];
-            const uint32_t n_cig = rd16(rec + 12);
+            const uint32_t n_cig_field = rd16(rec + 12);
+            const uint64_t n_cig = b->cig_off[i + 1] - b->cig_off[i];
             flag[i] = rd16(rec + 14);
             l_seq[i] = (int32_t)rd32(rec + 16);
             name_id[i] = b->name_id[i];
             cig_off[i] = (int64_t)b->cig_off[i];
-            memcpy(cigar + b->cig_off[i], rec + 32 + l_name, 4ull * n_cig);
-            if (seq_off) seq_off[i] = (int64_t)(b->rec_off[i] + 4 + 32 + l_name + 4ull * n_cig);
+            memcpy(cigar + b->cig_off[i], &r[b->cig_src[i]], 4ull * n_cig);
+            if (seq_off) seq_off[i] = (int64_t)(b->rec_off[i] + 4 + 32 + l_name + 4ull * n_cig_field);
         }
     });
     cig_off[n] = (int64_t)b->cig_off[n];

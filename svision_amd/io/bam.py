@@ -10,7 +10,7 @@ objects are never built.
 
 Follows the SAM/BAM specification (SAMv1 section 4): BGZF blocks are gzip members with a
 ``BC`` extra field; BAM records are little-endian.  CIGARs longer than 65535
-ops (``CG`` tag) are not supported yet.
+ops (``CG:B,I`` tag) are handled by the native decoder and the writer.
 """
 import struct
 import zlib
@@ -314,14 +314,19 @@ def write_bam(path, table, with_seq=True, level=1):
         name = table.names[table.name_id[i]].encode() + b"\x00"
         l_seq = int(table.l_seq[i]) if with_seq else 0
         pos = int(table.pos[i])
+        aux = b""
+        cig_field = cw.astype("<u4").tobytes()
+        if cw.size > 65535:                                   # SAMv1 4.2.2: real CIGAR in CG:B,I, placeholder kSmN in the record
+            aux = b"CGBI" + struct.pack("<I", cw.size) + cig_field
+            cig_field = struct.pack("<II", (l_seq << 4) | 4, (span << 4) | 3)
         body = struct.pack("<iiBBHHHIiii", int(table.tid[i]), pos, len(name), int(table.mapq[i]),
-                           _reg2bin(pos, pos + max(span, 1)), cw.size, int(table.flag[i]), l_seq, -1, -1, 0)
+                           _reg2bin(pos, pos + max(span, 1)), len(cig_field) // 4, int(table.flag[i]), l_seq, -1, -1, 0)
         if l_seq and table.seq_packed is not None:
             o = int(table.seq_off[i])
             seq_bytes = bytes(table.seq_packed[o:o + (l_seq + 1) // 2])
         else:
             seq_bytes = b"\xff" * ((l_seq + 1) // 2)       # N's
-        body += name + cw.astype("<u4").tobytes() + seq_bytes + b"\xff" * l_seq
+        body += name + cig_field + seq_bytes + b"\xff" * l_seq + aux
         parts.append(struct.pack("<i", len(body)) + body)
     with open(path, "wb") as f:
         f.write(bgzf_compress(b"".join(parts), level))

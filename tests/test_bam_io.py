@@ -72,3 +72,20 @@ def test_decoder_error_paths(tmp_path):
     t = bam.AlignmentTable(["c"], [1000], [], [], [], [], [], [], [], [], [0])
     bam.write_bam(str(empty), t)
     assert len(bam.read_bam(str(empty))) == 0
+
+
+def test_long_cigar_cg_tag(tmp_path):
+    """> 65535 CIGAR operations (assembly-vs-reference contigs): CG:B,I tag round trip."""
+    n_ops = 70_001
+    ops = np.tile(np.array([7, 8, 7, 1, 7, 2], np.uint32), n_ops // 6 + 1)[:n_ops]
+    lens = (np.arange(n_ops, dtype=np.uint32) % 9) + 1
+    words = (lens << 4) | ops
+    qlen = int(lens[np.isin(ops, (7, 8, 1))].sum())
+    cig = np.concatenate([words, np.array([(5 << 4) | 7], np.uint32)])
+    t = bam.AlignmentTable(["ctg"], [5_000_000], [0, 0], [100, 200], [0, 0], [60, 60], [qlen, 5], [0, 1], ["long", "short"],
+                           cig, [0, n_ops, n_ops + 1])
+    path = str(tmp_path / "cg.bam")
+    bam.write_bam(path, t)
+    back = bam.read_bam(path)
+    assert back.cig_off.tolist() == [0, n_ops, n_ops + 1]
+    assert np.array_equal(back.cigar, cig) and back.l_seq.tolist() == [qlen, 5] and back.names == ["long", "short"]

@@ -88,3 +88,19 @@ def test_tasking_matches_reference_quirks():
     assert cli.build_tasks(o, refs, lens, ["chr1", "chr2"]) == {"chr1": [[0, 10_000_000], [10_000_000, 20_000_000], [20_000_000, 25_000_001]]}
     o = types.SimpleNamespace(chrom="chr2:100-5000", contig=False, window_size=10_000_000)
     assert cli.build_tasks(o, refs, lens, ["chr1", "chr2"]) == {"chr2": [[100, 5000]]}
+
+
+def test_shard_chromosomes_lpt():
+    from svision_amd import dist as sdist
+    chroms = ["chr1", "chr2", "chr3", "chr4", "chr5"]
+    lens = [248, 242, 198, 190, 181]
+    shards = sdist.shard_chromosomes(chroms, lens, 2)
+    assert sorted(c for s in shards for c in s) == sorted(chroms)
+    assert shards == [["chr1", "chr4", "chr5"], ["chr2", "chr3"]]           # LPT, task order kept inside a rank
+    loads = [sum(lens[chroms.index(c)] for c in s) for s in shards]
+    assert max(loads) - min(loads) <= max(lens)
+    assert sdist.shard_chromosomes(chroms, lens, 8)[5:] == [[], [], []]
+    assert sdist.exchange_score_range([]) == (None, None)
+    mx, mn = sdist.exchange_score_range([3.5, 1.25, 9.0])
+    assert (float(mx), float(mn)) == (9.0, 1.25)
+    assert sdist.gather_texts({"a": "x"}) == {"a": "x"}
