@@ -39,6 +39,10 @@ IMG_BYTES = 227 * 227 * 3 * 4 + 48            # 618,348 B written +
 CNN_FLOP = 1_440_662_592                      # FLOP per image
 HBM_PEAK = 8.0e12                             # MI355X_MICROARCH.md: HBM3E 8 TB/s
 F32_MFMA_PEAK = 157.3e12                      # MI355X_MICROARCH.md: FP32 matrix peak (f32-in MFMA)
+# HBM/fabric bytes per 64-image batch of the device stage, from PMC counters (rocprofv3 --pmc FETCH_SIZE and
+# --pmc WRITE_SIZE in separate passes, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md), summed over its
+# kernels: profiles/r01_pmc_traffic.md.  Offline measurement (counters cannot be read inside this process).
+PMC_TRAFFIC_PER_BATCH64 = 6.64e8
 CHR21 = 46_709_983
 
 
@@ -161,7 +165,10 @@ def main():
         "roofline": {"kernel": "device stage per batch of %d images: raster_kernel + AlexNet forward fp32 (MIOpen conv, hipBLASLt fc), "
                                "graph replays on %d streams" % (B, args.streams), "bound": "mfma",
                      "achieved": cnn_tflops, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
-                     "frac": cnn_tflops * 1e12 / F32_MFMA_PEAK, "traffic": None, "ms_per_batch": ms_batch,
+                     "frac": cnn_tflops * 1e12 / F32_MFMA_PEAK,
+                     "traffic": PMC_TRAFFIC_PER_BATCH64 * B / 64 if B == 64 else None,
+                     "traffic_unit": "bytes per batch (rocprofv3 PMC, profiles/r01_pmc_traffic.md; algorithmic minimum ~4.8e8: "
+                                     "227.6 MB weights + activations)", "ms_per_batch": ms_batch,
                      "device_busy_frac": dev_ms * 1e-3 / dt},
         "roofline_kernels": kernel_calibration(sample, net, dev, B),
     }
