@@ -115,9 +115,8 @@ void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w
     __syncthreads();
 
     const int fk = lane >> 5, fj = lane & 31;
-    // One slice: 24 fragment reads up front, then 16 MFMAs with the next slice's global loads and address
-    // arithmetic interleaved between them (an MFMA occupies the matrix pipe for 64 cycles but issues in 4, so
-    // a wave's own memory work hides under its own matrix work), then the LDS stores and one barrier.
+    // One slice: the next slice's global loads (no per-load address arithmetic) and the 24 fragment reads are
+    // issued up front, then 16 back-to-back MFMAs, then the LDS stores of the next slice and one barrier.
     auto compute_slice = [&](int buf, bool prefetch) {
         float fa[BK / 2], fb0[BK / 2], fb1[BK / 2];
 #pragma unroll
