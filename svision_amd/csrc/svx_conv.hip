@@ -21,15 +21,16 @@
 // below the LDS rate; the kernel is matrix-pipe bound.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/svx.h"
 
 namespace {
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-constexpr int BN = 64, BM = 128, THREADS = 256;
+constexpr int BN = 64, THREADS = 256;
 
-template <int KS, int BK>
+template <int KS, int BK, int BM>
 __global__ __launch_bounds__(THREADS, 2)
 void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
                        float* __restrict__ out, int nimg, int Cin, int Cout, int H, int W, int groups, int relu)
@@ -59,20 +60,23 @@ void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave & 1, wm = wave >> 1;
+    constexpr int MT = BM / 64;                    // 32-pixel MFMA tiles per wave (2 waves along m)
+    constexpr int WM = BM / 2;                     // pixels per wave
 
     // activation loader: one output pixel (column m) and k rows xk0, xk0+2, ..., xk0+14 per lane.  Addresses are
     // (uniform row base in SGPRs) + (one 32-bit lane offset): no per-load address arithmetic.
-    const int xm = tid & (BM - 1), xk0 = tid >> 7;
+    constexpr int XSTEP = THREADS / BM;            // k rows between two loads of a lane (2 or 4)
+    const int xm = tid & (BM - 1), xk0 = tid / BM;
     const long long m = (long long)m0 + xm;
     const bool m_ok = m < Mtot;
     const int b = m_ok ? (int)(m / HW) : 0;
     const int pix = m_ok ? (int)(m - (long long)b * HW) : 0;
     const int y = pix / W, x = pix - y * W;
     const unsigned tbase = (unsigned)((b * Cin + g * CinG + xk0) * HW);
-    constexpr int XR = BK / 2, WR = BK / 16;       // activation rows / weight float4s per lane and slice
+    constexpr int XR = BK / XSTEP, WR = BK / 16;   // activation rows / weight float4s per lane and slice
     const char* rowp[XR];
 #pragma unroll
-    for (int i = 0; i < XR; ++i) rowp[i] = reinterpret_cast<const char*>(in + (size_t)(2 * i) * HW);
+    for (int i = 0; i < XR; ++i) rowp[i] = reinterpret_cast<const char*>(in + (size_t)(XSTEP * i) * HW);
     // weight loader: k row wk, four consecutive output channels
     const int wk = tid >> 4, wn4 = (tid & 15) * 4;
     const unsigned wconst = (unsigned)(wk * Cout + g * CoutG + n0 + wn4);
@@ -80,9 +84,11 @@ void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w
     const int cblocks = CinG / BK;
     const int nk = KS * KS * cblocks;
 
-    v16f acc0, acc1;
+    v16f acc[MT];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
 
     float xr[XR];
     float4 wr[WR];
@@ -105,7 +111,7 @@ void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w
     };
     auto store_slice = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < XR; ++i) Xs[buf][xk0 + 2 * i][xm] = xr_ok ? xr[i] : 0.0f;
+        for (int i = 0; i < XR; ++i) Xs[buf][xk0 + XSTEP * i][xm] = xr_ok ? xr[i] : 0.0f;
 #pragma unroll
         for (int j = 0; j < WR; ++j) *reinterpret_cast<float4*>(&Ws[buf][wk + 16 * j][wn4]) = wr[j];
     };
@@ -118,19 +124,18 @@ void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w
     // One slice: the next slice's global loads (no per-load address arithmetic) and the 24 fragment reads are
     // issued up front, then 16 back-to-back MFMAs, then the LDS stores of the next slice and one barrier.
     auto compute_slice = [&](int buf, bool prefetch) {
-        float fa[BK / 2], fb0[BK / 2], fb1[BK / 2];
+        float fa[BK / 2], fb[MT][BK / 2];
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             fa[kk] = Ws[buf][2 * kk + fk][wn * 32 + fj];
-            fb0[kk] = Xs[buf][2 * kk + fk][wm * 64 + fj];
-            fb1[kk] = Xs[buf][2 * kk + fk][wm * 64 + 32 + fj];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) fb[t][kk] = Xs[buf][2 * kk + fk][wm * WM + t * 32 + fj];
         }
         if (prefetch) load_slice();
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk], fb0[kk], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk], fb1[kk], acc1, 0, 0, 0);
-        }
+        for (int kk = 0; kk < BK / 2; ++kk)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk], fb[t][kk], acc[t], 0, 0, 0);
     };
     for (int kt = 0; kt + 1 < nk; ++kt) {
         const int buf = kt & 1;
@@ -142,17 +147,16 @@ void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w
 
     // epilogue: D[row = channel][col = pixel]; lane holds col = lane & 31, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const long long mm = (long long)m0 + wm * 64 + t * 32 + fj;
+    for (int t = 0; t < MT; ++t) {
+        const long long mm = (long long)m0 + wm * WM + t * 32 + fj;
         if (mm >= Mtot) continue;
         const int bb = (int)(mm / HW);
         const int pp = (int)(mm - (long long)bb * HW);
         float* o = out + ((size_t)bb * Cout + (size_t)g * CoutG + n0 + wn * 32 + 4 * fk) * HW + pp;
-        const v16f& acc = t == 0 ? acc0 : acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int nl = (r & 3) + 8 * (r >> 2);
-            float v = acc[r];
+            float v = acc[t][r];
             if (bias) v += bias[g * CoutG + n0 + wn * 32 + 4 * fk + nl];
             if (relu) v = fmaxf(v, 0.0f);
             o[(size_t)nl * HW] = v;
@@ -172,15 +176,18 @@ extern "C" int svx_conv2d_same(const float* d_in, const float* d_w_hwio, const f
     if (cin_g % 16 || cout_g % BN || (ksize != 3 && ksize != 5)) return SVX_EINVAL;
     if ((reinterpret_cast<uintptr_t>(d_w_hwio) & 15u) || (cout % 4)) return SVX_EINVAL;
     const long long mtot = (long long)n * height * width;
-    const long long m_tiles = (mtot + BM - 1) / BM;
-    const long long total_tiles = m_tiles * groups * (cout_g / BN);
-    dim3 grid((unsigned)(8 * ((total_tiles + 7) / 8))), block(THREADS);
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define SVX_LAUNCH_CONV(KS_, BK_) hipLaunchKernelGGL((conv_igemm_kernel<KS_, BK_>), grid, block, 0, st, d_in, d_w_hwio, d_bias, \
+    // 64 x 128 tiles unless they leave the 256 CUs under two resident workgroups each (then 64 x 64: the partial last
+    // dispatch round of the big tiles costs more than the extra fragment reads of the small ones)
+    const long long tiles128 = ((mtot + 127) / 128) * groups * (cout_g / BN);
+    static const int force_bm = getenv("SVX_CONV_BM") ? atoi(getenv("SVX_CONV_BM")) : 0;
+    const int bm = force_bm ? force_bm : (tiles128 < 448 ? 64 : 128);
+    const long long total_tiles = ((mtot + bm - 1) / bm) * groups * (cout_g / BN);
+    dim3 grid((unsigned)(8 * ((total_tiles + 7) / 8))), block(THREADS);
+#define SVX_LAUNCH_CONV(KS_, BM_) hipLaunchKernelGGL((conv_igemm_kernel<KS_, 16, BM_>), grid, block, 0, st, d_in, d_w_hwio, d_bias, \
         d_out, (int)n, (int)cin, (int)cout, (int)height, (int)width, (int)groups, relu)
-    const bool k32 = false;   // 32-deep slices measured slower on MI355X (144 VGPRs, spills): kept for experiments only
-    if (ksize == 3) { if (k32) SVX_LAUNCH_CONV(3, 32); else SVX_LAUNCH_CONV(3, 16); }
-    else            { if (k32) SVX_LAUNCH_CONV(5, 32); else SVX_LAUNCH_CONV(5, 16); }
+    if (ksize == 3) { if (bm == 64) SVX_LAUNCH_CONV(3, 64); else SVX_LAUNCH_CONV(3, 128); }
+    else            { if (bm == 64) SVX_LAUNCH_CONV(5, 64); else SVX_LAUNCH_CONV(5, 128); }
 #undef SVX_LAUNCH_CONV
     return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
 }
