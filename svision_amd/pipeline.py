@@ -63,13 +63,11 @@ class DeviceStage:
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
         self.use_graph = use_graph
         self.slots = []
-        self.packed12 = {}
         for s in self.streams:
             rec = torch.zeros((batch, 12), dtype=torch.int32, device=self.device)
             rec[:] = torch.tensor(_PAD_REC, dtype=torch.int32, device=self.device)
             img = torch.empty((batch, 3, 227, 227), dtype=torch.float32, device=self.device)
-            out = torch.empty((batch, 6), dtype=torch.float32, device=self.device)
-            self.packed12[id(out)] = torch.empty((batch, 12), dtype=torch.float32, device=self.device)
+            out = torch.empty((batch, 12), dtype=torch.float32, device=self.device)   # softmax[5], class, logits[5], 0
             graph = None
             with torch.cuda.stream(s):
                 for _ in range(2):                           # warm MIOpen / hipBLASLt before capture
@@ -83,14 +81,13 @@ class DeviceStage:
 
     def _body(self, rec, img, out):
         if self.sparse_first_layer:
-            self.net.predict_records_packed(rec, out=self.packed12[id(out)])   # softmax[5], class, logits[5]
-            out.copy_(self.packed12[id(out)][:, :6])
+            self.net.predict_records_packed(rec, out=out)      # svx_encode_conv1 ... svx_fc8_softmax: no image tensor
             return
-        else:
-            kernels.rasterize(rec, layout="NCHW", out=img)
-            _logits, cls, prob = self.net.predict(img)
+        kernels.rasterize(rec, layout="NCHW", out=img)          # dense-image path (BatchGenerator API), for comparison
+        logits, cls, prob = self.net.predict(img)
         out[:, :5] = prob
         out[:, 5] = cls.to(torch.float32)
+        out[:, 6:11] = logits
 
     def run(self, d_rec, out):
         """d_rec: int32 [n_padded,12] on the device (n_padded % batch == 0); out: float32 [n_padded,6].
@@ -111,7 +108,7 @@ class DeviceStage:
                     graph.replay()
                 else:
                     self._body(rec, img, o)
-                out[lo:lo + b].copy_(o, non_blocking=True)
+                out[lo:lo + b].copy_(o[:, :6], non_blocking=True)
         for k in used:
             main.wait_stream(self.streams[k])
         return out
