@@ -151,6 +151,9 @@ int svx_conv2d_same(const float* d_in, const float* d_w_hwio, const float* d_bia
  *                      ref_lens [n_refs], and (if not NULL) seq_off = byte offset of each record's 4-bit SEQ
  *                      inside the decompressed file exposed by svx_bam_raw() */
 void*          svx_bam_open(const char* path, int threads);
+/* only the records between two BGZF virtual offsets taken from the .bai index (one chromosome = one rank's shard;
+ * replaces AlignmentFile.fetch(chrom, ...) random access, run_collection.py:26); voff_end <= voff_beg: header only */
+void*          svx_bam_open_range(const char* path, int threads, uint64_t voff_beg, uint64_t voff_end);
 const char*    svx_bam_error(void);
 void           svx_bam_sizes(void* handle, uint64_t* sizes);
 void           svx_bam_export(void* handle, int threads, int32_t* tid, int32_t* pos, uint16_t* flag, uint8_t* mapq,

@@ -104,6 +104,22 @@ def build_tasks(options, references, lengths, fasta_refs):
     return tasks
 
 
+def load_rank_table(options, rank, ws):
+    """The alignment records rank ``rank`` of ``ws`` needs.  With a ``.bai`` next to the BAM and more than one rank, a
+    rank is a set of chromosomes: the header gives the task list, the index gives the byte range holding this rank's
+    records, and only that range is read and inflated (upstream: AlignmentFile.fetch(chrom), run_collection.py:26)."""
+    index = next((c for c in (options.bam_path + ".bai", os.path.splitext(options.bam_path)[0] + ".bai") if os.path.exists(c)), None)
+    if ws == 1 or index is None:
+        return read_bam(options.bam_path, with_seq=bool(options.hash))
+    head = read_bam(options.bam_path, tids=[], index=index)
+    tasks = build_tasks(options, head.references, head.lengths, Fasta(options.genome).references)
+    length_of = dict(zip(head.references, head.lengths))
+    shard = sdist.shard_chromosomes(list(tasks), [length_of.get(c, 1) for c in tasks], ws)[rank]
+    table = read_bam(options.bam_path, with_seq=bool(options.hash), tids=[head.references.index(c) for c in shard], index=index)
+    logging.info("rank %d/%d: %d records of %s decoded through %s", rank, ws, len(table), ",".join(shard) or "-", index)
+    return table
+
+
 def run(options, sample=None, classifier=None):
     """Whole pipeline; returns the merged VCF path (rank 0) or None."""
     from . import sample as _sample
@@ -130,7 +146,7 @@ def run(options, sample=None, classifier=None):
     logging.info("INPUT BAM: %s", os.path.abspath(options.bam_path))
 
     if sample is None:
-        table = read_bam(options.bam_path, with_seq=bool(options.hash))
+        table = load_rank_table(options, rank, ws)
         if table.sort_order != "coordinate":
             logging.error("This is not a coordinate sorted BAM file")
             raise SystemExit(1)

@@ -81,13 +81,15 @@ void parallel_for(size_t n, int threads, F fn)
     for (auto& th : pool) th.join();
 }
 
-bool inflate_file(const std::vector<uint8_t>& file, int threads, std::vector<uint8_t>& out, std::string& err)
+// Inflate the BGZF blocks of file[from, to) (block-aligned) into `out`; max_blocks limits the number of blocks (0 = all).
+bool inflate_file(const std::vector<uint8_t>& file, int threads, std::vector<uint8_t>& out, std::string& err,
+                  uint64_t from = 0, uint64_t to = ~0ull, size_t max_blocks = 0)
 {
     struct Blk { uint64_t src, csize, dst; uint32_t isize; };
     std::vector<Blk> blocks;
-    uint64_t p = 0, total = 0;
-    const uint64_t n = file.size();
-    while (p + 18 <= n) {
+    uint64_t p = from, total = 0;
+    const uint64_t n = std::min<uint64_t>(file.size(), to);
+    while (p + 18 <= n && (max_blocks == 0 || blocks.size() < max_blocks)) {
         if (!(file[p] == 0x1f && file[p + 1] == 0x8b && file[p + 2] == 8 && (file[p + 3] & 4))) { err = "not a BGZF block"; return false; }
         const uint32_t xlen = rd16(&file[p + 10]);
         uint32_t bsize = 0;
@@ -133,20 +135,112 @@ extern "C" {
 // Decode a BAM file.  Returns an opaque handle (NULL on failure; message via svx_bam_error(NULL)).
 static thread_local std::string g_bam_error;
 
-void* svx_bam_open(const char* path, int threads)
+static bool read_bytes(const char* path, uint64_t from, uint64_t to, std::vector<uint8_t>& buf)
+{
+    FILE* f = fopen(path, "rb");
+    if (!f) { g_bam_error = std::string("cannot open ") + path; return false; }
+    fseek(f, 0, SEEK_END);
+    const uint64_t sz = (uint64_t)ftell(f);
+    to = std::min(to, sz);
+    from = std::min(from, to);
+    buf.resize(to - from);
+    fseek(f, (long)from, SEEK_SET);
+    const bool ok = buf.empty() || fread(buf.data(), 1, buf.size(), f) == buf.size();
+    fclose(f);
+    if (!ok) g_bam_error = "short read";
+    return ok;
+}
+
+static void* bam_open_impl(const char* path, int threads, bool ranged, uint64_t voff_beg, uint64_t voff_end)
 {
     g_bam_error.clear();
-    FILE* f = fopen(path, "rb");
-    if (!f) { g_bam_error = std::string("cannot open ") + path; return nullptr; }
-    fseek(f, 0, SEEK_END);
-    const long sz = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    std::vector<uint8_t> file((size_t)sz);
-    if (sz > 0 && fread(file.data(), 1, (size_t)sz, f) != (size_t)sz) { fclose(f); g_bam_error = "short read"; return nullptr; }
-    fclose(f);
     if (threads <= 0) threads = (int)std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
     Bam* b = new Bam();
-    if (!inflate_file(file, threads, b->raw, b->error)) { g_bam_error = b->error; delete b; return nullptr; }
+    std::vector<uint8_t> file;
+    uint64_t rec_begin = 0, rec_end = ~0ull;      // record byte range inside b->raw (ranged mode)
+    if (!ranged) {
+        if (!read_bytes(path, 0, ~0ull, file)) { delete b; return nullptr; }
+        if (!inflate_file(file, threads, b->raw, b->error)) { g_bam_error = b->error; delete b; return nullptr; }
+    } else {
+        // header: inflate leading blocks until the reference dictionary is complete (grow the window if needed)
+        std::vector<uint8_t> head;
+        for (uint64_t want = 1 << 20;; want *= 4) {
+            if (!read_bytes(path, 0, want, file)) { delete b; return nullptr; }
+            // drop a trailing partial block: keep only whole blocks
+            head.clear();
+            std::string err;
+            uint64_t p = 0;
+            while (p + 18 <= file.size()) {
+                if (!(file[p] == 0x1f && file[p + 1] == 0x8b)) break;
+                const uint32_t xlen = rd16(&file[p + 10]);
+                if (p + 12 + xlen > file.size()) break;
+                uint32_t bsize = 0;
+                for (uint64_t q = p + 12; q + 4 <= p + 12 + xlen;) {
+                    const uint32_t slen = rd16(&file[q + 2]);
+                    if (file[q] == 'B' && file[q + 1] == 'C') bsize = rd16(&file[q + 4]);
+                    q += 4 + slen;
+                }
+                if (!bsize || p + bsize + 1 > file.size()) break;
+                p += bsize + 1;
+            }
+            if (!inflate_file(file, 1, head, err, 0, p)) { g_bam_error = err; delete b; return nullptr; }
+            bool complete = false;
+            if (head.size() >= 12 && memcmp(head.data(), "BAM\1", 4) == 0) {
+                uint64_t q = 8 + rd32(&head[4]);
+                if (q + 4 <= head.size()) {
+                    const uint32_t n_ref = rd32(&head[q]); q += 4;
+                    uint32_t i = 0;
+                    for (; i < n_ref && q + 4 <= head.size(); ++i) {
+                        const uint32_t l_name = rd32(&head[q]);
+                        if (q + 8 + l_name > head.size()) break;
+                        q += 8 + l_name;
+                    }
+                    complete = i == n_ref;
+                }
+            } else if (head.size() >= 4) { g_bam_error = "not a BAM file"; delete b; return nullptr; }
+            if (complete || want > file.size() * 2 + (1 << 20)) break;     // whole file read already
+        }
+        // records: the compressed range [coffset(voff_beg), block after coffset(voff_end)]
+        std::vector<uint8_t> body;
+        if (voff_end > voff_beg) {
+            const uint64_t c0 = voff_beg >> 16, c1 = voff_end >> 16;
+            if (!read_bytes(path, c0, c1 + 65536 + 26, file)) { delete b; return nullptr; }
+            std::string err;
+            // inflate whole blocks from c0 up to and including the block that starts at c1
+            uint64_t p = 0, stop = 0;
+            std::vector<uint64_t> starts;
+            while (p + 18 <= file.size()) {
+                if (!(file[p] == 0x1f && file[p + 1] == 0x8b)) break;
+                const uint32_t xlen = rd16(&file[p + 10]);
+                uint32_t bsize = 0;
+                for (uint64_t q = p + 12; q + 4 <= p + 12 + xlen && q + 6 <= file.size();) {
+                    const uint32_t slen = rd16(&file[q + 2]);
+                    if (file[q] == 'B' && file[q + 1] == 'C') bsize = rd16(&file[q + 4]);
+                    q += 4 + slen;
+                }
+                if (!bsize || p + bsize + 1 > file.size()) break;
+                starts.push_back(p);
+                p += bsize + 1;
+                stop = p;
+                if (starts.back() + c0 >= c1) break;
+            }
+            if (!inflate_file(file, threads, body, err, 0, stop)) { g_bam_error = err; delete b; return nullptr; }
+            // uncompressed offset of the last block = sum of the isizes before it
+            uint64_t last_u = 0;
+            for (size_t i = 0; i + 1 < starts.size(); ++i) {
+                const uint64_t end = (i + 1 < starts.size()) ? starts[i + 1] : stop;
+                last_u += rd32(&file[end - 4]);
+            }
+            rec_begin = voff_beg & 0xffff;
+            rec_end = (starts.empty() || starts.back() + c0 < c1) ? body.size() : last_u + (voff_end & 0xffff);
+        }
+        // stitch: header bytes followed by the record range so that the common parser below applies
+        uint64_t hdr_end = 8 + rd32(&head[4]);
+        const uint32_t n_ref = rd32(&head[hdr_end]); hdr_end += 4;
+        for (uint32_t i = 0; i < n_ref; ++i) hdr_end += 8 + rd32(&head[hdr_end]);
+        b->raw.assign(head.begin(), head.begin() + hdr_end);
+        if (!body.empty() && rec_end > rec_begin) b->raw.insert(b->raw.end(), body.begin() + rec_begin, body.begin() + std::min<uint64_t>(rec_end, body.size()));
+    }
     const std::vector<uint8_t>& r = b->raw;
     if (r.size() < 12 || memcmp(r.data(), "BAM\1", 4) != 0) { g_bam_error = "not a BAM file"; delete b; return nullptr; }
     uint64_t p = 4;
@@ -194,6 +288,15 @@ void* svx_bam_open(const char* path, int threads)
         p += 4 + bs;
     }
     return b;
+}
+
+void* svx_bam_open(const char* path, int threads) { return bam_open_impl(path, threads, false, 0, 0); }
+
+// Only the records between two BGZF virtual offsets (from the .bai index: one chromosome, one rank's shard);
+// the header / reference dictionary is always decoded.  voff_end <= voff_beg: header only.
+void* svx_bam_open_range(const char* path, int threads, uint64_t voff_beg, uint64_t voff_end)
+{
+    return bam_open_impl(path, threads, true, voff_beg, voff_end);
 }
 
 const char* svx_bam_error(void) { return g_bam_error.c_str(); }

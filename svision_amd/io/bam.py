@@ -55,9 +55,10 @@ def bgzf_decompress(data):
     return b"".join(out)
 
 
-def bgzf_compress(data, level=1):
-    """bytes -> BGZF blocks (+ EOF marker)."""
+def bgzf_compress(data, level=1, block_offsets=None):
+    """bytes -> BGZF blocks (+ EOF marker); ``block_offsets`` (a list) receives the file offset of every block."""
     out = []
+    at = 0
     for i in range(0, len(data), _MAX_BLOCK):
         chunk = data[i:i + _MAX_BLOCK]
         co = zlib.compressobj(level, zlib.DEFLATED, -15)
@@ -65,6 +66,11 @@ def bgzf_compress(data, level=1):
         bsize = len(cdata) + 25
         out.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize)
                    + cdata + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+        if block_offsets is not None:
+            block_offsets.append(at)
+        at += len(out[-1])
+    if block_offsets is not None:
+        block_offsets.append(at)                            # the EOF block
     out.append(_BGZF_EOF)
     return b"".join(out)
 
@@ -130,6 +136,22 @@ class AlignmentTable:
         codes[1::2] = raw & 15
         return _SEQ_LUT[codes[:n]].tobytes().decode()
 
+    def subset(self, rows):
+        """A new table holding only ``rows`` (ascending record indices); QNAME ids are re-assigned by first occurrence."""
+        rows = np.asarray(rows, np.int64)
+        n_cig = self.cig_off[rows + 1] - self.cig_off[rows]
+        new_off = np.zeros(rows.size + 1, np.int64)
+        new_off[1:] = np.cumsum(n_cig)
+        idx = np.repeat(self.cig_off[rows] - new_off[:-1], n_cig) + np.arange(int(new_off[-1]))
+        uniq, first, inv = np.unique(self.name_id[rows], return_index=True, return_inverse=True)
+        order = np.argsort(first, kind="stable")
+        rank = np.empty(order.size, np.int64)
+        rank[order] = np.arange(order.size)
+        return AlignmentTable(self.references, self.lengths, self.tid[rows], self.pos[rows], self.flag[rows], self.mapq[rows],
+                              self.l_seq[rows], rank[inv].astype(np.int32), [self.names[int(uniq[j])] for j in order],
+                              self.cigar[idx] if idx.size else np.empty(0, np.uint32), new_off, self.header_text,
+                              self.seq_packed, None if self.seq_off is None else self.seq_off[rows])
+
     def ids_of(self, names):
         """name_id values of the given QNAMEs (unknown names are ignored)."""
         if getattr(self, "_name_index", None) is None:
@@ -191,13 +213,54 @@ class AlignmentTable:
         return np.where(ends >= starts, n_pos_lt_end - n_end_le_start, 0)
 
 
-def read_bam(path, with_seq=False, threads=0):
-    """Decode a whole BAM file into an :class:`AlignmentTable` with the native multi-threaded decoder of
-    libsvx.so (svx_bam_*); ``with_seq``: keep the 4-bit read bases (needed by --hash only)."""
+def read_bai(path):
+    """.bai index -> per reference (first virtual offset, last virtual offset) of its records, or None when the
+    reference has none (SAMv1 5.2; the pseudo-bin 37450 carries metadata, not chunks)."""
+    with open(path, "rb") as f:
+        raw = f.read()
+    if raw[:4] != b"BAI\x01":
+        raise ValueError("%s is not a BAI index" % path)
+    n_ref = struct.unpack_from("<i", raw, 4)[0]
+    p = 8
+    out = []
+    for _ in range(n_ref):
+        n_bin = struct.unpack_from("<i", raw, p)[0]
+        p += 4
+        lo, hi = None, None
+        for _b in range(n_bin):
+            bin_id, n_chunk = struct.unpack_from("<Ii", raw, p)
+            p += 8
+            for _c in range(n_chunk):
+                beg, end = struct.unpack_from("<QQ", raw, p)
+                p += 16
+                if bin_id != 37450:
+                    lo = beg if lo is None else min(lo, beg)
+                    hi = end if hi is None else max(hi, end)
+        n_intv = struct.unpack_from("<i", raw, p)[0]
+        p += 4 + 8 * n_intv
+        out.append(None if lo is None else (lo, hi))
+    return out
+
+
+def read_bam(path, with_seq=False, threads=0, tids=None, index=None):
+    """Decode a BAM file into an :class:`AlignmentTable` with the native multi-threaded decoder of libsvx.so
+    (svx_bam_*); ``with_seq``: keep the 4-bit read bases (needed by --hash only).  ``tids`` (with a ``.bai`` next to
+    the file or given as ``index``): decode only the byte range holding those references' records -- one rank's
+    chromosome shard -- instead of the whole file."""
     import ctypes
     from .. import _lib
     lib = _lib.load()
-    h = lib.svx_bam_open(path.encode(), int(threads))
+    if tids is not None:
+        spans = read_bai(index or (path + ".bai"))
+        have = [spans[t] for t in tids if t < len(spans) and spans[t] is not None]
+        if have:
+            h = lib.svx_bam_open_range(path.encode(), int(threads), min(s[0] for s in have), max(s[1] for s in have))
+        else:
+            h = lib.svx_bam_open_range(path.encode(), int(threads), 0, 0)
+        keep_tids = set(int(t) for t in tids)
+    else:
+        h = lib.svx_bam_open(path.encode(), int(threads))
+        keep_tids = None
     if not h:
         msg = lib.svx_bam_error().decode()
         raise ValueError("%s: %s" % (path, msg))
@@ -222,8 +285,11 @@ def read_bam(path, with_seq=False, threads=0):
         lib.svx_bam_close(h)
     name_list = names.tobytes().decode().split("\n")[:-1] if nb else []
     refs = ref_names.tobytes().decode().split("\n")[:-1] if rb else []
-    return AlignmentTable(refs, [int(v) for v in ref_lens], tid, pos, flag, mapq, l_seq, name_id, name_list, cigar, cig_off,
-                          header.tobytes().decode(), seq_packed, seq_off)
+    table = AlignmentTable(refs, [int(v) for v in ref_lens], tid, pos, flag, mapq, l_seq, name_id, name_list, cigar, cig_off,
+                           header.tobytes().decode(), seq_packed, seq_off)
+    if keep_tids is not None and len(table) and not set(np.unique(table.tid).tolist()) <= keep_tids:
+        table = table.subset(np.flatnonzero(np.isin(table.tid, list(keep_tids))))     # references between two requested ones
+    return table
 
 
 def read_bam_python(path, with_seq=False):
@@ -299,7 +365,7 @@ def _reg2bin(beg, end):
     return 0
 
 
-def write_bam(path, table, with_seq=True, level=1):
+def write_bam(path, table, with_seq=True, level=1, index=False):
     """Encode an :class:`AlignmentTable` as a coordinate-sorted BAM (SEQ = N's for
     records with l_seq > 0, '*' otherwise; QUAL 0xFF; no tags)."""
     text = table.header_text or ("@HD\tVN:1.6\tSO:coordinate\n" + "".join(
@@ -328,8 +394,55 @@ def write_bam(path, table, with_seq=True, level=1):
             seq_bytes = b"\xff" * ((l_seq + 1) // 2)       # N's
         body += name + cig_field + seq_bytes + b"\xff" * l_seq + aux
         parts.append(struct.pack("<i", len(body)) + body)
+    block_coff = []
     with open(path, "wb") as f:
-        f.write(bgzf_compress(b"".join(parts), level))
+        f.write(bgzf_compress(b"".join(parts), level, block_coff))
+    if index:
+        _write_bai(path + ".bai", table, block_coff, [len(x) for x in parts])
+
+
+def _write_bai(path, table, block_coff, part_sizes):
+    """Standard .bai (binning + 16 kb linear index, SAMv1 5.2) for a file written by :func:`write_bam`."""
+    def voff(u):                                        # blocks are cut every _MAX_BLOCK uncompressed bytes
+        blk = u // _MAX_BLOCK
+        if blk >= len(block_coff) - 1:                  # end of data: start of the EOF block
+            return block_coff[-1] << 16
+        return (block_coff[blk] << 16) | (u - blk * _MAX_BLOCK)
+
+    n_head = len(part_sizes) - len(table)
+    u = sum(part_sizes[:n_head])
+    span_ops = np.array([1, 0, 1, 1, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0], np.int64)
+    bins = [dict() for _ in table.references]
+    linear = [dict() for _ in table.references]
+    for i in range(len(table)):
+        size = part_sizes[n_head + i]
+        t = int(table.tid[i])
+        if t >= 0:
+            cw = table.cigar[table.cig_off[i]:table.cig_off[i + 1]]
+            span = max(1, int(((cw >> 4).astype(np.int64) * span_ops[cw & 15]).sum()))
+            beg, end = int(table.pos[i]), int(table.pos[i]) + span
+            v0, v1 = voff(u), voff(u + size)
+            chunks = bins[t].setdefault(_reg2bin(beg, end), [])
+            if chunks and chunks[-1][1] == v0:
+                chunks[-1][1] = v1
+            else:
+                chunks.append([v0, v1])
+            for w in range(beg >> 14, ((end - 1) >> 14) + 1):
+                linear[t].setdefault(w, v0)
+        u += size
+    out = [b"BAI\x01", struct.pack("<i", len(table.references))]
+    for t in range(len(table.references)):
+        out.append(struct.pack("<i", len(bins[t])))
+        for b, chunks in sorted(bins[t].items()):
+            out.append(struct.pack("<Ii", b, len(chunks)) + b"".join(struct.pack("<QQ", c0, c1) for c0, c1 in chunks))
+        n_intv = (max(linear[t]) + 1) if linear[t] else 0
+        out.append(struct.pack("<i", n_intv))
+        last = 0
+        for w in range(n_intv):
+            last = linear[t].get(w, last)
+            out.append(struct.pack("<Q", last))
+    with open(path, "wb") as f:
+        f.write(b"".join(out))
 
 
 def pack_sequence(seq):

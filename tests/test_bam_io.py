@@ -89,3 +89,45 @@ def test_long_cigar_cg_tag(tmp_path):
     back = bam.read_bam(path)
     assert back.cig_off.tolist() == [0, n_ops, n_ops + 1]
     assert np.array_equal(back.cigar, cig) and back.l_seq.tolist() == [qlen, 5] and back.names == ["long", "short"]
+
+
+def test_indexed_shard_decoding(tmp_path):
+    """.bai-driven decoding of one rank's chromosome shard == the same rows of the whole-file decode."""
+    cfg = synth.SimConfig(contigs=[("c1", 600_000), ("c2", 400_000), ("c3", 300_000), ("c4", 40_000)], coverage=8, read_len_mean=4000,
+                          read_len_sd=600, sv_spacing=9000, sv_min_gap=5000, sv_max=1000, seed=12)
+    table, _genome, _ = synth.simulate(cfg, with_genome=False)
+    path = str(tmp_path / "idx.bam")
+    bam.write_bam(path, table, index=True)
+    whole = bam.read_bam(path)
+    spans = bam.read_bai(path + ".bai")
+    assert len(spans) == 4 and all(s is not None for s in spans)
+    for tids in ([0], [1], [3], [1, 2], [0, 3], [2]):
+        part = bam.read_bam(path, tids=tids)
+        want = whole.subset(np.flatnonzero(np.isin(whole.tid, tids)))
+        _same(part, want)
+        assert part.references == whole.references
+    empty = bam.read_bam(path, tids=[])
+    assert len(empty) == 0 and empty.references == whole.references
+
+
+def test_rank_tables_partition_the_file(tmp_path):
+    """cli.load_rank_table: with an index every rank decodes its own chromosomes only; together they are the whole file."""
+    from svision_amd import cli, dist as sdist
+    cfg = synth.SimConfig(contigs=[("c1", 300_000), ("c2", 200_000), ("c3", 150_000)], coverage=6, read_len_mean=4000,
+                          read_len_sd=600, sv_spacing=9000, sv_min_gap=5000, sv_max=1000, seed=4)
+    table, genome, _ = synth.simulate(cfg, with_genome=True)
+    path, fa = str(tmp_path / "r.bam"), str(tmp_path / "r.fa")
+    bam.write_bam(path, table, index=True)
+    bam.write_fasta(fa, genome)
+    opts = cli.parse_arguments(["-o", str(tmp_path), "-b", path, "-m", "/virtual/m.ckpt", "-g", fa, "-n", "x"])
+    whole = cli.load_rank_table(opts, 0, 1)
+    shards = sdist.shard_chromosomes(["c1", "c2", "c3"], [300_000, 200_000, 150_000], 2)
+    seen = 0
+    for rank in range(2):
+        part = cli.load_rank_table(opts, rank, 2)
+        tids = [whole.references.index(c) for c in shards[rank]]
+        _same(part, whole.subset(np.flatnonzero(np.isin(whole.tid, tids))))
+        seen += len(part)
+    assert seen == len(whole)
+    os.remove(path + ".bai")                                   # no index: every rank falls back to the whole file
+    assert len(cli.load_rank_table(opts, 1, 2)) == len(whole)
