@@ -131,3 +131,13 @@ def test_rank_tables_partition_the_file(tmp_path):
     assert seen == len(whole)
     os.remove(path + ".bai")                                   # no index: every rank falls back to the whole file
     assert len(cli.load_rank_table(opts, 1, 2)) == len(whole)
+
+
+def test_read_bai_on_the_reference_demo_index():
+    """Known answer from an htslib-written index: the .bai of the reference's demo BAM (supports/, data fixture) holds
+    3366 references with records on tid 8 only, in one run of blocks from file offset 37193 to 26266501."""
+    spans = bam.read_bai(os.path.join(os.path.dirname(__file__), "golden", "demo.bam.bai"))
+    assert len(spans) == 3366
+    assert [i for i, s in enumerate(spans) if s is not None] == [8]
+    lo, hi = spans[8]
+    assert (lo >> 16, lo & 0xFFFF, hi >> 16, hi & 0xFFFF) == (37193, 0, 26266501, 0)
