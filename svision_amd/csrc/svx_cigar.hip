@@ -6,17 +6,19 @@
 // batch of alignments whose packed BAM CIGAR words already sit in HBM.
 //
 // HBM-read bound: 4 B per CIGAR op, 16 B per alignment of CSR/start data,
-// 24 B written per long gap (rare).  Two data passes so that the output is
-// deterministic and sorted by (alignment, op) without a sort:
-//   1. count_kernel : sixteen lanes per alignment (four alignments in flight per
-//                     wave) stream the CIGAR once and reduce the per-alignment
-//                     spans, clip runs and the number of long gaps;
-//   2. scan_*       : exclusive scan of the counts -> CSR offsets d_gap_off;
-//   3. emit_kernel  : a block checks 256 gap counts at once; only alignments that own
-//                     a gap are re-read (a few % of the reads) by a whole wave;
-//                     wave-level prefix sums of read/ref advance
-//                     give readPos/refPos at every op, ballot-ranked stores
-//                     keep op order.
+// 24 B written per long gap (rare).  Four launches, no atomics, output deterministic and
+// sorted by (alignment, op) without a sort:
+//   1. count_kernel  : eight lanes per alignment (eight alignments in flight per wave)
+//                      stream the CIGAR once in 16-byte quads and reduce the per-alignment
+//                      spans, clip runs and the number of long gaps; every workgroup also
+//                      stores its gap and owner totals;
+//   2. scan_kernel   : exclusive prefix of the totals per tile of 256 alignments (one workgroup);
+//   3. offsets_kernel: a workgroup per tile scans its counts into the CSR offsets d_gap_off
+//                      and writes the alignments that own a gap (a few % of HiFi reads, most
+//                      ONT reads) into a work list, in alignment order;
+//   4. emit_kernel   : resident waves walk the work list, one wave per alignment, 256
+//                      CIGAR words per step: wave prefix sums of read/ref advance give
+//                      readPos/refPos at every op, ballot-ranked stores keep op order.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/svx.h"
@@ -25,9 +27,6 @@ namespace {
 
 constexpr int WAVE = 64;
 constexpr int BLOCK = 256;
-constexpr int WAVES_PER_BLOCK = BLOCK / WAVE;
-constexpr int SCAN_ITEMS = 8;                       // per thread in the offset scan
-constexpr int SCAN_TILE = BLOCK * SCAN_ITEMS;       // 2048 counts per block
 
 // op codes: M0 I1 D2 N3 S4 H5 P6 =7 X8.  Read-advancing per the reference walk:
 // M,I,N(!),S,H(as S),=,X ; ref-advancing: M,D,=,X (N does not move refPos).
@@ -37,12 +36,6 @@ __device__ inline bool span_ref(uint32_t op) { return (0x18Du >> op) & 1u; }   /
 __device__ inline bool in_query(uint32_t op) { return (0x1B3u >> op) & 1u; }   // 0,1,4,5,7,8
 __device__ inline bool is_clip(uint32_t op)  { return op == 4u || op == 5u; }
 
-__device__ inline long long wave_sum(long long v)
-{
-#pragma unroll
-    for (int o = WAVE / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
-}
 __device__ inline unsigned wave_sum_u(unsigned v)
 {
 #pragma unroll
@@ -50,194 +43,306 @@ __device__ inline unsigned wave_sum_u(unsigned v)
     return v;
 }
 
-constexpr int GROUP = 16;                           // lanes per alignment in the count pass
-constexpr int ALN_PER_BLOCK = BLOCK / GROUP;
+constexpr int TILE_SHIFT = 8;
+constexpr int TILE = 1 << TILE_SHIFT;               // alignments per workgroup of the count / offsets passes
+#ifndef SVX_CGROUP
+#define SVX_CGROUP 8
+#define SVX_CQUADS 2
+#endif
+constexpr int CGROUP = SVX_CGROUP;                  // lanes per alignment in the count pass
+constexpr int CQUADS = SVX_CQUADS;                  // 16-byte loads in flight per lane
+constexpr int ALN_PER_CBLOCK = BLOCK / CGROUP;      // alignments per workgroup of the count pass
+constexpr int CBLOCKS_PER_TILE = TILE / ALN_PER_CBLOCK;
 
-__device__ inline unsigned group_sum(unsigned v)
+__device__ inline unsigned cgroup_sum(unsigned v)
 {
 #pragma unroll
-    for (int o = GROUP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    for (int o = CGROUP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
     return v;
 }
-__device__ inline int group_min(int v)
+
+// one CIGAR word into the three per-alignment sums (32-bit modular; "0M" is inert)
+__device__ inline void tally(uint32_t w, int32_t min_sv, unsigned& ref_span, unsigned& qlen, unsigned& ngap)
 {
-#pragma unroll
-    for (int o = GROUP / 2; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, WAVE));
-    return v;
-}
-__device__ inline int group_max(int v)
-{
-#pragma unroll
-    for (int o = GROUP / 2; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, WAVE));
-    return v;
+    const uint32_t op = w & 15u, len = w >> 4;
+    ref_span += len & (0u - ((0x18Du >> op) & 1u));                 // M D N = X (reference_end)
+    qlen += len & (0u - ((0x1B3u >> op) & 1u));                     // M I S H = X
+    ngap += (uint32_t)((op - 1u) < 2u) & (uint32_t)((int32_t)len >= min_sv);
 }
 
 // Count pass.  HiFi CIGARs are 30-300 ops: a whole wave per alignment leaves most lanes idle and the
-// kernel latency bound (offset load -> CIGAR load -> store, one alignment in flight per wave).  Sixteen
-// lanes per alignment keep four alignments in flight per wave; sums are 32-bit modular (identical to the
-// truncated 64-bit sums of the restatement).  Clip runs: every lane tracks the first / last non-clip op
-// index it saw; after the group reduction the (0-2) clip ops outside [first, last] are re-read in parallel.
+// kernel latency bound (offset load -> CIGAR load -> store, one alignment in flight per wave).  Eight lanes
+// per alignment keep eight alignments in flight per wave, and every lane streams 16-byte quads of CIGAR
+// words (two in flight): whole aligned quads are tallied unmasked and the (at most 3 + 3) words of the
+// neighbouring alignments that the first and last quad drag in are subtracted once per alignment -- the sums
+// are 32-bit modular (identical to the truncated 64-bit sums of the restatement), so that is exact.  The clip
+// runs (query_alignment_start / _end) are the maximal runs of S/H words at either end, found with a ballot
+// over the first / last eight words (longer runs loop).  All loads of an alignment are requested up front.
+// The gap count of an alignment goes to gap_off[a] (turned into an offset by the offsets pass); the tile's
+// workgroup's totals (gaps, alignments owning one) are plain stores: no atomics anywhere.
 __global__ __launch_bounds__(BLOCK)
 void count_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict__ cig_off,
-                  uint32_t n_aln, int32_t min_sv, uint32_t* __restrict__ cnt, int32_t* __restrict__ stats)
+                  uint32_t n_aln, int32_t min_sv, uint32_t* __restrict__ gap_off, int32_t* __restrict__ stats,
+                  uint2* __restrict__ block_tot)
 {
-    const int sub = threadIdx.x & (GROUP - 1);
-    const uint32_t a = blockIdx.x * ALN_PER_BLOCK + (threadIdx.x / GROUP);
+    __shared__ uint32_t s_tot[3];                        // gaps, owners, waves done
+    if (threadIdx.x < 3) s_tot[threadIdx.x] = 0u;
+    __syncthreads();                                     // the only barrier: before the waves drift apart
+    const int sub = threadIdx.x & (CGROUP - 1);
+    const int gshift = (threadIdx.x & (WAVE - 1)) & ~(CGROUP - 1);
+    const uint32_t a = blockIdx.x * ALN_PER_CBLOCK + (threadIdx.x / CGROUP);
     const bool live = a < n_aln;
+    const uint64_t full = cig_off[n_aln] >> 2;           // quads that lie entirely inside the array
     const uint64_t b = live ? cig_off[a] : 0, e = live ? cig_off[a + 1] : 0;
     const long long n = (long long)(e - b);
+    const uint64_t q0 = b >> 2, q1 = min((e + 3) >> 2, full);
+    // the words at either end for the clip runs, the neighbours' words inside the first / last quad (lanes 0-2
+    // look before b and from e on), the alignment's words beyond the last whole quad of the array (at most 3,
+    // last alignments only), then the quads
+    const long long it = n - 1 - sub;
+    const uint32_t w_head = sub < n ? cigar[b + sub] : 0u;
+    const uint32_t w_tail = it >= 0 ? cigar[b + it] : 0u;
+    const uint64_t fl = (b & ~3ull) + sub, ft = e + sub, tg = max(b, 4 * full) + sub;
+    const uint32_t w_before = (q0 < q1 && sub < 3 && fl < b) ? cigar[fl] : 0u;
+    const uint32_t w_after = (q0 < q1 && sub < 3 && ft < 4 * q1) ? cigar[ft] : 0u;
+    const uint32_t w_loose = (sub < 3 && tg < e) ? cigar[tg] : 0u;
     unsigned ref_span = 0, qlen = 0, ngap = 0;
-    int first = 0x7fffffff, last = -1;                 // first / last non-clip op index (clamped to int)
-    for (long long i = sub; i < n; i += 4 * GROUP) {
-        uint32_t w[4];
+    const uint4* __restrict__ quads = reinterpret_cast<const uint4*>(cigar);
+    for (uint64_t q = q0 + sub; q < q1; q += CQUADS * CGROUP) {
+        uint4 w[CQUADS];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const long long ii = i + (long long)u * GROUP;
-            w[u] = ii < n ? cigar[b + ii] : 0u;            // "0M": inert in every sum
+        for (int u = 0; u < CQUADS; ++u) w[u] = quads[min(q + u * CGROUP, q1 - 1)];    // clamped, dropped below when out of range
+#pragma unroll
+        for (int u = 0; u < CQUADS; ++u) {
+            const bool in = q + u * CGROUP < q1;
+            tally(in ? w[u].x : 0u, min_sv, ref_span, qlen, ngap); tally(in ? w[u].y : 0u, min_sv, ref_span, qlen, ngap);
+            tally(in ? w[u].z : 0u, min_sv, ref_span, qlen, ngap); tally(in ? w[u].w : 0u, min_sv, ref_span, qlen, ngap);
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t op = w[u] & 15u, len = w[u] >> 4;
-            if (span_ref(op)) ref_span += len;
-            if (in_query(op)) qlen += len;
-            ngap += ((op == 1u) | (op == 2u)) & ((long long)len >= (long long)min_sv);
-            const long long ii = i + (long long)u * GROUP;
-            if (ii < n && !is_clip(op)) {
-                const int idx = ii > 0x7ffffffe ? 0x7ffffffe : (int)ii;
-                first = min(first, idx);
-                last = max(last, idx);
+    }
+    tally(w_loose, min_sv, ref_span, qlen, ngap);
+    {
+        unsigned fr = 0, fq = 0, fn = 0;
+        tally(w_before, min_sv, fr, fq, fn);
+        tally(w_after, min_sv, fr, fq, fn);
+        ref_span -= fr; qlen -= fq; ngap -= fn;
+    }
+    ngap = cgroup_sum(ngap);
+    if (live && sub == 0) gap_off[a] = ngap;
+    // workgroup totals without a closing barrier and off the waves' critical path: the (few) owners add to LDS,
+    // fire and forget; the last wave to arrive stores the totals (LDS operations of a wave stay in order)
+    if (sub == 0 && ngap != 0u) { atomicAdd(&s_tot[0], ngap); atomicAdd(&s_tot[1], 1u); }
+    if ((threadIdx.x & (WAVE - 1)) == 0 && atomicAdd(&s_tot[2], 1u) == BLOCK / WAVE - 1)
+        block_tot[blockIdx.x] = make_uint2(atomicAdd(&s_tot[0], 0u), atomicAdd(&s_tot[1], 0u));
+    if (stats) {
+        ref_span = cgroup_sum(ref_span);
+        qlen = cgroup_sum(qlen);
+        unsigned lead = 0, trail = 0;
+        long long n_lead = 0;                                  // words in the leading clip run
+        {
+            const unsigned m = (unsigned)(__ballot(sub < n && is_clip(w_head & 15u)) >> gshift) & ((1u << CGROUP) - 1u);
+            int run = __ffs((int)~m) - 1;                      // 0..CGROUP
+            if (sub < run) lead += w_head >> 4;
+            n_lead = run;
+            for (long long base = CGROUP; run == CGROUP && base < n; base += CGROUP) {     // longer runs: rare
+                const long long i = base + sub;
+                const uint32_t w = i < n ? cigar[b + i] : 0u;
+                const unsigned mm = (unsigned)(__ballot(i < n && is_clip(w & 15u)) >> gshift) & ((1u << CGROUP) - 1u);
+                run = __ffs((int)~mm) - 1;
+                if (sub < run) lead += w >> 4;
+                n_lead += run;
             }
         }
-    }
-    ngap = group_sum(ngap);
-    if (live && sub == 0) cnt[a] = ngap;
-    if (stats) {
-        ref_span = group_sum(ref_span);
-        qlen = group_sum(qlen);
-        first = group_min(first);
-        last = group_max(last);
-        unsigned lead = 0, trail = 0;
-        if (last < 0) {
-            lead = qlen;                               // empty or all-clip CIGAR: everything is leading clip
-        } else {
-            for (long long i = sub; i < first; i += GROUP) lead += cigar[b + i] >> 4;
-            for (long long i = (long long)last + 1 + sub; i < n; i += GROUP) trail += cigar[b + i] >> 4;
-            lead = group_sum(lead);
-            trail = group_sum(trail);
+        if (n_lead < n) {                                      // an all-clip CIGAR is all leading clip
+            const unsigned m = (unsigned)(__ballot(it >= n_lead && is_clip(w_tail & 15u)) >> gshift) & ((1u << CGROUP) - 1u);
+            int run = __ffs((int)~m) - 1;
+            if (sub < run) trail += w_tail >> 4;
+            for (long long base = CGROUP; run == CGROUP && base < n - n_lead; base += CGROUP) {
+                const long long i = n - 1 - base - sub;
+                const uint32_t w = i >= n_lead ? cigar[b + i] : 0u;
+                const unsigned mm = (unsigned)(__ballot(i >= n_lead && is_clip(w & 15u)) >> gshift) & ((1u << CGROUP) - 1u);
+                run = __ffs((int)~mm) - 1;
+                if (sub < run) trail += w >> 4;
+            }
         }
+        lead = cgroup_sum(lead);
+        trail = cgroup_sum(trail);
         if (live && sub == 0) {
-            int4 s;
-            s.x = (int)ref_span; s.y = (int)lead; s.z = (int)trail; s.w = (int)qlen;
-            reinterpret_cast<int4*>(stats)[a] = s;
+            int4 s4;
+            s4.x = (int)ref_span; s4.y = (int)lead; s4.z = (int)trail; s4.w = (int)qlen;
+            reinterpret_cast<int4*>(stats)[a] = s4;
         }
     }
 }
 
-// ---- exclusive scan of cnt[n] into off[n+1] (3 small kernels) ---------------------------
-__global__ __launch_bounds__(BLOCK)
-void scan_tiles_kernel(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t* __restrict__ off,
-                       uint32_t* __restrict__ tile_sum)
-{
-    __shared__ uint32_t wsum[WAVES_PER_BLOCK];
-    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
-    uint32_t v[SCAN_ITEMS], t = 0;
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) { v[i] = base + i < n ? cnt[base + i] : 0u; t += v[i]; }
-    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
-    uint32_t inc = t;
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) { uint32_t u = __shfl_up(inc, o, WAVE); if (lane >= o) inc += u; }
-    if (lane == WAVE - 1) wsum[wv] = inc;
-    __syncthreads();
-    uint32_t pre = inc - t;
-    for (int w = 0; w < wv; ++w) pre += wsum[w];
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; ++i) { if (base + i < n) off[base + i] = pre; pre += v[i]; }
-    if (threadIdx.x == BLOCK - 1) tile_sum[blockIdx.x] = pre;
-}
+// Exclusive prefix over the tiles of 256 alignments (a tile = CBLOCKS_PER_TILE consecutive count workgroups);
+// tile_pre[n_tiles] receives the grand totals.  One workgroup of 1024 threads; per step the totals of 1024 tiles
+// are read with coalesced loads (all requested at once), folded per tile with lane shuffles and scanned.
+constexpr int SBLOCK = 1024;
 
-__global__ __launch_bounds__(WAVE)
-void scan_tile_sums_kernel(uint32_t* __restrict__ tile_sum, uint32_t n_tiles, uint32_t* __restrict__ off, uint32_t n)
+__global__ __launch_bounds__(SBLOCK)
+void scan_kernel(const uint2* __restrict__ block_tot, uint32_t n_blocks, uint2* __restrict__ tile_pre, uint32_t n_tiles)
 {
-    // one wave walks the tile sums (n_aln / 2048 of them) 64 at a time
-    const int lane = threadIdx.x;
-    uint32_t carry = 0;
-    for (uint32_t i = 0; i < n_tiles; i += WAVE) {
-        const uint32_t t = i + lane < n_tiles ? tile_sum[i + lane] : 0u;
-        uint32_t inc = t;
+    __shared__ uint2 s_tile[SBLOCK];
+    __shared__ uint2 s_wave[SBLOCK / WAVE];
+    const int t = threadIdx.x, lane = t & (WAVE - 1), wv = t >> 6;
+    uint2 carry = make_uint2(0u, 0u);                      // kept by every thread
+    for (uint32_t base = 0; base < n_tiles; base += SBLOCK) {
+        uint2 x[CBLOCKS_PER_TILE];
 #pragma unroll
-        for (int o = 1; o < WAVE; o <<= 1) { uint32_t u = __shfl_up(inc, o, WAVE); if (lane >= o) inc += u; }
-        if (i + lane < n_tiles) tile_sum[i + lane] = carry + inc - t;
-        carry += __shfl(inc, WAVE - 1, WAVE);
+        for (int r = 0; r < CBLOCKS_PER_TILE; ++r) {
+            const uint32_t blk = base * CBLOCKS_PER_TILE + r * SBLOCK + t;
+            x[r] = block_tot[min(blk, n_blocks - 1)];
+            if (blk >= n_blocks) x[r] = make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int r = 0; r < CBLOCKS_PER_TILE; ++r) {
+#pragma unroll
+            for (int o = 1; o < CBLOCKS_PER_TILE; o <<= 1) { x[r].x += __shfl_xor(x[r].x, o, WAVE); x[r].y += __shfl_xor(x[r].y, o, WAVE); }
+            if ((t & (CBLOCKS_PER_TILE - 1)) == 0) s_tile[(r * SBLOCK + t) / CBLOCKS_PER_TILE] = x[r];
+        }
+        __syncthreads();
+        const uint2 v = s_tile[t];
+        uint2 inc = v;
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const uint32_t ux = __shfl_up(inc.x, o, WAVE), uy = __shfl_up(inc.y, o, WAVE);
+            if (lane >= o) { inc.x += ux; inc.y += uy; }
+        }
+        if (lane == WAVE - 1) s_wave[wv] = inc;
+        __syncthreads();
+        uint2 pre = carry, all = carry;
+#pragma unroll
+        for (int w = 0; w < SBLOCK / WAVE; ++w) {
+            const uint2 y = s_wave[w];
+            if (w < wv) { pre.x += y.x; pre.y += y.y; }
+            all.x += y.x; all.y += y.y;
+        }
+        if (base + t < n_tiles) tile_pre[base + t] = make_uint2(pre.x + inc.x - v.x, pre.y + inc.y - v.y);
+        carry = all;
+        __syncthreads();
     }
-    if (lane == 0) off[n] = carry;
+    if (t == 0) tile_pre[n_tiles] = carry;
 }
 
+// Offsets pass, one workgroup per tile of 256 alignments: a workgroup scan on top of the tile's prefix turns
+// the 256 counts into CSR offsets; the (few) alignments that own a long gap go to the work list (alignment,
+// first slot) at the position given by the prefix of the owner counts, i.e. in alignment order.
 __global__ __launch_bounds__(BLOCK)
-void scan_add_kernel(uint32_t* __restrict__ off, uint32_t n, const uint32_t* __restrict__ tile_pre)
+void offsets_kernel(uint32_t n_aln, uint32_t* __restrict__ gap_off, const uint2* __restrict__ tile_pre, uint2* __restrict__ work)
 {
-    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) off[i] += tile_pre[i / SCAN_TILE];
+    __shared__ uint32_t s_wave[2 * BLOCK / WAVE];
+    constexpr int NW = BLOCK / WAVE;
+    const int t = threadIdx.x, lane = t & (WAVE - 1), wv = t >> 6;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t a = (tile << TILE_SHIFT) + t;
+    const uint32_t c = a < n_aln ? gap_off[a] : 0u;
+    const uint2 before = tile_pre[tile];
+    uint32_t inc = c;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) { const uint32_t u = __shfl_up(inc, o, WAVE); if (lane >= o) inc += u; }
+    const unsigned long long owners = __ballot(c != 0u);
+    if (lane == WAVE - 1) { s_wave[wv] = inc; s_wave[NW + wv] = (uint32_t)__popcll(owners); }
+    __syncthreads();
+    uint32_t off = before.x + inc - c, rank = before.y + (uint32_t)__popcll(owners & ((1ull << lane) - 1ull));
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+        if (w < wv) { off += s_wave[w]; rank += s_wave[NW + w]; }
+    if (a < n_aln) {
+        gap_off[a] = off;
+        if (a == n_aln - 1) gap_off[n_aln] = off + c;
+        if (c) work[rank] = make_uint2(a, off);
+    }
 }
 
-// Emit pass: a block looks at 256 alignments' gap counts with one coalesced load; each wave then
-// walks only the (rare) alignments of its 64 that own a long gap.
+// Emit pass: resident waves take the work list with a grid stride, one wave per alignment, 4 consecutive
+// CIGAR words per lane (256 words per step).  Lane-local sums + a wave prefix sum of the read / reference
+// advance (32-bit modular = the truncated 64-bit positions) give readPos / refPos at every word; ballot
+// ranks keep the stores in op order.
 __global__ __launch_bounds__(BLOCK)
 void emit_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict__ cig_off,
-                 const int32_t* __restrict__ ref_start, uint32_t n_aln, int32_t min_sv,
-                 const uint32_t* __restrict__ gap_off, SvxGap* __restrict__ gaps, uint64_t gaps_cap)
+                 const int32_t* __restrict__ ref_start, int32_t min_sv, SvxGap* __restrict__ gaps, uint64_t gaps_cap,
+                 const uint2* __restrict__ totals, const uint2* __restrict__ work)
 {
     const int lane = threadIdx.x & (WAVE - 1);
-    const uint32_t mine = blockIdx.x * BLOCK + threadIdx.x;
-    const bool has = mine < n_aln && gap_off[mine + 1] != gap_off[mine];
-    unsigned long long todo = __ballot(has);
-    const uint32_t wave_base = blockIdx.x * BLOCK + (threadIdx.x & ~(WAVE - 1));
-    while (todo) {
-        const int bit = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        const uint32_t a = wave_base + bit;
-        uint64_t dst = gap_off[a];
-        const uint64_t b = cig_off[a], e = cig_off[a + 1];
-        long long read_pos = 0, ref_pos = ref_start[a];    // carried across 64-op chunks
-        for (uint64_t j0 = b; j0 < e; j0 += WAVE) {
-            const uint64_t j = j0 + lane;
-            const uint32_t w = j < e ? cigar[j] : 6u;
-            const uint32_t op = w & 15u;
-            const long long len = w >> 4;
-            const long long dr = adv_read(op) ? len : 0, df = adv_ref(op) ? len : 0;
-            long long ir = dr, irf = df;                   // inclusive wave prefix sums
+    const uint32_t n_work = totals->y;                     // alignments owning a long gap
+    const uint32_t n_waves = gridDim.x * (BLOCK / WAVE);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (uint32_t k = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6); k < n_work; k += n_waves) {
+        const uint2 item = work[k];
+        const uint32_t a = item.x;
+        uint32_t dst = item.y;
+        const uint64_t b = cig_off[a];
+        const long long n = (long long)(cig_off[a + 1] - b);
+        uint32_t read_pos = 0, ref_pos = (uint32_t)ref_start[a];
+        for (long long j0 = 0; j0 < n; j0 += 4 * WAVE) {
+            const long long j = j0 + 4 * lane;
+            uint32_t w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) w[u] = j + u < n ? cigar[b + j + u] : 6u;      // "0P": advances nothing
+            uint32_t dr[4], df[4], tr = 0, tf = 0;
+            bool hit[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t op = w[u] & 15u, len = w[u] >> 4;
+                dr[u] = tr; df[u] = tf;                        // advance of this lane's earlier words
+                tr += adv_read(op) ? len : 0u;
+                tf += adv_ref(op) ? len : 0u;
+                hit[u] = ((op - 1u) < 2u) & ((int32_t)len >= min_sv);
+            }
+            uint32_t ir = tr, irf = tf;                        // inclusive wave prefix sums of the lane totals
 #pragma unroll
             for (int o = 1; o < WAVE; o <<= 1) {
-                const long long ur = __shfl_up(ir, o, WAVE), uf = __shfl_up(irf, o, WAVE);
+                const uint32_t ur = __shfl_up(ir, o, WAVE), uf = __shfl_up(irf, o, WAVE);
                 if (lane >= o) { ir += ur; irf += uf; }
             }
-            const bool hit = ((op == 1u) | (op == 2u)) & (len >= (long long)min_sv);
-            const unsigned long long m = __ballot(hit);
-            if (hit) {
-                const uint64_t slot = dst + __popcll(m & ((1ull << lane) - 1ull));
-                if (slot < gaps_cap) {
-                    SvxGap g;
-                    g.aln = a; g.op = (uint32_t)(j - b);
-                    g.read_pos = (int32_t)(read_pos + ir - dr);
-                    g.ref_pos = (int32_t)(ref_pos + irf - df);
-                    g.len = (int32_t)len; g.kind = op;     // I=1, D=2 match SVX_GAP_*
-                    gaps[slot] = g;
+            // slot of a hit = hits in the lanes below (all four of their words) + this lane's earlier hits
+            uint32_t mine = 0, all = 0, lower = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned long long m = __ballot(hit[u]);
+                lower += (uint32_t)__popcll(m & below);
+                all += (uint32_t)__popcll(m);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (hit[u]) {
+                    const uint64_t slot = (uint64_t)dst + lower + mine;
+                    if (slot < gaps_cap) {
+                        SvxGap g;
+                        g.aln = a; g.op = (uint32_t)(j + u);
+                        g.read_pos = (int32_t)(read_pos + ir - tr + dr[u]);
+                        g.ref_pos = (int32_t)(ref_pos + irf - tf + df[u]);
+                        g.len = (int32_t)(w[u] >> 4); g.kind = w[u] & 15u;     // I=1, D=2 match SVX_GAP_*
+                        gaps[slot] = g;
+                    }
+                    ++mine;
                 }
             }
-            dst += __popcll(m);
+            dst += all;
             read_pos += __shfl(ir, WAVE - 1, WAVE);
             ref_pos += __shfl(irf, WAVE - 1, WAVE);
         }
     }
 }
 
+// workspace: [block_tot: uint2 {gaps, owners} per count workgroup][tile_pre: uint2 per 256 alignments, + 1 for the
+// totals] | [work: uint2 per alignment]
+inline size_t ws_tile_offset(uint32_t n_aln)
+{
+    const size_t blocks = ((size_t)n_aln + ALN_PER_CBLOCK - 1) / ALN_PER_CBLOCK;
+    return (blocks * sizeof(uint2) + 255) & ~(size_t)255;
+}
+inline size_t ws_work_offset(uint32_t n_aln)
+{
+    const size_t tiles = (((size_t)n_aln + TILE - 1) >> TILE_SHIFT) + 1;
+    return ws_tile_offset(n_aln) + ((tiles * sizeof(uint2) + 255) & ~(size_t)255);
+}
+
 }  // namespace
 
 extern "C" size_t svx_cigar_scan_ws_bytes(uint32_t n_aln)
 {
-    const size_t tiles = ((size_t)n_aln + SCAN_TILE - 1) / SCAN_TILE + 1;
-    // [cnt: n_aln u32][tile_sum: tiles u32], 256 B aligned pieces
-    return (((size_t)n_aln * 4 + 255) & ~(size_t)255) + ((tiles * 4 + 255) & ~(size_t)255);
+    return ws_work_offset(n_aln) + (size_t)n_aln * sizeof(uint2);
 }
 
 extern "C" int svx_cigar_scan(const uint32_t* d_cigar, const uint64_t* d_cig_off,
@@ -252,16 +357,17 @@ extern "C" int svx_cigar_scan(const uint32_t* d_cigar, const uint64_t* d_cig_off
     }
     if (!d_cigar || !d_cig_off || !d_ref_start || !d_ws || (!d_gaps && gaps_cap)) return SVX_EINVAL;
     if (d_stats && (reinterpret_cast<uintptr_t>(d_stats) & 15u)) return SVX_EINVAL;
-    uint32_t* cnt = static_cast<uint32_t*>(d_ws);
-    uint32_t* tile_sum = reinterpret_cast<uint32_t*>(static_cast<char*>(d_ws) + (((size_t)n_aln * 4 + 255) & ~(size_t)255));
-    const uint32_t count_blocks = (n_aln + ALN_PER_BLOCK - 1) / ALN_PER_BLOCK;
-    const uint32_t emit_blocks = (n_aln + BLOCK - 1) / BLOCK;
-    const uint32_t tiles = (n_aln + SCAN_TILE - 1) / SCAN_TILE;
-    hipLaunchKernelGGL(count_kernel, dim3(count_blocks), dim3(BLOCK), 0, st, d_cigar, d_cig_off, n_aln, min_sv, cnt, d_stats);
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(tiles), dim3(BLOCK), 0, st, cnt, n_aln, d_gap_off, tile_sum);
-    hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(1), dim3(WAVE), 0, st, tile_sum, tiles, d_gap_off, n_aln);
-    hipLaunchKernelGGL(scan_add_kernel, dim3((n_aln + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d_gap_off, n_aln, tile_sum);
-    hipLaunchKernelGGL(emit_kernel, dim3(emit_blocks), dim3(BLOCK), 0, st, d_cigar, d_cig_off, d_ref_start, n_aln, min_sv,
-                       d_gap_off, d_gaps, gaps_cap);
+    if ((reinterpret_cast<uintptr_t>(d_ws) & 7u) || (reinterpret_cast<uintptr_t>(d_cigar) & 15u)) return SVX_EINVAL;
+    const uint32_t tiles = (n_aln + TILE - 1) >> TILE_SHIFT, count_blocks = (n_aln + ALN_PER_CBLOCK - 1) / ALN_PER_CBLOCK;
+    uint2* block_tot = static_cast<uint2*>(d_ws);
+    uint2* tile_pre = reinterpret_cast<uint2*>(static_cast<char*>(d_ws) + ws_tile_offset(n_aln));
+    uint2* work = reinterpret_cast<uint2*>(static_cast<char*>(d_ws) + ws_work_offset(n_aln));
+    hipLaunchKernelGGL(count_kernel, dim3(count_blocks), dim3(BLOCK), 0, st, d_cigar, d_cig_off, n_aln, min_sv, d_gap_off, d_stats, block_tot);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(SBLOCK), 0, st, block_tot, count_blocks, tile_pre, tiles);
+    hipLaunchKernelGGL(offsets_kernel, dim3(tiles), dim3(BLOCK), 0, st, n_aln, d_gap_off, tile_pre, work);
+    // resident waves (8 workgroups per CU at most); small inputs get one wave per 4 alignments
+    const uint32_t emit_blocks = min(2048u, (n_aln + 15u) / 16u);
+    hipLaunchKernelGGL(emit_kernel, dim3(emit_blocks), dim3(BLOCK), 0, st, d_cigar, d_cig_off, d_ref_start, min_sv, d_gaps, gaps_cap,
+                       tile_pre + tiles, work);
     return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
 }

@@ -28,9 +28,10 @@ def init_from_env():
     # SVX_FORCE_DIST=1 initialises the group even for a single rank (exercises the RCCL path on one GPU)
     force = os.environ.get("SVX_FORCE_DIST") == "1" and "RANK" in os.environ
     if (ws > 1 or force) and not dist.is_initialized():
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        # SVX_DIST_BACKEND=gloo: several ranks sharing one GPU (1-GPU test boxes; RCCL refuses duplicate devices)
+        backend = os.environ.get("SVX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
         dist.init_process_group(backend)
     return world()
 

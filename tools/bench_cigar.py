@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""CIGAR scan timing at two sizes (HIP events): 2 M alignments x ~147 ops (leaves the caches) and a
+chr21-sized 100 k alignments (launch-latency regime)."""
+import json, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from svision_amd import kernels
+from tests import datagen
+dev = torch.device("cuda:0")
+reps = int(os.environ.get("REPS", "20"))
+out = {}
+SIZES = ((2_000_000, 150), (100_000, 150), (50_000, 6000))
+if os.environ.get("ONLY"):
+    SIZES = (SIZES[int(os.environ["ONLY"])],)
+for na, mean_ops in SIZES:
+    cigar, off, ref_start = datagen.random_cigars(na, seed=5, mean_ops=mean_ops, long_gap_rate=0.0005)
+    d_c = torch.from_numpy(cigar.view(np.int32)).to(dev); d_o = torch.from_numpy(off.astype(np.int64)).to(dev); d_r = torch.from_numpy(ref_start).to(dev)
+    cap = 1 << 22
+    res = kernels.cigar_scan(d_c, d_o, d_r, 50, gaps_cap=cap)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        kernels.cigar_scan(d_c, d_o, d_r, 50, gaps_cap=cap)
+    e1.record(); torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / reps * 1e-3
+    alg = 4 * cigar.size + 32 * na + 24 * res.total()
+    out["%d x %d" % (na, mean_ops)] = {"us": t * 1e6, "GBps": alg / t / 1e9, "gaps": res.total()}
+print(json.dumps(out))
