@@ -59,7 +59,8 @@ size_t svx_cigar_scan_ws_bytes(uint32_t n_aln);
  * reference_end / query_alignment_start / query_alignment_end
  * (src/collection/analyze_reads.py:650-667) for a whole batch of alignments.
  *
- *   d_cigar     packed BAM CIGAR words (len << 4 | op) of all alignments, concatenated
+ *   d_cigar     packed BAM CIGAR words (len << 4 | op) of all alignments, concatenated;
+ *               16-byte aligned (read in quads), d_cig_off[n_aln] words long
  *   d_cig_off   [n_aln + 1] word offsets into d_cigar (CSR)
  *   d_ref_start [n_aln] 0-based reference start of each alignment
  *   min_sv      options.min_sv_size
@@ -70,7 +71,7 @@ size_t svx_cigar_scan_ws_bytes(uint32_t n_aln);
  *   d_stats     [n_aln][4] out, may be NULL: ref_span (M,D,N,=,X),
  *               lead_clip (leading S/H), trail_clip (trailing S/H),
  *               query_len (M,I,S,H,=,X)
- *   d_ws        scratch of svx_cigar_scan_ws_bytes(n_aln) bytes
+ *   d_ws        scratch of svx_cigar_scan_ws_bytes(n_aln) bytes, 8-byte aligned, contents ignored
  * H is treated as S (the reference rewrites H to S, collect_signatures.py:91);
  * N advances the read position only (analyze_reads.py:831-832). */
 int svx_cigar_scan(const uint32_t* d_cigar, const uint64_t* d_cig_off,
