@@ -143,24 +143,27 @@ int svx_conv2d_same(const float* d_in, const float* d_w_hwio, const float* d_bia
 /* ---- host side: native BGZF/BAM ingestion (no device work) -------------------------------------------
  * Replaces the per-record pysam iteration of the reference (aln_file.fetch at
  * src/collection/run_collection.py:23-26, field reads at src/collection/collect_signatures.py:128-155):
- * block-parallel inflate, then all records scattered into caller-owned arrays.
- *   svx_bam_open    -> opaque handle or NULL (svx_bam_error() tells why); threads <= 0: all cores (max 64)
+ * the file is streamed in chunks of BGZF blocks (block-parallel inflate) and the records' fields are appended to
+ * packed arrays; SEQ is kept only on request, QUAL and tags never (resident size = the arrays, not the file).
+ *   svx_bam_open    -> opaque handle or NULL (svx_bam_error() tells why); threads <= 0: all cores (max 64);
+ *                      flags: SVX_BAM_KEEP_SEQ keeps the 4-bit read bases (the --hash re-aligner needs them)
  *   svx_bam_sizes   -> sizes[8] = n_records, n_cigar_words, n_refs, n_names, names_bytes, header_bytes,
- *                      ref_names_bytes, raw_bytes
+ *                      ref_names_bytes, seq_bytes
  *   svx_bam_export  -> fills tid/pos/flag/mapq/l_seq/name_id [n_records], cig_off [n_records+1], cigar
  *                      [n_cigar_words], names / ref_names ('\n'-separated, first-occurrence order), header text,
  *                      ref_lens [n_refs], and (if not NULL) seq_off = byte offset of each record's 4-bit SEQ
- *                      inside the decompressed file exposed by svx_bam_raw() */
-void*          svx_bam_open(const char* path, int threads);
+ *                      inside the pool exposed by svx_bam_seq() (seq_bytes long) */
+#define SVX_BAM_KEEP_SEQ 1
+void*          svx_bam_open(const char* path, int threads, int flags);
 /* only the records between two BGZF virtual offsets taken from the .bai index (one chromosome = one rank's shard;
  * replaces AlignmentFile.fetch(chrom, ...) random access, run_collection.py:26); voff_end <= voff_beg: header only */
-void*          svx_bam_open_range(const char* path, int threads, uint64_t voff_beg, uint64_t voff_end);
+void*          svx_bam_open_range(const char* path, int threads, int flags, uint64_t voff_beg, uint64_t voff_end);
 const char*    svx_bam_error(void);
 void           svx_bam_sizes(void* handle, uint64_t* sizes);
 void           svx_bam_export(void* handle, int threads, int32_t* tid, int32_t* pos, uint16_t* flag, uint8_t* mapq,
                               int32_t* l_seq, int32_t* name_id, int64_t* cig_off, uint32_t* cigar, char* names,
                               char* header, char* ref_names, int32_t* ref_lens, int64_t* seq_off);
-const uint8_t* svx_bam_raw(void* handle);
+const uint8_t* svx_bam_seq(void* handle);
 void           svx_bam_close(void* handle);
 
 #ifdef __cplusplus

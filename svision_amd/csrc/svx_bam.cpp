@@ -1,18 +1,23 @@
 // svx_bam.cpp -- native BGZF/BAM ingestion: file -> packed structure of arrays (host side of libsvx.so).
 //
 // Replaces what the reference obtains record by record from pysam/htslib (AlignmentFile iteration at
-// src/collection/run_collection.py:23-26, src/collection/collect_signatures.py:128-155): the whole file is
-// inflated block-parallel (BGZF blocks are independent gzip members; zlib raw inflate on a thread pool),
-// record offsets are chained once, and the fixed fields / CIGAR words / names / 4-bit sequences are
-// scattered in parallel into caller-owned arrays that go to the GPU unchanged (svx_cigar_scan input).
-// SAMv1 section 4 layouts, including CIGARs with more than 65535 operations (CG:B,I tag).
+// src/collection/run_collection.py:23-26, src/collection/collect_signatures.py:128-155).  The file is
+// streamed: a chunk of whole BGZF blocks is read, inflated block-parallel (BGZF blocks are independent
+// gzip members; zlib raw inflate on a thread pool), its records are chained once and their fixed fields,
+// CIGAR words, names and (on request) 4-bit sequences are appended to growing arrays; the decompressed
+// bytes of a chunk (mostly SEQ/QUAL, which the hot path never reads) are dropped before the next chunk is
+// read, so the resident size is that of the packed arrays that go to the GPU unchanged (svx_cigar_scan
+// input), not that of the file.  SAMv1 section 4 layouts, including CIGARs with more than 65535 operations
+// (CG:B,I tag).  With two virtual offsets from the .bai index only that byte range is read.
 #include <zlib.h>
 
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <string_view>
 #include <thread>
@@ -23,49 +28,74 @@
 
 namespace {
 
-struct Bam {
-    std::vector<uint8_t> raw;              // decompressed file
-    std::string header_text;
-    std::vector<std::string> ref_names;
-    std::vector<int32_t> ref_lens;
-    std::vector<uint64_t> rec_off;         // offset of each record's block_size field
-    std::vector<uint64_t> cig_off;         // CSR over CIGAR words, n_rec + 1
-    std::vector<uint64_t> cig_src;         // byte offset of each record's CIGAR words (record body or CG:B,I tag)
-    std::vector<int32_t> name_id;
-    std::vector<uint32_t> name_first;      // record index of the first occurrence of every distinct QNAME
-    uint64_t names_bytes = 0;
-    std::string error;
-};
-
 inline uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
 inline uint16_t rd16(const uint8_t* p) { uint16_t v; memcpy(&v, p, 2); return v; }
 
+// append-only storage for the distinct read names (stable addresses for the hash map's keys)
+struct Arena {
+    static constexpr size_t SLAB = 1 << 20;
+    std::vector<std::unique_ptr<char[]>> slabs;
+    size_t used = SLAB;
+    std::string_view keep(std::string_view s)
+    {
+        if (s.size() > SLAB) { slabs.emplace_back(new char[s.size()]); memcpy(slabs.back().get(), s.data(), s.size()); used = SLAB; return {slabs.back().get(), s.size()}; }
+        if (used + s.size() > SLAB) { slabs.emplace_back(new char[SLAB]); used = 0; }
+        char* at = slabs.back().get() + used;
+        memcpy(at, s.data(), s.size());
+        used += s.size();
+        return {at, s.size()};
+    }
+};
+
+struct Bam {
+    std::string header_text;
+    std::vector<std::string> ref_names;
+    std::vector<int32_t> ref_lens;
+    // one entry per record
+    std::vector<int32_t> tid, pos, l_seq, name_id;
+    std::vector<uint16_t> flag;
+    std::vector<uint8_t> mapq;
+    std::vector<uint64_t> cig_off{0};      // CSR over CIGAR words, n_rec + 1
+    std::vector<uint32_t> cigar;
+    std::vector<uint64_t> seq_off;         // byte offset of each record's 4-bit SEQ in `seq` (SVX_BAM_KEEP_SEQ)
+    std::vector<uint8_t> seq;
+    // distinct QNAMEs in order of first occurrence
+    Arena arena;
+    std::vector<std::string_view> names;
+    std::unordered_map<std::string_view, int32_t> seen;
+    uint64_t names_bytes = 0;
+};
+
 // CIGARs with more than 65535 operations live in the CG:B,I tag; the record then carries "<l_seq>S<ref_len>N"
-// (SAMv1 4.2.2).  Returns the byte offset of the tag's uint32 array and its length, or 0.
-uint64_t find_long_cigar(const std::vector<uint8_t>& r, uint64_t aux, uint64_t end, uint32_t* count)
+// (SAMv1 4.2.2).  Returns the tag's uint32 array and its length, or NULL.
+const uint8_t* find_long_cigar(const uint8_t* aux, const uint8_t* end, uint32_t* count)
 {
     while (aux + 3 <= end) {
-        const uint8_t t0 = r[aux], t1 = r[aux + 1], ty = r[aux + 2];
-        uint64_t p = aux + 3;
+        const uint8_t t0 = aux[0], t1 = aux[1], ty = aux[2];
+        const uint8_t* p = aux + 3;
         switch (ty) {
         case 'A': case 'c': case 'C': p += 1; break;
         case 's': case 'S': p += 2; break;
         case 'i': case 'I': case 'f': p += 4; break;
-        case 'Z': case 'H': while (p < end && r[p]) ++p; ++p; break;
+        case 'Z': case 'H': while (p < end && *p) ++p; ++p; break;
         case 'B': {
-            if (p + 5 > end) return 0;
-            const uint8_t sub = r[p];
-            const uint32_t n = rd32(&r[p + 1]);
+            if (p + 5 > end) return nullptr;
+            const uint8_t sub = p[0];
+            const uint32_t n = rd32(p + 1);
             const uint32_t width = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
-            if (t0 == 'C' && t1 == 'G' && sub == 'I') { *count = n; return p + 5; }
+            if (t0 == 'C' && t1 == 'G' && sub == 'I') {
+                if (p + 5 + (uint64_t)n * 4 > end) return nullptr;
+                *count = n;
+                return p + 5;
+            }
             p += 5 + (uint64_t)n * width;
             break;
         }
-        default: return 0;
+        default: return nullptr;
         }
         aux = p;
     }
-    return 0;
+    return nullptr;
 }
 
 template <class F>
@@ -81,270 +111,309 @@ void parallel_for(size_t n, int threads, F fn)
     for (auto& th : pool) th.join();
 }
 
-// Inflate the BGZF blocks of file[from, to) (block-aligned) into `out`; max_blocks limits the number of blocks (0 = all).
-bool inflate_file(const std::vector<uint8_t>& file, int threads, std::vector<uint8_t>& out, std::string& err,
-                  uint64_t from = 0, uint64_t to = ~0ull, size_t max_blocks = 0)
-{
-    struct Blk { uint64_t src, csize, dst; uint32_t isize; };
-    std::vector<Blk> blocks;
-    uint64_t p = from, total = 0;
-    const uint64_t n = std::min<uint64_t>(file.size(), to);
-    while (p + 18 <= n && (max_blocks == 0 || blocks.size() < max_blocks)) {
-        if (!(file[p] == 0x1f && file[p + 1] == 0x8b && file[p + 2] == 8 && (file[p + 3] & 4))) { err = "not a BGZF block"; return false; }
-        const uint32_t xlen = rd16(&file[p + 10]);
-        uint32_t bsize = 0;
-        bool found = false;
-        for (uint64_t q = p + 12; q + 4 <= p + 12 + xlen;) {
-            const uint32_t slen = rd16(&file[q + 2]);
-            if (file[q] == 'B' && file[q + 1] == 'C') { bsize = rd16(&file[q + 4]); found = true; }
-            q += 4 + slen;
-        }
-        if (!found || p + bsize + 1 > n) { err = "corrupt BGZF block"; return false; }
-        const uint64_t data = p + 12 + xlen, end = p + bsize + 1;
-        const uint32_t isize = rd32(&file[end - 4]);
-        blocks.push_back({data, end - 8 - data, total, isize});
-        total += isize;
-        p = end;
+// Sequential reader of the whole BGZF blocks of file[pos, end): next() appends the inflated bytes of the next
+// chunk of blocks to `out`.
+class BgzfStream {
+public:
+    size_t chunk;                                        // compressed bytes read per step
+
+    BgzfStream(FILE* f, uint64_t pos, uint64_t end, int threads, size_t first_chunk)
+        : chunk(first_chunk), f_(f), pos_(pos), end_(end), threads_(threads)
+    {
+        fseeko(f_, (off_t)pos, SEEK_SET);
     }
-    out.resize(total);
-    std::atomic<bool> ok{true};
-    parallel_for(blocks.size(), threads, [&](size_t lo, size_t hi) {
-        z_stream zs;
-        for (size_t i = lo; i < hi && ok; ++i) {
-            const Blk& b = blocks[i];
-            if (b.isize == 0) continue;
-            memset(&zs, 0, sizeof zs);
-            if (inflateInit2(&zs, -15) != Z_OK) { ok = false; return; }
-            zs.next_in = const_cast<Bytef*>(&file[b.src]);
-            zs.avail_in = (uInt)b.csize;
-            zs.next_out = &out[b.dst];
-            zs.avail_out = b.isize;
-            const int rc = inflate(&zs, Z_FINISH);
-            inflateEnd(&zs);
-            if (rc != Z_STREAM_END || zs.avail_out != 0) { ok = false; return; }
+    // compressed file offset of the first block of the last chunk, and of every block in it with its position in `out`
+    struct Block { uint64_t coff, dst; uint32_t isize; };
+    const std::vector<Block>& blocks() const { return blocks_; }
+    bool done() const { return eof_ && carry_.empty(); }
+    const std::string& error() const { return err_; }
+
+    // false on error (error() says why); appends nothing when done()
+    bool next(std::vector<uint8_t>& out)
+    {
+        blocks_.clear();
+        if (done()) return true;
+        const size_t have = carry_.size();
+        const uint64_t want = std::min<uint64_t>(chunk, end_ - pos_);
+        cbuf_.resize(have + want);
+        if (have) memcpy(cbuf_.data(), carry_.data(), have);
+        const size_t got = want ? fread(cbuf_.data() + have, 1, want, f_) : 0;
+        if (got < want) eof_ = true;
+        cbuf_.resize(have + got);
+        const uint64_t base = pos_ - have;                 // file offset of cbuf_[0]
+        pos_ += got;
+        if (pos_ >= end_) eof_ = true;
+        struct Src { uint64_t data, csize; };
+        std::vector<Src> src;
+        uint64_t p = 0, total = out.size();
+        while (p + 18 <= cbuf_.size()) {
+            if (!(cbuf_[p] == 0x1f && cbuf_[p + 1] == 0x8b && cbuf_[p + 2] == 8 && (cbuf_[p + 3] & 4))) { err_ = "not a BGZF block"; return false; }
+            const uint32_t xlen = rd16(&cbuf_[p + 10]);
+            if (p + 12 + xlen > cbuf_.size()) break;
+            uint32_t bsize = 0;
+            bool found = false;
+            for (uint64_t q = p + 12; q + 4 <= p + 12 + xlen;) {
+                const uint32_t slen = rd16(&cbuf_[q + 2]);
+                if (cbuf_[q] == 'B' && cbuf_[q + 1] == 'C') { bsize = rd16(&cbuf_[q + 4]); found = true; }
+                q += 4 + slen;
+            }
+            if (!found) { err_ = "corrupt BGZF block"; return false; }
+            if (p + bsize + 1 > cbuf_.size()) break;       // partial block: wait for the next read
+            const uint64_t data = p + 12 + xlen, end = p + bsize + 1;
+            if (end < data + 8) { err_ = "corrupt BGZF block"; return false; }
+            const uint32_t isize = rd32(&cbuf_[end - 4]);
+            src.push_back({data, end - 8 - data});
+            blocks_.push_back({base + p, total, isize});
+            total += isize;
+            p = end;
+        }
+        if (eof_ && p != cbuf_.size()) {
+            if (end_ == ~0ull) { err_ = "truncated BGZF file"; return false; }
+            // a byte range cut in the middle of its last block: callers ask for one block more than they need
+        }
+        out.resize(total);
+        std::atomic<bool> ok{true};
+        parallel_for(src.size(), threads_, [&](size_t lo, size_t hi) {
+            z_stream zs;
+            for (size_t i = lo; i < hi && ok; ++i) {
+                if (blocks_[i].isize == 0) continue;
+                memset(&zs, 0, sizeof zs);
+                if (inflateInit2(&zs, -15) != Z_OK) { ok = false; return; }
+                zs.next_in = const_cast<Bytef*>(&cbuf_[src[i].data]);
+                zs.avail_in = (uInt)src[i].csize;
+                zs.next_out = &out[blocks_[i].dst];
+                zs.avail_out = blocks_[i].isize;
+                const int rc = inflate(&zs, Z_FINISH);
+                inflateEnd(&zs);
+                if (rc != Z_STREAM_END || zs.avail_out != 0) { ok = false; return; }
+            }
+        });
+        if (!ok) { err_ = "BGZF inflate failed"; return false; }
+        carry_.assign(cbuf_.begin() + p, cbuf_.end());
+        if (eof_) carry_.clear();
+        return true;
+    }
+
+private:
+    FILE* f_;
+    uint64_t pos_, end_;
+    int threads_;
+    bool eof_ = false;
+    std::vector<uint8_t> cbuf_, carry_;
+    std::vector<Block> blocks_;
+    std::string err_;
+};
+
+// Header (magic, text, reference dictionary) at the start of `buf`: 0 = needs more bytes, -1 = not BAM, else its size.
+long long parse_header(const std::vector<uint8_t>& buf, Bam* b)
+{
+    if (buf.size() < 12) return 0;
+    if (memcmp(buf.data(), "BAM\1", 4) != 0) return -1;
+    const uint64_t l_text = rd32(&buf[4]);
+    uint64_t p = 8 + l_text;
+    if (p + 4 > buf.size()) return 0;
+    const uint32_t n_ref = rd32(&buf[p]); p += 4;
+    uint64_t q = p;
+    for (uint32_t i = 0; i < n_ref; ++i) {
+        if (q + 4 > buf.size()) return 0;
+        const uint64_t l_name = rd32(&buf[q]);
+        if (q + 8 + l_name > buf.size()) return 0;
+        q += 8 + l_name;
+    }
+    b->header_text.assign(reinterpret_cast<const char*>(&buf[8]), strnlen(reinterpret_cast<const char*>(&buf[8]), l_text));
+    for (uint32_t i = 0; i < n_ref; ++i) {
+        const uint32_t l_name = rd32(&buf[p]);
+        b->ref_names.emplace_back(reinterpret_cast<const char*>(&buf[p + 4]), l_name ? l_name - 1 : 0);
+        b->ref_lens.push_back((int32_t)rd32(&buf[p + 4 + l_name]));
+        p += 8 + l_name;
+    }
+    return (long long)p;
+}
+
+// Appends the whole records of buf[from, limit) to the arrays; returns the offset of the first byte not consumed
+// (a partial record at the end stays for the next chunk), or -1 on a malformed record.
+long long parse_records(const std::vector<uint8_t>& buf, uint64_t from, uint64_t limit, int threads, bool keep_seq, Bam* b)
+{
+    struct Rec { uint64_t at; const uint8_t* cig; uint32_t n_cig; };
+    std::vector<Rec> recs;
+    uint64_t p = from, words = 0, seq_bytes = 0;
+    while (p + 4 <= limit) {
+        const uint64_t bs = rd32(&buf[p]);
+        if (p + 4 + bs > limit) break;
+        if (bs < 32) return -1;
+        const uint8_t* rec = &buf[p + 4];
+        const uint32_t l_name = rec[8], l_seq = rd32(rec + 16);
+        uint32_t n_cig = rd16(rec + 12);
+        if (32ull + l_name + 4ull * n_cig + (l_seq + 1ull) / 2 + l_seq > bs) return -1;
+        const uint8_t* cig = rec + 32 + l_name;
+        if (n_cig == 2) {                                     // possible CG-tag placeholder
+            const uint32_t w0 = rd32(cig), w1 = rd32(cig + 4);
+            if ((w0 & 15) == 4 && (w0 >> 4) == l_seq && (w1 & 15) == 3) {
+                uint32_t cnt = 0;
+                const uint8_t* at = find_long_cigar(cig + 8 + (l_seq + 1) / 2 + l_seq, rec + bs, &cnt);
+                if (at) { cig = at; n_cig = cnt; }
+            }
+        }
+        recs.push_back({p, cig, n_cig});
+        words += n_cig;
+        seq_bytes += (l_seq + 1ull) / 2;
+        // QNAME ids by first occurrence (sequential: the order defines the ids)
+        std::string_view nm(reinterpret_cast<const char*>(rec + 32), l_name ? l_name - 1 : 0);
+        auto it = b->seen.find(nm);
+        if (it == b->seen.end()) {
+            const std::string_view kept = b->arena.keep(nm);
+            it = b->seen.emplace(kept, (int32_t)b->names.size()).first;
+            b->names.push_back(kept);
+            b->names_bytes += kept.size() + 1;
+        }
+        b->name_id.push_back(it->second);
+        p += 4 + bs;
+    }
+    const size_t n0 = b->tid.size(), n = recs.size();
+    b->tid.resize(n0 + n); b->pos.resize(n0 + n); b->l_seq.resize(n0 + n); b->flag.resize(n0 + n); b->mapq.resize(n0 + n);
+    b->cig_off.resize(n0 + n + 1);
+    const uint64_t w0 = b->cigar.size();
+    b->cigar.resize(w0 + words);
+    const uint64_t s0 = b->seq.size();
+    if (keep_seq) { b->seq.resize(s0 + seq_bytes); b->seq_off.resize(n0 + n); }
+    {   // CSR offsets (sequential prefix), then the scatter in parallel
+        uint64_t w = w0, s = s0;
+        for (size_t i = 0; i < n; ++i) {
+            w += recs[i].n_cig;
+            b->cig_off[n0 + i + 1] = w;
+            if (keep_seq) { b->seq_off[n0 + i] = s; s += (rd32(&buf[recs[i].at + 4 + 16]) + 1ull) / 2; }
+        }
+    }
+    parallel_for(n, threads, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            const uint8_t* rec = &buf[recs[i].at + 4];
+            const size_t k = n0 + i;
+            b->tid[k] = (int32_t)rd32(rec); b->pos[k] = (int32_t)rd32(rec + 4);
+            b->mapq[k] = rec[9];
+            b->flag[k] = rd16(rec + 14);
+            b->l_seq[k] = (int32_t)rd32(rec + 16);
+            memcpy(&b->cigar[b->cig_off[k]], recs[i].cig, 4ull * recs[i].n_cig);
+            if (keep_seq) memcpy(&b->seq[b->seq_off[k]], rec + 32 + rec[8] + 4ull * rd16(rec + 12), ((uint32_t)b->l_seq[k] + 1ull) / 2);
         }
     });
-    if (!ok) { err = "BGZF inflate failed"; return false; }
-    return true;
+    return (long long)p;
+}
+
+thread_local std::string g_bam_error;
+
+void* bam_open_impl(const char* path, int threads, int flags, bool ranged, uint64_t voff_beg, uint64_t voff_end)
+{
+    g_bam_error.clear();
+    if (threads <= 0) threads = (int)std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    const bool keep_seq = flags & SVX_BAM_KEEP_SEQ;
+    FILE* f = fopen(path, "rb");
+    if (!f) { g_bam_error = std::string("cannot open ") + path; return nullptr; }
+    std::unique_ptr<Bam> b(new Bam());
+    std::vector<uint8_t> buf;
+    auto fail = [&](const std::string& why) -> void* { g_bam_error = why; fclose(f); return nullptr; };
+
+    // header: from the start of the file, chunk by chunk until the reference dictionary is complete
+    // SVX_BAM_CHUNK (bytes) shrinks the read size so that tests cross chunk boundaries on small files
+    const char* env = getenv("SVX_BAM_CHUNK");
+    const size_t steady = env && atol(env) > 0 ? (size_t)atol(env) : (16u << 20);   // inflated chunk stays cache-warm for the parse
+    BgzfStream head(f, 0, ~0ull, threads, std::min<size_t>(steady, 256u << 10));
+    long long hdr = 0;
+    while (hdr == 0) {
+        if (head.done()) return fail(buf.empty() ? "empty file" : "truncated BAM header");
+        if (!head.next(buf)) return fail(head.error());
+        hdr = parse_header(buf, b.get());
+        head.chunk = std::min<size_t>(head.chunk * 4, steady);
+    }
+    if (hdr < 0) return fail("not a BAM file");
+    head.chunk = steady;
+
+    if (!ranged) {
+        uint64_t cur = (uint64_t)hdr;
+        for (;;) {
+            const long long used = parse_records(buf, cur, buf.size(), threads, keep_seq, b.get());
+            if (used < 0) return fail("malformed BAM record");
+            buf.erase(buf.begin(), buf.begin() + used);        // keeps a partial record for the next chunk
+            cur = 0;
+            if (head.done()) break;
+            if (!head.next(buf)) return fail(head.error());
+        }
+        if (!buf.empty()) return fail("truncated BAM record");
+    } else if (voff_end > voff_beg) {
+        // the compressed range [coffset(voff_beg), end of the block at coffset(voff_end)): one spare block is read
+        const uint64_t c0 = voff_beg >> 16, c1 = voff_end >> 16;
+        BgzfStream body(f, c0, c1 + 65536 + 26, threads, steady);
+        buf.clear();
+        uint64_t cur = voff_beg & 0xffff, limit = ~0ull;      // limit: position in buf of (c1, voff_end & 0xffff)
+        bool reached = false;
+        while (!reached && !body.done()) {
+            if (!body.next(buf)) return fail(body.error());
+            for (const auto& blk : body.blocks()) {
+                if (reached) break;
+                if (blk.coff == c1) { limit = blk.dst + (voff_end & 0xffff); reached = true; }
+                else if (blk.coff > c1) { limit = blk.dst; reached = true; }
+            }
+            const uint64_t stop = std::min<uint64_t>(limit, buf.size());
+            if (cur > stop) {                                  // the first block has not arrived in full yet
+                if (reached) return fail("BAM index does not match the file");
+                continue;
+            }
+            const long long used = parse_records(buf, cur, stop, threads, keep_seq, b.get());
+            if (used < 0) return fail("malformed BAM record");
+            if (reached) { if ((uint64_t)used != stop) return fail("BAM index does not match the file"); break; }
+            buf.erase(buf.begin(), buf.begin() + used);
+            cur = 0;
+        }
+        if (!reached) return fail("BAM index does not match the file");
+    }
+    fclose(f);
+    return b.release();
 }
 
 }  // namespace
 
 extern "C" {
 
-// Decode a BAM file.  Returns an opaque handle (NULL on failure; message via svx_bam_error(NULL)).
-static thread_local std::string g_bam_error;
-
-static bool read_bytes(const char* path, uint64_t from, uint64_t to, std::vector<uint8_t>& buf)
-{
-    FILE* f = fopen(path, "rb");
-    if (!f) { g_bam_error = std::string("cannot open ") + path; return false; }
-    fseek(f, 0, SEEK_END);
-    const uint64_t sz = (uint64_t)ftell(f);
-    to = std::min(to, sz);
-    from = std::min(from, to);
-    buf.resize(to - from);
-    fseek(f, (long)from, SEEK_SET);
-    const bool ok = buf.empty() || fread(buf.data(), 1, buf.size(), f) == buf.size();
-    fclose(f);
-    if (!ok) g_bam_error = "short read";
-    return ok;
-}
-
-static void* bam_open_impl(const char* path, int threads, bool ranged, uint64_t voff_beg, uint64_t voff_end)
-{
-    g_bam_error.clear();
-    if (threads <= 0) threads = (int)std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
-    Bam* b = new Bam();
-    std::vector<uint8_t> file;
-    uint64_t rec_begin = 0, rec_end = ~0ull;      // record byte range inside b->raw (ranged mode)
-    if (!ranged) {
-        if (!read_bytes(path, 0, ~0ull, file)) { delete b; return nullptr; }
-        if (!inflate_file(file, threads, b->raw, b->error)) { g_bam_error = b->error; delete b; return nullptr; }
-    } else {
-        // header: inflate leading blocks until the reference dictionary is complete (grow the window if needed)
-        std::vector<uint8_t> head;
-        for (uint64_t want = 1 << 20;; want *= 4) {
-            if (!read_bytes(path, 0, want, file)) { delete b; return nullptr; }
-            // drop a trailing partial block: keep only whole blocks
-            head.clear();
-            std::string err;
-            uint64_t p = 0;
-            while (p + 18 <= file.size()) {
-                if (!(file[p] == 0x1f && file[p + 1] == 0x8b)) break;
-                const uint32_t xlen = rd16(&file[p + 10]);
-                if (p + 12 + xlen > file.size()) break;
-                uint32_t bsize = 0;
-                for (uint64_t q = p + 12; q + 4 <= p + 12 + xlen;) {
-                    const uint32_t slen = rd16(&file[q + 2]);
-                    if (file[q] == 'B' && file[q + 1] == 'C') bsize = rd16(&file[q + 4]);
-                    q += 4 + slen;
-                }
-                if (!bsize || p + bsize + 1 > file.size()) break;
-                p += bsize + 1;
-            }
-            if (!inflate_file(file, 1, head, err, 0, p)) { g_bam_error = err; delete b; return nullptr; }
-            bool complete = false;
-            if (head.size() >= 12 && memcmp(head.data(), "BAM\1", 4) == 0) {
-                uint64_t q = 8 + rd32(&head[4]);
-                if (q + 4 <= head.size()) {
-                    const uint32_t n_ref = rd32(&head[q]); q += 4;
-                    uint32_t i = 0;
-                    for (; i < n_ref && q + 4 <= head.size(); ++i) {
-                        const uint32_t l_name = rd32(&head[q]);
-                        if (q + 8 + l_name > head.size()) break;
-                        q += 8 + l_name;
-                    }
-                    complete = i == n_ref;
-                }
-            } else if (head.size() >= 4) { g_bam_error = "not a BAM file"; delete b; return nullptr; }
-            if (complete || want > file.size() * 2 + (1 << 20)) break;     // whole file read already
-        }
-        // records: the compressed range [coffset(voff_beg), block after coffset(voff_end)]
-        std::vector<uint8_t> body;
-        if (voff_end > voff_beg) {
-            const uint64_t c0 = voff_beg >> 16, c1 = voff_end >> 16;
-            if (!read_bytes(path, c0, c1 + 65536 + 26, file)) { delete b; return nullptr; }
-            std::string err;
-            // inflate whole blocks from c0 up to and including the block that starts at c1
-            uint64_t p = 0, stop = 0;
-            std::vector<uint64_t> starts;
-            while (p + 18 <= file.size()) {
-                if (!(file[p] == 0x1f && file[p + 1] == 0x8b)) break;
-                const uint32_t xlen = rd16(&file[p + 10]);
-                uint32_t bsize = 0;
-                for (uint64_t q = p + 12; q + 4 <= p + 12 + xlen && q + 6 <= file.size();) {
-                    const uint32_t slen = rd16(&file[q + 2]);
-                    if (file[q] == 'B' && file[q + 1] == 'C') bsize = rd16(&file[q + 4]);
-                    q += 4 + slen;
-                }
-                if (!bsize || p + bsize + 1 > file.size()) break;
-                starts.push_back(p);
-                p += bsize + 1;
-                stop = p;
-                if (starts.back() + c0 >= c1) break;
-            }
-            if (!inflate_file(file, threads, body, err, 0, stop)) { g_bam_error = err; delete b; return nullptr; }
-            // uncompressed offset of the last block = sum of the isizes before it
-            uint64_t last_u = 0;
-            for (size_t i = 0; i + 1 < starts.size(); ++i) {
-                const uint64_t end = (i + 1 < starts.size()) ? starts[i + 1] : stop;
-                last_u += rd32(&file[end - 4]);
-            }
-            rec_begin = voff_beg & 0xffff;
-            rec_end = (starts.empty() || starts.back() + c0 < c1) ? body.size() : last_u + (voff_end & 0xffff);
-        }
-        // stitch: header bytes followed by the record range so that the common parser below applies
-        uint64_t hdr_end = 8 + rd32(&head[4]);
-        const uint32_t n_ref = rd32(&head[hdr_end]); hdr_end += 4;
-        for (uint32_t i = 0; i < n_ref; ++i) hdr_end += 8 + rd32(&head[hdr_end]);
-        b->raw.assign(head.begin(), head.begin() + hdr_end);
-        if (!body.empty() && rec_end > rec_begin) b->raw.insert(b->raw.end(), body.begin() + rec_begin, body.begin() + std::min<uint64_t>(rec_end, body.size()));
-    }
-    const std::vector<uint8_t>& r = b->raw;
-    if (r.size() < 12 || memcmp(r.data(), "BAM\1", 4) != 0) { g_bam_error = "not a BAM file"; delete b; return nullptr; }
-    uint64_t p = 4;
-    const uint32_t l_text = rd32(&r[p]); p += 4;
-    b->header_text.assign(reinterpret_cast<const char*>(&r[p]), strnlen(reinterpret_cast<const char*>(&r[p]), l_text));
-    p += l_text;
-    const uint32_t n_ref = rd32(&r[p]); p += 4;
-    for (uint32_t i = 0; i < n_ref; ++i) {
-        const uint32_t l_name = rd32(&r[p]);
-        b->ref_names.emplace_back(reinterpret_cast<const char*>(&r[p + 4]), l_name ? l_name - 1 : 0);
-        b->ref_lens.push_back((int32_t)rd32(&r[p + 4 + l_name]));
-        p += 8 + l_name;
-    }
-    // chain the record offsets, build the CIGAR CSR and the first-occurrence QNAME ids
-    std::unordered_map<std::string_view, int32_t> seen;
-    b->cig_off.push_back(0);
-    while (p + 4 <= r.size()) {
-        const uint32_t bs = rd32(&r[p]);
-        if (p + 4 + bs > r.size() || bs < 32) { g_bam_error = "truncated BAM record"; delete b; return nullptr; }
-        b->rec_off.push_back(p);
-        const uint8_t* rec = &r[p + 4];
-        const uint32_t l_name = rec[8];
-        uint32_t n_cig = rd16(rec + 12);
-        uint64_t src = p + 4 + 32 + l_name;
-        if (n_cig == 2) {                                     // possible CG-tag placeholder
-            const uint32_t w0 = rd32(&r[src]), w1 = rd32(&r[src + 4]);
-            const uint32_t l_seq = rd32(rec + 16);
-            if ((w0 & 15) == 4 && (w0 >> 4) == l_seq && (w1 & 15) == 3) {
-                uint32_t cnt = 0;
-                const uint64_t aux = src + 8 + (l_seq + 1) / 2 + l_seq;
-                const uint64_t at = find_long_cigar(r, aux, p + 4 + bs, &cnt);
-                if (at) { src = at; n_cig = cnt; }
-            }
-        }
-        b->cig_src.push_back(src);
-        b->cig_off.push_back(b->cig_off.back() + n_cig);
-        std::string_view nm(reinterpret_cast<const char*>(rec + 32), l_name ? l_name - 1 : 0);
-        auto it = seen.find(nm);
-        if (it == seen.end()) {
-            it = seen.emplace(nm, (int32_t)b->name_first.size()).first;
-            b->name_first.push_back((uint32_t)(b->rec_off.size() - 1));
-            b->names_bytes += nm.size() + 1;
-        }
-        b->name_id.push_back(it->second);
-        p += 4 + bs;
-    }
-    return b;
-}
-
-void* svx_bam_open(const char* path, int threads) { return bam_open_impl(path, threads, false, 0, 0); }
+void* svx_bam_open(const char* path, int threads, int flags) { return bam_open_impl(path, threads, flags, false, 0, 0); }
 
 // Only the records between two BGZF virtual offsets (from the .bai index: one chromosome, one rank's shard);
 // the header / reference dictionary is always decoded.  voff_end <= voff_beg: header only.
-void* svx_bam_open_range(const char* path, int threads, uint64_t voff_beg, uint64_t voff_end)
+void* svx_bam_open_range(const char* path, int threads, int flags, uint64_t voff_beg, uint64_t voff_end)
 {
-    return bam_open_impl(path, threads, true, voff_beg, voff_end);
+    return bam_open_impl(path, threads, flags, true, voff_beg, voff_end);
 }
 
 const char* svx_bam_error(void) { return g_bam_error.c_str(); }
 
-// sizes: [n_records, n_cigar_words, n_refs, n_names, names_bytes, header_bytes, ref_names_bytes, raw_bytes]
+// sizes: [n_records, n_cigar_words, n_refs, n_names, names_bytes, header_bytes, ref_names_bytes, seq_bytes]
 void svx_bam_sizes(void* h, uint64_t* sizes)
 {
     const Bam* b = static_cast<const Bam*>(h);
     uint64_t rn = 0;
     for (auto& s : b->ref_names) rn += s.size() + 1;
-    sizes[0] = b->rec_off.size(); sizes[1] = b->cig_off.back(); sizes[2] = b->ref_names.size();
-    sizes[3] = b->name_first.size(); sizes[4] = b->names_bytes; sizes[5] = b->header_text.size();
-    sizes[6] = rn; sizes[7] = b->raw.size();
+    sizes[0] = b->tid.size(); sizes[1] = b->cigar.size(); sizes[2] = b->ref_names.size();
+    sizes[3] = b->names.size(); sizes[4] = b->names_bytes; sizes[5] = b->header_text.size();
+    sizes[6] = rn; sizes[7] = b->seq.size();
 }
 
 // Fill caller-owned arrays (all sized from svx_bam_sizes).  seq_off may be NULL; otherwise it receives the byte
-// offset of each record's 4-bit SEQ inside the decompressed file, which svx_bam_raw() exposes.
+// offset of each record's 4-bit SEQ inside the pool svx_bam_seq() exposes (handles opened with SVX_BAM_KEEP_SEQ).
 void svx_bam_export(void* h, int threads, int32_t* tid, int32_t* pos, uint16_t* flag, uint8_t* mapq, int32_t* l_seq,
                     int32_t* name_id, int64_t* cig_off, uint32_t* cigar, char* names, char* header, char* ref_names,
                     int32_t* ref_lens, int64_t* seq_off)
 {
+    (void)threads;
     const Bam* b = static_cast<const Bam*>(h);
-    const std::vector<uint8_t>& r = b->raw;
-    const size_t n = b->rec_off.size();
-    if (threads <= 0) threads = (int)std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
-    parallel_for(n, threads, [&](size_t lo, size_t hi) {
-        for (size_t i = lo; i < hi; ++i) {
-            const uint8_t* rec = &r[b->rec_off[i] + 4];
-            tid[i] = (int32_t)rd32(rec); pos[i] = (int32_t)rd32(rec + 4);
-            const uint32_t l_name = rec[8];
-            mapq[i] = rec[9];
-            const uint32_t n_cig_field = rd16(rec + 12);
-            const uint64_t n_cig = b->cig_off[i + 1] - b->cig_off[i];
-            flag[i] = rd16(rec + 14);
-            l_seq[i] = (int32_t)rd32(rec + 16);
-            name_id[i] = b->name_id[i];
-            cig_off[i] = (int64_t)b->cig_off[i];
-            memcpy(cigar + b->cig_off[i], &r[b->cig_src[i]], 4ull * n_cig);
-            if (seq_off) seq_off[i] = (int64_t)(b->rec_off[i] + 4 + 32 + l_name + 4ull * n_cig_field);
-        }
-    });
-    cig_off[n] = (int64_t)b->cig_off[n];
-    char* w = names;
-    for (uint32_t first : b->name_first) {
-        const uint8_t* rec = &r[b->rec_off[first] + 4];
-        const uint32_t l = rec[8] ? rec[8] - 1 : 0;
-        memcpy(w, rec + 32, l); w[l] = '\n'; w += l + 1;
+    const size_t n = b->tid.size();
+    if (n) {
+        memcpy(tid, b->tid.data(), 4 * n); memcpy(pos, b->pos.data(), 4 * n); memcpy(flag, b->flag.data(), 2 * n);
+        memcpy(mapq, b->mapq.data(), n); memcpy(l_seq, b->l_seq.data(), 4 * n); memcpy(name_id, b->name_id.data(), 4 * n);
     }
+    for (size_t i = 0; i <= n; ++i) cig_off[i] = (int64_t)b->cig_off[i];
+    if (!b->cigar.empty()) memcpy(cigar, b->cigar.data(), 4 * b->cigar.size());
+    if (seq_off)
+        for (size_t i = 0; i < n; ++i) seq_off[i] = i < b->seq_off.size() ? (int64_t)b->seq_off[i] : 0;
+    char* w = names;
+    for (const auto& nm : b->names) { memcpy(w, nm.data(), nm.size()); w[nm.size()] = '\n'; w += nm.size() + 1; }
     memcpy(header, b->header_text.data(), b->header_text.size());
     w = ref_names;
     for (size_t i = 0; i < b->ref_names.size(); ++i) {
@@ -354,7 +423,7 @@ void svx_bam_export(void* h, int threads, int32_t* tid, int32_t* pos, uint16_t* 
     }
 }
 
-const uint8_t* svx_bam_raw(void* h) { return static_cast<const Bam*>(h)->raw.data(); }
+const uint8_t* svx_bam_seq(void* h) { return static_cast<const Bam*>(h)->seq.data(); }
 
 void svx_bam_close(void* h) { delete static_cast<Bam*>(h); }
 

@@ -250,16 +250,17 @@ def read_bam(path, with_seq=False, threads=0, tids=None, index=None):
     import ctypes
     from .. import _lib
     lib = _lib.load()
+    flags = 1 if with_seq else 0                          # SVX_BAM_KEEP_SEQ
     if tids is not None:
         spans = read_bai(index or (path + ".bai"))
         have = [spans[t] for t in tids if t < len(spans) and spans[t] is not None]
         if have:
-            h = lib.svx_bam_open_range(path.encode(), int(threads), min(s[0] for s in have), max(s[1] for s in have))
+            h = lib.svx_bam_open_range(path.encode(), int(threads), flags, min(s[0] for s in have), max(s[1] for s in have))
         else:
-            h = lib.svx_bam_open_range(path.encode(), int(threads), 0, 0)
+            h = lib.svx_bam_open_range(path.encode(), int(threads), flags, 0, 0)
         keep_tids = set(int(t) for t in tids)
     else:
-        h = lib.svx_bam_open(path.encode(), int(threads))
+        h = lib.svx_bam_open(path.encode(), int(threads), flags)
         keep_tids = None
     if not h:
         msg = lib.svx_bam_error().decode()
@@ -280,7 +281,7 @@ def read_bam(path, with_seq=False, threads=0, tids=None, index=None):
                            seq_off.ctypes.data if with_seq else None)
         seq_packed = None
         if with_seq:
-            seq_packed = ctypes.string_at(lib.svx_bam_raw(h), rawb)
+            seq_packed = ctypes.string_at(lib.svx_bam_seq(h), rawb) if rawb else b""
     finally:
         lib.svx_bam_close(h)
     name_list = names.tobytes().decode().split("\n")[:-1] if nb else []

@@ -9,6 +9,8 @@ from svision_amd import synth
 from svision_amd.io import bam
 from tests import helpers
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def _same(a, b):
     for f in ("tid", "pos", "flag", "mapq", "l_seq", "name_id", "cigar", "cig_off"):
@@ -141,3 +143,30 @@ def test_read_bai_on_the_reference_demo_index():
     assert [i for i, s in enumerate(spans) if s is not None] == [8]
     lo, hi = spans[8]
     assert (lo >> 16, lo & 0xFFFF, hi >> 16, hi & 0xFFFF) == (37193, 0, 26266501, 0)
+
+
+@pytest.mark.parametrize("chunk", ["700", "20000", "70000"])
+def test_streaming_decode_across_chunk_boundaries(tmp_path, chunk):
+    """The decoder streams the file chunk by chunk; with a tiny chunk every block / record / header straddles reads."""
+    import subprocess, sys
+    cfg = synth.SimConfig(contigs=[("c1", 200_000), ("c2", 120_000)], coverage=6, read_len_mean=5000, read_len_sd=800,
+                          sv_spacing=9000, sv_min_gap=5000, sv_max=1000, seed=21)
+    table, _g, _ = synth.simulate(cfg, with_genome=False, with_seq=True)
+    path = str(tmp_path / "s.bam")
+    bam.write_bam(path, table, index=True)
+    want = bam.read_bam_python(path, with_seq=True)
+    code = ("import sys, pickle; sys.path.insert(0, %r); from svision_amd.io import bam; "
+            "t = bam.read_bam(%r, with_seq=True); p = bam.read_bam(%r, tids=[1]); "
+            "pickle.dump([(x.tid, x.pos, x.flag, x.mapq, x.l_seq, x.name_id, x.names, x.cigar, x.cig_off, x.references, "
+            "[x.query_sequence(i) for i in range(0, len(x), 37)] if x.seq_packed is not None else None) for x in (t, p)], sys.stdout.buffer)"
+            % (ROOT, path, path))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SVX_BAM_CHUNK=chunk), capture_output=True, timeout=120)
+    assert out.returncode == 0, out.stderr.decode()
+    import pickle
+    full, part = pickle.loads(out.stdout)
+    for got, ref in ((full, want), (part, want.subset(np.flatnonzero(want.tid == 1)))):
+        for k, name in enumerate(("tid", "pos", "flag", "mapq", "l_seq", "name_id")):
+            assert np.array_equal(got[k], getattr(ref, name)), name
+        assert got[6] == ref.names and np.array_equal(got[7], ref.cigar) and np.array_equal(got[8], ref.cig_off)
+        assert got[9] == ref.references
+    assert full[10] == [want.query_sequence(i) for i in range(0, len(want), 37)]

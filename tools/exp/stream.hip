@@ -32,6 +32,30 @@ __global__ __launch_bounds__(256) void stream_kernel(const uint4* __restrict__ i
     if ((r ^ q ^ g) == 0x12345678u) out[0] = r;
 }
 
+typedef float vf4 __attribute__((ext_vector_type(4)));
+template <int NT>
+__global__ __launch_bounds__(256) void write_kernel(const uint4* __restrict__ in, size_t nq, uint32_t* out)
+{
+    vf4* o = reinterpret_cast<vf4*>(const_cast<uint4*>(in));
+    const size_t stride = (size_t)gridDim.x * 256;
+    const vf4 v = {1.f, 2.f, 3.f, (float)blockIdx.x};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nq; i += stride) {
+        if (NT) __builtin_nontemporal_store(v, &o[i]); else o[i] = v;
+    }
+}
+// contiguous slice per workgroup (like the rasteriser: one image per workgroup)
+template <int NT>
+__global__ __launch_bounds__(256) void write_slice_kernel(const uint4* __restrict__ in, size_t nq, uint32_t* out)
+{
+    vf4* o = reinterpret_cast<vf4*>(const_cast<uint4*>(in));
+    const size_t per = (nq + gridDim.x - 1) / gridDim.x;
+    const size_t lo = per * blockIdx.x, hi = lo + per < nq ? lo + per : nq;
+    const vf4 v = {1.f, 2.f, 3.f, (float)blockIdx.x};
+    for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
+        if (NT) __builtin_nontemporal_store(v, &o[i]); else o[i] = v;
+    }
+}
+
 int main()
 {
     const size_t bytes = 1200ull << 20;
@@ -56,6 +80,12 @@ int main()
         run("stream u4", stream_kernel<4, false>, grid);
         run("stream+tally u2", stream_kernel<2, true>, grid);
         run("stream+tally u4", stream_kernel<4, true>, grid);
+    }
+    for (int grid : {2048, 4096, 16384}) {
+        run("write grid-stride", write_kernel<0>, grid);
+        run("write grid-stride nontemporal", write_kernel<1>, grid);
+        run("write slices", write_slice_kernel<0>, grid);
+        run("write slices nontemporal", write_slice_kernel<1>, grid);
     }
     return 0;
 }
