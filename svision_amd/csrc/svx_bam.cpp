@@ -9,6 +9,7 @@
 // read, so the resident size is that of the packed arrays that go to the GPU unchanged (svx_cigar_scan
 // input), not that of the file.  SAMv1 section 4 layouts, including CIGARs with more than 65535 operations
 // (CG:B,I tag).  With two virtual offsets from the .bai index only that byte range is read.
+#include <sched.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -304,7 +305,11 @@ thread_local std::string g_bam_error;
 void* bam_open_impl(const char* path, int threads, int flags, bool ranged, uint64_t voff_beg, uint64_t voff_end)
 {
     g_bam_error.clear();
-    if (threads <= 0) threads = (int)std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    if (threads <= 0) {                                   // the CPUs this process may run on (not the machine's), at most 64
+        cpu_set_t set;
+        const int avail = sched_getaffinity(0, sizeof set, &set) == 0 ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
+        threads = std::max(1, std::min(64, avail));
+    }
     const bool keep_seq = flags & SVX_BAM_KEEP_SEQ;
     FILE* f = fopen(path, "rb");
     if (!f) { g_bam_error = std::string("cannot open ") + path; return nullptr; }
