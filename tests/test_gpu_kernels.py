@@ -68,6 +68,29 @@ def test_cigar_scan_matches_oracle(oracle_lib, n_aln, mean_ops, rate):
     assert gaps.tobytes() == o_gaps.tobytes()
 
 
+def test_cigar_scan_full_size(oracle_lib):
+    """A whole-chromosome-sized batch (1.5 M alignments: several scan steps of 1024 tiles, a last partial tile, a work list
+    of tens of thousands of alignments) against the C oracle, plus the size-independent properties of the output."""
+    from oracle import cbind
+    n_aln = 1_500_003
+    cigar, off, ref_start = datagen.random_cigars(n_aln, seed=11, mean_ops=24, long_gap_rate=0.004)
+    res = kernels.cigar_scan(_dev(cigar.view(np.int32)), _dev(off.astype(np.int64)), _dev(ref_start), 50)
+    gaps, gap_off, stats = res.to_host()
+    o_gaps, o_off, o_stats = cbind.cigar_scan(cigar, off, ref_start, 50)
+    assert np.array_equal(gap_off, o_off)
+    assert np.array_equal(stats, o_stats)
+    assert gaps.tobytes() == o_gaps.tobytes()
+    g = np.frombuffer(gaps.tobytes(), np.int32).reshape(-1, 6)
+    assert g.shape[0] == int(gap_off[-1]) > 20_000
+    key = g[:, 0].astype(np.int64) * (1 << 32) + g[:, 1].astype(np.uint32)
+    assert np.all(np.diff(key) > 0)                                      # sorted by (alignment, op), no duplicates
+    assert np.array_equal(np.bincount(g[:, 0], minlength=n_aln), np.diff(gap_off.astype(np.int64)))   # CSR consistent
+    words = cigar[off[g[:, 0]].astype(np.int64) + g[:, 1]]
+    assert np.array_equal(words >> 4, g[:, 4].astype(np.uint32)) and np.array_equal(words & 15, g[:, 5].astype(np.uint32))
+    again = kernels.cigar_scan(_dev(cigar.view(np.int32)), _dev(off.astype(np.int64)), _dev(ref_start), 50)
+    assert again.to_host()[0].tobytes() == gaps.tobytes()                # deterministic
+
+
 def test_cigar_scan_ragged_and_empty(oracle_lib):
     from oracle import cbind
     # empty batch
