@@ -215,6 +215,17 @@ def kernel_calibration(sample, net, dev, B, reps=20):
     alg = 4 * int(table.cigar.size) + 32 * n + 24 * int(sample.gap_off[-1])
     out["cigar_scan (4 kernels)"] = {"bound": "hbm", "launch": "%d alignments, %d ops" % (n, table.cigar.size), "us": t * 1e6,
                                      "achieved": alg / t / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / t / HBM_PEAK}
+    # the dominant kernel: fp32 MFMA implicit-GEMM convolution on the four layer shapes (2 x MAC algorithmic FLOP per launch)
+    for name, cin, cout, hw, k, groups in (("conv2", 96, 256, 27, 5, 2), ("conv3", 256, 384, 13, 3, 1), ("conv4", 384, 384, 13, 3, 2),
+                                           ("conv5", 384, 256, 13, 3, 2)):
+        x = torch.randn(B, cin, hw, hw, device=dev)
+        w = torch.randn(k, k, cin // groups, cout, device=dev) * 0.05
+        bias = torch.randn(cout, device=dev)
+        t = timed(lambda: kernels.conv2d_same(x, w, bias, groups=groups, relu=True))
+        flop = 2.0 * B * hw * hw * cout * (cin // groups) * k * k
+        out["conv_igemm_kernel %s" % name] = {"bound": "mfma", "launch": "%d x %d x %d x %d -> %d, %dx%d, %d group(s)" % (B, cin, hw, hw, cout, k, k, groups),
+                                               "us": t * 1e6, "achieved": flop / t / 1e12, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
+                                               "frac": flop / t / F32_MFMA_PEAK}
     t = timed(lambda: net.predict_records(rec))
     out["device_stage_eager_1_stream"] = {"bound": "mfma", "launch": "%d images" % B, "us": t * 1e6,
                                           "achieved": CNN_FLOP * B / t / 1e12, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
