@@ -16,12 +16,12 @@
 // filter tap (Cin/groups is a multiple of 16), so the padding test is one predicate per slice and the
 // eight activation loads of a lane are a constant stride apart.  Both operands are staged in LDS as
 // [k][n] / [k][m] (unit stride across lanes: no bank conflicts on write or on the ds_read_b32 fragment
-// reads), double buffered, with the global loads of slice k+1 in flight under the MFMAs of slice k and
-// one barrier per slice.  fp32 MFMA issues every 64 cycles, so 24 KB of LDS traffic per slice is far
-// below the LDS rate; the kernel is matrix-pipe bound.
+// reads), double buffered; within a slice the wave's own LDS reads / stores and the global loads of slice
+// k+1 are interleaved with its 16 MFMAs (software pipelined, one barrier per slice).  fp32 MFMA issues
+// every 64 cycles, so 24 KB of LDS traffic per slice is far below the LDS rate; the kernel is
+// matrix-pipe bound.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 #include "../../include/svx.h"
 
 namespace {
@@ -121,31 +121,55 @@ void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w
     __syncthreads();
 
     const int fk = lane >> 5, fj = lane & 31;
-    // One slice: the next slice's global loads (no per-load address arithmetic) and the 24 fragment reads are
-    // issued up front, then 16 back-to-back MFMAs, then the LDS stores of the next slice and one barrier.
+    // One slice: the non-matrix instructions sit between the MFMAs of the wave itself -- fragment reads one
+    // k-pair ahead in a ring of register sets, the next slice's global loads (no per-load address arithmetic) up front,
+    // its LDS stores under the last four k-pairs -- so a wave keeps the matrix pipe fed without relying on the other
+    // resident wave being in its matrix phase (sched_barrier pins the order); one barrier per slice.
+    auto read_frag = [&](int buf, int kk, float& a, float (&b)[MT]) {
+        a = Ws[buf][2 * kk + fk][wn * 32 + fj];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) b[t] = Xs[buf][2 * kk + fk][wm * WM + t * 32 + fj];
+    };
+#ifndef SVX_CONV_AHEAD
+#define SVX_CONV_AHEAD 1                     // k-pairs the fragment reads run ahead of the MFMAs (1, 2, 3 measured: 735 / 755 / 760 us per batch)
+#define SVX_CONV_S0 4                        // first k-pair that carries LDS stores of the next slice
+#endif
     auto compute_slice = [&](int buf, bool prefetch) {
-        float fa[BK / 2], fb[MT][BK / 2];
+        constexpr int NKK = BK / 2, AHEAD = SVX_CONV_AHEAD, RING = AHEAD + 1, S0 = SVX_CONV_S0, SPAN = NKK - S0;
+        float ra[RING], rb[RING][MT];
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            fa[kk] = Ws[buf][2 * kk + fk][wn * 32 + fj];
-#pragma unroll
-            for (int t = 0; t < MT; ++t) fb[t][kk] = Xs[buf][2 * kk + fk][wm * WM + t * 32 + fj];
-        }
+        for (int kk = 0; kk < AHEAD; ++kk) read_frag(buf, kk, ra[kk], rb[kk]);
         if (prefetch) load_slice();
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk)
+        for (int kk = 0; kk < NKK; ++kk) {
+            if (kk + AHEAD < NKK) read_frag(buf, kk + AHEAD, ra[(kk + AHEAD) % RING], rb[(kk + AHEAD) % RING]);
 #pragma unroll
-            for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk], fb[t][kk], acc[t], 0, 0, 0);
+            for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[kk % RING], rb[kk % RING][t], acc[t], 0, 0, 0);
+            if (prefetch && kk >= S0) {
+                // a share of the next slice's LDS stores per k-pair
+                const int q = kk - S0;
+#pragma unroll
+                for (int i = q * XR / SPAN; i < (q + 1) * XR / SPAN; ++i) Xs[buf ^ 1][xk0 + XSTEP * i][xm] = xr_ok ? xr[i] : 0.0f;
+                if (q < WR) *reinterpret_cast<float4*>(&Ws[buf ^ 1][wk + 16 * q][wn4]) = wr[q];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
     for (int kt = 0; kt + 1 < nk; ++kt) {
-        const int buf = kt & 1;
-        compute_slice(buf, true);
-        store_slice(buf ^ 1);
+        compute_slice(kt & 1, true);
         __syncthreads();
     }
     compute_slice((nk - 1) & 1, false);
 
     // epilogue: D[row = channel][col = pixel]; lane holds col = lane & 31, rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    float bv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bv[r] = 0.0f;
+    if (bias) {                                            // one batch of loads, not one round trip per row
+        const float* bp = bias + g * CoutG + n0 + wn * 32 + 4 * fk;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bv[r] = bp[(r & 3) + 8 * (r >> 2)];
+    }
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         const long long mm = (long long)m0 + wm * WM + t * 32 + fj;
@@ -156,8 +180,7 @@ void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int nl = (r & 3) + 8 * (r >> 2);
-            float v = acc[t][r];
-            if (bias) v += bias[g * CoutG + n0 + wn * 32 + 4 * fk + nl];
+            float v = acc[t][r] + bv[r];
             if (relu) v = fmaxf(v, 0.0f);
             o[(size_t)nl * HW] = v;
         }
@@ -180,8 +203,7 @@ extern "C" int svx_conv2d_same(const float* d_in, const float* d_w_hwio, const f
     // 64 x 128 tiles unless they leave the 256 CUs under two resident workgroups each (then 64 x 64: the partial last
     // dispatch round of the big tiles costs more than the extra fragment reads of the small ones)
     const long long tiles128 = ((mtot + 127) / 128) * groups * (cout_g / BN);
-    static const int force_bm = getenv("SVX_CONV_BM") ? atoi(getenv("SVX_CONV_BM")) : 0;
-    const int bm = force_bm ? force_bm : (tiles128 < 448 ? 64 : 128);
+    const int bm = tiles128 < 448 ? 64 : 128;
     const long long total_tiles = ((mtot + bm - 1) / bm) * groups * (cout_g / BN);
     dim3 grid((unsigned)(8 * ((total_tiles + 7) / 8))), block(THREADS);
 #define SVX_LAUNCH_CONV(KS_, BM_) hipLaunchKernelGGL((conv_igemm_kernel<KS_, 16, BM_>), grid, block, 0, st, d_in, d_w_hwio, d_bias, \
