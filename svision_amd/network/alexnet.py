@@ -152,8 +152,12 @@ class AlexNet(torch.nn.Module):
             elif name == "conv5":
                 x = F.max_pool2d(x, 3, 2)
         x = x.reshape(x.shape[0], 9216) if not self.channels_last else x.contiguous().reshape(x.shape[0], 9216)
-        x = F.relu_(F.linear(x, self.fc6_w, self.fc6_b))
-        x = F.relu_(F.linear(x, self.fc7_w, self.fc7_b))
+        if x.is_cuda:                                       # bias + ReLU in the hipBLASLt epilogue
+            x = torch._addmm_activation(self.fc6_b, x, self.fc6_w.t(), use_gelu=False)
+            x = torch._addmm_activation(self.fc7_b, x, self.fc7_w.t(), use_gelu=False)
+        else:
+            x = F.relu_(F.linear(x, self.fc6_w, self.fc6_b))
+            x = F.relu_(F.linear(x, self.fc7_w, self.fc7_b))
         if upto_fc7:
             return x
         return F.linear(x, self.fc8_w, self.fc8_b)
