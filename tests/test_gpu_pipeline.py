@@ -148,3 +148,30 @@ def test_streaming_cli_equals_file_based_cli(checkpoint, tmp_path):
     assert outs["stream"].keys() == outs["files"].keys()
     for k in outs["stream"]:
         assert outs["stream"][k] == outs["files"][k], k
+
+
+def test_two_ranks_from_an_indexed_bam_equal_one_rank(checkpoint, tmp_path):
+    """The whole multi-rank command line from files: two torchrun ranks (gloo here: one GPU is shared, RCCL refuses
+    duplicate devices; the driver's multi-GPU runs use nccl) each decode only their chromosomes through the .bai, stream
+    them through the device path, and the single exchange gives rank 0 the merged VCF of the one-rank run, byte for byte."""
+    import subprocess, sys
+    from svision_amd.io import bam
+    prefix, _params = checkpoint
+    fasta = helpers.load_golden_fasta()
+    fa = str(tmp_path / "genome.fa")
+    bam.write_fasta(fa, {n: fasta._seq[n] for n in fasta.references})
+    src = bam.read_bam(os.path.join(helpers.GOLDEN, "collect_small.bam"))
+    path = str(tmp_path / "indexed.bam")
+    bam.write_bam(path, src, index=True)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ["-b", path, "-m", prefix, "-g", fa, "-n", "HGtest", "-s", "3", "--window_size", "150000", "--batch_size", "64"]
+    one = cli.run(cli.parse_arguments(["-o", str(tmp_path / "one")] + args))
+    env = dict(os.environ, PYTHONPATH=root, SVX_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT="29641")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29641", os.path.join(root, "SVision"), "-o", str(tmp_path / "two")] + args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    two = os.path.join(str(tmp_path / "two"), os.path.basename(one))
+    assert open(two).read() == open(one).read()
+    logs = [f for f in os.listdir(str(tmp_path / "two")) if f.endswith(".log")]
+    assert any("decoded through" in open(os.path.join(str(tmp_path / "two"), f)).read() for f in logs)
