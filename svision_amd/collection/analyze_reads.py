@@ -116,6 +116,10 @@ def analyze_gap(cur, nxt, chrom_of, fetch_ref, options, qname, help_segs=()):
     if cur.is_reverse == nxt.is_reverse:
         lo = min(cur.ref_start, cur.ref_end, nxt.ref_start, nxt.ref_end)
         hi = max(cur.ref_start, cur.ref_end, nxt.ref_start, nxt.ref_end)
+        if lo < 0:
+            # the reference fetches [lo, hi) here whether it is needed or not (:182) and pysam refuses a negative start;
+            # run_detect then drops the whole window (run_collection.py:44-47)
+            raise ValueError("start out of range (%d)" % lo)
         ref_seq = None
         for seg in helpers:                                   # :184-193 forward helpers are left-shifted
             if not seg.is_reverse:

@@ -19,6 +19,8 @@ import io
 import multiprocessing as mp
 import multiprocessing.connection as mpc
 
+import logging
+
 import numpy as np
 import torch
 
@@ -37,8 +39,15 @@ class WindowResult:
 
 
 def _collect_lines(sample, options, chrom, start, end):
-    _sigs, clusters = detect_window(options, sample, chrom, start, end)
-    return collect_pair_lines(clusters, options)
+    """The TSV lines of one window.  As in the reference's run_detect (run_collection.py:15-47) a window whose
+    collection raises -- e.g. pysam's ValueError for a reference fetch that starts before 0 -- contributes nothing:
+    the error is turned into a message there (and dropped by the driver, SVision:273); here it is logged."""
+    try:
+        _sigs, clusters = detect_window(options, sample, chrom, start, end)
+        return collect_pair_lines(clusters, options)
+    except Exception as exc:                                  # noqa: BLE001 -- the reference catches everything
+        logging.error("[ERROR]: %s. window %s:%s-%s skipped (reference behaviour)", exc, chrom, start, end)
+        return []
 
 
 def _vote(sample, options, chrom, lines, classes, probs):

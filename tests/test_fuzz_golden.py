@@ -89,3 +89,24 @@ def test_linear_and_score_fuzz(fx):
         a, b = Segment(*case["a"]), Segment(*case["b"])
         assert oc.linearOrNot(a, b) == case["linear"]
         assert oc.cal_non_linear([a, b]) == case["score"]
+
+
+def test_negative_reference_start_drops_the_window(tmp_path):
+    """Found by tools/diff_ref.py (seed 5039): the reference fetches [min, max) of the two segments' reference
+    coordinates in analyze_gap whether it needs the bases or not (analyze_reads.py:182); pysam refuses a negative start,
+    run_detect turns the exception into its error string and the window writes nothing (run_collection.py:44-47)."""
+    from svision_amd import pipeline
+    opts = helpers.default_options()
+    cur = Seg(0, 5000, -12, 4988, 0, False, False, "main", 60)
+    nxt = Seg(5300, 9000, 4990, 8690, 0, False, False, "main", 60)
+    with pytest.raises(ValueError):
+        ar.analyze_gap(cur, nxt, lambda tid: "chr0", lambda c, s, e: b"A" * (e - s), opts, "r", [])
+
+    class Boom:
+        table = None
+    orig = pipeline.detect_window
+    pipeline.detect_window = lambda *a, **k: (_ for _ in ()).throw(ValueError("start out of range (-12)"))
+    try:
+        assert pipeline._collect_lines(Boom(), opts, "chr0", 0, 1000) == []
+    finally:
+        pipeline.detect_window = orig

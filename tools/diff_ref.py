@@ -39,8 +39,9 @@ def one_case(seed):
                           sv_spacing=float(rng.choice([3000, 6000, 12000])), sv_min_gap=int(rng.choice([2000, 5000, 9000])),
                           sv_max=int(rng.choice([800, 4000, 20000])), inline_max=int(rng.choice([300, 1500, 4000])),
                           het_frac=float(rng.choice([0.0, 0.5, 1.0])), seed=int(seed), sv_mix=MIXES[int(rng.integers(0, len(MIXES)))])
-    table, genome, _svs = synth.simulate(cfg)
-    over = dict(min_support=int(rng.choice([1, 2, 3, 5, 8])), min_mapq=int(rng.choice([0, 10, 20, 40])),
+    use_hash = bool(rng.random() < 0.2)
+    table, genome, _svs = synth.simulate(cfg, with_seq=use_hash)
+    over = dict(hash=use_hash, min_support=int(rng.choice([1, 2, 3, 5, 8])), min_mapq=int(rng.choice([0, 10, 20, 40])),
                 min_sv_size=int(rng.choice([30, 50, 100])), max_sv_size=int(rng.choice([3000, 1000000])),
                 patition_max_distance=int(rng.choice([500, 5000])), cluster_max_distance=float(rng.choice([0.1, 0.3, 0.6])),
                 contig=bool(rng.random() < 0.15), qname=bool(rng.random() < 0.2))
@@ -70,8 +71,13 @@ def one_case(seed):
                 if os.path.exists(path):
                     os.remove(path)
                 sample = Sample.with_scan(table, fasta, over["min_sv_size"], scan)
-                _sigs, clusters = detect_window(popts, sample, chrom, pos, end, part)
-                got = "".join(p.text() for p in collect_pair_lines(clusters, popts))
+                try:                                         # run_detect's catch-all: a failing window writes nothing
+                    _sigs, clusters = detect_window(popts, sample, chrom, pos, end, part)
+                    got = "".join(p.text() for p in collect_pair_lines(clusters, popts))
+                except Exception as exc:
+                    got = ""
+                    if err is None:
+                        return "PRODUCT-ONLY EXCEPTION seed %d %s:%d-%d: %r" % (seed, chrom, pos, end, exc), n_lines
                 if (want or "") != got:
                     return "MISMATCH seed %d %s:%d-%d part %d opts %s cfg %s (ref err %r): want %d lines, got %d" % (
                         seed, chrom, pos, end, part, over, cfg, err, (want or "").count("\n"), got.count("\n")), n_lines
