@@ -170,3 +170,33 @@ def test_streaming_decode_across_chunk_boundaries(tmp_path, chunk):
         assert got[6] == ref.names and np.array_equal(got[7], ref.cigar) and np.array_equal(got[8], ref.cig_off)
         assert got[9] == ref.references
     assert full[10] == [want.query_sequence(i) for i in range(0, len(want), 37)]
+
+
+def test_native_decoder_rejects_damaged_files(tmp_path):
+    """Errors are reported (ValueError with the decoder's message), never a crash or a silent partial table."""
+    cfg = synth.SimConfig(contigs=[("c1", 120_000)], coverage=5, read_len_mean=4000, read_len_sd=500, seed=3)
+    table, _g, _ = synth.simulate(cfg, with_genome=False)
+    good = str(tmp_path / "good.bam")
+    bam.write_bam(good, table, index=True)
+    raw = open(good, "rb").read()
+    cases = {
+        "truncated.bam": raw[:len(raw) // 2],                       # cut inside a block
+        "no_eof_half_record.bam": raw[:len(raw) - 28 - 4000],       # EOF marker and the tail of the last blocks missing
+        "garbage.bam": b"this is not a BGZF file at all" * 100,
+        "gzip_not_bam.bam": bam.bgzf_compress(b"SAM\x01" + b"\x00" * 100),
+        "empty.bam": b"",
+    }
+    for name, data in cases.items():
+        p = str(tmp_path / name)
+        with open(p, "wb") as f:
+            f.write(data)
+        with pytest.raises(ValueError):
+            bam.read_bam(p)
+    with pytest.raises(ValueError):
+        bam.read_bam(str(tmp_path / "does_not_exist.bam"))
+    # an index that points past the data
+    spans = bam.read_bai(good + ".bai")
+    from svision_amd import _lib
+    lib = _lib.load()
+    h = lib.svx_bam_open_range(good.encode(), 1, 0, spans[0][0] + 7, spans[0][1])      # starts in the middle of a record
+    assert not h and lib.svx_bam_error()
