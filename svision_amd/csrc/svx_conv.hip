@@ -203,7 +203,10 @@ extern "C" int svx_conv2d_same(const float* d_in, const float* d_w_hwio, const f
     // 64 x 128 tiles unless they leave the 256 CUs under two resident workgroups each (then 64 x 64: the partial last
     // dispatch round of the big tiles costs more than the extra fragment reads of the small ones)
     const long long tiles128 = ((mtot + 127) / 128) * groups * (cout_g / BN);
-    const int bm = tiles128 < 448 ? 64 : 128;
+#ifndef SVX_CONV_BM64_BELOW
+#define SVX_CONV_BM64_BELOW 448
+#endif
+    const int bm = tiles128 < SVX_CONV_BM64_BELOW ? 64 : 128;
     const long long total_tiles = ((mtot + bm - 1) / bm) * groups * (cout_g / BN);
     dim3 grid((unsigned)(8 * ((total_tiles + 7) / 8))), block(THREADS);
 #define SVX_LAUNCH_CONV(KS_, BM_) hipLaunchKernelGGL((conv_igemm_kernel<KS_, 16, BM_>), grid, block, 0, st, d_in, d_w_hwio, d_bias, \
