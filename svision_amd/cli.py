@@ -127,7 +127,7 @@ def run(options, sample=None, classifier=None):
     from .network.output import cal_scores_max_min, merge_split_vcfs
     from .network.predict import Predict
 
-    rank, ws = sdist.init_from_env()
+    rank, ws = sdist.env_rank()              # the process group comes up after the host helpers are forked (below)
     if options.graph:
         raise SystemExit("--graph (GFA output) is outside the MI355X hot path of this build (SURVEY 8(f))")
     work_dir = options.out_path
@@ -175,7 +175,10 @@ def run(options, sample=None, classifier=None):
     if classifier is None:
         # device path: Step 1 and Step 2 streamed window by window (collection of window k+1 on the host while the
         # device classifies window k), one vote stream per chromosome in window order = the order of all.bed
-        _run_streaming(options, sample, tasks, mine, seg_dir, pred_dir)
+        if options.thread_num > 1:
+            _run_pooled(options, sample, tasks, mine, seg_dir, pred_dir)
+        else:
+            _run_streaming(options, sample, tasks, mine, seg_dir, pred_dir)
         t1 = t2 = datetime.datetime.now()
         logging.info("[Coding + prediction finished]: streamed, Cost time: %s", (t2 - t0).seconds)
     else:
@@ -203,6 +206,7 @@ def run(options, sample=None, classifier=None):
         logging.info("[Prediction finished]: Predicting types, Cost time: %s", (t2 - t1).seconds)
 
     # ---- the single cross-shard exchange: score range + record gather ----
+    sdist.init_from_env()
     local_scores = cal_scores_max_min(pred_dir) if ws == 1 else _scores_of(pred_dir, mine, options)
     max_score, min_score = sdist.exchange_score_range(local_scores)
     if max_score is None:
@@ -273,6 +277,38 @@ def _run_streaming(options, sample, tasks, chroms, seg_dir, pred_dir):
             if prev is not None:
                 feed(prev)
             voter.finish()
+
+
+def _run_pooled(options, sample, tasks, chroms, seg_dir, pred_dir):
+    """``-t N`` (the reference's process-pool size, SVision:261,311): N forked helper processes run the collection and
+    the vote of whole windows while this process feeds the device (pipeline.PooledHotPath); windows complete in any
+    order and are written out in task order, so the files are those of the one-process path."""
+    from .network.predict import load_network
+    from .pipeline import PooledHotPath
+    net = load_network(options.model_path)
+    windows = [(chrom, start, end) for chrom in chroms for start, end in tasks[chrom]]
+    part_of = [part for chrom in chroms for part in range(len(tasks[chrom]))]
+    hot = PooledHotPath(sample, options, net, n_workers=options.thread_num, n_streams=3, max_inflight=6, want_tsv=True)
+    done = {}
+    try:
+        for res in hot.run_windows(windows, rescan=False):
+            done[res.wid] = res
+    finally:
+        hot.close()
+    wid = 0
+    for chrom in chroms:
+        prefix = os.path.join(pred_dir, "%s.predict.s%s" % (chrom, options.min_support))
+        logging.info("Predicting " + chrom)
+        with open(prefix + ".score.txt", "w") as score_out, open(prefix + ".vcf", "w") as vcf_out, \
+                open(os.path.join(seg_dir, chrom + ".segments.all.bed"), "w") as all_bed:
+            for _ in tasks[chrom]:
+                res = done[wid]
+                with open(os.path.join(seg_dir, "%s.segments.%d.bed" % (chrom, part_of[wid])), "w") as f:
+                    f.write(res.tsv)
+                all_bed.write(res.tsv)
+                vcf_out.write(res.vcf)
+                score_out.write(res.scores)
+                wid += 1
 
 
 def _scores_of(pred_dir, chroms, options):

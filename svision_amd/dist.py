@@ -22,6 +22,11 @@ def world():
     return 0, 1
 
 
+def env_rank():
+    """(rank, world size) from the launcher's environment, without bringing the process group up."""
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
 def init_from_env():
     """Initialise the process group when launched under torchrun (RANK/WORLD_SIZE set)."""
     ws = int(os.environ.get("WORLD_SIZE", "1"))

@@ -35,7 +35,7 @@ _PAD_REC = parse_data_fields(PAD_DATA.split("_"))
 
 class WindowResult:
     __slots__ = ("chrom", "start", "end", "lines", "n_images", "packed", "vcf", "scores", "n_sites", "n_records",
-                 "records", "done_event", "t_device")
+                 "records", "done_event", "t_device", "wid", "tsv")
 
 
 def _collect_lines(sample, options, chrom, start, end):
@@ -202,7 +202,7 @@ _POOL_STATE = {}
 def _worker_main(conn):
     """Helper process: never touches the GPU.  Protocol on the duplex pipe:
        owner -> ("win", wid, chrom, start, end)   helper -> ("rec", wid, records int32[n,12])
-       owner -> ("pred", wid, classes, probs)      helper -> ("done", wid, vcf, scores, n_sites, n_images)
+       owner -> ("pred", wid, classes, probs)      helper -> ("done", wid, vcf, scores, n_sites, n_images, tsv)
        owner -> ("stop",)"""
     sample, options = _POOL_STATE["sample"], _POOL_STATE["options"]
     held = {}
@@ -220,15 +220,17 @@ def _worker_main(conn):
             _t, wid, classes, probs = msg
             chrom, lines = held.pop(wid)
             vcf, scores, n_sites = _vote(sample, options, chrom, lines, classes, probs)
-            conn.send(("done", wid, vcf, scores, n_sites, len(lines)))
+            tsv = "".join(ln.text() for ln in lines) if _POOL_STATE.get("want_tsv") else None
+            conn.send(("done", wid, vcf, scores, n_sites, len(lines), tsv))
 
 
 class PooledHotPath(HotPath):
     """Owner process = device feeder; ``n_workers`` forked helpers do the Python glue."""
 
-    def __init__(self, sample, options, net, device="cuda", n_workers=8, n_streams=2, use_graph=True, max_inflight=3):
+    def __init__(self, sample, options, net, device="cuda", n_workers=8, n_streams=2, use_graph=True, max_inflight=3,
+                 want_tsv=False):
         super().__init__(sample, options, net, device, n_streams, use_graph)
-        _POOL_STATE["sample"], _POOL_STATE["options"] = sample, options
+        _POOL_STATE["sample"], _POOL_STATE["options"], _POOL_STATE["want_tsv"] = sample, options, want_tsv
         ctx = mp.get_context("fork")                         # helpers inherit the resident host arrays copy-on-write
         self.conns, self.procs = [], []
         for _ in range(n_workers):
@@ -291,9 +293,10 @@ class PooledHotPath(HotPath):
                     res.t_device = None
                     ready.append((ci, res))
                 else:
-                    _t, wid, vcf, scores, n_sites, n_images = msg
+                    _t, wid, vcf, scores, n_sites, n_images, tsv = msg
                     res = WindowResult()
                     res.chrom, res.start, res.end = windows[wid]
+                    res.wid, res.tsv = wid, tsv
                     res.vcf, res.scores, res.n_sites, res.n_images = vcf, scores, n_sites, n_images
                     res.n_records = vcf.count("\n")
                     del busy[ci]

@@ -175,3 +175,22 @@ def test_two_ranks_from_an_indexed_bam_equal_one_rank(checkpoint, tmp_path):
     assert open(two).read() == open(one).read()
     logs = [f for f in os.listdir(str(tmp_path / "two")) if f.endswith(".log")]
     assert any("decoded through" in open(os.path.join(str(tmp_path / "two"), f)).read() for f in logs)
+
+
+def test_cli_with_helper_processes_equals_one_process(checkpoint, tmp_path):
+    """``-t 4`` (four forked host helpers, windows finishing in any order) writes the same files as the one-process run."""
+    from svision_amd.io import bam
+    prefix, _params = checkpoint
+    fasta = helpers.load_golden_fasta()
+    fa = str(tmp_path / "genome.fa")
+    bam.write_fasta(fa, {n: fasta._seq[n] for n in fasta.references})
+    args = ["-b", os.path.join(helpers.GOLDEN, "collect_small.bam"), "-m", prefix, "-g", fa, "-n", "HGtest", "-s", "3",
+            "--window_size", "60000", "--batch_size", "64", "--debug"]
+    one = cli.run(cli.parse_arguments(["-o", str(tmp_path / "one")] + args))
+    four = cli.run(cli.parse_arguments(["-o", str(tmp_path / "four"), "-t", "4"] + args))
+    assert open(four).read() == open(one).read() and open(one).read().count("\n") > 20
+    for sub in ("segments", "predict_results"):
+        names = sorted(os.listdir(str(tmp_path / "one" / sub)))
+        assert names == sorted(os.listdir(str(tmp_path / "four" / sub))) and len(names) >= 4
+        for n in names:
+            assert open(str(tmp_path / "four" / sub / n)).read() == open(str(tmp_path / "one" / sub / n)).read(), n
