@@ -145,6 +145,7 @@ def run(options, sample=None, classifier=None):
     logging.info("CNN MODEL: %s", os.path.abspath(options.model_path))
     logging.info("INPUT BAM: %s", os.path.abspath(options.bam_path))
 
+    pool = None
     if sample is None:
         table = load_rank_table(options, rank, ws)
         if table.sort_order != "coordinate":
@@ -153,7 +154,13 @@ def run(options, sample=None, classifier=None):
         fasta = Fasta(options.genome)
         if options.contig:
             options.min_support = 1
+        if options.thread_num > 1 and classifier is None:
+            # -t N: fork the host helpers before the first HIP call (pipeline.HelperPool); they get the scan below
+            from .pipeline import HelperPool
+            pool = HelperPool(options.thread_num, options, table=table, fasta=fasta, want_tsv=True)
         sample = _sample.Sample.from_table(table, fasta, options.min_sv_size)
+        if pool is not None:
+            pool.attach_scan(sample)
     elif options.contig:
         options.min_support = 1
     _sample.register(options.bam_path, sample)
@@ -176,7 +183,7 @@ def run(options, sample=None, classifier=None):
         # device path: Step 1 and Step 2 streamed window by window (collection of window k+1 on the host while the
         # device classifies window k), one vote stream per chromosome in window order = the order of all.bed
         if options.thread_num > 1:
-            _run_pooled(options, sample, tasks, mine, seg_dir, pred_dir)
+            _run_pooled(options, sample, tasks, mine, seg_dir, pred_dir, pool)
         else:
             _run_streaming(options, sample, tasks, mine, seg_dir, pred_dir)
         t1 = t2 = datetime.datetime.now()
@@ -246,8 +253,11 @@ def _run_streaming(options, sample, tasks, chroms, seg_dir, pred_dir):
     import numpy as np
     from .network.predict import Predict, SiteVoter, load_network
     from .pipeline import HotPath
+    import time as _time
+    _t0 = _time.time()
     net = load_network(options.model_path)
     hot = HotPath(sample, options, net, n_streams=3)
+    _t1 = _time.time()
     for chrom in chroms:
         prefix = os.path.join(pred_dir, "%s.predict.s%s" % (chrom, options.min_support))
         with open(prefix + ".score.txt", "w") as score_out, open(prefix + ".vcf", "w") as vcf_out, \
@@ -277,9 +287,11 @@ def _run_streaming(options, sample, tasks, chroms, seg_dir, pred_dir):
             if prev is not None:
                 feed(prev)
             voter.finish()
+    if os.environ.get("SVX_TIMING"):
+        print("network + graphs %.3f, windows %.3f" % (_t1 - _t0, _time.time() - _t1), flush=True)
 
 
-def _run_pooled(options, sample, tasks, chroms, seg_dir, pred_dir):
+def _run_pooled(options, sample, tasks, chroms, seg_dir, pred_dir, pool=None):
     """``-t N`` (the reference's process-pool size, SVision:261,311): N forked helper processes run the collection and
     the vote of whole windows while this process feeds the device (pipeline.PooledHotPath); windows complete in any
     order and are written out in task order, so the files are those of the one-process path."""
@@ -288,13 +300,19 @@ def _run_pooled(options, sample, tasks, chroms, seg_dir, pred_dir):
     net = load_network(options.model_path)
     windows = [(chrom, start, end) for chrom in chroms for start, end in tasks[chrom]]
     part_of = [part for chrom in chroms for part in range(len(tasks[chrom]))]
-    hot = PooledHotPath(sample, options, net, n_workers=options.thread_num, n_streams=3, max_inflight=6, want_tsv=True)
+    import time as _time
+    _t0 = _time.time()
+    hot = PooledHotPath(sample, options, net, n_workers=options.thread_num, n_streams=3, max_inflight=6, want_tsv=True, pool=pool)
+    _t1 = _time.time()
     done = {}
     try:
         for res in hot.run_windows(windows, rescan=False):
             done[res.wid] = res
     finally:
+        _t2 = _time.time()
         hot.close()
+    if os.environ.get("SVX_TIMING"):
+        print("pool up %.3f, windows %.3f, close %.3f" % (_t1 - _t0, _t2 - _t1, _time.time() - _t2), flush=True)
     wid = 0
     for chrom in chroms:
         prefix = os.path.join(pred_dir, "%s.predict.s%s" % (chrom, options.min_support))

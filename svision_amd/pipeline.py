@@ -203,6 +203,7 @@ def _worker_main(conn):
     """Helper process: never touches the GPU.  Protocol on the duplex pipe:
        owner -> ("win", wid, chrom, start, end)   helper -> ("rec", wid, records int32[n,12])
        owner -> ("pred", wid, classes, probs)      helper -> ("done", wid, vcf, scores, n_sites, n_images, tsv)
+       owner -> ("scan", min_sv, gaps, gap_off, stats)   (HelperPool.attach_scan: helpers forked before the scan)
        owner -> ("stop",)"""
     sample, options = _POOL_STATE["sample"], _POOL_STATE["options"]
     held = {}
@@ -210,6 +211,11 @@ def _worker_main(conn):
         msg = conn.recv()
         if msg[0] == "stop":
             return
+        if msg[0] == "scan":                                  # forked before the device scan existed: build the Sample now
+            from .sample import Sample
+            _t, min_sv, gaps, gap_off, stats = msg
+            sample = Sample.with_scan(_POOL_STATE["table"], _POOL_STATE["fasta"], min_sv, (gaps, gap_off, stats))
+            continue
         if msg[0] == "win":
             _t, wid, chrom, start, end = msg
             lines = _collect_lines(sample, options, chrom, start, end)
@@ -224,13 +230,15 @@ def _worker_main(conn):
             conn.send(("done", wid, vcf, scores, n_sites, len(lines), tsv))
 
 
-class PooledHotPath(HotPath):
-    """Owner process = device feeder; ``n_workers`` forked helpers do the Python glue."""
+class HelperPool:
+    """Forked host helpers.  Forking a process that owns a live GPU context is expensive on this stack (the driver
+    evicts and restores the parent's queues around the copy-on-write protection of its pinned ranges: the first device
+    work after 16 forks stalled for 3.5 s), so a command-line run creates the pool *before* the first HIP call, with the
+    decoded table and the reference only, and sends the device scan's result afterwards (``attach_scan``).  Given a
+    complete ``sample`` the helpers are usable at once (bench: the fork cost falls into the warm-up)."""
 
-    def __init__(self, sample, options, net, device="cuda", n_workers=8, n_streams=2, use_graph=True, max_inflight=3,
-                 want_tsv=False):
-        super().__init__(sample, options, net, device, n_streams, use_graph)
-        _POOL_STATE["sample"], _POOL_STATE["options"], _POOL_STATE["want_tsv"] = sample, options, want_tsv
+    def __init__(self, n_workers, options, sample=None, table=None, fasta=None, want_tsv=False):
+        _POOL_STATE.update(sample=sample, table=table, fasta=fasta, options=options, want_tsv=want_tsv)
         ctx = mp.get_context("fork")                         # helpers inherit the resident host arrays copy-on-write
         self.conns, self.procs = [], []
         for _ in range(n_workers):
@@ -240,7 +248,11 @@ class PooledHotPath(HotPath):
             b.close()
             self.conns.append(a)
             self.procs.append(p)
-        self.max_inflight = max_inflight
+        _POOL_STATE.clear()
+
+    def attach_scan(self, sample):
+        for c in self.conns:
+            c.send(("scan", sample.min_sv, sample.gaps, sample.gap_off, sample.stats))
 
     def close(self):
         for c in self.conns:
@@ -250,6 +262,21 @@ class PooledHotPath(HotPath):
                 pass
         for p in self.procs:
             p.join(timeout=5)
+        self.conns, self.procs = [], []
+
+
+class PooledHotPath(HotPath):
+    """Owner process = device feeder; the helpers of a :class:`HelperPool` do the Python glue."""
+
+    def __init__(self, sample, options, net, device="cuda", n_workers=8, n_streams=2, use_graph=True, max_inflight=3,
+                 want_tsv=False, pool=None):
+        super().__init__(sample, options, net, device, n_streams, use_graph)
+        self.pool = pool if pool is not None else HelperPool(n_workers, options, sample=sample, want_tsv=want_tsv)
+        self.conns, self.procs = self.pool.conns, self.pool.procs
+        self.max_inflight = max_inflight
+
+    def close(self):
+        self.pool.close()
         self.conns, self.procs = [], []
 
     def run_windows(self, windows, rescan=True):

@@ -21,7 +21,8 @@ class Sample:
         self.gap_off = np.asarray(gap_off).astype(np.int64)
         self.min_sv = min_sv
         self.device_buffers = device_buffers
-        table.attach_scan(np.asarray(stats))
+        self.stats = np.asarray(stats)
+        table.attach_scan(self.stats)
 
     # -- construction -----------------------------------------------------------------
     @classmethod
