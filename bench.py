@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 from svision_amd import dist as sdist, kernels, synth  # noqa: E402
 from svision_amd.io import bam  # noqa: E402
 from svision_amd.network.alexnet import AlexNet, checkpoint_shapes  # noqa: E402
-from svision_amd.pipeline import PooledHotPath  # noqa: E402
+from svision_amd.pipeline import HelperPool, PooledHotPath  # noqa: E402
 from svision_amd.sample import Sample  # noqa: E402
 
 IMG_BYTES = 227 * 227 * 3 * 4 + 48            # 618,348 B written + 48 B read per image
@@ -81,19 +81,23 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    # order matters for robustness: device scan (HIP only), then fork the host helpers, then bring up RCCL
+    # order matters: the host helpers are forked before the first HIP call (forking with a live GPU context makes the
+    # driver evict / restore the queues: seconds of stall), then the device scan, then RCCL
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
 
     # ---- untimed set-up: synthetic sample -> packed arrays -> HBM ----
     cfg = synth.SimConfig(contigs=[("chr21", args.contig_len)], coverage=args.coverage, seed=1 + rank)
     table, genome, _svs = synth.simulate(cfg)
     opts = options_ns(args.batch)
-    sample = Sample.from_table(table, bam.Fasta(sequences=genome), opts.min_sv_size, device=dev)
+    fasta = bam.Fasta(sequences=genome)
+    pool = HelperPool(args.workers, opts, table=table, fasta=fasta)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    sample = Sample.from_table(table, fasta, opts.min_sv_size, device=dev)
+    pool.attach_scan(sample)
     net = AlexNet(random_weights(0), device=dev)
-    hot = PooledHotPath(sample, opts, net, device=dev, n_workers=args.workers, n_streams=args.streams, max_inflight=args.inflight)
+    hot = PooledHotPath(sample, opts, net, device=dev, n_streams=args.streams, max_inflight=args.inflight, pool=pool)
     rank, world = sdist.init_from_env()
     windows = []
     pos = 0
