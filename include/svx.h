@@ -100,9 +100,21 @@ int svx_rasterize(const int32_t* d_records, uint32_t n, float* d_out, int layout
  *   d_records [n][12] int32 as for svx_rasterize
  *   d_w1      conv1/weights in checkpoint layout HWIO [11][11][3][96], 16-B aligned
  *   d_base    [96]: biases[k] - sum_{ky,kx,ch} mean[ch] * w[ky][kx][ch][k], 16-B aligned
- *   d_y       float32 [n][96][27][27] (NCHW) = norm1 output */
+ *   d_y       float32 [n][96][27][27] (NCHW) = norm1 output
+ *   d_touched [n][27] or NULL: bit x of word [i][y] = pooled pixel (y, x) of image i has a set tap under it; every
+ *             other pixel holds the same constant vector (the response to an empty image) */
 int svx_encode_conv1(const int32_t* d_records, uint32_t n, const float* d_w1, const float* d_base, float* d_y,
-                     int lrn, uint32_t radius, float alpha, float beta, float k, void* stream);
+                     int lrn, uint32_t radius, float alpha, float beta, float k, uint32_t* d_touched, void* stream);
+
+/* Active sets of the AlexNet body (conv2 5x5 on 27x27 -> pool 3x3/2 -> conv3..conv5 3x3 on 13x13,
+ * src/network/alexnet.py:34-46): the outputs that can differ from the network's response to an empty image, given
+ * the touched pixels of the first layer.  The similarity image is a few thin lines, so only ~37 % of conv2's and
+ * 50-90 % of conv3..5's outputs have a line in their receptive field; all others equal a precomputed, image
+ * independent background tensor (exactly: every operation is local).
+ *   d_list2 [n*729], d_list3 / d_list4 / d_list5 [n*169]: out, pixel ids image * H*W + y * W + x, ascending
+ *   d_counts [4]: out, entries in the four lists */
+int svx_alexnet_active_sets(const uint32_t* d_touched, uint32_t n, int32_t* d_list2, int32_t* d_list3,
+                            int32_t* d_list4, int32_t* d_list5, uint32_t* d_counts, void* stream);
 
 /* Fused conv epilogue: bias add + ReLU + 3x3/2 VALID max-pool (+ TF local response
  * normalisation across channels when lrn != 0), NCHW float32.
@@ -135,10 +147,13 @@ int svx_bias_relu(float* d_x, const float* d_bias, uint32_t n, uint32_t channels
  *   d_w_hwio  float32 [ksize][ksize][cin/groups][cout]  -- the checkpoint layout, 16-B aligned
  *   d_bias    float32 [cout] or NULL (raw convolution output, e.g. in front of svx_bias_relu_pool_lrn)
  *   d_out     float32 [n][cout][height][width]
+ *   d_pixels, d_pixel_count: NULL, or a list of output pixel ids (image * H*W + y * W + x) and its length in device
+ *             memory (svx_alexnet_active_sets): only those outputs are computed and stored, the rest of d_out is
+ *             left as it is (the caller holds the background there)
  * Requires (cin/groups) % 16 == 0 and (cout/groups) % 64 == 0. */
 int svx_conv2d_same(const float* d_in, const float* d_w_hwio, const float* d_bias, float* d_out, uint32_t n,
                     uint32_t cin, uint32_t cout, uint32_t height, uint32_t width, uint32_t ksize,
-                    uint32_t groups, int relu, void* stream);
+                    uint32_t groups, int relu, const int32_t* d_pixels, const uint32_t* d_pixel_count, void* stream);
 
 /* ---- host side: native BGZF/BAM ingestion (no device work) -------------------------------------------
  * Replaces the per-record pysam iteration of the reference (aln_file.fetch at

@@ -79,7 +79,8 @@ __device__ inline unsigned window_mask(const unsigned* row_words, int c0)
 
 __global__ __launch_bounds__(ENC_BLOCK)
 void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __restrict__ w1, const float* __restrict__ base,
-                         float* __restrict__ y, int lrn, int radius, float alpha, float beta, float kk)
+                         float* __restrict__ y, int lrn, int radius, float alpha, float beta, float kk,
+                         uint32_t* __restrict__ touched)
 {
     using namespace svx_raster;
     __shared__ unsigned bits[3 * PLANE_WORDS];
@@ -103,11 +104,18 @@ void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __res
         rowany[dy][w] = any;
     }
     __syncthreads();
-    if (tid < P1) {                                   // does this pooled pixel see at least one empty window?
-        bool any_empty = false;
-        for (int win = 0; win < 9; ++win)
-            any_empty |= window_mask(rowany[win / 3], 4 * (2 * tid + win % 3)) == 0;
-        has_empty[tid] = any_empty ? 1 : 0;
+    {                                                 // does this pooled pixel see at least one empty window?
+        bool any_empty = false, any_set = false;
+        if (tid < P1)
+            for (int win = 0; win < 9; ++win) {
+                const bool empty = window_mask(rowany[win / 3], 4 * (2 * tid + win % 3)) == 0;
+                any_empty |= empty;
+                any_set |= !empty;
+            }
+        if (tid < P1) has_empty[tid] = any_empty ? 1 : 0;
+        // pooled pixels with a set tap under them: everything else in this row is the constant background vector
+        const unsigned long long t = __ballot(tid < P1 && any_set);
+        if (touched && tid == 0) touched[blockIdx.x] = (uint32_t)t;     // P1 = 27 lanes of the first wave
     }
     __syncthreads();
     for (int i = tid; i < P1 * C1; i += ENC_BLOCK) {  // empty windows all respond relu(base[k]); relu floor otherwise
@@ -170,13 +178,13 @@ void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __res
 }  // namespace
 
 extern "C" int svx_encode_conv1(const int32_t* d_records, uint32_t n, const float* d_w1, const float* d_base, float* d_y,
-                                int lrn, uint32_t radius, float alpha, float beta, float k, void* stream)
+                                int lrn, uint32_t radius, float alpha, float beta, float k, uint32_t* d_touched, void* stream)
 {
     if (n == 0) return SVX_OK;
     if (!d_records || !d_w1 || !d_base || !d_y) return SVX_EINVAL;
     if ((reinterpret_cast<uintptr_t>(d_w1) & 15u) || (reinterpret_cast<uintptr_t>(d_base) & 15u)) return SVX_EINVAL;
     hipLaunchKernelGGL(encode_conv1_kernel, dim3(n * P1), dim3(ENC_BLOCK), 0, static_cast<hipStream_t>(stream),
-                       d_records, d_w1, d_base, d_y, lrn, (int)radius, alpha, beta, k);
+                       d_records, d_w1, d_base, d_y, lrn, (int)radius, alpha, beta, k, d_touched);
     return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
 }
 
@@ -215,6 +223,95 @@ extern "C" int svx_bias_relu(float* d_x, const float* d_bias, uint32_t n, uint32
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(bias_relu_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, static_cast<hipStream_t>(stream),
                        d_x, d_bias, (int)channels, (int)plane, total);
+    return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
+}
+
+namespace {
+// Which outputs of conv2..conv5 can differ from the network's response to an empty image?  Everything downstream of
+// the first layer is local: a pooled conv1 pixel without a set tap under it holds the constant background vector,
+// a conv output whose window sees only background inputs holds the (position dependent, image independent) background
+// response, and so on through the pools.  One lane per image turns the 27 touched-row words of svx_encode_conv1 into
+// the active masks of the four convolutions (5x5 dilation -> 3x3/2 pool -> three 3x3 dilations) and the workgroup
+// compacts them into pixel lists (image * H*W + y * W + x, ascending) for svx_conv2d_same.
+constexpr int A1 = 27, A2 = 13;
+
+__device__ inline uint32_t dilate(uint32_t m, int r, uint32_t full) { uint32_t o = m; for (int i = 1; i <= r; ++i) o |= (m << i) | (m >> i); return o & full; }
+
+__global__ __launch_bounds__(BLOCK)
+void active_sets_kernel(const uint32_t* __restrict__ touched, uint32_t n, int32_t* __restrict__ list2, int32_t* __restrict__ list3,
+                        int32_t* __restrict__ list4, int32_t* __restrict__ list5, uint32_t* __restrict__ counts)
+{
+    __shared__ uint32_t s_cnt[4][BLOCK];
+    __shared__ uint32_t s_base[4];
+    const int t = threadIdx.x;
+    if (t < 4) s_base[t] = 0;
+    __syncthreads();
+    for (uint32_t img0 = 0; img0 < n; img0 += BLOCK) {
+        const uint32_t img = img0 + t;
+        uint32_t m2[A1], m3[A2], m4[A2], m5[A2];
+        uint32_t c[4] = {0, 0, 0, 0};
+        if (img < n) {
+            uint32_t t1[A1], h[A1];
+            for (int y = 0; y < A1; ++y) { t1[y] = touched[(size_t)img * A1 + y]; h[y] = dilate(t1[y], 2, (1u << A1) - 1u); }
+            for (int y = 0; y < A1; ++y) {                       // conv2: 5x5 window
+                uint32_t v = 0;
+                for (int d = -2; d <= 2; ++d) if (y + d >= 0 && y + d < A1) v |= h[y + d];
+                m2[y] = v; c[0] += __popc(v);
+            }
+            uint32_t p[A2];
+            for (int y = 0; y < A2; ++y) {                       // pool2: 3x3 stride 2 (VALID)
+                const uint32_t rows = m2[2 * y] | m2[2 * y + 1] | m2[2 * y + 2];
+                uint32_t v = 0;
+                for (int x = 0; x < A2; ++x) if ((rows >> (2 * x)) & 7u) v |= 1u << x;
+                p[y] = v;
+            }
+            const uint32_t full = (1u << A2) - 1u;
+            uint32_t* in = p;
+            uint32_t* outs[3] = {m3, m4, m5};
+            for (int l = 0; l < 3; ++l) {                        // conv3, conv4, conv5: 3x3 windows
+                uint32_t hh[A2];
+                for (int y = 0; y < A2; ++y) hh[y] = dilate(in[y], 1, full);
+                for (int y = 0; y < A2; ++y) {
+                    uint32_t v = hh[y];
+                    if (y > 0) v |= hh[y - 1];
+                    if (y + 1 < A2) v |= hh[y + 1];
+                    outs[l][y] = v; c[1 + l] += __popc(v);
+                }
+                in = outs[l];
+            }
+        }
+        for (int l = 0; l < 4; ++l) s_cnt[l][t] = c[l];
+        __syncthreads();
+        uint32_t off[4];
+        for (int l = 0; l < 4; ++l) {                            // exclusive prefix over the images of this step (small)
+            uint32_t o = s_base[l];
+            for (int i = 0; i < t; ++i) o += s_cnt[l][i];
+            off[l] = o;
+        }
+        __syncthreads();
+        if (t == BLOCK - 1) for (int l = 0; l < 4; ++l) s_base[l] = off[l] + c[l];
+        if (img < n) {
+            for (int y = 0; y < A1; ++y)
+                for (uint32_t v = m2[y]; v; v &= v - 1) list2[off[0]++] = (int32_t)(img * (A1 * A1) + y * A1 + (__ffs(v) - 1));
+            uint32_t* ms[3] = {m3, m4, m5};
+            int32_t* ls[3] = {list3, list4, list5};
+            for (int l = 0; l < 3; ++l)
+                for (int y = 0; y < A2; ++y)
+                    for (uint32_t v = ms[l][y]; v; v &= v - 1) ls[l][off[1 + l]++] = (int32_t)(img * (A2 * A2) + y * A2 + (__ffs(v) - 1));
+        }
+        __syncthreads();
+    }
+    if (t < 4) counts[t] = s_base[t];
+}
+}  // namespace
+
+extern "C" int svx_alexnet_active_sets(const uint32_t* d_touched, uint32_t n, int32_t* d_list2, int32_t* d_list3,
+                                       int32_t* d_list4, int32_t* d_list5, uint32_t* d_counts, void* stream)
+{
+    if (!d_counts) return SVX_EINVAL;
+    if (n && (!d_touched || !d_list2 || !d_list3 || !d_list4 || !d_list5)) return SVX_EINVAL;
+    hipLaunchKernelGGL(active_sets_kernel, dim3(1), dim3(BLOCK), 0, static_cast<hipStream_t>(stream), d_touched, n, d_list2, d_list3,
+                       d_list4, d_list5, d_counts);
     return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
 }
 

@@ -33,7 +33,8 @@ constexpr int BN = 64, THREADS = 256;
 template <int KS, int BK, int BM>
 __global__ __launch_bounds__(THREADS, 2)
 void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
-                       float* __restrict__ out, int nimg, int Cin, int Cout, int H, int W, int groups, int relu)
+                       float* __restrict__ out, int nimg, int Cin, int Cout, int H, int W, int groups, int relu,
+                       const int32_t* __restrict__ pixels, const uint32_t* __restrict__ pixel_count)
 {
     constexpr int P = KS / 2;
     __shared__ float Ws[2][BK][BN];
@@ -42,7 +43,8 @@ void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w
     const int CinG = Cin / groups, CoutG = Cout / groups;
     const int n_tiles = CoutG / BN;
     const int HW = H * W;
-    const long long Mtot = (long long)nimg * HW;
+    // columns of the GEMM: every output pixel, or the listed ones only (active set; the grid is sized for all of them)
+    const long long Mtot = pixels ? (long long)*pixel_count : (long long)nimg * HW;
     // XCD-aware tile order (workgroup b runs on XCD b % 8, each XCD has its own 4 MB L2): the (pixel tile,
     // channel tile) pairs, channel tile fastest, are cut into 8 equal contiguous runs, one per XCD, so the
     // activation slice of a pixel tile is fetched into one L2 once and re-used by all its (group, n-tile)
@@ -69,8 +71,9 @@ void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w
     const int xm = tid & (BM - 1), xk0 = tid / BM;
     const long long m = (long long)m0 + xm;
     const bool m_ok = m < Mtot;
-    const int b = m_ok ? (int)(m / HW) : 0;
-    const int pix = m_ok ? (int)(m - (long long)b * HW) : 0;
+    const long long pid = !m_ok ? 0 : (pixels ? (long long)pixels[m] : m);
+    const int b = (int)(pid / HW);
+    const int pix = (int)(pid - (long long)b * HW);
     const int y = pix / W, x = pix - y * W;
     const unsigned tbase = (unsigned)((b * Cin + g * CinG + xk0) * HW);
     constexpr int XR = BK / XSTEP, WR = BK / 16;   // activation rows / weight float4s per lane and slice
@@ -174,8 +177,9 @@ void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w
     for (int t = 0; t < MT; ++t) {
         const long long mm = (long long)m0 + wm * WM + t * 32 + fj;
         if (mm >= Mtot) continue;
-        const int bb = (int)(mm / HW);
-        const int pp = (int)(mm - (long long)bb * HW);
+        const long long pid2 = pixels ? (long long)pixels[mm] : mm;
+        const int bb = (int)(pid2 / HW);
+        const int pp = (int)(pid2 - (long long)bb * HW);
         float* o = out + ((size_t)bb * Cout + (size_t)g * CoutG + n0 + wn * 32 + 4 * fk) * HW + pp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -191,10 +195,11 @@ void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w
 
 extern "C" int svx_conv2d_same(const float* d_in, const float* d_w_hwio, const float* d_bias, float* d_out, uint32_t n,
                                uint32_t cin, uint32_t cout, uint32_t height, uint32_t width, uint32_t ksize,
-                               uint32_t groups, int relu, void* stream)
+                               uint32_t groups, int relu, const int32_t* d_pixels, const uint32_t* d_pixel_count, void* stream)
 {
     if (n == 0) return SVX_OK;
     if (!d_in || !d_w_hwio || !d_out || groups == 0 || cin % groups || cout % groups) return SVX_EINVAL;
+    if ((d_pixels == nullptr) != (d_pixel_count == nullptr)) return SVX_EINVAL;
     const uint32_t cin_g = cin / groups, cout_g = cout / groups;
     if (cin_g % 16 || cout_g % BN || (ksize != 3 && ksize != 5)) return SVX_EINVAL;
     if ((reinterpret_cast<uintptr_t>(d_w_hwio) & 15u) || (cout % 4)) return SVX_EINVAL;
@@ -210,7 +215,7 @@ extern "C" int svx_conv2d_same(const float* d_in, const float* d_w_hwio, const f
     const long long total_tiles = ((mtot + bm - 1) / bm) * groups * (cout_g / BN);
     dim3 grid((unsigned)(8 * ((total_tiles + 7) / 8))), block(THREADS);
 #define SVX_LAUNCH_CONV(KS_, BM_) hipLaunchKernelGGL((conv_igemm_kernel<KS_, 16, BM_>), grid, block, 0, st, d_in, d_w_hwio, d_bias, \
-        d_out, (int)n, (int)cin, (int)cout, (int)height, (int)width, (int)groups, relu)
+        d_out, (int)n, (int)cin, (int)cout, (int)height, (int)width, (int)groups, relu, d_pixels, d_pixel_count)
     if (ksize == 3) { if (bm == 64) SVX_LAUNCH_CONV(3, 64); else SVX_LAUNCH_CONV(3, 128); }
     else            { if (bm == 64) SVX_LAUNCH_CONV(5, 64); else SVX_LAUNCH_CONV(5, 128); }
 #undef SVX_LAUNCH_CONV

@@ -113,9 +113,10 @@ def bias_relu_pool_lrn(x, bias, lrn=True, radius=2, alpha=2e-05, beta=0.75, k=1.
     return y
 
 
-def encode_conv1(records, w1_hwio, base, lrn=True, radius=2, alpha=2e-05, beta=0.75, k=1.0):
+def encode_conv1(records, w1_hwio, base, lrn=True, radius=2, alpha=2e-05, beta=0.75, k=1.0, touched=False):
     """records int32 [n,12] -> float32 [n,96,27,27]: rasterise + conv1 + relu + pool1 + norm1 in one
-    kernel, exploiting the sparsity of the similarity image.  See include/svx.h svx_encode_conv1."""
+    kernel, exploiting the sparsity of the similarity image.  See include/svx.h svx_encode_conv1.
+    ``touched=True``: also return the int32 [n,27] row masks of the pooled pixels with a set tap under them."""
     lib = _lib.load()
     for t, nm in ((records, "records"), (w1_hwio, "w1"), (base, "base")):
         _require_cuda(t, nm)
@@ -125,10 +126,28 @@ def encode_conv1(records, w1_hwio, base, lrn=True, radius=2, alpha=2e-05, beta=0
         raise _lib.SvxError("w1 must be float32 HWIO [11,11,3,96] and base float32 [96]")
     n = records.shape[0]
     y = torch.empty((n, 96, 27, 27), dtype=torch.float32, device=records.device)
+    mask = torch.empty((n, 27), dtype=torch.int32, device=records.device) if touched else None
     rc = lib.svx_encode_conv1(records.data_ptr(), n, w1_hwio.data_ptr(), base.data_ptr(), y.data_ptr(), 1 if lrn else 0,
-                              radius, alpha, beta, k, _stream_ptr(records.device))
+                              radius, alpha, beta, k, mask.data_ptr() if touched else None, _stream_ptr(records.device))
     _lib.check(rc, "svx_encode_conv1")
-    return y
+    return (y, mask) if touched else y
+
+
+def alexnet_active_sets(touched):
+    """touched int32 [n,27] (encode_conv1) -> (list2 [n*729], list3, list4, list5 [n*169], counts [4]) int32 device
+    tensors: the output pixels of conv2..conv5 that can differ from the response to an empty image.
+    See include/svx.h svx_alexnet_active_sets."""
+    lib = _lib.load()
+    _require_cuda(touched, "touched")
+    if touched.dtype != torch.int32 or touched.dim() != 2 or touched.shape[1] != 27:
+        raise _lib.SvxError("touched must be int32 [n,27]")
+    n, dev = touched.shape[0], touched.device
+    lists = [torch.empty(n * hw, dtype=torch.int32, device=dev) for hw in (729, 169, 169, 169)]
+    counts = torch.empty(4, dtype=torch.int32, device=dev)
+    rc = lib.svx_alexnet_active_sets(touched.data_ptr(), n, lists[0].data_ptr(), lists[1].data_ptr(), lists[2].data_ptr(),
+                                     lists[3].data_ptr(), counts.data_ptr(), _stream_ptr(dev))
+    _lib.check(rc, "svx_alexnet_active_sets")
+    return lists[0], lists[1], lists[2], lists[3], counts
 
 
 def bias_relu_(x, bias):
@@ -144,10 +163,11 @@ def bias_relu_(x, bias):
     return x
 
 
-def conv2d_same(x, w_hwio, bias=None, groups=1, relu=False):
+def conv2d_same(x, w_hwio, bias=None, groups=1, relu=False, pixels=None, pixel_count=None, out=None):
     """x float32 [n,Cin,H,W], w_hwio float32 [k,k,Cin/groups,Cout] (checkpoint layout) -> [n,Cout,H,W]:
     stride-1 SAME convolution on the fp32 matrix cores, optional fused bias + ReLU.
-    See include/svx.h svx_conv2d_same."""
+    ``pixels`` / ``pixel_count`` (device int32 list and its length, a one-element view): compute only those output
+    pixels into ``out``, which already holds the values of all others.  See include/svx.h svx_conv2d_same."""
     lib = _lib.load()
     _require_cuda(x, "x")
     _require_cuda(w_hwio, "w_hwio")
@@ -159,9 +179,15 @@ def conv2d_same(x, w_hwio, bias=None, groups=1, relu=False):
         raise _lib.SvxError("weight shape %s does not match input %s with %d groups" % (tuple(w_hwio.shape), tuple(x.shape), groups))
     if bias is not None:
         _require_cuda(bias, "bias")
-    y = torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
+    if (pixels is None) != (pixel_count is None) or (pixels is not None and out is None):
+        raise _lib.SvxError("pixels, pixel_count and out go together")
+    y = out if out is not None else torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
+    if tuple(y.shape) != (n, cout, h, w) or y.dtype != torch.float32 or not y.is_contiguous():
+        raise _lib.SvxError("out must be a contiguous float32 [n,Cout,H,W] tensor")
     rc = lib.svx_conv2d_same(x.data_ptr(), w_hwio.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
-                             n, cin, cout, h, w, k, groups, 1 if relu else 0, _stream_ptr(x.device))
+                             n, cin, cout, h, w, k, groups, 1 if relu else 0,
+                             pixels.data_ptr() if pixels is not None else None,
+                             pixel_count.data_ptr() if pixel_count is not None else None, _stream_ptr(x.device))
     _lib.check(rc, "svx_conv2d_same")
     return y
 

@@ -54,7 +54,8 @@ def checkpoint_shapes():
 class AlexNet(torch.nn.Module):
     """Inference-only AlexNet holding device-layout parameters."""
 
-    def __init__(self, params, device="cuda", channels_last=False, fused=None, mean=(104.0, 117.0, 124.0), own_conv=None):
+    def __init__(self, params, device="cuda", channels_last=False, fused=None, mean=(104.0, 117.0, 124.0), own_conv=None,
+                 active=None):
         super().__init__()
         # own_conv: layer names whose convolution runs on the hand-written MFMA implicit-GEMM kernel
         # (svx_conv2d_same) instead of MIOpen; default on the GPU: conv2..conv5 (measured 7 % faster per batch)
@@ -63,6 +64,11 @@ class AlexNet(torch.nn.Module):
         self.own_conv = tuple(own_conv)
         # fused: conv epilogues (bias+relu+pool+LRN) as one hand-written HIP kernel; default on the GPU
         self.fused = (torch.device(device).type == "cuda" and not channels_last) if fused is None else fused
+        # active: conv2..conv5 compute only the outputs with a line of the similarity image in their receptive field;
+        # all others are copied from the network's (image independent) response to an empty image -- exact, every
+        # operation between the first layer and pool5 being local (records path only; default with the own kernels)
+        self.active = (len(self.own_conv) == 4 and self.fused) if active is None else active
+        self._background = None
         want = checkpoint_shapes()
         missing = [k for k in want if k not in params]
         if missing:
@@ -100,9 +106,55 @@ class AlexNet(torch.nn.Module):
     def forward_records(self, records):
         """records: int32 device tensor [B,12] (TSV columns 1..12) -> logits [B,5].  The image is never
         materialised: rasterisation + conv1 + relu + pool1 + norm1 run as one sparse HIP kernel."""
+        return self._body_records(records, upto_fc7=False)
+
+    def _body_records(self, records, upto_fc7):
         from .. import kernels
-        x = kernels.encode_conv1(records, self.conv1_hwio, self.conv1_base)
-        return self._tail(x, first=1)
+        if not self.active:
+            x = kernels.encode_conv1(records, self.conv1_hwio, self.conv1_base)
+            return self._tail(x, first=1, upto_fc7=upto_fc7)
+        bg = self.background()
+        n = records.shape[0]
+        x, touched = kernels.encode_conv1(records, self.conv1_hwio, self.conv1_base, touched=True)
+        l2, l3, l4, l5, counts = kernels.alexnet_active_sets(touched)
+
+        def conv(name, x, pixels, k, bias, relu, groups):
+            out = torch.empty((n,) + tuple(bg[name].shape[1:]), dtype=torch.float32, device=x.device)
+            out.copy_(bg[name])                                            # background everywhere (a fresh buffer), then the active pixels
+            return kernels.conv2d_same(x, getattr(self, name + "_hwio"), bias, groups=groups, relu=relu, pixels=pixels,
+                                       pixel_count=counts[k:k + 1], out=out)
+        x = conv("conv2", x, l2, 0, None, False, 2)
+        x = kernels.bias_relu_pool_lrn(x, self.conv2_b, lrn=True)
+        x = conv("conv3", x, l3, 1, self.conv3_b, True, 1)
+        x = conv("conv4", x, l4, 2, self.conv4_b, True, 2)
+        x = conv("conv5", x, l5, 3, None, False, 2)
+        x = kernels.bias_relu_pool_lrn(x, self.conv5_b, lrn=False)
+        return self._fc(x, upto_fc7)
+
+    @torch.no_grad()
+    def background(self):
+        """Outputs of conv2..conv5 for an empty image ([1,C,H,W] each), computed once with the same kernels: the first
+        layer's constant vector (any pooled pixel without a set tap under it) pushed through the dense path."""
+        if self._background is None:
+            from .. import kernels
+            from .create_batch import PAD_DATA, parse_data_fields
+            dev = self.conv1_base.device
+            rec = torch.tensor([parse_data_fields(PAD_DATA.split("_"))], dtype=torch.int32, device=dev)
+            x1, touched = kernels.encode_conv1(rec, self.conv1_hwio, self.conv1_base, touched=True)
+            rows = touched[0].cpu().numpy().astype("int64") & ((1 << 27) - 1)
+            free = [(y, x) for y in range(27) for x in range(27) if not (int(rows[y]) >> x) & 1]
+            if not free:
+                raise RuntimeError("the padding record touches every pooled pixel")
+            c = x1[0, :, free[0][0], free[0][1]]
+            x = c.reshape(1, 96, 1, 1).expand(1, 96, 27, 27).contiguous()
+            bg = {}
+            bg["conv2"] = kernels.conv2d_same(x, self.conv2_hwio, None, groups=2)
+            x = kernels.bias_relu_pool_lrn(bg["conv2"], self.conv2_b, lrn=True)
+            bg["conv3"] = kernels.conv2d_same(x, self.conv3_hwio, self.conv3_b, groups=1, relu=True)
+            bg["conv4"] = kernels.conv2d_same(bg["conv3"], self.conv4_hwio, self.conv4_b, groups=2, relu=True)
+            bg["conv5"] = kernels.conv2d_same(bg["conv4"], self.conv5_hwio, None, groups=2)
+            self._background = bg
+        return self._background
 
     @torch.no_grad()
     def predict_records(self, records):
@@ -120,8 +172,7 @@ class AlexNet(torch.nn.Module):
     def predict_records_packed(self, records, out=None):
         """records int32 [B,12] -> float32 [B,12] = softmax[5], class, logits[5], 0 (all hand-written kernels except fc6/fc7)."""
         from .. import kernels
-        x = kernels.encode_conv1(records, self.conv1_hwio, self.conv1_base)
-        h7 = self._tail(x, first=1, upto_fc7=True)
+        h7 = self._body_records(records, upto_fc7=True)
         return kernels.fc8_softmax(h7, self.fc8_w, self.fc8_b, out=out)
 
     def _tail(self, x, first, upto_fc7=False):
@@ -151,6 +202,9 @@ class AlexNet(torch.nn.Module):
                 x = F.local_response_norm(x, size=5, alpha=2e-05 * 5, beta=0.75, k=1.0)
             elif name == "conv5":
                 x = F.max_pool2d(x, 3, 2)
+        return self._fc(x, upto_fc7)
+
+    def _fc(self, x, upto_fc7=False):
         x = x.reshape(x.shape[0], 9216) if not self.channels_last else x.contiguous().reshape(x.shape[0], 9216)
         if x.is_cuda:                                       # bias + ReLU in the hipBLASLt epilogue
             x = torch._addmm_activation(self.fc6_b, x, self.fc6_w.t(), use_gelu=False)

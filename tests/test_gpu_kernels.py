@@ -219,3 +219,62 @@ def test_fc8_softmax_and_packed_predict():
     packed = net.predict_records_packed(rec).cpu().numpy()
     _l, cls, prob = net.predict_records(rec)
     assert np.abs(packed[:, :5] - prob.cpu().numpy()).max() < 1e-5
+
+
+def _dilate(m, r):
+    out = np.zeros_like(m)
+    h, w = m.shape[-2:]
+    pad = np.pad(m, [(0, 0)] * (m.ndim - 2) + [(r, r), (r, r)])
+    for dy in range(2 * r + 1):
+        for dx in range(2 * r + 1):
+            out |= pad[..., dy:dy + h, dx:dx + w]
+    return out
+
+
+def test_active_sets_match_a_numpy_restatement(oracle_lib):
+    """Touched pixels of the first layer (vs the oracle's rasterised images) and the four pixel lists derived from them
+    (vs dilation / pooling of boolean arrays)."""
+    from oracle import cbind
+    from bench import random_weights
+    from svision_amd.network.alexnet import AlexNet
+    n = 70
+    rec_np = datagen.random_records(n, seed=21, hostile=True)
+    net = AlexNet(random_weights(0), device=DEV)
+    _y, touched = kernels.encode_conv1(_dev(rec_np), net.conv1_hwio, net.conv1_base, touched=True)
+    img = cbind.rasterize(rec_np, "NHWC") + np.array([104, 117, 124], np.float32)
+    on = (img > 0).any(3)
+    want = np.zeros((n, 27, 27), bool)
+    for y in range(27):
+        for x in range(27):
+            want[:, y, x] = on[:, 8 * y:8 * y + 19, 8 * x:8 * x + 19].any((1, 2))
+    rows = touched.cpu().numpy().astype(np.int64) & ((1 << 27) - 1)
+    got = ((rows[:, :, None] >> np.arange(27)[None, None, :]) & 1).astype(bool)
+    assert np.array_equal(got, want)
+    l2, l3, l4, l5, counts = kernels.alexnet_active_sets(touched)
+    counts = counts.cpu().numpy()
+    a2 = _dilate(want, 2)
+    p2 = np.zeros((n, 13, 13), bool)
+    for y in range(13):
+        for x in range(13):
+            p2[:, y, x] = a2[:, 2 * y:2 * y + 3, 2 * x:2 * x + 3].any((1, 2))
+    a3 = _dilate(p2, 1)
+    a4 = _dilate(a3, 1)
+    a5 = _dilate(a4, 1)
+    for lst, cnt, mask in ((l2, counts[0], a2), (l3, counts[1], a3), (l4, counts[2], a4), (l5, counts[3], a5)):
+        assert np.array_equal(lst.cpu().numpy()[:cnt], np.flatnonzero(mask.reshape(-1)))
+    assert 0 < counts[0] < n * 729
+
+
+def test_active_path_is_bit_identical_to_the_dense_path():
+    """conv2..conv5 restricted to the active pixels + background elsewhere == the dense computation, bit for bit."""
+    from bench import random_weights
+    from svision_amd.network.alexnet import AlexNet
+    params = random_weights(3)
+    dense, sparse = AlexNet(params, device=DEV, active=False), AlexNet(params, device=DEV, active=True)
+    for seed, hostile, n in ((1, False, 64), (2, True, 37), (3, False, 1), (4, True, 130)):
+        rec = _dev(datagen.random_records(n, seed=seed, hostile=hostile))
+        a = dense.predict_records_packed(rec)
+        b = sparse.predict_records_packed(rec)
+        assert torch.equal(a, b)
+    pad = torch.tensor([[0, 1, 0, 1, 1, 1, 1, 1, 1, 1, 2, 2]] * 5, dtype=torch.int32, device=DEV)
+    assert torch.equal(dense.predict_records_packed(pad), sparse.predict_records_packed(pad))
