@@ -112,9 +112,9 @@ int svx_encode_conv1(const int32_t* d_records, uint32_t n, const float* d_w1, co
  * 50-90 % of conv3..5's outputs have a line in their receptive field; all others equal a precomputed, image
  * independent background tensor (exactly: every operation is local).
  *   d_list2 [n*729], d_list3 / d_list4 / d_list5 [n*169]: out, pixel ids image * H*W + y * W + x, ascending
- *   d_counts [4]: out, entries in the four lists */
+ *   d_counts [4]: out, entries in the four lists;  d_ws: scratch, 16 * n bytes, 16-B aligned */
 int svx_alexnet_active_sets(const uint32_t* d_touched, uint32_t n, int32_t* d_list2, int32_t* d_list3,
-                            int32_t* d_list4, int32_t* d_list5, uint32_t* d_counts, void* stream);
+                            int32_t* d_list4, int32_t* d_list5, uint32_t* d_counts, uint32_t* d_ws, void* stream);
 
 /* Fused conv epilogue: bias add + ReLU + 3x3/2 VALID max-pool (+ TF local response
  * normalisation across channels when lrn != 0), NCHW float32.

@@ -12,7 +12,7 @@
 
 namespace {
 
-constexpr int BLOCK = 256;
+constexpr int BLOCK = 256, WAVE = 64;
 
 // v / (k + alpha*s)^beta.  The reference network uses beta = 0.75: x^-0.75 = rsqrt(x) * rsqrt(sqrt(x)),
 // three hardware ops (a few ulp) instead of a ~100-instruction powf.
@@ -230,88 +230,121 @@ namespace {
 // Which outputs of conv2..conv5 can differ from the network's response to an empty image?  Everything downstream of
 // the first layer is local: a pooled conv1 pixel without a set tap under it holds the constant background vector,
 // a conv output whose window sees only background inputs holds the (position dependent, image independent) background
-// response, and so on through the pools.  One lane per image turns the 27 touched-row words of svx_encode_conv1 into
-// the active masks of the four convolutions (5x5 dilation -> 3x3/2 pool -> three 3x3 dilations) and the workgroup
-// compacts them into pixel lists (image * H*W + y * W + x, ascending) for svx_conv2d_same.
+// response, and so on through the pools.  A workgroup per image turns the 27 touched-row words of svx_encode_conv1
+// into the active masks of the four convolutions (5x5 dilation -> 3x3/2 pool -> three 3x3 dilations); a first pass
+// counts, a second one derives every image's offsets from the earlier counts and writes the pixel lists
+// (image * H*W + y * W + x, ascending) for svx_conv2d_same.
 constexpr int A1 = 27, A2 = 13;
 
 __device__ inline uint32_t dilate(uint32_t m, int r, uint32_t full) { uint32_t o = m; for (int i = 1; i <= r; ++i) o |= (m << i) | (m >> i); return o & full; }
 
-__global__ __launch_bounds__(BLOCK)
-void active_sets_kernel(const uint32_t* __restrict__ touched, uint32_t n, int32_t* __restrict__ list2, int32_t* __restrict__ list3,
-                        int32_t* __restrict__ list4, int32_t* __restrict__ list5, uint32_t* __restrict__ counts)
+// masks of one image in LDS: rows [0,27) conv2, then 13 each for conv3, conv4, conv5
+constexpr int MASK_ROWS = A1 + 3 * A2;
+
+__device__ inline void image_masks(const uint32_t* __restrict__ touched_rows, uint32_t* masks, uint32_t* tmp, int t)
 {
-    __shared__ uint32_t s_cnt[4][BLOCK];
-    __shared__ uint32_t s_base[4];
-    const int t = threadIdx.x;
-    if (t < 4) s_base[t] = 0;
+    // all threads of the workgroup call this; t = thread index (>= 32 threads do the work)
+    const uint32_t full1 = (1u << A1) - 1u, full2 = (1u << A2) - 1u;
+    if (t < A1) tmp[t] = dilate(touched_rows[t], 2, full1);
     __syncthreads();
-    for (uint32_t img0 = 0; img0 < n; img0 += BLOCK) {
-        const uint32_t img = img0 + t;
-        uint32_t m2[A1], m3[A2], m4[A2], m5[A2];
-        uint32_t c[4] = {0, 0, 0, 0};
-        if (img < n) {
-            uint32_t t1[A1], h[A1];
-            for (int y = 0; y < A1; ++y) { t1[y] = touched[(size_t)img * A1 + y]; h[y] = dilate(t1[y], 2, (1u << A1) - 1u); }
-            for (int y = 0; y < A1; ++y) {                       // conv2: 5x5 window
-                uint32_t v = 0;
-                for (int d = -2; d <= 2; ++d) if (y + d >= 0 && y + d < A1) v |= h[y + d];
-                m2[y] = v; c[0] += __popc(v);
-            }
-            uint32_t p[A2];
-            for (int y = 0; y < A2; ++y) {                       // pool2: 3x3 stride 2 (VALID)
-                const uint32_t rows = m2[2 * y] | m2[2 * y + 1] | m2[2 * y + 2];
-                uint32_t v = 0;
-                for (int x = 0; x < A2; ++x) if ((rows >> (2 * x)) & 7u) v |= 1u << x;
-                p[y] = v;
-            }
-            const uint32_t full = (1u << A2) - 1u;
-            uint32_t* in = p;
-            uint32_t* outs[3] = {m3, m4, m5};
-            for (int l = 0; l < 3; ++l) {                        // conv3, conv4, conv5: 3x3 windows
-                uint32_t hh[A2];
-                for (int y = 0; y < A2; ++y) hh[y] = dilate(in[y], 1, full);
-                for (int y = 0; y < A2; ++y) {
-                    uint32_t v = hh[y];
-                    if (y > 0) v |= hh[y - 1];
-                    if (y + 1 < A2) v |= hh[y + 1];
-                    outs[l][y] = v; c[1 + l] += __popc(v);
-                }
-                in = outs[l];
-            }
-        }
-        for (int l = 0; l < 4; ++l) s_cnt[l][t] = c[l];
-        __syncthreads();
-        uint32_t off[4];
-        for (int l = 0; l < 4; ++l) {                            // exclusive prefix over the images of this step (small)
-            uint32_t o = s_base[l];
-            for (int i = 0; i < t; ++i) o += s_cnt[l][i];
-            off[l] = o;
+    if (t < A1) {                                            // conv2: 5x5 window
+        uint32_t v = 0;
+        for (int d = -2; d <= 2; ++d) if (t + d >= 0 && t + d < A1) v |= tmp[t + d];
+        masks[t] = v;
+    }
+    __syncthreads();
+    if (t < A2) {                                            // pool2: 3x3 stride 2 (VALID), then the conv3 row dilation
+        const uint32_t rows = masks[2 * t] | masks[2 * t + 1] | masks[2 * t + 2];
+        uint32_t v = 0;
+        for (int x = 0; x < A2; ++x) if ((rows >> (2 * x)) & 7u) v |= 1u << x;
+        tmp[t] = dilate(v, 1, full2);
+    }
+    __syncthreads();
+    for (int l = 0; l < 3; ++l) {                            // conv3, conv4, conv5: 3x3 windows
+        uint32_t v = 0;
+        if (t < A2) {
+            v = tmp[t];
+            if (t > 0) v |= tmp[t - 1];
+            if (t + 1 < A2) v |= tmp[t + 1];
+            masks[A1 + l * A2 + t] = v;
         }
         __syncthreads();
-        if (t == BLOCK - 1) for (int l = 0; l < 4; ++l) s_base[l] = off[l] + c[l];
-        if (img < n) {
-            for (int y = 0; y < A1; ++y)
-                for (uint32_t v = m2[y]; v; v &= v - 1) list2[off[0]++] = (int32_t)(img * (A1 * A1) + y * A1 + (__ffs(v) - 1));
-            uint32_t* ms[3] = {m3, m4, m5};
-            int32_t* ls[3] = {list3, list4, list5};
-            for (int l = 0; l < 3; ++l)
-                for (int y = 0; y < A2; ++y)
-                    for (uint32_t v = ms[l][y]; v; v &= v - 1) ls[l][off[1 + l]++] = (int32_t)(img * (A2 * A2) + y * A2 + (__ffs(v) - 1));
-        }
+        if (t < A2) tmp[t] = dilate(v, 1, full2);
         __syncthreads();
     }
-    if (t < 4) counts[t] = s_base[t];
+}
+
+// pass 1: a workgroup per image: the number of active pixels of the four layers
+__global__ __launch_bounds__(64)
+void active_counts_kernel(const uint32_t* __restrict__ touched, uint32_t* __restrict__ per_image)
+{
+    __shared__ uint32_t masks[MASK_ROWS], tmp[A1];
+    const int t = threadIdx.x;
+    image_masks(touched + (size_t)blockIdx.x * A1, masks, tmp, t);
+    if (t < 4) {
+        const int lo = t == 0 ? 0 : A1 + (t - 1) * A2, hi = t == 0 ? A1 : lo + A2;
+        uint32_t c = 0;
+        for (int r = lo; r < hi; ++r) c += __popc(masks[r]);
+        per_image[blockIdx.x * 4 + t] = c;
+    }
+}
+
+// pass 2: a workgroup per image: its offsets = sum of the earlier images' counts, then the ascending pixel ids
+__global__ __launch_bounds__(BLOCK)
+void active_lists_kernel(const uint32_t* __restrict__ touched, const uint32_t* __restrict__ per_image, uint32_t n,
+                         int32_t* __restrict__ list2, int32_t* __restrict__ list3, int32_t* __restrict__ list4,
+                         int32_t* __restrict__ list5, uint32_t* __restrict__ counts)
+{
+    __shared__ uint32_t masks[MASK_ROWS], tmp[A1], rowoff[MASK_ROWS];
+    __shared__ uint32_t s_part[4][BLOCK / WAVE];
+    __shared__ uint32_t s_off[4];
+    const int t = threadIdx.x, lane = t & (WAVE - 1), wv = t >> 6;
+    const uint32_t img = blockIdx.x;
+    uint32_t part[4] = {0, 0, 0, 0};
+    for (uint32_t i = t; i < img; i += BLOCK) {
+        const uint4 c = reinterpret_cast<const uint4*>(per_image)[i];
+        part[0] += c.x; part[1] += c.y; part[2] += c.z; part[3] += c.w;
+    }
+    for (int l = 0; l < 4; ++l) {
+        uint32_t v = part[l];
+        for (int o = WAVE / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+        if (lane == 0) s_part[l][wv] = v;
+    }
+    image_masks(touched + (size_t)img * A1, masks, tmp, t);          // (contains barriers)
+    if (t < 4) {
+        uint32_t o = 0;
+        for (int w = 0; w < BLOCK / WAVE; ++w) o += s_part[t][w];
+        s_off[t] = o;
+        const int lo = t == 0 ? 0 : A1 + (t - 1) * A2, hi = t == 0 ? A1 : lo + A2;
+        uint32_t run = o;
+        for (int r = lo; r < hi; ++r) { rowoff[r] = run; run += __popc(masks[r]); }
+        if (img == n - 1) counts[t] = run;
+    }
+    __syncthreads();
+    for (int p = t; p < A1 * A1; p += BLOCK) {
+        const int y = p / A1, x = p - y * A1;
+        const uint32_t m = masks[y];
+        if ((m >> x) & 1u) list2[rowoff[y] + __popc(m & ((1u << x) - 1u))] = (int32_t)(img * (A1 * A1) + p);
+    }
+    int32_t* ls[3] = {list3, list4, list5};
+    for (int p = t; p < 3 * A2 * A2; p += BLOCK) {
+        const int l = p / (A2 * A2), q = p - l * (A2 * A2);
+        const int y = q / A2, x = q - y * A2;
+        const uint32_t m = masks[A1 + l * A2 + y];
+        if ((m >> x) & 1u) ls[l][rowoff[A1 + l * A2 + y] + __popc(m & ((1u << x) - 1u))] = (int32_t)(img * (A2 * A2) + q);
+    }
 }
 }  // namespace
 
 extern "C" int svx_alexnet_active_sets(const uint32_t* d_touched, uint32_t n, int32_t* d_list2, int32_t* d_list3,
-                                       int32_t* d_list4, int32_t* d_list5, uint32_t* d_counts, void* stream)
+                                       int32_t* d_list4, int32_t* d_list5, uint32_t* d_counts, uint32_t* d_ws, void* stream)
 {
     if (!d_counts) return SVX_EINVAL;
-    if (n && (!d_touched || !d_list2 || !d_list3 || !d_list4 || !d_list5)) return SVX_EINVAL;
-    hipLaunchKernelGGL(active_sets_kernel, dim3(1), dim3(BLOCK), 0, static_cast<hipStream_t>(stream), d_touched, n, d_list2, d_list3,
-                       d_list4, d_list5, d_counts);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (n == 0) return hipMemsetAsync(d_counts, 0, 4 * sizeof(uint32_t), st) == hipSuccess ? SVX_OK : SVX_ELAUNCH;
+    if (!d_touched || !d_list2 || !d_list3 || !d_list4 || !d_list5 || !d_ws || (reinterpret_cast<uintptr_t>(d_ws) & 15u)) return SVX_EINVAL;
+    hipLaunchKernelGGL(active_counts_kernel, dim3(n), dim3(64), 0, st, d_touched, d_ws);
+    hipLaunchKernelGGL(active_lists_kernel, dim3(n), dim3(BLOCK), 0, st, d_touched, d_ws, n, d_list2, d_list3, d_list4, d_list5, d_counts);
     return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
 }
 

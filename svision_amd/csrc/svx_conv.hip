@@ -29,6 +29,9 @@ namespace {
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int BN = 64, THREADS = 256;
+#ifndef SVX_CONV_BM64_BELOW
+#define SVX_CONV_BM64_BELOW 448          // 64 x 128 tiles below this many of them: use 64 x 64
+#endif
 
 template <int KS, int BK, int BM>
 __global__ __launch_bounds__(THREADS, 2)
@@ -50,6 +53,9 @@ void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w
     // activation slice of a pixel tile is fetched into one L2 once and re-used by all its (group, n-tile)
     // pairs -- measured 6-8x less L2-miss traffic -- without adding a dispatch round (equal run lengths)
     const int ny = groups * n_tiles;
+    // with a pixel list both tile shapes are launched and the list's length picks the one that runs (the host does
+    // not know it): 64 x 128 tiles unless they would leave the 256 CUs under two resident workgroups each
+    if (pixels && ((((Mtot + 127) / 128) * ny < SVX_CONV_BM64_BELOW) != (BM == 64))) return;
     const long long m_tiles = (Mtot + BM - 1) / BM;
     const long long total = m_tiles * ny;
     const long long per_xcd = (total + 7) / 8;
@@ -208,16 +214,13 @@ extern "C" int svx_conv2d_same(const float* d_in, const float* d_w_hwio, const f
     // 64 x 128 tiles unless they leave the 256 CUs under two resident workgroups each (then 64 x 64: the partial last
     // dispatch round of the big tiles costs more than the extra fragment reads of the small ones)
     const long long tiles128 = ((mtot + 127) / 128) * groups * (cout_g / BN);
-#ifndef SVX_CONV_BM64_BELOW
-#define SVX_CONV_BM64_BELOW 448
-#endif
     const int bm = tiles128 < SVX_CONV_BM64_BELOW ? 64 : 128;
-    const long long total_tiles = ((mtot + bm - 1) / bm) * groups * (cout_g / BN);
-    dim3 grid((unsigned)(8 * ((total_tiles + 7) / 8))), block(THREADS);
-#define SVX_LAUNCH_CONV(KS_, BM_) hipLaunchKernelGGL((conv_igemm_kernel<KS_, 16, BM_>), grid, block, 0, st, d_in, d_w_hwio, d_bias, \
-        d_out, (int)n, (int)cin, (int)cout, (int)height, (int)width, (int)groups, relu, d_pixels, d_pixel_count)
-    if (ksize == 3) { if (bm == 64) SVX_LAUNCH_CONV(3, 64); else SVX_LAUNCH_CONV(3, 128); }
-    else            { if (bm == 64) SVX_LAUNCH_CONV(5, 64); else SVX_LAUNCH_CONV(5, 128); }
+#define SVX_LAUNCH_CONV(KS_, BM_) do { \
+        const long long tt = ((mtot + BM_ - 1) / BM_) * groups * (cout_g / BN); \
+        hipLaunchKernelGGL((conv_igemm_kernel<KS_, 16, BM_>), dim3((unsigned)(8 * ((tt + 7) / 8))), dim3(THREADS), 0, st, d_in, d_w_hwio, \
+            d_bias, d_out, (int)n, (int)cin, (int)cout, (int)height, (int)width, (int)groups, relu, d_pixels, d_pixel_count); } while (0)
+    if (ksize == 3) { if (bm == 64 || d_pixels) SVX_LAUNCH_CONV(3, 64); if (bm == 128 || d_pixels) SVX_LAUNCH_CONV(3, 128); }
+    else            { if (bm == 64 || d_pixels) SVX_LAUNCH_CONV(5, 64); if (bm == 128 || d_pixels) SVX_LAUNCH_CONV(5, 128); }
 #undef SVX_LAUNCH_CONV
     return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
 }

@@ -144,8 +144,9 @@ def alexnet_active_sets(touched):
     n, dev = touched.shape[0], touched.device
     lists = [torch.empty(n * hw, dtype=torch.int32, device=dev) for hw in (729, 169, 169, 169)]
     counts = torch.empty(4, dtype=torch.int32, device=dev)
+    ws = torch.empty(max(n, 1) * 4, dtype=torch.int32, device=dev)
     rc = lib.svx_alexnet_active_sets(touched.data_ptr(), n, lists[0].data_ptr(), lists[1].data_ptr(), lists[2].data_ptr(),
-                                     lists[3].data_ptr(), counts.data_ptr(), _stream_ptr(dev))
+                                     lists[3].data_ptr(), counts.data_ptr(), ws.data_ptr(), _stream_ptr(dev))
     _lib.check(rc, "svx_alexnet_active_sets")
     return lists[0], lists[1], lists[2], lists[3], counts
 

@@ -8,7 +8,20 @@ from svision_amd.network.alexnet import AlexNet
 from tests import datagen
 dev = torch.device("cuda:0")
 net = AlexNet(random_weights(0), device=dev)
-rec = torch.from_numpy(datagen.random_records(64, seed=1, hostile=False)).to(dev)
+if os.environ.get("REAL"):                        # records of real candidate sites (bench-like sample) instead of random segments
+    from bench import options_ns
+    from svision_amd import synth
+    from svision_amd.io import bam
+    from svision_amd.sample import Sample
+    from svision_amd.collection.output_clusters import collect_pair_lines
+    from svision_amd.collection.run_collection import detect_window
+    table, genome, _ = synth.simulate(synth.SimConfig(contigs=[("chr21", 4_000_000)], coverage=30, seed=1))
+    sample = Sample.from_table(table, bam.Fasta(sequences=genome), 50, device=dev)
+    _s, clusters = detect_window(options_ns(64), sample, "chr21", 0, 4_000_000)
+    lines = collect_pair_lines(clusters, options_ns(64))
+    rec = torch.from_numpy(np.asarray([ln.record() for ln in lines[:64]], np.int32)).to(dev)
+else:
+    rec = torch.from_numpy(datagen.random_records(64, seed=1, hostile=False)).to(dev)
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 30):
     net.predict_records(rec)
 torch.cuda.synchronize()
