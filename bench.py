@@ -142,6 +142,7 @@ def main():
     tot_sites, tot_images = float(totals[0].item()), float(totals[1].item())
 
     B = args.batch
+    active = active_fractions(hot, net, windows[0], dev)
     dev_ms = sum(e0.elapsed_time(e1) for e0, e1, _n in hot.device_events)
     dev_images = sum(n for _e0, _e1, n in hot.device_events)
     hot.close()
@@ -166,10 +167,20 @@ def main():
                    "sites_per_step": sites / args.steps, "images_per_site": images / max(sites, 1),
                    "images_per_s": tot_images / dt, "host_workers": args.workers, "streams": args.streams, "parallelism": "one process per GPU, chromosome-sized shard per rank, "
                    "no data-path collective (score-range all_reduce + record gather once)"},
-        "roofline": {"kernel": "device stage per batch of %d images: encode_conv1_kernel (rasterise + sparse conv1) + conv_igemm_kernel x4 "
-                               "(fp32 MFMA, conv2-5) + pool/LRN epilogues + fc6/fc7 (hipBLASLt) + fc8_softmax_kernel, graph replays on %d streams" % (B, args.streams), "bound": "mfma",
+        "roofline": {"kernel": "device stage per batch of %d images: encode_conv1_kernel (rasterise + sparse conv1) + active-set lists + "
+                               "conv_igemm_kernel x4 (fp32 MFMA, conv2-5 on the active pixels) + pool/LRN epilogues + fc6/fc7 (hipBLASLt) + "
+                               "fc8_softmax_kernel, graph replays on %d streams" % (B, args.streams), "bound": "mfma",
                      "achieved": cnn_tflops, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                      "frac": cnn_tflops * 1e12 / F32_MFMA_PEAK,
+                     "note": "achieved = ALGORITHMIC FLOP of the dense network (SURVEY 8(d): 1.44 GFLOP per image) / device time.  "
+                             "Two exact structural savings execute fewer of them, so frac can exceed 1: the sparse first layer "
+                             "(conv1's 211 MFLOP per image are never issued) and the active-set convolutions (conv2..conv5 compute "
+                             "only the outputs with a line of the image in their receptive field; the rest is the precomputed "
+                             "response to an empty image, bit-identical to the dense result).  executed_* = what the matrix "
+                             "pipe actually ran, from the active fractions of one window.",
+                     "active_fraction": active["fractions"], "executed_flop_per_image": active["executed_flop"],
+                     "executed_tflops": active["executed_flop"] * dev_images / (dev_ms * 1e-3) / 1e12,
+                     "executed_frac": active["executed_flop"] * dev_images / (dev_ms * 1e-3) / F32_MFMA_PEAK,
                      "traffic": PMC_TRAFFIC_PER_BATCH64 * B / 64 if B == 64 else None,
                      "traffic_unit": "bytes per batch (rocprofv3 PMC, profiles/r01_pmc_traffic.md; algorithmic minimum ~4.8e8: "
                                      "227.6 MB weights + activations)", "ms_per_batch": ms_batch,
@@ -182,6 +193,24 @@ def main():
         print(json.dumps(line))
     if grouped:
         tdist.destroy_process_group()
+
+
+# dense FLOP per image of the layers behind the first one (2 x MAC)
+LAYER_FLOP = {"conv2": 447_897_600, "conv3": 299_040_768, "conv4": 224_280_576, "conv5": 149_520_384, "fc": 109_092_864}
+
+
+def active_fractions(hot, net, window, dev):
+    """Share of conv2..conv5 outputs the active-set path computes, measured on one window's records (untimed)."""
+    res = hot.collect(*window, rescan=False)
+    rec = torch.from_numpy(res.records).to(dev)
+    if not getattr(net, "active", False) or rec.shape[0] == 0:
+        return {"fractions": None, "executed_flop": float(sum(LAYER_FLOP.values()))}
+    _x, touched = kernels.encode_conv1(rec, net.conv1_hwio, net.conv1_base, touched=True)
+    counts = kernels.alexnet_active_sets(touched)[4].cpu().numpy().astype(np.float64)
+    n = rec.shape[0]
+    frac = {"conv2": counts[0] / (n * 729), "conv3": counts[1] / (n * 169), "conv4": counts[2] / (n * 169), "conv5": counts[3] / (n * 169)}
+    executed = sum(LAYER_FLOP[k] * frac[k] for k in frac) + LAYER_FLOP["fc"]
+    return {"fractions": {k: round(float(v), 4) for k, v in frac.items()}, "executed_flop": float(executed)}
 
 
 def kernel_calibration(sample, net, dev, B, reps=20):

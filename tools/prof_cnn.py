@@ -4,6 +4,9 @@ import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import random_weights
+from svision_amd import _lib
+if os.environ.get("SVX_EXP_LIB"):
+    _lib.LIB_PATH = os.environ["SVX_EXP_LIB"]
 from svision_amd.network.alexnet import AlexNet
 from tests import datagen
 dev = torch.device("cuda:0")
@@ -22,6 +25,14 @@ if os.environ.get("REAL"):                        # records of real candidate si
     rec = torch.from_numpy(np.asarray([ln.record() for ln in lines[:64]], np.int32)).to(dev)
 else:
     rec = torch.from_numpy(datagen.random_records(64, seed=1, hostile=False)).to(dev)
-for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 30):
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+for _ in range(3):
     net.predict_records(rec)
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(reps):
+    net.predict_records(rec)
+e1.record()
+torch.cuda.synchronize()
+print("eager device stage: %.1f us per batch (%s)" % (e0.elapsed_time(e1) / reps * 1e3, os.environ.get("SVX_EXP_LIB")))
