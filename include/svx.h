@@ -111,8 +111,9 @@ int svx_encode_conv1(const int32_t* d_records, uint32_t n, const float* d_w1, co
  * the touched pixels of the first layer.  The similarity image is a few thin lines, so only ~37 % of conv2's and
  * 50-90 % of conv3..5's outputs have a line in their receptive field; all others equal a precomputed, image
  * independent background tensor (exactly: every operation is local).
- *   d_list2 [n*729], d_list3 / d_list4 / d_list5 [n*169]: out, pixel ids image * H*W + y * W + x, ascending
- *   d_counts [4]: out, entries in the four lists;  d_ws: scratch, 16 * n bytes, 16-B aligned */
+ *   d_list2 [n*729], d_list3 / d_list4 / d_list5 [n*169]: out, permutations of all pixel ids image * H*W + y * W + x:
+ *             the active ones first (ascending), then the inactive ones (ascending)
+ *   d_counts [4]: out, number of active entries in the four lists;  d_ws: scratch, 16 * n bytes, 16-B aligned */
 int svx_alexnet_active_sets(const uint32_t* d_touched, uint32_t n, int32_t* d_list2, int32_t* d_list3,
                             int32_t* d_list4, int32_t* d_list5, uint32_t* d_counts, uint32_t* d_ws, void* stream);
 
@@ -147,13 +148,16 @@ int svx_bias_relu(float* d_x, const float* d_bias, uint32_t n, uint32_t channels
  *   d_w_hwio  float32 [ksize][ksize][cin/groups][cout]  -- the checkpoint layout, 16-B aligned
  *   d_bias    float32 [cout] or NULL (raw convolution output, e.g. in front of svx_bias_relu_pool_lrn)
  *   d_out     float32 [n][cout][height][width]
- *   d_pixels, d_pixel_count: NULL, or a list of output pixel ids (image * H*W + y * W + x) and its length in device
- *             memory (svx_alexnet_active_sets): only those outputs are computed and stored, the rest of d_out is
- *             left as it is (the caller holds the background there)
+ *   d_pixels, d_pixel_count: NULL, or a permutation of all n*H*W output pixel ids (image * H*W + y * W + x) and, in
+ *             device memory, the number of leading entries that are active (svx_alexnet_active_sets): only those
+ *             outputs are computed (all of them when they are more than 97 %)
+ *   d_background: NULL (the other pixels of d_out are left as they are) or float32 [cout][height][width], the layer's
+ *             response to an empty image, copied to the pixels behind the active ones
  * Requires (cin/groups) % 16 == 0 and (cout/groups) % 64 == 0. */
 int svx_conv2d_same(const float* d_in, const float* d_w_hwio, const float* d_bias, float* d_out, uint32_t n,
                     uint32_t cin, uint32_t cout, uint32_t height, uint32_t width, uint32_t ksize,
-                    uint32_t groups, int relu, const int32_t* d_pixels, const uint32_t* d_pixel_count, void* stream);
+                    uint32_t groups, int relu, const int32_t* d_pixels, const uint32_t* d_pixel_count,
+                    const float* d_background, void* stream);
 
 /* ---- host side: native BGZF/BAM ingestion (no device work) -------------------------------------------
  * Replaces the per-record pysam iteration of the reference (aln_file.fetch at

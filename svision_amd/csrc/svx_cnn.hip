@@ -232,8 +232,9 @@ namespace {
 // a conv output whose window sees only background inputs holds the (position dependent, image independent) background
 // response, and so on through the pools.  A workgroup per image turns the 27 touched-row words of svx_encode_conv1
 // into the active masks of the four convolutions (5x5 dilation -> 3x3/2 pool -> three 3x3 dilations); a first pass
-// counts, a second one derives every image's offsets from the earlier counts and writes the pixel lists
-// (image * H*W + y * W + x, ascending) for svx_conv2d_same.
+// counts, a second one derives every image's offsets from the counts and writes, per layer, a permutation of all
+// pixel ids (image * H*W + y * W + x): the active ones first (ascending), then the inactive ones (ascending) --
+// svx_conv2d_same computes the first part and copies the background into the second.
 constexpr int A1 = 27, A2 = 13;
 
 __device__ inline uint32_t dilate(uint32_t m, int r, uint32_t full) { uint32_t o = m; for (int i = 1; i <= r; ++i) o |= (m << i) | (m >> i); return o & full; }
@@ -296,42 +297,50 @@ void active_lists_kernel(const uint32_t* __restrict__ touched, const uint32_t* _
                          int32_t* __restrict__ list5, uint32_t* __restrict__ counts)
 {
     __shared__ uint32_t masks[MASK_ROWS], tmp[A1], rowoff[MASK_ROWS];
-    __shared__ uint32_t s_part[4][BLOCK / WAVE];
-    __shared__ uint32_t s_off[4];
+    __shared__ uint32_t s_part[8][BLOCK / WAVE];
+    __shared__ uint32_t inoff[MASK_ROWS];                    // first slot of every mask row's inactive pixels
     const int t = threadIdx.x, lane = t & (WAVE - 1), wv = t >> 6;
     const uint32_t img = blockIdx.x;
-    uint32_t part[4] = {0, 0, 0, 0};
-    for (uint32_t i = t; i < img; i += BLOCK) {
+    uint32_t part[8] = {0, 0, 0, 0, 0, 0, 0, 0};             // [0..4): images before this one, [4..8): all images
+    for (uint32_t i = t; i < n; i += BLOCK) {
         const uint4 c = reinterpret_cast<const uint4*>(per_image)[i];
-        part[0] += c.x; part[1] += c.y; part[2] += c.z; part[3] += c.w;
+        if (i < img) { part[0] += c.x; part[1] += c.y; part[2] += c.z; part[3] += c.w; }
+        part[4] += c.x; part[5] += c.y; part[6] += c.z; part[7] += c.w;
     }
-    for (int l = 0; l < 4; ++l) {
+    for (int l = 0; l < 8; ++l) {
         uint32_t v = part[l];
         for (int o = WAVE / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
         if (lane == 0) s_part[l][wv] = v;
     }
     image_masks(touched + (size_t)img * A1, masks, tmp, t);          // (contains barriers)
     if (t < 4) {
-        uint32_t o = 0;
-        for (int w = 0; w < BLOCK / WAVE; ++w) o += s_part[t][w];
-        s_off[t] = o;
+        uint32_t before = 0, total = 0;
+        for (int w = 0; w < BLOCK / WAVE; ++w) { before += s_part[t][w]; total += s_part[4 + t][w]; }
         const int lo = t == 0 ? 0 : A1 + (t - 1) * A2, hi = t == 0 ? A1 : lo + A2;
-        uint32_t run = o;
-        for (int r = lo; r < hi; ++r) { rowoff[r] = run; run += __popc(masks[r]); }
-        if (img == n - 1) counts[t] = run;
+        const uint32_t width = t == 0 ? A1 : A2, hw = width * width;
+        // active pixels fill [0, total) in image order; the inactive ones follow in [total, n * hw), also in image order
+        uint32_t run = before, irun = total + (img * hw - before);
+        for (int r = lo; r < hi; ++r) {
+            const uint32_t c = __popc(masks[r]);
+            rowoff[r] = run; inoff[r] = irun;
+            run += c; irun += width - c;
+        }
+        if (img == n - 1) counts[t] = total;
     }
     __syncthreads();
     for (int p = t; p < A1 * A1; p += BLOCK) {
         const int y = p / A1, x = p - y * A1;
-        const uint32_t m = masks[y];
-        if ((m >> x) & 1u) list2[rowoff[y] + __popc(m & ((1u << x) - 1u))] = (int32_t)(img * (A1 * A1) + p);
+        const uint32_t m = masks[y], below = (1u << x) - 1u;
+        const uint32_t slot = ((m >> x) & 1u) ? rowoff[y] + __popc(m & below) : inoff[y] + __popc(~m & below);
+        list2[slot] = (int32_t)(img * (A1 * A1) + p);
     }
     int32_t* ls[3] = {list3, list4, list5};
     for (int p = t; p < 3 * A2 * A2; p += BLOCK) {
         const int l = p / (A2 * A2), q = p - l * (A2 * A2);
-        const int y = q / A2, x = q - y * A2;
-        const uint32_t m = masks[A1 + l * A2 + y];
-        if ((m >> x) & 1u) ls[l][rowoff[A1 + l * A2 + y] + __popc(m & ((1u << x) - 1u))] = (int32_t)(img * (A2 * A2) + q);
+        const int y = q / A2, x = q - y * A2, r = A1 + l * A2 + y;
+        const uint32_t m = masks[r], below = (1u << x) - 1u;
+        const uint32_t slot = ((m >> x) & 1u) ? rowoff[r] + __popc(m & below) : inoff[r] + __popc(~m & below);
+        ls[l][slot] = (int32_t)(img * (A2 * A2) + q);
     }
 }
 }  // namespace

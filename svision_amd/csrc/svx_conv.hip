@@ -37,7 +37,8 @@ template <int KS, int BK, int BM>
 __global__ __launch_bounds__(THREADS, 2)
 void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
                        float* __restrict__ out, int nimg, int Cin, int Cout, int H, int W, int groups, int relu,
-                       const int32_t* __restrict__ pixels, const uint32_t* __restrict__ pixel_count)
+                       const int32_t* __restrict__ pixels, const uint32_t* __restrict__ pixel_count,
+                       const float* __restrict__ background)
 {
     constexpr int P = KS / 2;
     __shared__ float Ws[2][BK][BN];
@@ -46,8 +47,13 @@ void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w
     const int CinG = Cin / groups, CoutG = Cout / groups;
     const int n_tiles = CoutG / BN;
     const int HW = H * W;
-    // columns of the GEMM: every output pixel, or the listed ones only (active set; the grid is sized for all of them)
-    const long long Mtot = pixels ? (long long)*pixel_count : (long long)nimg * HW;
+    // columns of the GEMM: every output pixel, or only the first *pixel_count entries of the pixel permutation (the
+    // active set; the grid is sized for all pixels).  The pixels behind them receive the background (image independent
+    // response to an empty image) from the workgroups the active tiles leave over.  When nearly all pixels are active
+    // (97 %) everything is computed; below that the list still pays (measured with 81 % and 91 % active).
+    const long long Mall = (long long)nimg * HW;
+    long long Mtot = Mall;
+    if (pixels) { const long long a = (long long)*pixel_count; if (a * 100 < Mall * 97) Mtot = a; }
     // XCD-aware tile order (workgroup b runs on XCD b % 8, each XCD has its own 4 MB L2): the (pixel tile,
     // channel tile) pairs, channel tile fastest, are cut into 8 equal contiguous runs, one per XCD, so the
     // activation slice of a pixel tile is fetched into one L2 once and re-used by all its (group, n-tile)
@@ -57,13 +63,31 @@ void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w
     // not know it): 64 x 128 tiles unless they would leave the 256 CUs under two resident workgroups each
     if (pixels && ((((Mtot + 127) / 128) * ny < SVX_CONV_BM64_BELOW) != (BM == 64))) return;
     const long long m_tiles = (Mtot + BM - 1) / BM;
-    const long long total = m_tiles * ny;
-    const long long per_xcd = (total + 7) / 8;
-    const long long pair = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if ((long long)(blockIdx.x >> 3) >= per_xcd || pair >= total) return;
+    const long long fill_tiles = (pixels && background) ? (Mall - Mtot + BM - 1) / BM : 0;
+    // every XCD gets an equal contiguous run of the compute pairs and, behind it, of the background pairs
+    const long long total_c = m_tiles * ny, total_f = fill_tiles * ny;
+    const long long per_c = (total_c + 7) / 8, per_f = (total_f + 7) / 8;
+    const long long local = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+    long long pair;
+    bool fill = false;
+    if (local < per_c) { pair = xcd * per_c + local; if (pair >= total_c) return; }
+    else if (local < per_c + per_f) { pair = xcd * per_f + (local - per_c); if (pair >= total_f) return; fill = true; }
+    else return;
     const int mt = (int)(pair / ny), yy_ = (int)(pair - (long long)mt * ny);
     const int g = yy_ / n_tiles;
     const int n0 = (yy_ - g * n_tiles) * BN;
+    if (fill) {
+        // background tile: BM inactive pixels x BN channels, lanes along the (ascending) pixel list
+        const long long q = Mtot + (long long)mt * BM + (threadIdx.x & (BM - 1));
+        if (q < Mall) {
+            const int id = pixels[q];
+            const int bb = id / HW, pp = id - bb * HW;
+            const int c0 = g * CoutG + n0;
+            for (int c = threadIdx.x / BM; c < BN; c += THREADS / BM)
+                out[((size_t)bb * Cout + c0 + c) * HW + pp] = background[(size_t)(c0 + c) * HW + pp];
+        }
+        return;
+    }
     const int m0 = mt * BM;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -201,11 +225,12 @@ void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w
 
 extern "C" int svx_conv2d_same(const float* d_in, const float* d_w_hwio, const float* d_bias, float* d_out, uint32_t n,
                                uint32_t cin, uint32_t cout, uint32_t height, uint32_t width, uint32_t ksize,
-                               uint32_t groups, int relu, const int32_t* d_pixels, const uint32_t* d_pixel_count, void* stream)
+                               uint32_t groups, int relu, const int32_t* d_pixels, const uint32_t* d_pixel_count,
+                               const float* d_background, void* stream)
 {
     if (n == 0) return SVX_OK;
     if (!d_in || !d_w_hwio || !d_out || groups == 0 || cin % groups || cout % groups) return SVX_EINVAL;
-    if ((d_pixels == nullptr) != (d_pixel_count == nullptr)) return SVX_EINVAL;
+    if ((d_pixels == nullptr) != (d_pixel_count == nullptr) || (d_background && !d_pixels)) return SVX_EINVAL;
     const uint32_t cin_g = cin / groups, cout_g = cout / groups;
     if (cin_g % 16 || cout_g % BN || (ksize != 3 && ksize != 5)) return SVX_EINVAL;
     if ((reinterpret_cast<uintptr_t>(d_w_hwio) & 15u) || (cout % 4)) return SVX_EINVAL;
@@ -216,9 +241,9 @@ extern "C" int svx_conv2d_same(const float* d_in, const float* d_w_hwio, const f
     const long long tiles128 = ((mtot + 127) / 128) * groups * (cout_g / BN);
     const int bm = tiles128 < SVX_CONV_BM64_BELOW ? 64 : 128;
 #define SVX_LAUNCH_CONV(KS_, BM_) do { \
-        const long long tt = ((mtot + BM_ - 1) / BM_) * groups * (cout_g / BN); \
+        const long long tt = ((mtot + BM_ - 1) / BM_ + 1) * groups * (cout_g / BN) + 16;   /* active and background tiles both round up, per XCD too */ \
         hipLaunchKernelGGL((conv_igemm_kernel<KS_, 16, BM_>), dim3((unsigned)(8 * ((tt + 7) / 8))), dim3(THREADS), 0, st, d_in, d_w_hwio, \
-            d_bias, d_out, (int)n, (int)cin, (int)cout, (int)height, (int)width, (int)groups, relu, d_pixels, d_pixel_count); } while (0)
+            d_bias, d_out, (int)n, (int)cin, (int)cout, (int)height, (int)width, (int)groups, relu, d_pixels, d_pixel_count, d_background); } while (0)
     if (ksize == 3) { if (bm == 64 || d_pixels) SVX_LAUNCH_CONV(3, 64); if (bm == 128 || d_pixels) SVX_LAUNCH_CONV(3, 128); }
     else            { if (bm == 64 || d_pixels) SVX_LAUNCH_CONV(5, 64); if (bm == 128 || d_pixels) SVX_LAUNCH_CONV(5, 128); }
 #undef SVX_LAUNCH_CONV

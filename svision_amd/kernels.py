@@ -164,11 +164,12 @@ def bias_relu_(x, bias):
     return x
 
 
-def conv2d_same(x, w_hwio, bias=None, groups=1, relu=False, pixels=None, pixel_count=None, out=None):
+def conv2d_same(x, w_hwio, bias=None, groups=1, relu=False, pixels=None, pixel_count=None, out=None, background=None):
     """x float32 [n,Cin,H,W], w_hwio float32 [k,k,Cin/groups,Cout] (checkpoint layout) -> [n,Cout,H,W]:
     stride-1 SAME convolution on the fp32 matrix cores, optional fused bias + ReLU.
-    ``pixels`` / ``pixel_count`` (device int32 list and its length, a one-element view): compute only those output
-    pixels into ``out``, which already holds the values of all others.  See include/svx.h svx_conv2d_same."""
+    ``pixels`` / ``pixel_count`` (device int32 permutation of the pixel ids and the number of leading active entries,
+    a one-element view): compute only the active output pixels; the others receive ``background`` ([Cout,H,W]) or,
+    without it, keep what ``out`` holds.  See include/svx.h svx_conv2d_same."""
     lib = _lib.load()
     _require_cuda(x, "x")
     _require_cuda(w_hwio, "w_hwio")
@@ -180,15 +181,18 @@ def conv2d_same(x, w_hwio, bias=None, groups=1, relu=False, pixels=None, pixel_c
         raise _lib.SvxError("weight shape %s does not match input %s with %d groups" % (tuple(w_hwio.shape), tuple(x.shape), groups))
     if bias is not None:
         _require_cuda(bias, "bias")
-    if (pixels is None) != (pixel_count is None) or (pixels is not None and out is None):
-        raise _lib.SvxError("pixels, pixel_count and out go together")
+    if (pixels is None) != (pixel_count is None) or (pixels is not None and out is None and background is None):
+        raise _lib.SvxError("pixels and pixel_count go together, with out or background")
+    if background is not None and (pixels is None or tuple(background.shape[-3:]) != (cout, h, w) or not background.is_contiguous()):
+        raise _lib.SvxError("background must be a contiguous float32 [Cout,H,W] tensor and needs pixels")
     y = out if out is not None else torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
     if tuple(y.shape) != (n, cout, h, w) or y.dtype != torch.float32 or not y.is_contiguous():
         raise _lib.SvxError("out must be a contiguous float32 [n,Cout,H,W] tensor")
     rc = lib.svx_conv2d_same(x.data_ptr(), w_hwio.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
                              n, cin, cout, h, w, k, groups, 1 if relu else 0,
                              pixels.data_ptr() if pixels is not None else None,
-                             pixel_count.data_ptr() if pixel_count is not None else None, _stream_ptr(x.device))
+                             pixel_count.data_ptr() if pixel_count is not None else None,
+                             background.data_ptr() if background is not None else None, _stream_ptr(x.device))
     _lib.check(rc, "svx_conv2d_same")
     return y
 

@@ -119,10 +119,9 @@ class AlexNet(torch.nn.Module):
         l2, l3, l4, l5, counts = kernels.alexnet_active_sets(touched)
 
         def conv(name, x, pixels, k, bias, relu, groups):
-            out = torch.empty((n,) + tuple(bg[name].shape[1:]), dtype=torch.float32, device=x.device)
-            out.copy_(bg[name])                                            # background everywhere (a fresh buffer), then the active pixels
+            # active pixels computed, the others copied from the background by the workgroups the active tiles leave over
             return kernels.conv2d_same(x, getattr(self, name + "_hwio"), bias, groups=groups, relu=relu, pixels=pixels,
-                                       pixel_count=counts[k:k + 1], out=out)
+                                       pixel_count=counts[k:k + 1], background=bg[name])
         x = conv("conv2", x, l2, 0, None, False, 2)
         x = kernels.bias_relu_pool_lrn(x, self.conv2_b, lrn=True)
         x = conv("conv3", x, l3, 1, self.conv3_b, True, 1)

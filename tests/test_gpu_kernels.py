@@ -261,7 +261,8 @@ def test_active_sets_match_a_numpy_restatement(oracle_lib):
     a4 = _dilate(a3, 1)
     a5 = _dilate(a4, 1)
     for lst, cnt, mask in ((l2, counts[0], a2), (l3, counts[1], a3), (l4, counts[2], a4), (l5, counts[3], a5)):
-        assert np.array_equal(lst.cpu().numpy()[:cnt], np.flatnonzero(mask.reshape(-1)))
+        assert np.array_equal(lst.cpu().numpy()[:cnt], np.flatnonzero(mask.reshape(-1)))          # active first, ascending
+        assert np.array_equal(lst.cpu().numpy()[cnt:], np.flatnonzero(~mask.reshape(-1)))         # then everything else
     assert 0 < counts[0] < n * 729
 
 
