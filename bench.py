@@ -42,7 +42,7 @@ F32_MFMA_PEAK = 157.3e12                      # MI355X_MICROARCH.md: FP32 matrix
 # HBM/fabric bytes per 64-image batch of the device stage, from PMC counters (rocprofv3 --pmc FETCH_SIZE and
 # --pmc WRITE_SIZE in separate passes, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md), summed over its
 # kernels: profiles/r01_pmc_traffic.md.  Offline measurement (counters cannot be read inside this process).
-PMC_TRAFFIC_PER_BATCH64 = 6.79e8
+PMC_TRAFFIC_PER_BATCH64 = 7.04e8
 CHR21 = 46_709_983
 
 
