@@ -259,6 +259,13 @@ def kernel_calibration(sample, net, dev, B, reps=20):
         out["conv_igemm_kernel %s" % name] = {"bound": "mfma", "launch": "%d x %d x %d x %d -> %d, %dx%d, %d group(s)" % (B, cin, hw, hw, cout, k, k, groups),
                                                "us": t * 1e6, "achieved": flop / t / 1e12, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                                                "frac": flop / t / F32_MFMA_PEAK}
+    dense_net = AlexNet(random_weights(0), device=dev, active=False)
+    t = timed(lambda: dense_net.predict_records(rec))
+    out["device_stage_eager_1_stream_dense_convolutions"] = {
+        "bound": "mfma", "launch": "%d images" % B, "us": t * 1e6, "achieved": CNN_FLOP * B / t / 1e12, "peak": F32_MFMA_PEAK / 1e12,
+        "unit": "TFLOP/s", "frac": CNN_FLOP * B / t / F32_MFMA_PEAK,
+        "note": "the same stage with conv2..conv5 computed at every pixel (AlexNet(active=False)); outputs bit-identical"}
+    del dense_net
     t = timed(lambda: net.predict_records(rec))
     out["device_stage_eager_1_stream"] = {"bound": "mfma", "launch": "%d images" % B, "us": t * 1e6,
                                           "achieved": CNN_FLOP * B / t / 1e12, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",

@@ -279,3 +279,39 @@ def test_active_path_is_bit_identical_to_the_dense_path():
         assert torch.equal(a, b)
     pad = torch.tensor([[0, 1, 0, 1, 1, 1, 1, 1, 1, 1, 2, 2]] * 5, dtype=torch.int32, device=DEV)
     assert torch.equal(dense.predict_records_packed(pad), sparse.predict_records_packed(pad))
+
+
+@pytest.mark.parametrize("fill", [0.0, 0.3, 0.99, 1.0])
+def test_conv_with_pixel_list_and_background(fill):
+    """List mode of svx_conv2d_same at the kernel level: active pixels = the dense result, all others = the given
+    background, for empty / partial / nearly full (everything is computed above 97 %) / full touched masks."""
+    rng = np.random.default_rng(int(fill * 100))
+    n = 9
+    touched = np.zeros((n, 27), np.int64)
+    if fill >= 0.99:
+        touched[:] = (1 << 27) - 1
+        if fill < 1.0:
+            touched[0, :3] = 0                          # a corner of one image stays inactive even after the 5x5 dilation
+    elif fill > 0:
+        for i in range(n):
+            for _ in range(int(fill * 20)):
+                y, x = rng.integers(0, 27, 2)
+                touched[i, y] |= 1 << int(x)
+    lists = kernels.alexnet_active_sets(_dev(touched.astype(np.int32)))
+    counts = lists[4].cpu().numpy()
+    for (cin, cout, hw, k, groups, li) in ((96, 256, 27, 5, 2, 0), (256, 384, 13, 3, 1, 1)):
+        x = torch.randn(n, cin, hw, hw, device=DEV)
+        w = torch.randn(k, k, cin // groups, cout, device=DEV) * 0.05
+        b = torch.randn(cout, device=DEV)
+        bg = torch.randn(cout, hw, hw, device=DEV)
+        dense = kernels.conv2d_same(x, w, b, groups=groups, relu=True)
+        got = kernels.conv2d_same(x, w, b, groups=groups, relu=True, pixels=lists[li], pixel_count=lists[4][li:li + 1], background=bg)
+        active = torch.zeros(n * hw * hw, dtype=torch.bool, device=DEV)
+        active[lists[li][:int(counts[li])].long()] = True
+        active = active.view(n, 1, hw, hw)
+        if int(counts[li]) * 100 >= n * hw * hw * 97:
+            active[:] = True                            # nearly full: the kernel computes every pixel
+        want = torch.where(active, dense, bg.unsqueeze(0).expand(n, -1, -1, -1))
+        assert torch.equal(got, want)
+        if fill == 0.0:
+            assert int(counts[li]) == 0
