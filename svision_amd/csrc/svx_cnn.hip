@@ -89,6 +89,8 @@ void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __res
     __shared__ unsigned pooled_bits[P1 * C1P];        // [ox][k] pooled activations as float bit patterns (row padded: no bank conflicts)
     __shared__ unsigned rowany[3][ROW_WORDS];
     __shared__ int has_empty[P1];         // per conv row of this strip: OR of its 11 image rows x 3 planes
+    __shared__ unsigned short queue[P1 * 9];
+    __shared__ int n_queue;
 
     const int img = blockIdx.x / P1;
     const int oyp = blockIdx.x - img * P1;
@@ -113,6 +115,7 @@ void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __res
                 any_set |= !empty;
             }
         if (tid < P1) has_empty[tid] = any_empty ? 1 : 0;
+        if (tid == 0) n_queue = 0;
         // pooled pixels with a set tap under them: everything else in this row is the constant background vector
         const unsigned long long t = __ballot(tid < P1 && any_set);
         if (touched && tid == 0) touched[blockIdx.x] = (uint32_t)t;     // P1 = 27 lanes of the first wave
@@ -123,16 +126,21 @@ void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __res
         pooled_bits[ox * C1P + k] = has_empty[ox] ? __float_as_uint(fmaxf(base[k], 0.0f)) : 0u;
     }
     __syncthreads();
-    // One lane per (pooled pixel, conv window under it, 8-channel group): 27 x 9 x 12 items.  ~90 % of the
-    // windows are empty (constant response base[k]); a touched window walks its 33 row masks and adds the
-    // weight rows of its set taps.  Max-pool = integer atomic max on the (non-negative) float bit patterns:
-    // exact and order independent.
-    for (int item = tid; item < P1 * 9 * C1_GROUPS; item += ENC_BLOCK) {
-        const int g = item % C1_GROUPS, pw = item / C1_GROUPS;
+    // ~90 % of the 27 x 9 (pooled pixel, conv window under it) pairs of the row are empty (constant response base[k]);
+    // the touched ones are compacted into a queue so that every lane below has work: one lane per (touched window,
+    // 8-channel group) walks the window's 33 row masks and adds the weight rows of its set taps.  Max-pool = integer
+    // atomic max on the (non-negative) float bit patterns: exact and order independent.
+    if (tid < P1 * 9) {
+        const int oxp = tid / 9, win = tid - oxp * 9;
+        if (window_mask(rowany[win / 3], 4 * (2 * oxp + win % 3)) != 0) queue[atomicAdd(&n_queue, 1)] = (unsigned short)tid;
+    }
+    __syncthreads();
+    const int n_items = n_queue * C1_GROUPS;
+    for (int item = tid; item < n_items; item += ENC_BLOCK) {
+        const int g = item % C1_GROUPS, pw = queue[item / C1_GROUPS];
         const int oxp = pw / 9, win = pw - oxp * 9;
         const int dy = win / 3, dx = win - dy * 3;
         const int oy = 2 * oyp + dy, ox = 2 * oxp + dx;
-        if (window_mask(rowany[dy], 4 * ox) == 0) continue;
         const float4 b0 = reinterpret_cast<const float4*>(base)[2 * g];
         const float4 b1 = reinterpret_cast<const float4*>(base)[2 * g + 1];
         float acc[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
