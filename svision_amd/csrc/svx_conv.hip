@@ -33,16 +33,18 @@ constexpr int BN = 64, THREADS = 256;
 #define SVX_CONV_BM64_BELOW 448          // 64 x 128 tiles below this many of them: use 64 x 64
 #endif
 
+constexpr int lds_floats(int bk, int bm) { return 2 * bk * (BN + bm); }
+
 template <int KS, int BK, int BM>
-__global__ __launch_bounds__(THREADS, 2)
-void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
-                       float* __restrict__ out, int nimg, int Cin, int Cout, int H, int W, int groups, int relu,
-                       const int32_t* __restrict__ pixels, const uint32_t* __restrict__ pixel_count,
-                       const float* __restrict__ background)
+__device__ __forceinline__
+void conv_igemm_tile(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
+                     float* __restrict__ out, int nimg, int Cin, int Cout, int H, int W, int groups, int relu,
+                     const int32_t* __restrict__ pixels, const uint32_t* __restrict__ pixel_count,
+                     const float* __restrict__ background, float* lds)
 {
     constexpr int P = KS / 2;
-    __shared__ float Ws[2][BK][BN];
-    __shared__ float Xs[2][BK][BM];
+    float (*Ws)[BK][BN] = reinterpret_cast<float (*)[BK][BN]>(lds);                    // [2][BK][BN]
+    float (*Xs)[BK][BM] = reinterpret_cast<float (*)[BK][BM]>(lds + 2 * BK * BN);      // [2][BK][BM]
 
     const int CinG = Cin / groups, CoutG = Cout / groups;
     const int n_tiles = CoutG / BN;
@@ -59,9 +61,6 @@ void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w
     // activation slice of a pixel tile is fetched into one L2 once and re-used by all its (group, n-tile)
     // pairs -- measured 6-8x less L2-miss traffic -- without adding a dispatch round (equal run lengths)
     const int ny = groups * n_tiles;
-    // with a pixel list both tile shapes are launched and the list's length picks the one that runs (the host does
-    // not know it): 64 x 128 tiles unless they would leave the 256 CUs under two resident workgroups each
-    if (pixels && ((((Mtot + 127) / 128) * ny < SVX_CONV_BM64_BELOW) != (BM == 64))) return;
     const long long m_tiles = (Mtot + BM - 1) / BM;
     const long long fill_tiles = (pixels && background) ? (Mall - Mtot + BM - 1) / BM : 0;
     // every XCD gets an equal contiguous run of the compute pairs and, behind it, of the background pairs
@@ -221,6 +220,36 @@ void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w
     }
 }
 
+// dense mode: the host picks the tile shape
+template <int KS, int BK, int BM>
+__global__ __launch_bounds__(THREADS, 2)
+void conv_igemm_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
+                       float* __restrict__ out, int nimg, int Cin, int Cout, int H, int W, int groups, int relu)
+{
+    __shared__ float lds[lds_floats(BK, BM)];
+    conv_igemm_tile<KS, BK, BM>(in, w, bias, out, nimg, Cin, Cout, H, W, groups, relu, nullptr, nullptr, nullptr, lds);
+}
+
+// list mode: the host does not know the list's length, so the workgroup picks the tile shape itself -- 64 x 128 unless
+// that would leave the 256 CUs under two resident workgroups each (the grid is sized for the smaller tiles)
+template <int KS, int BK>
+__global__ __launch_bounds__(THREADS, 2)
+void conv_igemm_list_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
+                            float* __restrict__ out, int nimg, int Cin, int Cout, int H, int W, int groups, int relu,
+                            const int32_t* __restrict__ pixels, const uint32_t* __restrict__ pixel_count,
+                            const float* __restrict__ background)
+{
+    __shared__ float lds[lds_floats(BK, 128)];
+    const long long Mall = (long long)nimg * H * W;
+    long long Mtot = (long long)*pixel_count;
+    if (Mtot * 100 >= Mall * 97) Mtot = Mall;
+    const long long tiles128 = ((Mtot + 127) / 128) * groups * ((Cout / groups) / BN);
+    if (tiles128 < SVX_CONV_BM64_BELOW)
+        conv_igemm_tile<KS, BK, 64>(in, w, bias, out, nimg, Cin, Cout, H, W, groups, relu, pixels, pixel_count, background, lds);
+    else
+        conv_igemm_tile<KS, BK, 128>(in, w, bias, out, nimg, Cin, Cout, H, W, groups, relu, pixels, pixel_count, background, lds);
+}
+
 }  // namespace
 
 extern "C" int svx_conv2d_same(const float* d_in, const float* d_w_hwio, const float* d_bias, float* d_out, uint32_t n,
@@ -240,12 +269,23 @@ extern "C" int svx_conv2d_same(const float* d_in, const float* d_w_hwio, const f
     // dispatch round of the big tiles costs more than the extra fragment reads of the small ones)
     const long long tiles128 = ((mtot + 127) / 128) * groups * (cout_g / BN);
     const int bm = tiles128 < SVX_CONV_BM64_BELOW ? 64 : 128;
+    if (d_pixels) {
+        const long long tt = ((mtot + 63) / 64 + 1) * groups * (cout_g / BN) + 16;     /* active and background tiles both round up, per XCD too */
+        const dim3 grid((unsigned)(8 * ((tt + 7) / 8)));
+        if (ksize == 3)
+            hipLaunchKernelGGL((conv_igemm_list_kernel<3, 16>), grid, dim3(THREADS), 0, st, d_in, d_w_hwio, d_bias, d_out, (int)n, (int)cin,
+                               (int)cout, (int)height, (int)width, (int)groups, relu, d_pixels, d_pixel_count, d_background);
+        else
+            hipLaunchKernelGGL((conv_igemm_list_kernel<5, 16>), grid, dim3(THREADS), 0, st, d_in, d_w_hwio, d_bias, d_out, (int)n, (int)cin,
+                               (int)cout, (int)height, (int)width, (int)groups, relu, d_pixels, d_pixel_count, d_background);
+        return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
+    }
 #define SVX_LAUNCH_CONV(KS_, BM_) do { \
-        const long long tt = ((mtot + BM_ - 1) / BM_ + 1) * groups * (cout_g / BN) + 16;   /* active and background tiles both round up, per XCD too */ \
+        const long long tt = ((mtot + BM_ - 1) / BM_) * groups * (cout_g / BN); \
         hipLaunchKernelGGL((conv_igemm_kernel<KS_, 16, BM_>), dim3((unsigned)(8 * ((tt + 7) / 8))), dim3(THREADS), 0, st, d_in, d_w_hwio, \
-            d_bias, d_out, (int)n, (int)cin, (int)cout, (int)height, (int)width, (int)groups, relu, d_pixels, d_pixel_count, d_background); } while (0)
-    if (ksize == 3) { if (bm == 64 || d_pixels) SVX_LAUNCH_CONV(3, 64); if (bm == 128 || d_pixels) SVX_LAUNCH_CONV(3, 128); }
-    else            { if (bm == 64 || d_pixels) SVX_LAUNCH_CONV(5, 64); if (bm == 128 || d_pixels) SVX_LAUNCH_CONV(5, 128); }
+            d_bias, d_out, (int)n, (int)cin, (int)cout, (int)height, (int)width, (int)groups, relu); } while (0)
+    if (ksize == 3) { if (bm == 64) SVX_LAUNCH_CONV(3, 64); else SVX_LAUNCH_CONV(3, 128); }
+    else            { if (bm == 64) SVX_LAUNCH_CONV(5, 64); else SVX_LAUNCH_CONV(5, 128); }
 #undef SVX_LAUNCH_CONV
     return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
 }
