@@ -153,7 +153,7 @@ int svx_bias_relu(float* d_x, const float* d_bias, uint32_t n, uint32_t channels
  *             outputs are computed (all of them when they are more than 97 %)
  *   d_background: NULL (the other pixels of d_out are left as they are) or float32 [cout][height][width], the layer's
  *             response to an empty image, copied to the pixels behind the active ones
- * Requires (cin/groups) % 16 == 0 and (cout/groups) % 64 == 0. */
+ * Requires (cin/groups) % 16 == 0, (cout/groups) % 64 == 0 and an input tensor below 4 GB. */
 int svx_conv2d_same(const float* d_in, const float* d_w_hwio, const float* d_bias, float* d_out, uint32_t n,
                     uint32_t cin, uint32_t cout, uint32_t height, uint32_t width, uint32_t ksize,
                     uint32_t groups, int relu, const int32_t* d_pixels, const uint32_t* d_pixel_count,

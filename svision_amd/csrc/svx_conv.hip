@@ -263,6 +263,8 @@ extern "C" int svx_conv2d_same(const float* d_in, const float* d_w_hwio, const f
     const uint32_t cin_g = cin / groups, cout_g = cout / groups;
     if (cin_g % 16 || cout_g % BN || (ksize != 3 && ksize != 5)) return SVX_EINVAL;
     if ((reinterpret_cast<uintptr_t>(d_w_hwio) & 15u) || (cout % 4)) return SVX_EINVAL;
+    // 32-bit byte offsets into the input, 32-bit pixel ids
+    if ((uint64_t)n * cin * height * width * 4 > 0xffffffffull || (uint64_t)n * height * width > 0x7fffffffull) return SVX_EINVAL;
     const long long mtot = (long long)n * height * width;
     hipStream_t st = static_cast<hipStream_t>(stream);
     // 64 x 128 tiles unless they leave the 256 CUs under two resident workgroups each (then 64 x 64: the partial last
