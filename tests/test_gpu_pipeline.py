@@ -150,7 +150,8 @@ def test_streaming_cli_equals_file_based_cli(checkpoint, tmp_path):
         assert outs["stream"][k] == outs["files"][k], k
 
 
-def test_two_ranks_from_an_indexed_bam_equal_one_rank(checkpoint, tmp_path):
+@pytest.mark.parametrize("threads", ["1", "3"])
+def test_two_ranks_from_an_indexed_bam_equal_one_rank(checkpoint, tmp_path, threads):
     """The whole multi-rank command line from files: two torchrun ranks (gloo here: one GPU is shared, RCCL refuses
     duplicate devices; the driver's multi-GPU runs use nccl) each decode only their chromosomes through the .bai, stream
     them through the device path, and the single exchange gives rank 0 the merged VCF of the one-rank run, byte for byte."""
@@ -168,7 +169,7 @@ def test_two_ranks_from_an_indexed_bam_equal_one_rank(checkpoint, tmp_path):
     one = cli.run(cli.parse_arguments(["-o", str(tmp_path / "one")] + args))
     env = dict(os.environ, PYTHONPATH=root, SVX_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT="29641")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29641", os.path.join(root, "SVision"), "-o", str(tmp_path / "two")] + args
+           "--master-port", "29641", os.path.join(root, "SVision"), "-o", str(tmp_path / "two"), "-t", threads] + args
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     two = os.path.join(str(tmp_path / "two"), os.path.basename(one))
