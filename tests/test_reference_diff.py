@@ -2,7 +2,7 @@
 samples and option sets through the reference's run_detect / Predict.run / merge_split_vcfs (imported with stand-ins for
 pysam, cv2, tensorflow: tests/golden/refdriver.py) and through the product's host code, outputs compared byte for byte.
 Run in subprocesses: the stand-in modules must not leak into the other tests.  tools/diff_ref*.py take a seed range for
-longer runs (200 collection cases / 80,000 TSV lines and 80 prediction cases were compared that way in round 1)."""
+longer runs (580 collection cases / 230,000 TSV lines and 230 prediction cases were compared that way in round 1)."""
 import os
 import subprocess
 import sys
