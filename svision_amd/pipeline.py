@@ -16,6 +16,7 @@ process that owns the GPU.  The device stage replays a captured HIP graph per ba
 """
 import collections
 import io
+import os
 import multiprocessing as mp
 import multiprocessing.connection as mpc
 
@@ -203,7 +204,7 @@ def _worker_main(conn):
     """Helper process: never touches the GPU.  Protocol on the duplex pipe:
        owner -> ("win", wid, chrom, start, end)   helper -> ("rec", wid, records int32[n,12])
        owner -> ("pred", wid, classes, probs)      helper -> ("done", wid, vcf, scores, n_sites, n_images, tsv)
-       owner -> ("scan", min_sv, gaps, gap_off, stats)   (HelperPool.attach_scan: helpers forked before the scan)
+       owner -> ("scan", min_sv, gaps.npy, gap_off.npy, stats.npy)   (HelperPool.attach_scan: helpers forked before the scan)
        owner -> ("stop",)"""
     sample, options = _POOL_STATE["sample"], _POOL_STATE["options"]
     held = {}
@@ -214,6 +215,7 @@ def _worker_main(conn):
         if msg[0] == "scan":                                  # forked before the device scan existed: build the Sample now
             from .sample import Sample
             _t, min_sv, gaps, gap_off, stats = msg
+            gaps, gap_off, stats = (np.load(p, mmap_mode="r") for p in (gaps, gap_off, stats))
             sample = Sample.with_scan(_POOL_STATE["table"], _POOL_STATE["fasta"], min_sv, (gaps, gap_off, stats))
             continue
         if msg[0] == "win":
@@ -251,8 +253,18 @@ class HelperPool:
         _POOL_STATE.clear()
 
     def attach_scan(self, sample):
+        """Hand the device scan's result to the helpers through one set of files in shared memory (mapped read-only by
+        every helper) rather than through N pipes."""
+        import tempfile
+        shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+        self._scan_dir = tempfile.mkdtemp(prefix="svx_scan_", dir=shm)
+        paths = []
+        for name, arr in (("gaps", sample.gaps), ("gap_off", sample.gap_off), ("stats", sample.stats)):
+            path = os.path.join(self._scan_dir, name + ".npy")
+            np.save(path, np.ascontiguousarray(arr))
+            paths.append(path)
         for c in self.conns:
-            c.send(("scan", sample.min_sv, sample.gaps, sample.gap_off, sample.stats))
+            c.send(("scan", sample.min_sv, *paths))
 
     def close(self):
         for c in self.conns:
@@ -263,6 +275,10 @@ class HelperPool:
         for p in self.procs:
             p.join(timeout=5)
         self.conns, self.procs = [], []
+        if getattr(self, "_scan_dir", None):
+            import shutil
+            shutil.rmtree(self._scan_dir, ignore_errors=True)
+            self._scan_dir = None
 
 
 class PooledHotPath(HotPath):
