@@ -12,6 +12,7 @@ Follows the SAM/BAM specification (SAMv1 section 4): BGZF blocks are gzip member
 ``BC`` extra field; BAM records are little-endian.  CIGARs longer than 65535
 ops (``CG:B,I`` tag) are handled by the native decoder and the writer.
 """
+import os
 import struct
 import zlib
 
@@ -454,33 +455,80 @@ def pack_sequence(seq):
     return ((codes[0::2] << 4) | codes[1::2]).astype(np.uint8).tobytes()
 
 
+class _LazySequences(dict):
+    """name -> bases; a contig of a FASTA file is read (one slice of the memory map, newlines dropped at C speed) the
+    first time it is asked for."""
+
+    def __init__(self, loader):
+        super().__init__()
+        self._loader = loader
+
+    def __missing__(self, name):
+        seq = self._loader(name)
+        self[name] = seq
+        return seq
+
+
 class Fasta:
-    """In-memory FASTA with pysam.FastaFile's ``references`` / ``fetch`` / ``get_reference_length``."""
+    """FASTA with pysam.FastaFile's ``references`` / ``fetch`` / ``get_reference_length``.  A file is memory mapped and
+    indexed by its header lines (or its ``.fai``); contigs are materialised on first use, so a rank that works on three
+    chromosomes does not parse the other twenty-one."""
 
     def __init__(self, path=None, sequences=None):
         self.references = []
         self._seq = {}
+        self._length = {}
         if sequences is not None:
             for name, seq in sequences.items():
                 self.references.append(name)
                 self._seq[name] = seq if isinstance(seq, (bytes, bytearray)) else str(seq).encode()
         elif path is not None:
-            name, chunks = None, []
-            with open(path, "rb") as f:
+            self._open(path)
+
+    def _open(self, path):
+        import mmap
+        self._ranges = {}
+        size = os.path.getsize(path)
+        if size == 0:
+            return
+        self._file = open(path, "rb")
+        self._map = mmap.mmap(self._file.fileno(), 0, access=mmap.ACCESS_READ)
+        mm = self._map
+        fai = path + ".fai"
+        if os.path.exists(fai) and os.path.getmtime(fai) >= os.path.getmtime(path):
+            with open(fai) as f:                       # name, length, offset, bases per line, bytes per line (faidx)
                 for line in f:
-                    if line.startswith(b">"):
-                        if name is not None:
-                            self._seq[name] = b"".join(chunks)
-                        name = line[1:].split()[0].decode()
-                        self.references.append(name)
-                        chunks = []
-                    else:
-                        chunks.append(line.strip())
-            if name is not None:
-                self._seq[name] = b"".join(chunks)
+                    p = line.rstrip("\n").split("\t")
+                    if len(p) < 5:
+                        continue
+                    name, length, offset, linebases, linewidth = p[0], int(p[1]), int(p[2]), int(p[3]), int(p[4])
+                    n_lines = (length + linebases - 1) // linebases if linebases else 0
+                    end = min(size, offset + length + n_lines * max(linewidth - linebases, 0))
+                    self.references.append(name)
+                    self._ranges[name] = (offset, end)
+                    self._length[name] = length
+        else:
+            pos = 0 if mm[:1] == b">" else mm.find(b"\n>") + 1
+            while 0 <= pos < size and mm[pos:pos + 1] == b">":
+                eol = mm.find(b"\n", pos)
+                eol = size if eol < 0 else eol
+                name = mm[pos + 1:eol].split()[0].decode() if eol > pos + 1 else ""
+                nxt = mm.find(b"\n>", eol)
+                end = size if nxt < 0 else nxt + 1
+                self.references.append(name)
+                self._ranges[name] = (min(eol + 1, size), end)
+                pos = end
+        self._seq = _LazySequences(lambda name: self._map[self._ranges[name][0]:self._ranges[name][1]].translate(None, b"\r\n \t"))
 
     def get_reference_length(self, name):
-        return len(self._seq[name])
+        if name not in self._length:
+            if name in self._seq or not hasattr(self, "_ranges"):
+                self._length[name] = len(self._seq[name])
+            else:                                       # count the bases without keeping them
+                lo, hi = self._ranges[name]
+                raw = self._map[lo:hi]
+                self._length[name] = len(raw) - raw.count(b"\n") - raw.count(b"\r") - raw.count(b" ") - raw.count(b"\t")
+        return self._length[name]
 
     def fetch(self, name, start, end):
         """0-based half-open; clipped to the contig like htslib faidx."""

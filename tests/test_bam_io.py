@@ -200,3 +200,28 @@ def test_native_decoder_rejects_damaged_files(tmp_path):
     lib = _lib.load()
     h = lib.svx_bam_open_range(good.encode(), 1, 0, spans[0][0] + 7, spans[0][1])      # starts in the middle of a record
     assert not h and lib.svx_bam_error()
+
+
+def test_fasta_file_is_indexed_and_read_lazily(tmp_path):
+    """With and without a .fai: reference order, lengths, fetch semantics (clipping, case kept), empty contigs; only the
+    contigs that are asked for are materialised."""
+    rng = np.random.default_rng(0)
+    genome = {"chr%d" % i: bytes(rng.choice(list(b"ACGTacgtN"), size=int(rng.integers(1, 5000))).astype(np.uint8)) for i in range(5)}
+    genome["empty"] = b""
+    genome["last"] = b"ACGT" * 15
+    path = str(tmp_path / "g.fa")
+    bam.write_fasta(path, genome, width=60)
+    for use_fai in (True, False):
+        if not use_fai:
+            os.remove(path + ".fai")
+        f = bam.Fasta(path)
+        assert f.references == list(genome)
+        assert [f.get_reference_length(n) for n in genome] == [len(genome[n]) for n in genome]
+        assert len(f._seq) == 0                                    # nothing parsed yet
+        assert f.fetch("chr2", 3, 17) == genome["chr2"][3:17].decode()
+        assert list(f._seq) == ["chr2"]
+        assert f.fetch_bytes("chr1", -5, 10 ** 9) == genome["chr1"] and f.fetch("empty", 0, 10) == ""
+    with open(str(tmp_path / "crlf.fa"), "wb") as out:              # Windows line ends, description after the name
+        out.write(b">a some text\r\nACGT\r\nAC\r\n>b\r\nTTTT\r\n")
+    f = bam.Fasta(str(tmp_path / "crlf.fa"))
+    assert f.references == ["a", "b"] and f.fetch("a", 0, 99) == "ACGTAC" and f.get_reference_length("b") == 4
