@@ -104,6 +104,20 @@ def build_tasks(options, references, lengths, fasta_refs):
     return tasks
 
 
+class _Ticker:
+    """SVX_TIMING=1: wall time of the phases of a run on stdout."""
+
+    def __init__(self):
+        import time
+        self.clock, self.last, self.on = time.time, time.time(), bool(os.environ.get("SVX_TIMING"))
+
+    def __call__(self, what):
+        now = self.clock()
+        if self.on:
+            print("%-36s %.3f s" % (what, now - self.last), flush=True)
+        self.last = now
+
+
 def load_rank_table(options, rank, ws):
     """The alignment records rank ``rank`` of ``ws`` needs.  With a ``.bai`` next to the BAM and more than one rank, a
     rank is a set of chromosomes: the header gives the task list, the index gives the byte range holding this rank's
@@ -146,8 +160,10 @@ def run(options, sample=None, classifier=None):
     logging.info("INPUT BAM: %s", os.path.abspath(options.bam_path))
 
     pool = None
+    _tick = _Ticker()
     if sample is None:
         table = load_rank_table(options, rank, ws)
+        _tick("decode BAM")
         if table.sort_order != "coordinate":
             logging.error("This is not a coordinate sorted BAM file")
             raise SystemExit(1)
@@ -158,9 +174,11 @@ def run(options, sample=None, classifier=None):
             # -t N: fork the host helpers before the first HIP call (pipeline.HelperPool); they get the scan below
             from .pipeline import HelperPool
             pool = HelperPool(options.thread_num, options, table=table, fasta=fasta, want_tsv=True)
+        _tick("open FASTA, fork helpers")
         sample = _sample.Sample.from_table(table, fasta, options.min_sv_size)
         if pool is not None:
             pool.attach_scan(sample)
+        _tick("upload + device scan")
     elif options.contig:
         options.min_support = 1
     _sample.register(options.bam_path, sample)
@@ -212,6 +230,7 @@ def run(options, sample=None, classifier=None):
         t2 = datetime.datetime.now()
         logging.info("[Prediction finished]: Predicting types, Cost time: %s", (t2 - t1).seconds)
 
+    _tick("collection + encode + CNN + vote")
     # ---- the single cross-shard exchange: score range + record gather ----
     sdist.init_from_env()
     local_scores = cal_scores_max_min(pred_dir) if ws == 1 else _scores_of(pred_dir, mine, options)
@@ -234,6 +253,7 @@ def run(options, sample=None, classifier=None):
         options.source_version = REFERENCE_VERSION
         merge_split_vcfs(pred_dir, merged_path, max_score, min_score, chroms, options, fasta=fasta)
         logging.info("[All steps finished] Total Cost time: %ss", (datetime.datetime.now() - t0).seconds)
+    _tick("exchange + merge")
     if ws > 1:
         import torch.distributed as tdist
         tdist.barrier()

@@ -99,6 +99,31 @@ const uint8_t* find_long_cigar(const uint8_t* aux, const uint8_t* end, uint32_t*
     return nullptr;
 }
 
+// The inflated stream of the chunk in hand: grown without zero filling (a vector's resize would memset gigabytes that
+// inflate overwrites right away) and reused from chunk to chunk.
+struct RawBuf {
+    std::unique_ptr<uint8_t[]> p;
+    size_t n = 0, cap = 0;
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    const uint8_t& operator[](size_t i) const { return p[i]; }
+    uint8_t* data() { return p.get(); }
+    const uint8_t* data() const { return p.get(); }
+    void resize(size_t want)
+    {
+        if (want > cap) {
+            const size_t grown = std::max(want, cap + cap / 2);
+            std::unique_ptr<uint8_t[]> q(new uint8_t[grown]);
+            if (n) memcpy(q.get(), p.get(), n);
+            p = std::move(q);
+            cap = grown;
+        }
+        n = want;
+    }
+    void drop_front(size_t k) { if (k) { memmove(p.get(), p.get() + k, n - k); n -= k; } }
+    void clear() { n = 0; }
+};
+
 template <class F>
 void parallel_for(size_t n, int threads, F fn)
 {
@@ -117,6 +142,7 @@ void parallel_for(size_t n, int threads, F fn)
 class BgzfStream {
 public:
     size_t chunk;                                        // compressed bytes read per step
+    static constexpr uint64_t MAX_INFLATED = 96ull << 20; // inflated bytes per step (keeps the stream buffer cache sized)
 
     BgzfStream(FILE* f, uint64_t pos, uint64_t end, int threads, size_t first_chunk)
         : chunk(first_chunk), f_(f), pos_(pos), end_(end), threads_(threads)
@@ -130,12 +156,13 @@ public:
     const std::string& error() const { return err_; }
 
     // false on error (error() says why); appends nothing when done()
-    bool next(std::vector<uint8_t>& out)
+    bool next(RawBuf& out)
     {
         blocks_.clear();
         if (done()) return true;
         const size_t have = carry_.size();
-        const uint64_t want = std::min<uint64_t>(chunk, end_ - pos_);
+        // (no new read while the carry still holds whole blocks the inflated-size cap left over: highly compressible input)
+        const uint64_t want = capped_ ? 0 : std::min<uint64_t>(chunk, end_ - pos_);
         cbuf_.resize(have + want);
         if (have) memcpy(cbuf_.data(), carry_.data(), have);
         const size_t got = want ? fread(cbuf_.data() + have, 1, want, f_) : 0;
@@ -167,8 +194,11 @@ public:
             blocks_.push_back({base + p, total, isize});
             total += isize;
             p = end;
+            if (total - out.size() >= MAX_INFLATED) break;  // highly compressible input: the rest waits in the carry
         }
-        if (eof_ && p != cbuf_.size()) {
+        const bool capped = total - out.size() >= MAX_INFLATED && p != cbuf_.size();
+        capped_ = capped;
+        if (eof_ && p != cbuf_.size() && !capped) {
             if (end_ == ~0ull) { err_ = "truncated BGZF file"; return false; }
             // a byte range cut in the middle of its last block: callers ask for one block more than they need
         }
@@ -182,7 +212,7 @@ public:
                 if (inflateInit2(&zs, -15) != Z_OK) { ok = false; return; }
                 zs.next_in = const_cast<Bytef*>(&cbuf_[src[i].data]);
                 zs.avail_in = (uInt)src[i].csize;
-                zs.next_out = &out[blocks_[i].dst];
+                zs.next_out = out.data() + blocks_[i].dst;
                 zs.avail_out = blocks_[i].isize;
                 const int rc = inflate(&zs, Z_FINISH);
                 inflateEnd(&zs);
@@ -191,7 +221,7 @@ public:
         });
         if (!ok) { err_ = "BGZF inflate failed"; return false; }
         carry_.assign(cbuf_.begin() + p, cbuf_.end());
-        if (eof_) carry_.clear();
+        if (eof_ && !capped) carry_.clear();
         return true;
     }
 
@@ -199,14 +229,14 @@ private:
     FILE* f_;
     uint64_t pos_, end_;
     int threads_;
-    bool eof_ = false;
+    bool eof_ = false, capped_ = false;
     std::vector<uint8_t> cbuf_, carry_;
     std::vector<Block> blocks_;
     std::string err_;
 };
 
 // Header (magic, text, reference dictionary) at the start of `buf`: 0 = needs more bytes, -1 = not BAM, else its size.
-long long parse_header(const std::vector<uint8_t>& buf, Bam* b)
+long long parse_header(const RawBuf& buf, Bam* b)
 {
     if (buf.size() < 12) return 0;
     if (memcmp(buf.data(), "BAM\1", 4) != 0) return -1;
@@ -233,7 +263,7 @@ long long parse_header(const std::vector<uint8_t>& buf, Bam* b)
 
 // Appends the whole records of buf[from, limit) to the arrays; returns the offset of the first byte not consumed
 // (a partial record at the end stays for the next chunk), or -1 on a malformed record.
-long long parse_records(const std::vector<uint8_t>& buf, uint64_t from, uint64_t limit, int threads, bool keep_seq, Bam* b)
+long long parse_records(const RawBuf& buf, uint64_t from, uint64_t limit, int threads, bool keep_seq, Bam* b)
 {
     struct Rec { uint64_t at; const uint8_t* cig; uint32_t n_cig; };
     std::vector<Rec> recs;
@@ -314,7 +344,7 @@ void* bam_open_impl(const char* path, int threads, int flags, bool ranged, uint6
     FILE* f = fopen(path, "rb");
     if (!f) { g_bam_error = std::string("cannot open ") + path; return nullptr; }
     std::unique_ptr<Bam> b(new Bam());
-    std::vector<uint8_t> buf;
+    RawBuf buf;
     auto fail = [&](const std::string& why) -> void* { g_bam_error = why; fclose(f); return nullptr; };
 
     // header: from the start of the file, chunk by chunk until the reference dictionary is complete
@@ -337,7 +367,7 @@ void* bam_open_impl(const char* path, int threads, int flags, bool ranged, uint6
         for (;;) {
             const long long used = parse_records(buf, cur, buf.size(), threads, keep_seq, b.get());
             if (used < 0) return fail("malformed BAM record");
-            buf.erase(buf.begin(), buf.begin() + used);        // keeps a partial record for the next chunk
+            buf.drop_front((size_t)used);                       // keeps a partial record for the next chunk
             cur = 0;
             if (head.done()) break;
             if (!head.next(buf)) return fail(head.error());
@@ -365,7 +395,7 @@ void* bam_open_impl(const char* path, int threads, int flags, bool ranged, uint6
             const long long used = parse_records(buf, cur, stop, threads, keep_seq, b.get());
             if (used < 0) return fail("malformed BAM record");
             if (reached) { if ((uint64_t)used != stop) return fail("BAM index does not match the file"); break; }
-            buf.erase(buf.begin(), buf.begin() + used);
+            buf.drop_front((size_t)used);
             cur = 0;
         }
         if (!reached) return fail("BAM index does not match the file");

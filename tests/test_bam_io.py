@@ -225,3 +225,17 @@ def test_fasta_file_is_indexed_and_read_lazily(tmp_path):
         out.write(b">a some text\r\nACGT\r\nAC\r\n>b\r\nTTTT\r\n")
     f = bam.Fasta(str(tmp_path / "crlf.fa"))
     assert f.references == ["a", "b"] and f.fetch("a", 0, 99) == "ACGTAC" and f.get_reference_length("b") == 4
+
+
+def test_highly_compressible_file_goes_through_the_inflated_size_cap(tmp_path):
+    """SEQ of N's and 0xFF qualities inflate ~50x: the decoder limits the inflated bytes per step and keeps the
+    left-over compressed blocks for the next one."""
+    cfg = synth.SimConfig(contigs=[("c1", 3_000_000)], coverage=30, seed=9)
+    table, _g, _ = synth.simulate(cfg, with_genome=False)
+    path = str(tmp_path / "n.bam")
+    bam.write_bam(path, table)                                   # ~140 MB inflated, a few MB on disk
+    assert os.path.getsize(path) < 20_000_000
+    got = bam.read_bam(path)
+    for f in ("tid", "pos", "flag", "mapq", "l_seq", "name_id", "cigar", "cig_off"):
+        assert np.array_equal(getattr(got, f), getattr(table, f)), f
+    assert got.names == table.names and got.references == table.references
