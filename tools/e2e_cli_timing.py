@@ -27,6 +27,6 @@ for nt in threads:                                   # a fresh process per run: 
             % (root, out, os.path.join(d, "s.bam"), os.path.join(d, "m.ckpt"), os.path.join(d, "g.fa"), nt))
     t = time.time()
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, SVX_TIMING="1"))
-    print("-t %d: %s (process wall %.2f s)" % (nt, " | ".join(l for l in r.stdout.strip().splitlines() if "window " not in l and "helper" not in l and "owner" not in l) or r.stderr[-500:], time.time() - t), flush=True)
+    print("-t %d: %s (process wall %.2f s)" % (nt, " | ".join(l for l in r.stdout.strip().splitlines() if "window " not in l and "owner: " not in l and "  helper " not in l) or r.stderr[-500:], time.time() - t), flush=True)
     for line in open([os.path.join(out, f) for f in os.listdir(out) if f.endswith(".log")][0]):
         if "Cost time" in line: print("   ", line.rstrip())
