@@ -125,9 +125,13 @@ def test_cli_hash_mode_on_device(checkpoint, tmp_path):
     assert open(os.path.join(out, "segments", "chrH.segments.all.bed")).read() == want["tsv"]
 
 
-def test_streaming_cli_equals_file_based_cli(checkpoint, tmp_path):
+@pytest.mark.parametrize("extra", [[], ["--contig"], ["-c", "chrA"], ["-c", "chrB:1000-120000"], ["--qname", "--min_mapq", "30"],
+                                   ["--max_sv_size", "3000", "--min_sv_size", "80", "-s", "2"]],
+                         ids=["default", "contig", "one-chromosome", "region", "qname-mapq", "size-limits"])
+def test_streaming_cli_equals_file_based_cli(checkpoint, tmp_path, extra):
     """The device CLI (windows streamed, no TSV round trip) writes the same segment files, per-chromosome VCF bodies,
-    scores and merged VCF as the file-based flow (run_detect -> cat -> Predict.run) with the same network."""
+    scores and merged VCF as the file-based flow (run_detect -> cat -> Predict.run) with the same network, for several
+    option sets of the command line."""
     from svision_amd.io import bam
     from svision_amd.network.predict import load_classifier
     prefix, _params = checkpoint
@@ -138,7 +142,7 @@ def test_streaming_cli_equals_file_based_cli(checkpoint, tmp_path):
     for kind in ("stream", "files"):
         out = str(tmp_path / kind)
         opts = cli.parse_arguments(["-o", out, "-b", os.path.join(helpers.GOLDEN, "collect_small.bam"), "-m", prefix, "-g", fa,
-                                    "-n", "HGtest", "-s", "3", "--window_size", "150000", "--batch_size", "64", "--debug"])
+                                    "-n", "HGtest", "-s", "3", "--window_size", "150000", "--batch_size", "64", "--debug"] + extra)
         merged = cli.run(opts, classifier=None if kind == "stream" else load_classifier(prefix, device="cuda:0"))
         files = {"merged": open(merged).read()}
         for sub in ("segments", "predict_results"):
