@@ -235,7 +235,7 @@ def _worker_main(conn):
 class HelperPool:
     """Forked host helpers.  Forking a process that owns a live GPU context is expensive on this stack (the driver
     evicts and restores the parent's queues around the copy-on-write protection of its pinned ranges: the first device
-    work after 16 forks stalled for 3.5 s), so a command-line run creates the pool *before* the first HIP call, with the
+    work after 16 forks stalled for 3.5 s, and for over a minute in a long-lived process holding gigabytes of device allocations), so a command-line run creates the pool *before* the first HIP call, with the
     decoded table and the reference only, and sends the device scan's result afterwards (``attach_scan``).  Given a
     complete ``sample`` the helpers are usable at once (bench: the fork cost falls into the warm-up)."""
 

@@ -15,6 +15,17 @@ from tests import helpers
 from tests.test_cli_e2e import ChromInjected, _case, make_options
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_cli_fresh(args, timeout=600):
+    """The command line in a fresh process (``-t N`` forks its helpers before the first HIP call there; forking from this
+    long-lived test process, which owns a GPU context and gigabytes of device allocations, can stall for a minute)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "SVision")] + list(args), capture_output=True, text=True, timeout=timeout,
+                       env=dict(os.environ, PYTHONPATH=ROOT))
+    return r
 
 
 def test_cli_with_device_scan_reproduces_reference_vcf(tmp_path):
@@ -192,7 +203,9 @@ def test_cli_with_helper_processes_equals_one_process(checkpoint, tmp_path):
     args = ["-b", os.path.join(helpers.GOLDEN, "collect_small.bam"), "-m", prefix, "-g", fa, "-n", "HGtest", "-s", "3",
             "--window_size", "60000", "--batch_size", "64", "--debug"]
     one = cli.run(cli.parse_arguments(["-o", str(tmp_path / "one")] + args))
-    four = cli.run(cli.parse_arguments(["-o", str(tmp_path / "four"), "-t", "4"] + args))
+    r = run_cli_fresh(["-o", str(tmp_path / "four"), "-t", "4"] + args)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    four = os.path.join(str(tmp_path / "four"), os.path.basename(one))
     assert open(four).read() == open(one).read() and open(one).read().count("\n") > 20
     for sub in ("segments", "predict_results"):
         names = sorted(os.listdir(str(tmp_path / "one" / sub)))
@@ -228,3 +241,21 @@ def test_device_scan_equals_oracle_scan_on_simulated_samples(seed):
         ta = "".join(p.text() for p in collect_pair_lines(a, opts))
         tb = "".join(p.text() for p in collect_pair_lines(b, opts))
         assert ta == tb and ta.count("\n") > 10
+
+
+def test_hash_mode_with_helper_processes(checkpoint, tmp_path):
+    """--hash (read bases resident, k-mer re-aligner in the collection step) with -t 3: the helpers' segment TSV is the
+    reference's, as in the one-process run."""
+    import json
+    from svision_amd.io import bam
+    prefix, _params = checkpoint
+    fasta = helpers.load_golden_fasta("hash_collect.fa.gz")
+    fa = str(tmp_path / "genome.fa")
+    bam.write_fasta(fa, {n: fasta._seq[n] for n in fasta.references})
+    out = str(tmp_path / "out")
+    r = run_cli_fresh(["-o", out, "-b", os.path.join(helpers.GOLDEN, "hash_collect.bam"), "-m", prefix, "-g", fa,
+                       "-n", "HGhash", "-s", "3", "--hash", "--batch_size", "64", "--debug", "-t", "3"])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]     # ("Empty output" exits with 0, as upstream)
+    with open(os.path.join(helpers.GOLDEN, "hash_collect.expected.json")) as f:
+        want = [w for w in json.load(f)["windows"] if w["hash"]][0]
+    assert open(os.path.join(out, "segments", "chrH.segments.all.bed")).read() == want["tsv"]
