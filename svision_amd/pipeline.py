@@ -202,7 +202,7 @@ _POOL_STATE = {}
 
 def _worker_main(conn):
     """Helper process: never touches the GPU.  Protocol on the duplex pipe:
-       owner -> ("win", wid, chrom, start, end)   helper -> ("rec", wid, records int32[n,12])
+       owner -> ("win", wid, chrom, start, end, scan of the window's rows or None)   helper -> ("rec", wid, records int32[n,12])
        owner -> ("pred", wid, classes, probs)      helper -> ("done", wid, vcf, scores, n_sites, n_images, tsv)
        owner -> ("scan", min_sv, gaps.npy, gap_off.npy, stats.npy)   (HelperPool.attach_scan: helpers forked before the scan)
        owner -> ("stop",)"""
@@ -215,11 +215,13 @@ def _worker_main(conn):
         if msg[0] == "scan":                                  # forked before the device scan existed: build the Sample now
             from .sample import Sample
             _t, min_sv, gaps, gap_off, stats = msg
-            gaps, gap_off, stats = (np.load(p, mmap_mode="r") for p in (gaps, gap_off, stats))
+            gaps, gap_off, stats = (np.load(p, mmap_mode="c") for p in (gaps, gap_off, stats))     # copy-on-write: windows' rescans land here
             sample = Sample.with_scan(_POOL_STATE["table"], _POOL_STATE["fasta"], min_sv, (gaps, gap_off, stats))
             continue
         if msg[0] == "win":
-            _t, wid, chrom, start, end = msg
+            _t, wid, chrom, start, end, scan = msg
+            if scan is not None:
+                sample.apply_window_scan(*scan)
             lines = _collect_lines(sample, options, chrom, start, end)
             held[wid] = (chrom, lines)
             recs = np.asarray([ln.record() for ln in lines], np.int32).reshape(-1, 12)
@@ -308,9 +310,10 @@ class PooledHotPath(HotPath):
             while idle and nxt < len(windows):
                 ci = idle.pop()
                 chrom, start, end = windows[nxt]
-                if rescan:
-                    self.sample.rescan_window(chrom, start, end)      # device scan of the window's block
-                self.conns[ci].send(("win", nxt, chrom, start, end))
+                scan = None
+                if rescan:                                            # device scan of the window's block: the helper collects on ITS result
+                    scan = self.sample.last_window_scan if self.sample.rescan_window(chrom, start, end) else None
+                self.conns[ci].send(("win", nxt, chrom, start, end, scan))
                 busy[ci] = nxt
                 nxt += 1
             while ready and len(inflight) < self.max_inflight:

@@ -21,6 +21,7 @@ class Sample:
         self.gap_off = np.asarray(gap_off).astype(np.int64)
         self.min_sv = min_sv
         self.device_buffers = device_buffers
+        self.last_window_scan = None
         self.stats = np.asarray(stats)
         table.attach_scan(self.stats)
 
@@ -72,9 +73,16 @@ class Sample:
             raise RuntimeError("window rescan disagrees with the resident scan")
         gaps = gaps.copy()
         gaps["aln"] += lo
+        self.apply_window_scan(lo, hi, gaps, stats)
+        self.last_window_scan = (lo, hi, gaps, stats)           # what a helper process needs to follow (apply_window_scan)
+        return hi - lo
+
+    def apply_window_scan(self, lo, hi, gaps, stats):
+        """Install the scan of the rows [lo, hi) (gaps with absolute alignment indices, stats [hi-lo, 4])."""
+        table = self.table
         self.gaps[self.gap_off[lo]:self.gap_off[hi]] = gaps
         table.ref_span[lo:hi], table.lead_clip[lo:hi], table.trail_clip[lo:hi] = stats[:, 0], stats[:, 1], stats[:, 2]
-        return hi - lo
+        table._ref_end = None
 
     # -- accessors used by the collection step ----------------------------------------
     def gaps_of(self, aln):
