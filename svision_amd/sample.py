@@ -81,8 +81,10 @@ class Sample:
         """Install the scan of the rows [lo, hi) (gaps with absolute alignment indices, stats [hi-lo, 4])."""
         table = self.table
         self.gaps[self.gap_off[lo]:self.gap_off[hi]] = gaps
+        changed = not np.array_equal(table.ref_span[lo:hi], stats[:, 0])
         table.ref_span[lo:hi], table.lead_clip[lo:hi], table.trail_clip[lo:hi] = stats[:, 0], stats[:, 1], stats[:, 2]
-        table._ref_end = None
+        if changed:
+            table._ref_end = None                               # reference ends (and their sorted copies) are derived from ref_span
 
     # -- accessors used by the collection step ----------------------------------------
     def gaps_of(self, aln):
