@@ -239,3 +239,36 @@ def test_highly_compressible_file_goes_through_the_inflated_size_cap(tmp_path):
     for f in ("tid", "pos", "flag", "mapq", "l_seq", "name_id", "cigar", "cig_off"):
         assert np.array_equal(getattr(got, f), getattr(table, f)), f
     assert got.names == table.names and got.references == table.references
+
+
+def test_unmapped_and_secondary_records(tmp_path, oracle_lib):
+    """A coordinate-sorted file ends with its unmapped reads (tid -1, no CIGAR); secondary records are skipped by the
+    collection step (collect_signatures.py:131-139).  Decoders agree, the ranged decode leaves the tail out, windows run."""
+    from svision_amd.collection.output_clusters import collect_pair_lines
+    from svision_amd.collection.run_collection import detect_window
+    from svision_amd.sample import Sample
+    cfg = synth.SimConfig(contigs=[("c1", 200_000), ("c2", 100_000)], coverage=10, read_len_mean=5000, read_len_sd=800,
+                          sv_spacing=6000, sv_min_gap=4000, sv_max=2000, seed=3)
+    t, genome, _ = synth.simulate(cfg)
+    extra = 5
+    flag = np.concatenate([t.flag, np.full(extra, 4, np.uint16)])
+    flag[[10, 20, 30]] |= 0x100
+    t2 = bam.AlignmentTable(t.references, t.lengths, np.concatenate([t.tid, np.full(extra, -1, np.int32)]),
+                            np.concatenate([t.pos, np.full(extra, -1, np.int32)]), flag, np.concatenate([t.mapq, np.zeros(extra, np.uint8)]),
+                            np.concatenate([t.l_seq, np.full(extra, 100, np.int32)]),
+                            np.concatenate([t.name_id, np.arange(len(t.names), len(t.names) + extra, dtype=np.int32)]),
+                            list(t.names) + ["unmapped%d" % i for i in range(extra)], t.cigar,
+                            np.concatenate([t.cig_off, np.full(extra, t.cig_off[-1], np.int64)]), "")
+    path = str(tmp_path / "u.bam")
+    bam.write_bam(path, t2, index=True)
+    a, b = bam.read_bam(path), bam.read_bam_python(path)
+    _same(a, b)
+    assert len(a) == len(t) + extra and (a.tid[-extra:] == -1).all()
+    part = bam.read_bam(path, tids=[1])
+    assert (part.tid == 1).all() and len(part) == int((t.tid == 1).sum())
+    fasta = bam.Fasta(sequences=genome)
+    opts = helpers.default_options(min_support=2)
+    from oracle import cbind
+    scan = cbind.cigar_scan(a.cigar, a.cig_off.astype(np.uint64), a.pos, 50)
+    lines = collect_pair_lines(detect_window(opts, Sample.with_scan(a, fasta, 50, scan), "c1", 0, 200_000)[1], opts)
+    assert len(lines) > 10
