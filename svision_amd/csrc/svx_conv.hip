@@ -29,6 +29,9 @@ namespace {
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int BN = 64, THREADS = 256;
+#ifndef SVX_CONV_DENSE_PCT
+#define SVX_CONV_DENSE_PCT 97             // a pixel list this full (percent) is not worth following: every pixel is computed
+#endif
 #ifndef SVX_CONV_BM64_BELOW
 #define SVX_CONV_BM64_BELOW 448          // 64 x 128 tiles below this many of them: use 64 x 64
 #endif
@@ -55,7 +58,7 @@ void conv_igemm_tile(const float* __restrict__ in, const float* __restrict__ w, 
     // (97 %) everything is computed; below that the list still pays (measured with 81 % and 91 % active).
     const long long Mall = (long long)nimg * HW;
     long long Mtot = Mall;
-    if (pixels) { const long long a = (long long)*pixel_count; if (a * 100 < Mall * 97) Mtot = a; }
+    if (pixels) { const long long a = (long long)*pixel_count; if (a * 100 < Mall * SVX_CONV_DENSE_PCT) Mtot = a; }
     // XCD-aware tile order (workgroup b runs on XCD b % 8, each XCD has its own 4 MB L2): the (pixel tile,
     // channel tile) pairs, channel tile fastest, are cut into 8 equal contiguous runs, one per XCD, so the
     // activation slice of a pixel tile is fetched into one L2 once and re-used by all its (group, n-tile)
@@ -242,7 +245,7 @@ void conv_igemm_list_kernel(const float* __restrict__ in, const float* __restric
     __shared__ float lds[lds_floats(BK, 128)];
     const long long Mall = (long long)nimg * H * W;
     long long Mtot = (long long)*pixel_count;
-    if (Mtot * 100 >= Mall * 97) Mtot = Mall;
+    if (Mtot * 100 >= Mall * SVX_CONV_DENSE_PCT) Mtot = Mall;
     const long long tiles128 = ((Mtot + 127) / 128) * groups * ((Cout / groups) / BN);
     if (tiles128 < SVX_CONV_BM64_BELOW)
         conv_igemm_tile<KS, BK, 64>(in, w, bias, out, nimg, Cin, Cout, H, W, groups, relu, pixels, pixel_count, background, lds);
