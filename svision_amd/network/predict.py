@@ -107,6 +107,10 @@ class SiteVoter:
 
     def feed_batch(self, labels, classes, probs):
         site = self.site
+        classes = np.asarray(classes)
+        probs = np.asarray(probs)
+        # round(probs[i][cls], 2) of predict.py:270 for the whole batch at once (np.float32.__round__ is np.round)
+        scores = np.round(probs[np.arange(len(labels)), classes[:len(labels)].astype(np.int64)], 2) if len(labels) else probs[:0, 0]
         for i, label in enumerate(labels):
             if "complement" in label:
                 continue
@@ -122,7 +126,7 @@ class SiteVoter:
             rid = read_num.replace("m", "")
             site.read_names[rid] = read_name
             site.sig_types.append(f[3])
-            site.predict_scores.append(round(probs[i][cls], 2))
+            site.predict_scores.append(scores[i])
             site.sig_scores[rid] = f[6]
             site.mechanisms[rid] = f[8]
             if "m" not in read_num and cls in (0, 1):                 # :278-280 only main x main pairs call INS/DEL
