@@ -12,7 +12,11 @@ thickness 1 / LINE_8 / shift 0 on a single-channel image, i.e. OpenCV's
 OpenCV is not vendored by the reference and is not installed in this image:
 the line arithmetic is restated from the published algorithm and is therefore
 **parity unpinned** (no reference test or fixture pins it).  Everything above
-``cv2.line`` is pinned by running the reference itself (tests/golden/).
+``cv2.line`` -- segment rebuilding, ratio / truncation, argument order, channel 1's column
+rule, mean subtraction, padding -- is pinned by the reference itself:
+tests/golden/make_image_fixture.py runs its ``BatchGenerator.next_batch`` on 1347 TSV lines
+(golden + hostile) and tests/test_image_golden.py compares this file, the C oracle and the HIP
+rasteriser with the stored images bit for bit.
 """
 import numpy as np
 
