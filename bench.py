@@ -259,8 +259,8 @@ def kernel_calibration(sample, net, dev, B, reps=20):
     # the dominant kernel: fp32 MFMA implicit-GEMM convolution on the four layer shapes (2 x MAC algorithmic FLOP per launch)
     for name, cin, cout, hw, k, groups in (("conv2", 96, 256, 27, 5, 2), ("conv3", 256, 384, 13, 3, 1), ("conv4", 384, 384, 13, 3, 2),
                                            ("conv5", 384, 256, 13, 3, 2)):
-        x = torch.randn(B, cin, hw, hw, device=dev)
-        w = torch.randn(k, k, cin // groups, cout, device=dev) * 0.05
+        x = kernels.to_c8(torch.randn(B, cin, hw, hw, device=dev))
+        w = kernels.pack_conv_weights(torch.randn(k, k, cin // groups, cout, device=dev) * 0.05)
         bias = torch.randn(cout, device=dev)
         t = timed(lambda: kernels.conv2d_same(x, w, bias, groups=groups, relu=True))
         flop = 2.0 * B * hw * hw * cout * (cin // groups) * k * k
@@ -311,7 +311,8 @@ def cpu_baseline(sample, opts, window, gpu_net):
     threads = min(cores, 64)
     torch.set_num_threads(threads)
     params = {}
-    net = AlexNet(random_weights(0), device="cpu")
+    from oracle.alexnet_torch import TorchAlexNet
+    net = TorchAlexNet(random_weights(0), device="cpu")
     table = sample.table
     chrom, start, end = window
     t0 = time.perf_counter()

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SVX_VERSION 100            /* 0.1.0 */
+#define SVX_VERSION 200            /* 0.2.0: C8 activation layout, packed conv weights, distance / hash kernels */
 
 #define SVX_OK            0
 #define SVX_EINVAL       (-1)      /* bad argument (null pointer, bad layout...) */
@@ -34,6 +34,11 @@ extern "C" {
 
 #define SVX_GAP_INS       1
 #define SVX_GAP_DEL       2
+
+/* "C8" activation layout of the CNN entry points: float32 [image][C/8][H][W][8] -- channel c of pixel (y, x) lives at
+ * ((image * C/8 + c/8) * H*W + y*W + x) * 8 + c%8, so the 8 channels of an octet are one 32-byte sector per pixel
+ * (C % 8 == 0).  It lets every MFMA operand fetch and every epilogue store of svx_conv2d_same be a 16-byte access of
+ * whole sectors, for dense pixel ranges and for gathered (active-set) pixels alike. */
 
 /* One long CIGAR gap (I or D with length >= min_sv), 24 bytes.
  * Replaces the entries of `all_long_gaps` built at
@@ -100,7 +105,7 @@ int svx_rasterize(const int32_t* d_records, uint32_t n, float* d_out, int layout
  *   d_records [n][12] int32 as for svx_rasterize
  *   d_w1      conv1/weights in checkpoint layout HWIO [11][11][3][96], 16-B aligned
  *   d_base    [96]: biases[k] - sum_{ky,kx,ch} mean[ch] * w[ky][kx][ch][k], 16-B aligned
- *   d_y       float32 [n][96][27][27] (NCHW) = norm1 output
+ *   d_y       float32 [n][12][27][27][8] (C8) = norm1 output
  *   d_touched [n][27] or NULL: bit x of word [i][y] = pooled pixel (y, x) of image i has a set tap under it; every
  *             other pixel holds the same constant vector (the response to an empty image) */
 int svx_encode_conv1(const int32_t* d_records, uint32_t n, const float* d_w1, const float* d_base, float* d_y,
@@ -118,12 +123,12 @@ int svx_alexnet_active_sets(const uint32_t* d_touched, uint32_t n, int32_t* d_li
                             int32_t* d_list4, int32_t* d_list5, uint32_t* d_counts, uint32_t* d_ws, void* stream);
 
 /* Fused conv epilogue: bias add + ReLU + 3x3/2 VALID max-pool (+ TF local response
- * normalisation across channels when lrn != 0), NCHW float32.
+ * normalisation across channels when lrn != 0), C8 float32 in and out.
  * Replaces the elementwise chain between two convolutions of the reference graph:
  * tf.nn.bias_add + relu (src/network/alexnet.py:132-135), max_pool (:158-161), lrn (:164-166)
  * as composed at alexnet.py:29-31, :34-36, :45-46.
- *   d_x   [n][channels][height][width]  raw convolution output (no bias)
- *   d_y   [n][channels][(height-3)/2+1][(width-3)/2+1]
+ *   d_x   C8 [n][channels/8][height][width][8]  raw convolution output (no bias); channels % 8 == 0
+ *   d_y   C8 [n][channels/8][(height-3)/2+1][(width-3)/2+1][8]
  *   LRN:  y = p / (k + alpha * sum_{|j-c| <= radius} p_j^2)^beta   (alpha NOT divided by the window) */
 int svx_bias_relu_pool_lrn(const float* d_x, const float* d_bias, float* d_y, uint32_t n, uint32_t channels,
                            uint32_t height, uint32_t width, int lrn, uint32_t radius, float alpha, float beta,
@@ -135,26 +140,23 @@ int svx_bias_relu_pool_lrn(const float* d_x, const float* d_bias, float* d_y, ui
  *   d_out [n][12] = softmax[5], class (as float), logits[5], 0 */
 int svx_fc8_softmax(const float* d_x, const float* d_w, const float* d_bias, float* d_out, uint32_t n, void* stream);
 
-/* In-place bias add + ReLU on an NCHW float32 tensor [n][channels][plane] (plane = H*W >= 4):
- * tf.nn.bias_add + tf.nn.relu of the layers without pooling (conv3, conv4;
- * src/network/alexnet.py:39,42 via :132-135). d_x must be 16-B aligned. */
-int svx_bias_relu(float* d_x, const float* d_bias, uint32_t n, uint32_t channels, uint32_t plane, void* stream);
-
 /* fp32 implicit-GEMM convolution on the matrix cores (v_mfma_f32_32x32x2_f32): stride 1, SAME padding,
  * square kernel 3 or 5, optional channel groups, optional fused bias + ReLU.
  * Replaces tf.nn.conv2d (+ split/concat for groups, + bias_add + relu) of the reference layers conv2..conv5
  * (src/network/alexnet.py:34,39,42,45 via :109-135).
- *   d_in      float32 [n][cin][height][width]  (NCHW)
- *   d_w_hwio  float32 [ksize][ksize][cin/groups][cout]  -- the checkpoint layout, 16-B aligned
- *   d_bias    float32 [cout] or NULL (raw convolution output, e.g. in front of svx_bias_relu_pool_lrn)
- *   d_out     float32 [n][cout][height][width]
+ *   d_in       C8 float32 [n][cin/8][height][width][8]
+ *   d_w_packed float32 [ksize][ksize][cin_g/8][cout][8], cin_g = cin/groups: the checkpoint tensor
+ *              (HWIO [ksize][ksize][cin_g][cout]) with its input-channel axis split into octets and the octet's 8
+ *              channels moved innermost -- packed[ky][kx][q][o][j] = hwio[ky][kx][8q + j][o] -- once per model
+ *   d_bias     float32 [cout] or NULL (raw convolution output, e.g. in front of svx_bias_relu_pool_lrn)
+ *   d_out      C8 float32 [n][cout/8][height][width][8]
  *   d_pixels, d_pixel_count: NULL, or a permutation of all n*H*W output pixel ids (image * H*W + y * W + x) and, in
  *             device memory, the number of leading entries that are active (svx_alexnet_active_sets): only those
  *             outputs are computed (all of them when they are more than 97 %)
- *   d_background: NULL (the other pixels of d_out are left as they are) or float32 [cout][height][width], the layer's
- *             response to an empty image, copied to the pixels behind the active ones
- * Requires (cin/groups) % 16 == 0, (cout/groups) % 64 == 0 and an input tensor below 4 GB. */
-int svx_conv2d_same(const float* d_in, const float* d_w_hwio, const float* d_bias, float* d_out, uint32_t n,
+ *   d_background: NULL (the other pixels of d_out are left as they are) or C8 float32 [cout/8][height][width][8], the
+ *             layer's response to an empty image, copied to the pixels behind the active ones
+ * Requires cin_g % 16 == 0, (cout/groups) % 64 == 0, 16-byte aligned pointers, input and weight tensors below 2 GB. */
+int svx_conv2d_same(const float* d_in, const float* d_w_packed, const float* d_bias, float* d_out, uint32_t n,
                     uint32_t cin, uint32_t cout, uint32_t height, uint32_t width, uint32_t ksize,
                     uint32_t groups, int relu, const int32_t* d_pixels, const uint32_t* d_pixel_count,
                     const float* d_background, void* stream);

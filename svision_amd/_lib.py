@@ -33,7 +33,6 @@ SYMBOLS = {
     "svx_alexnet_active_sets": (ctypes.c_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "svx_conv2d_same": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, ctypes.c_int, _vp, _vp, _vp, _vp]),
     "svx_fc8_softmax": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _vp]),
-    "svx_bias_relu": (ctypes.c_int, [_vp, _vp, _u32, _u32, _u32, _vp]),
     "svx_bias_relu_pool_lrn": (ctypes.c_int, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, ctypes.c_int, _u32,
                                               ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),
     "svx_bam_open": (_vp, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),

@@ -7,7 +7,8 @@
 // is one pass here instead of five elementwise launches: each workgroup produces one pooled
 // row of one image for ALL channels, keeps the pooled values in LDS, and applies the
 // cross-channel normalisation from there.  HBM traffic = conv output read once (+ halo
-// rows through L2) and the 4x smaller pooled tensor written once.
+// rows through L2) and the 4x smaller pooled tensor written once.  Activations are in the
+// C8 layout of include/svx.h ([image][C/8][H][W][8]).
 #include "svx_raster_common.hpp"
 
 namespace {
@@ -23,36 +24,43 @@ __device__ inline float lrn_scale(float v, float x, float beta)
 }
 
 // relu(max(window) + bias) == max(relu(x + bias)) : + and relu are monotonic.
+// C8 layout in and out ([image][C/8][H][W][8], include/svx.h): consecutive lanes walk the 8 channels of an octet, then
+// the pooled pixels of the row, so every load and store instruction touches whole 32-byte sectors.
 __global__ __launch_bounds__(BLOCK)
 void bias_relu_pool_lrn_kernel(const float* __restrict__ x, const float* __restrict__ bias, float* __restrict__ y,
                                int C, int H, int W, int OH, int OW, int lrn, int radius, float alpha, float beta, float k)
 {
-    extern __shared__ __attribute__((aligned(16))) float pooled[];    // [C][OW]
+    extern __shared__ __attribute__((aligned(16))) float pooled[];    // [OW][C + 1]
     const int b = blockIdx.x / OH;
     const int oy = blockIdx.x - b * OH;
-    const float* xb = x + (size_t)b * C * H * W + (size_t)(2 * oy) * W;
+    const int CP = C + 1, HW = H * W;
+    const float* xb = x + ((size_t)b * (C / 8) * HW + (size_t)(2 * oy) * W) * 8;
     const int n = C * OW;
     for (int idx = threadIdx.x; idx < n; idx += BLOCK) {
-        const int c = idx / OW, ox = idx - c * OW;
-        const float* p = xb + (size_t)c * H * W + 2 * ox;
+        const int c8 = idx & 7, rest = idx >> 3;
+        const int oct = rest / OW, ox = rest - oct * OW;
+        const float* p = xb + ((size_t)oct * HW + 2 * ox) * 8 + c8;
         float m = p[0];
-        m = fmaxf(m, p[1]); m = fmaxf(m, p[2]);
-        m = fmaxf(m, p[W]); m = fmaxf(m, p[W + 1]); m = fmaxf(m, p[W + 2]);
-        m = fmaxf(m, p[2 * W]); m = fmaxf(m, p[2 * W + 1]); m = fmaxf(m, p[2 * W + 2]);
-        pooled[idx] = fmaxf(m + bias[c], 0.0f);
+        m = fmaxf(m, p[8]); m = fmaxf(m, p[16]);
+        m = fmaxf(m, p[W * 8]); m = fmaxf(m, p[W * 8 + 8]); m = fmaxf(m, p[W * 8 + 16]);
+        m = fmaxf(m, p[2 * W * 8]); m = fmaxf(m, p[2 * W * 8 + 8]); m = fmaxf(m, p[2 * W * 8 + 16]);
+        const int c = oct * 8 + c8;
+        pooled[ox * CP + c] = fmaxf(m + bias[c], 0.0f);
     }
     __syncthreads();
-    float* yb = y + (size_t)b * C * OH * OW + (size_t)oy * OW;
+    float* yb = y + ((size_t)b * (C / 8) * OH * OW + (size_t)oy * OW) * 8;
     for (int idx = threadIdx.x; idx < n; idx += BLOCK) {
-        const int c = idx / OW, ox = idx - c * OW;
-        float v = pooled[idx];
+        const int c8 = idx & 7, rest = idx >> 3;
+        const int oct = rest / OW, ox = rest - oct * OW;
+        const int c = oct * 8 + c8;
+        float v = pooled[ox * CP + c];
         if (lrn) {
             float s = 0.0f;
             const int lo = max(0, c - radius), hi = min(C - 1, c + radius);
-            for (int j = lo; j <= hi; ++j) { const float q = pooled[j * OW + ox]; s += q * q; }
+            for (int j = lo; j <= hi; ++j) { const float q = pooled[ox * CP + j]; s += q * q; }
             v = lrn_scale(v, k + alpha * s, beta);
         }
-        yb[(size_t)c * OH * OW + ox] = v;
+        yb[((size_t)oct * OH * OW + ox) * 8 + c8] = v;
     }
 }
 
@@ -169,9 +177,13 @@ void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __res
     }
     __syncthreads();
     const float* pooled = reinterpret_cast<const float*>(pooled_bits);
-    float* yb = y + (size_t)img * C1 * P1 * P1 + (size_t)oyp * P1;
+    // C8 output [image][12 octets][27][27][8]: consecutive lanes -> the 8 channels of an octet, then consecutive ox
+    // (one contiguous 864-byte run per octet and row)
+    float* yb = y + ((size_t)img * (C1 / 8) * P1 * P1 + (size_t)oyp * P1) * 8;
     for (int idx = tid; idx < C1 * P1; idx += ENC_BLOCK) {
-        const int k = idx / P1, ox = idx - k * P1;            // consecutive lanes -> consecutive ox (coalesced rows)
+        const int c8 = idx & 7, rest = idx >> 3;
+        const int oct = rest / P1, ox = rest - oct * P1;
+        const int k = oct * 8 + c8;
         float v = pooled[ox * C1P + k];
         if (lrn) {
             float s = 0.0f;
@@ -179,7 +191,7 @@ void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __res
             for (int j = lo; j <= hi; ++j) { const float q = pooled[ox * C1P + j]; s += q * q; }
             v = lrn_scale(v, kk + alpha * s, beta);
         }
-        yb[(size_t)k * P1 * P1 + ox] = v;
+        yb[((size_t)oct * P1 * P1 + ox) * 8 + c8] = v;
     }
 }
 
@@ -193,44 +205,6 @@ extern "C" int svx_encode_conv1(const int32_t* d_records, uint32_t n, const floa
     if ((reinterpret_cast<uintptr_t>(d_w1) & 15u) || (reinterpret_cast<uintptr_t>(d_base) & 15u)) return SVX_EINVAL;
     hipLaunchKernelGGL(encode_conv1_kernel, dim3(n * P1), dim3(ENC_BLOCK), 0, static_cast<hipStream_t>(stream),
                        d_records, d_w1, d_base, d_y, lrn, (int)radius, alpha, beta, k, d_touched);
-    return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
-}
-
-namespace {
-// In-place relu(x + bias[c]) on an NCHW tensor: one 16-B load + store per lane (conv3 / conv4 epilogue,
-// src/network/alexnet.py:132-135).  plane = H*W elements per (image, channel).
-__global__ __launch_bounds__(BLOCK)
-void bias_relu_kernel(float* __restrict__ x, const float* __restrict__ bias, int channels, int plane, long long total)
-{
-    const long long stride = (long long)gridDim.x * BLOCK * 4;
-    for (long long e = ((long long)blockIdx.x * BLOCK + threadIdx.x) * 4; e < total; e += stride) {
-        if (e + 3 < total) {
-            float4 v = *reinterpret_cast<float4*>(x + e);
-            const long long p = e / plane;
-            const int c0 = (int)(p % channels);
-            const int rem = plane - (int)(e - p * plane);              // elements left in this plane
-            const float b0 = bias[c0], b1 = bias[c0 + 1 < channels ? c0 + 1 : 0];
-            v.x = fmaxf(v.x + b0, 0.0f);
-            v.y = fmaxf(v.y + (rem > 1 ? b0 : b1), 0.0f);
-            v.z = fmaxf(v.z + (rem > 2 ? b0 : b1), 0.0f);
-            v.w = fmaxf(v.w + (rem > 3 ? b0 : b1), 0.0f);
-            *reinterpret_cast<float4*>(x + e) = v;
-        } else {
-            for (long long q = e; q < total; ++q) x[q] = fmaxf(x[q] + bias[(q / plane) % channels], 0.0f);
-        }
-    }
-}
-}  // namespace
-
-extern "C" int svx_bias_relu(float* d_x, const float* d_bias, uint32_t n, uint32_t channels, uint32_t plane, void* stream)
-{
-    const long long total = (long long)n * channels * plane;
-    if (total == 0) return SVX_OK;
-    if (!d_x || !d_bias || plane < 4 || (reinterpret_cast<uintptr_t>(d_x) & 15u)) return SVX_EINVAL;
-    long long blocks = (total / 4 + BLOCK - 1) / BLOCK;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(bias_relu_kernel, dim3((unsigned)blocks), dim3(BLOCK), 0, static_cast<hipStream_t>(stream),
-                       d_x, d_bias, (int)channels, (int)plane, total);
     return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
 }
 
@@ -416,9 +390,9 @@ extern "C" int svx_bias_relu_pool_lrn(const float* d_x, const float* d_bias, flo
                                       float k, void* stream)
 {
     if (n == 0) return SVX_OK;
-    if (!d_x || !d_bias || !d_y || channels == 0 || height < 3 || width < 3) return SVX_EINVAL;
+    if (!d_x || !d_bias || !d_y || channels == 0 || channels % 8 || height < 3 || width < 3) return SVX_EINVAL;
     const int OH = (int)(height - 3) / 2 + 1, OW = (int)(width - 3) / 2 + 1;
-    const size_t lds = (size_t)channels * OW * sizeof(float);
+    const size_t lds = (size_t)(channels + 1) * OW * sizeof(float);
     if (lds > 64 * 1024) return SVX_EINVAL;
     hipLaunchKernelGGL(bias_relu_pool_lrn_kernel, dim3(n * OH), dim3(BLOCK), lds, static_cast<hipStream_t>(stream),
                        d_x, d_bias, d_y, (int)channels, (int)height, (int)width, OH, OW, lrn, (int)radius, alpha, beta, k);

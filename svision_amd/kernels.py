@@ -15,6 +15,29 @@ GAP_DTYPE = np.dtype([("aln", "<u4"), ("op", "<u4"), ("read_pos", "<i4"),
 MEAN = (104.0, 117.0, 124.0)   # reference src/network/create_batch.py:13
 
 
+# ---- layout plumbing (torch ops, once per model / in tests; include/svx.h describes the layouts) ----
+def to_c8(x):
+    """NCHW [n,C,H,W] -> C8 [n,C/8,H,W,8] (contiguous)."""
+    n, c, h, w = x.shape
+    if c % 8:
+        raise _lib.SvxError("the C8 layout needs a channel count that is a multiple of 8")
+    return x.reshape(n, c // 8, 8, h, w).permute(0, 1, 3, 4, 2).contiguous()
+
+
+def from_c8(x):
+    """C8 [n,C/8,H,W,8] -> NCHW [n,C,H,W] (contiguous)."""
+    n, o, h, w, e = x.shape
+    return x.permute(0, 1, 4, 2, 3).reshape(n, o * e, h, w).contiguous()
+
+
+def pack_conv_weights(w_hwio):
+    """Checkpoint conv weights HWIO [k,k,cin_g,cout] -> [k,k,cin_g/8,cout,8] (svx_conv2d_same's d_w_packed)."""
+    k, k2, cin_g, cout = w_hwio.shape
+    if cin_g % 8:
+        raise _lib.SvxError("cin/groups must be a multiple of 8")
+    return w_hwio.reshape(k, k2, cin_g // 8, 8, cout).permute(0, 1, 2, 4, 3).contiguous()
+
+
 def _stream_ptr(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
@@ -98,23 +121,23 @@ def cigar_scan(cigar, cig_off, ref_start, min_sv, gaps_cap=None):
 
 
 def bias_relu_pool_lrn(x, bias, lrn=True, radius=2, alpha=2e-05, beta=0.75, k=1.0):
-    """x: float32 [n,C,H,W] raw conv output -> relu(x+bias) -> max-pool 3x3/2 -> (LRN) as one kernel.
+    """x: float32 C8 [n,C/8,H,W,8] raw conv output -> relu(x+bias) -> max-pool 3x3/2 -> (LRN) as one kernel, C8 out.
     See include/svx.h svx_bias_relu_pool_lrn."""
     lib = _lib.load()
     _require_cuda(x, "x")
     _require_cuda(bias, "bias")
-    if x.dtype != torch.float32 or x.dim() != 4 or bias.dtype != torch.float32 or bias.numel() != x.shape[1]:
-        raise _lib.SvxError("x must be float32 [n,C,H,W] and bias float32 [C]")
-    n, c, h, w = x.shape
-    y = torch.empty((n, c, (h - 3) // 2 + 1, (w - 3) // 2 + 1), dtype=torch.float32, device=x.device)
-    rc = lib.svx_bias_relu_pool_lrn(x.data_ptr(), bias.data_ptr(), y.data_ptr(), n, c, h, w, 1 if lrn else 0, radius,
+    if x.dtype != torch.float32 or x.dim() != 5 or x.shape[4] != 8 or bias.dtype != torch.float32 or bias.numel() != x.shape[1] * 8:
+        raise _lib.SvxError("x must be float32 C8 [n,C/8,H,W,8] and bias float32 [C]")
+    n, o, h, w, _e = x.shape
+    y = torch.empty((n, o, (h - 3) // 2 + 1, (w - 3) // 2 + 1, 8), dtype=torch.float32, device=x.device)
+    rc = lib.svx_bias_relu_pool_lrn(x.data_ptr(), bias.data_ptr(), y.data_ptr(), n, o * 8, h, w, 1 if lrn else 0, radius,
                                     alpha, beta, k, _stream_ptr(x.device))
     _lib.check(rc, "svx_bias_relu_pool_lrn")
     return y
 
 
 def encode_conv1(records, w1_hwio, base, lrn=True, radius=2, alpha=2e-05, beta=0.75, k=1.0, touched=False):
-    """records int32 [n,12] -> float32 [n,96,27,27]: rasterise + conv1 + relu + pool1 + norm1 in one
+    """records int32 [n,12] -> float32 C8 [n,12,27,27,8]: rasterise + conv1 + relu + pool1 + norm1 in one
     kernel, exploiting the sparsity of the similarity image.  See include/svx.h svx_encode_conv1.
     ``touched=True``: also return the int32 [n,27] row masks of the pooled pixels with a set tap under them."""
     lib = _lib.load()
@@ -125,7 +148,7 @@ def encode_conv1(records, w1_hwio, base, lrn=True, radius=2, alpha=2e-05, beta=0
     if tuple(w1_hwio.shape) != (11, 11, 3, 96) or w1_hwio.dtype != torch.float32 or base.numel() != 96:
         raise _lib.SvxError("w1 must be float32 HWIO [11,11,3,96] and base float32 [96]")
     n = records.shape[0]
-    y = torch.empty((n, 96, 27, 27), dtype=torch.float32, device=records.device)
+    y = torch.empty((n, 12, 27, 27, 8), dtype=torch.float32, device=records.device)
     mask = torch.empty((n, 27), dtype=torch.int32, device=records.device) if touched else None
     rc = lib.svx_encode_conv1(records.data_ptr(), n, w1_hwio.data_ptr(), base.data_ptr(), y.data_ptr(), 1 if lrn else 0,
                               radius, alpha, beta, k, mask.data_ptr() if touched else None, _stream_ptr(records.device))
@@ -151,44 +174,32 @@ def alexnet_active_sets(touched):
     return lists[0], lists[1], lists[2], lists[3], counts
 
 
-def bias_relu_(x, bias):
-    """In-place relu(x + bias[c]) on a float32 NCHW device tensor.  See include/svx.h svx_bias_relu."""
-    lib = _lib.load()
-    _require_cuda(x, "x")
-    _require_cuda(bias, "bias")
-    if x.dtype != torch.float32 or x.dim() != 4 or bias.numel() != x.shape[1]:
-        raise _lib.SvxError("x must be float32 [n,C,H,W] and bias float32 [C]")
-    n, c, h, w = x.shape
-    rc = lib.svx_bias_relu(x.data_ptr(), bias.data_ptr(), n, c, h * w, _stream_ptr(x.device))
-    _lib.check(rc, "svx_bias_relu")
-    return x
-
-
-def conv2d_same(x, w_hwio, bias=None, groups=1, relu=False, pixels=None, pixel_count=None, out=None, background=None):
-    """x float32 [n,Cin,H,W], w_hwio float32 [k,k,Cin/groups,Cout] (checkpoint layout) -> [n,Cout,H,W]:
-    stride-1 SAME convolution on the fp32 matrix cores, optional fused bias + ReLU.
+def conv2d_same(x, w_packed, bias=None, groups=1, relu=False, pixels=None, pixel_count=None, out=None, background=None):
+    """x float32 C8 [n,Cin/8,H,W,8], w_packed float32 [k,k,Cin/groups/8,Cout,8] (:func:`pack_conv_weights`) -> C8
+    [n,Cout/8,H,W,8]: stride-1 SAME convolution on the fp32 matrix cores, optional fused bias + ReLU.
     ``pixels`` / ``pixel_count`` (device int32 permutation of the pixel ids and the number of leading active entries,
-    a one-element view): compute only the active output pixels; the others receive ``background`` ([Cout,H,W]) or,
+    a one-element view): compute only the active output pixels; the others receive ``background`` (C8 [Cout/8,H,W,8]) or,
     without it, keep what ``out`` holds.  See include/svx.h svx_conv2d_same."""
     lib = _lib.load()
     _require_cuda(x, "x")
-    _require_cuda(w_hwio, "w_hwio")
-    if x.dtype != torch.float32 or x.dim() != 4 or w_hwio.dtype != torch.float32 or w_hwio.dim() != 4:
-        raise _lib.SvxError("x must be float32 NCHW and w float32 HWIO")
-    n, cin, h, w = x.shape
-    k, k2, cin_g, cout = w_hwio.shape
-    if k != k2 or cin_g * groups != cin:
-        raise _lib.SvxError("weight shape %s does not match input %s with %d groups" % (tuple(w_hwio.shape), tuple(x.shape), groups))
+    _require_cuda(w_packed, "w_packed")
+    if x.dtype != torch.float32 or x.dim() != 5 or x.shape[4] != 8 or w_packed.dtype != torch.float32 or w_packed.dim() != 5 or w_packed.shape[4] != 8:
+        raise _lib.SvxError("x must be float32 C8 [n,C/8,H,W,8] and w float32 packed [k,k,cin_g/8,cout,8]")
+    n, cin8, h, w, _e = x.shape
+    cin = cin8 * 8
+    k, k2, cin_g8, cout, _e2 = w_packed.shape
+    if k != k2 or cin_g8 * 8 * groups != cin:
+        raise _lib.SvxError("weight shape %s does not match input %s with %d groups" % (tuple(w_packed.shape), tuple(x.shape), groups))
     if bias is not None:
         _require_cuda(bias, "bias")
     if (pixels is None) != (pixel_count is None) or (pixels is not None and out is None and background is None):
         raise _lib.SvxError("pixels and pixel_count go together, with out or background")
-    if background is not None and (pixels is None or tuple(background.shape[-3:]) != (cout, h, w) or not background.is_contiguous()):
-        raise _lib.SvxError("background must be a contiguous float32 [Cout,H,W] tensor and needs pixels")
-    y = out if out is not None else torch.empty((n, cout, h, w), dtype=torch.float32, device=x.device)
-    if tuple(y.shape) != (n, cout, h, w) or y.dtype != torch.float32 or not y.is_contiguous():
-        raise _lib.SvxError("out must be a contiguous float32 [n,Cout,H,W] tensor")
-    rc = lib.svx_conv2d_same(x.data_ptr(), w_hwio.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
+    if background is not None and (pixels is None or tuple(background.shape[-4:]) != (cout // 8, h, w, 8) or not background.is_contiguous()):
+        raise _lib.SvxError("background must be a contiguous float32 C8 [Cout/8,H,W,8] tensor and needs pixels")
+    y = out if out is not None else torch.empty((n, cout // 8, h, w, 8), dtype=torch.float32, device=x.device)
+    if tuple(y.shape) != (n, cout // 8, h, w, 8) or y.dtype != torch.float32 or not y.is_contiguous():
+        raise _lib.SvxError("out must be a contiguous float32 C8 [n,Cout/8,H,W,8] tensor")
+    rc = lib.svx_conv2d_same(x.data_ptr(), w_packed.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(),
                              n, cin, cout, h, w, k, groups, 1 if relu else 0,
                              pixels.data_ptr() if pixels is not None else None,
                              pixel_count.data_ptr() if pixel_count is not None else None,

@@ -6,7 +6,7 @@ Same stages and the same (parity-tested) functions as the file-based driver (cli
 
   device  svx_cigar_scan over the window's alignment block          (collection, analyze_reads.py:828-853)
   host    reads -> segments -> signatures -> clusters -> pair lines   (run_collection.py:15-47)
-  device  svx_rasterize + AlexNet, batches of `batch_size` images     (create_batch.py:88, predict.py:206-210)
+  device  encode + AlexNet (svx_encode_conv1 ...), batches of `batch_size` images  (create_batch.py:88, predict.py:206-210)
   host    per-site vote -> VCF body lines + scores                    (predict.py:213-300, output.py:469)
 
 The reference fans windows out to a ``multiprocessing.Pool`` (SVision:261-281); here the pool
@@ -65,39 +65,30 @@ def _vote(sample, options, chrom, lines, classes, probs):
 
 class DeviceStage:
     """records [n,12] -> (softmax[5], class) per image, in batches of ``batch`` images, each batch a
-    replay of one captured graph: svx_rasterize -> AlexNet forward -> softmax/argmax -> pack."""
+    replay of one captured graph: svx_encode_conv1 -> active sets -> conv2..5 -> fc6/7 -> svx_fc8_softmax."""
 
-    def __init__(self, net, batch, device, n_streams=2, use_graph=True, sparse_first_layer=True):
+    def __init__(self, net, batch, device, n_streams=2, use_graph=True):
         self.net, self.batch, self.device = net, batch, torch.device(device)
-        self.sparse_first_layer = sparse_first_layer
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
         self.use_graph = use_graph
         self.slots = []
         for s in self.streams:
             rec = torch.zeros((batch, 12), dtype=torch.int32, device=self.device)
             rec[:] = torch.tensor(_PAD_REC, dtype=torch.int32, device=self.device)
-            img = torch.empty((batch, 3, 227, 227), dtype=torch.float32, device=self.device)
             out = torch.empty((batch, 12), dtype=torch.float32, device=self.device)   # softmax[5], class, logits[5], 0
             graph = None
             with torch.cuda.stream(s):
-                for _ in range(2):                           # warm MIOpen / hipBLASLt before capture
-                    self._body(rec, img, out)
+                for _ in range(2):                           # warm hipBLASLt (and the model's background tensors) before capture
+                    self._body(rec, out)
             s.synchronize()
             if use_graph:
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=s):
-                    self._body(rec, img, out)
-            self.slots.append((rec, img, out, graph))
+                    self._body(rec, out)
+            self.slots.append((rec, out, graph))
 
-    def _body(self, rec, img, out):
-        if self.sparse_first_layer:
-            self.net.predict_records_packed(rec, out=out)      # svx_encode_conv1 ... svx_fc8_softmax: no image tensor
-            return
-        kernels.rasterize(rec, layout="NCHW", out=img)          # dense-image path (BatchGenerator API), for comparison
-        logits, cls, prob = self.net.predict(img)
-        out[:, :5] = prob
-        out[:, 5] = cls.to(torch.float32)
-        out[:, 6:11] = logits
+    def _body(self, rec, out):
+        self.net.predict_records_packed(rec, out=out)        # no image tensor: encoding is fused into the first layer
 
     def run(self, d_rec, out):
         """d_rec: int32 [n_padded,12] on the device (n_padded % batch == 0); out: float32 [n_padded,6].
@@ -108,7 +99,7 @@ class DeviceStage:
         for i, lo in enumerate(range(0, d_rec.shape[0], b)):
             k = i % len(self.streams)
             s = self.streams[k]
-            rec, img, o, graph = self.slots[k]
+            rec, o, graph = self.slots[k]
             if k not in used:
                 s.wait_stream(main)
                 used.add(k)
@@ -117,7 +108,7 @@ class DeviceStage:
                 if graph is not None:
                     graph.replay()
                 else:
-                    self._body(rec, img, o)
+                    self._body(rec, o)
                 out[lo:lo + b].copy_(o[:, :6], non_blocking=True)
         for k in used:
             main.wait_stream(self.streams[k])

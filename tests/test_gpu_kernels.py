@@ -120,29 +120,32 @@ def test_cigar_scan_ragged_and_empty(oracle_lib):
 
 
 def test_alexnet_matches_numpy_oracle():
+    """Product path (records -> packed softmax) vs the NumPy restatement on the oracle's images; the plain-PyTorch
+    restatement on the HIP rasteriser's images agrees with both (north_star tolerance: softmax within 1e-3, fp32)."""
     from oracle import alexnet_ref
+    from oracle.alexnet_torch import TorchAlexNet
     from svision_amd.network.alexnet import AlexNet
     params = alexnet_ref.random_params(seed=3)
     rec = datagen.random_records(6, seed=21, hostile=False)
     x = encode_ref.encode_records(rec)
     o_logits, o_cls, o_prob = alexnet_ref.predict(params, x)
-    for cl in (False, True):
-        net = AlexNet(params, device=DEV, channels_last=cl)
-        img = kernels.rasterize(_dev(rec), layout="NCHW")
-        logits, cls, prob = net.predict(img)
-        # north_star tolerance: CNN softmax within 1e-3 (fp32)
-        assert np.abs(prob.cpu().numpy() - o_prob).max() < 1e-3
-        assert np.allclose(logits.cpu().numpy(), o_logits, rtol=1e-3, atol=1e-3 * np.abs(o_logits).max())
+    logits, cls, prob = AlexNet(params, device=DEV).predict_records(_dev(rec))
+    assert np.abs(prob.cpu().numpy() - o_prob).max() < 1e-3
+    assert np.allclose(logits.cpu().numpy(), o_logits, rtol=1e-3, atol=1e-3 * np.abs(o_logits).max())
+    img = kernels.rasterize(_dev(rec), layout="NCHW")
+    t_logits, _c, t_prob = TorchAlexNet(params, device=DEV).predict(img)
+    assert np.abs(t_prob.cpu().numpy() - o_prob).max() < 1e-3
+    assert np.abs(t_prob.cpu().numpy() - prob.cpu().numpy()).max() < 1e-3
 
 
-@pytest.mark.parametrize("shape,lrn", [((3, 96, 55, 55), True), ((2, 256, 27, 27), True), ((4, 256, 13, 13), False), ((1, 7, 9, 11), True)])
+@pytest.mark.parametrize("shape,lrn", [((3, 96, 55, 55), True), ((2, 256, 27, 27), True), ((4, 256, 13, 13), False), ((1, 8, 9, 11), True)])
 def test_bias_relu_pool_lrn_matches_numpy_oracle(shape, lrn):
     """fp32 op: tolerance 1e-5 relative vs the NumPy restatement of relu(x+b) -> max_pool -> tf LRN."""
     from oracle import alexnet_ref
     rng = np.random.default_rng(shape[1])
     x = (rng.standard_normal(shape) * 30).astype(np.float32)
     b = rng.standard_normal(shape[1]).astype(np.float32)
-    got = kernels.bias_relu_pool_lrn(_dev(x), _dev(b), lrn=lrn).cpu().numpy()
+    got = kernels.from_c8(kernels.bias_relu_pool_lrn(kernels.to_c8(_dev(x)), _dev(b), lrn=lrn)).cpu().numpy()
     nhwc = np.maximum(x.transpose(0, 2, 3, 1) + b, 0)
     want = alexnet_ref._max_pool_3x3s2_valid(np.ascontiguousarray(nhwc))
     if lrn:
@@ -160,7 +163,7 @@ def test_encode_conv1_matches_dense_path():
     params = alexnet_ref.random_params(seed=11)
     rec = np.concatenate([datagen.random_records(24, seed=33), np.asarray([encode_ref.PAD_RECORD], np.int32)])
     net = AlexNet(params, device=DEV)
-    got = kernels.encode_conv1(_dev(rec), net.conv1_hwio, net.conv1_base).cpu().numpy()
+    got = kernels.from_c8(kernels.encode_conv1(_dev(rec), net.conv1_hwio, net.conv1_base)).cpu().numpy()
     x = encode_ref.encode_records(rec)
     a = alexnet_ref._conv_layer(x, params["conv1/weights"], params["conv1/biases"], 4, "VALID", 1)
     want = alexnet_ref._lrn(np.ascontiguousarray(alexnet_ref._max_pool_3x3s2_valid(a))).transpose(0, 3, 1, 2)
@@ -171,18 +174,8 @@ def test_encode_conv1_matches_dense_path():
     assert np.abs(prob.cpu().numpy() - o_prob).max() < 1e-3
 
 
-@pytest.mark.parametrize("shape", [(3, 384, 13, 13), (2, 5, 2, 3), (1, 7, 1, 5)])
-def test_bias_relu_inplace(shape):
-    rng = np.random.default_rng(1)
-    x = rng.standard_normal(shape).astype(np.float32)
-    b = rng.standard_normal(shape[1]).astype(np.float32)
-    t = _dev(x)
-    kernels.bias_relu_(t, _dev(b))
-    assert np.array_equal(t.cpu().numpy(), np.maximum(x + b[None, :, None, None], 0))
-
-
 @pytest.mark.parametrize("n,cin,cout,hw,k,groups", [(3, 96, 256, 27, 5, 2), (5, 256, 384, 13, 3, 1), (2, 384, 384, 13, 3, 2),
-                                                     (64, 384, 256, 13, 3, 2), (1, 16, 64, 5, 3, 1)])
+                                                     (64, 384, 256, 13, 3, 2), (1, 16, 64, 5, 3, 1), (2, 48, 128, 6, 5, 1)])
 def test_conv2d_same_matches_torch_fp32(n, cin, cout, hw, k, groups):
     """fp32 MFMA implicit GEMM vs a plain PyTorch fp32 conv of the same op (tolerance 2e-4 of the output scale)."""
     import torch.nn.functional as F
@@ -192,13 +185,34 @@ def test_conv2d_same_matches_torch_fp32(n, cin, cout, hw, k, groups):
     b = rng.standard_normal(cout).astype(np.float32)
     xt, wt, bt = _dev(x), _dev(w), _dev(b)
     want = F.conv2d(xt.double(), wt.permute(3, 2, 0, 1).contiguous().double(), bt.double(), 1, k // 2, 1, groups)
-    got = kernels.conv2d_same(xt, wt, bt, groups=groups, relu=False)
+    xc, wp = kernels.to_c8(xt), kernels.pack_conv_weights(wt)
+    got = kernels.from_c8(kernels.conv2d_same(xc, wp, bt, groups=groups, relu=False))
     scale = float(want.abs().max())
     assert float((got.double() - want).abs().max()) < 2e-4 * scale
-    got_raw = kernels.conv2d_same(xt, wt, None, groups=groups, relu=False)
+    got_raw = kernels.from_c8(kernels.conv2d_same(xc, wp, None, groups=groups, relu=False))
     assert float((got_raw.double() + bt.double().view(1, -1, 1, 1) - want).abs().max()) < 2e-4 * scale
-    got_relu = kernels.conv2d_same(xt, wt, bt, groups=groups, relu=True)
+    got_relu = kernels.from_c8(kernels.conv2d_same(xc, wp, bt, groups=groups, relu=True))
     assert float((got_relu.double() - want.clamp_min(0)).abs().max()) < 2e-4 * scale
+
+
+def test_conv2d_same_is_transpose_and_layout_sensitive():
+    """Asymmetric one-hot probe: a single input element and a single weight element must land on exactly one output
+    element (catches swapped MFMA operands, octet / half mix-ups in the C8 and packed layouts)."""
+    n, cin, cout, hw, k, groups = 2, 32, 128, 7, 3, 2
+    for (b, c, y, x0, ky, kx, o) in ((1, 5, 2, 3, 0, 2, 7), (0, 29, 6, 0, 2, 0, 100), (1, 16, 0, 6, 1, 1, 64)):
+        x = torch.zeros(n, cin, hw, hw, device=DEV)
+        w = torch.zeros(k, k, cin // groups, cout, device=DEV)
+        x[b, c, y, x0] = 3.0
+        g = c // (cin // groups)
+        if o // (cout // groups) != g:
+            o = g * (cout // groups) + o % (cout // groups)
+        w[ky, kx, c % (cin // groups), o] = 2.0
+        got = kernels.from_c8(kernels.conv2d_same(kernels.to_c8(x), kernels.pack_conv_weights(w), None, groups=groups))
+        yy, xx = y - (ky - 1), x0 - (kx - 1)                 # output position whose tap (ky, kx) reads (y, x0)
+        want = torch.zeros_like(got)
+        if 0 <= yy < hw and 0 <= xx < hw:
+            want[b, o, yy, xx] = 6.0
+        assert torch.equal(got, want)
 
 
 def test_fc8_softmax_and_packed_predict():
@@ -300,12 +314,14 @@ def test_conv_with_pixel_list_and_background(fill):
     lists = kernels.alexnet_active_sets(_dev(touched.astype(np.int32)))
     counts = lists[4].cpu().numpy()
     for (cin, cout, hw, k, groups, li) in ((96, 256, 27, 5, 2, 0), (256, 384, 13, 3, 1, 1)):
-        x = torch.randn(n, cin, hw, hw, device=DEV)
-        w = torch.randn(k, k, cin // groups, cout, device=DEV) * 0.05
+        x = kernels.to_c8(torch.randn(n, cin, hw, hw, device=DEV))
+        w = kernels.pack_conv_weights(torch.randn(k, k, cin // groups, cout, device=DEV) * 0.05)
         b = torch.randn(cout, device=DEV)
         bg = torch.randn(cout, hw, hw, device=DEV)
-        dense = kernels.conv2d_same(x, w, b, groups=groups, relu=True)
-        got = kernels.conv2d_same(x, w, b, groups=groups, relu=True, pixels=lists[li], pixel_count=lists[4][li:li + 1], background=bg)
+        bg8 = kernels.to_c8(bg.unsqueeze(0))[0]
+        dense = kernels.from_c8(kernels.conv2d_same(x, w, b, groups=groups, relu=True))
+        got = kernels.from_c8(kernels.conv2d_same(x, w, b, groups=groups, relu=True, pixels=lists[li], pixel_count=lists[4][li:li + 1],
+                                                  background=bg8))
         active = torch.zeros(n * hw * hw, dtype=torch.bool, device=DEV)
         active[lists[li][:int(counts[li])].long()] = True
         active = active.view(n, 1, hw, hw)

@@ -53,7 +53,8 @@ def test_classifier_from_checkpoint_matches_cpu_checker(checkpoint, tmp_path):
     bed.write_text(case["chroms"]["chrB"]["tsv"])
     gen = BatchGenerator(str(bed), nb_classes=5, batch_size=64, layout="NCHW")
     classify = load_classifier(prefix, device="cuda:0")           # records -> (logits, class, softmax), sparse first layer
-    checker = AlexNet(params, device="cpu")                       # plain PyTorch fp32 on the host
+    from oracle.alexnet_torch import TorchAlexNet
+    checker = TorchAlexNet(params, device="cpu")                  # plain PyTorch fp32 on the host
     for _ in range(gen.data_size // 64):
         lo = gen.pointer
         records, _labels = gen.next_records(64)

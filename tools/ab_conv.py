@@ -31,10 +31,11 @@ def timed(fn, reps=20):
 tot = {}
 for name, cin, cout, g, hw, k, fused, frac in (("conv2", 96, 256, 2, 27, 5, False, 0.37), ("conv3", 256, 384, 1, 13, 3, True, 0.67),
                                                 ("conv4", 384, 384, 2, 13, 3, True, 0.81), ("conv5", 384, 256, 2, 13, 3, False, 0.91)):
-    x = torch.randn(64, cin, hw, hw, device=dev).clamp_min(0)
-    w = torch.randn(k, k, cin // g, cout, device=dev) * 0.02
+    x_nchw = torch.randn(64, cin, hw, hw, device=dev).clamp_min(0)
+    w_hwio = torch.randn(k, k, cin // g, cout, device=dev) * 0.02
     b = torch.randn(cout, device=dev) if fused else None
-    ref = F.conv2d(x, w.permute(3, 2, 0, 1).contiguous(), b, 1, k // 2, 1, g)
+    ref = F.conv2d(x_nchw, w_hwio.permute(3, 2, 0, 1).contiguous(), b, 1, k // 2, 1, g)
+    x, w = kernels.to_c8(x_nchw), kernels.pack_conv_weights(w_hwio)
     if fused:
         ref = ref.clamp_min(0)
     fl = 2.0 * 64 * hw * hw * cout * (cin // g) * k * k
@@ -44,6 +45,7 @@ for name, cin, cout, g, hw, k, fused, frac in (("conv2", 96, 256, 2, 27, 5, Fals
     plist = torch.cat([ids[act], ids[~act]]).contiguous()
     cnt = act.sum().to(torch.int32).view(1)
     bg = torch.randn(cout, hw, hw, device=dev)
+    bg8 = kernels.to_c8(bg.unsqueeze(0))[0]
     want_list = torch.where(act.view(64, 1, hw, hw), ref, bg.unsqueeze(0).expand(64, -1, -1, -1))
     for mode in ("dense", "list"):
         outs = {}
@@ -56,10 +58,10 @@ for name, cin, cout, g, hw, k, fused, frac in (("conv2", 96, 256, 2, 27, 5, Fals
                 fn = lambda: kernels.conv2d_same(x, w, b, groups=g, relu=fused)
                 want, work = ref, fl
             else:
-                fn = lambda: kernels.conv2d_same(x, w, b, groups=g, relu=fused, pixels=plist, pixel_count=cnt, background=bg)
+                fn = lambda: kernels.conv2d_same(x, w, b, groups=g, relu=fused, pixels=plist, pixel_count=cnt, background=bg8)
                 want, work = want_list, fl * float(cnt.item()) / npix
             t = timed(fn)
-            out = fn()
+            out = kernels.from_c8(fn())
             outs[sh] = out
             d = (out - want).abs().max().item()
             same = "" if sh is None else (" bit-identical to default" if torch.equal(out, outs[None]) else " DIFFERS from default")

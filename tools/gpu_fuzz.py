@@ -25,7 +25,8 @@ dev = torch.device("cuda:0")
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 params = random_weights(5)
-dense, sparse, cpu = AlexNet(params, device=dev, active=False), AlexNet(params, device=dev, active=True), AlexNet(params, device="cpu")
+from oracle.alexnet_torch import TorchAlexNet
+dense, sparse, cpu = AlexNet(params, device=dev, active=False), AlexNet(params, device=dev, active=True), TorchAlexNet(params, device="cpu")
 bad = n_rec = 0
 worst = 0.0
 for seed in range(first, first + n):

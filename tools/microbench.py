@@ -38,7 +38,7 @@ out["cigar_scan"] = {"alignments": na, "ops": int(cigar.size), "gaps": res.total
 net = AlexNet(random_weights(0), device=dev)
 t = timed(lambda: kernels.encode_conv1(rec, net.conv1_hwio, net.conv1_base))
 out["encode_conv1"] = {"images": n, "s": t, "us_per_64": t / n * 64 * 1e6}
-x = torch.randn(256, 96, 55, 55, device=dev); b = torch.randn(96, device=dev)
+x = kernels.to_c8(torch.randn(256, 96, 55, 55, device=dev)); b = torch.randn(96, device=dev)
 t = timed(lambda: kernels.bias_relu_pool_lrn(x, b))
 out["pool_lrn_1"] = {"s": t, "GBps": (x.numel() * 4 + 256 * 96 * 27 * 27 * 4) / t / 1e9}
 print(json.dumps(out))

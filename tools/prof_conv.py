@@ -7,8 +7,8 @@ from svision_amd import kernels
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 for name, cin, cout, g, hw, k in (("conv2",96,256,2,27,5),("conv3",256,384,1,13,3),("conv4",384,384,2,13,3),("conv5",384,256,2,13,3)):
-    x = torch.randn(64, cin, hw, hw, device=dev).clamp_min(0)
-    w = torch.randn(k, k, cin // g, cout, device=dev) * 0.02
+    x = kernels.to_c8(torch.randn(64, cin, hw, hw, device=dev).clamp_min(0))
+    w = kernels.pack_conv_weights(torch.randn(k, k, cin // g, cout, device=dev) * 0.02)
     for _ in range(3):
         kernels.conv2d_same(x, w, None, groups=g)
 torch.cuda.synchronize()
