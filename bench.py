@@ -1,25 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- candidate SV sites/sec (encode+CNN) on N MI355X of one node.
 
-Workload (BASELINE.json configs[1] stand-in, synthetic: the reference ships no BAM):
-a chr21-sized contig (46,709,983 bp), HiFi reads N(15 kb, 2 kb) at 30x with planted
-SVs; its alignments are decoded to packed arrays and resident in HBM before the timed
-region.  A *step* is one collection window of the reference driver (10 Mb, SVision:88)
-through the whole hot path:
+Workloads (synthetic: the reference ships no BAM; svision_amd/synth.py, fixed seeds):
+
+  cfg2 (default)  BASELINE.json configs[1] stand-in: a chr21-sized contig (46,709,983 bp), HiFi reads
+                  N(15 kb, 2 kb) at 30x with planted SVs.  N > 1: every rank owns its own such shard (weak scaling).
+  wg              BASELINE.json configs[2] stand-in: 24 contigs with the GRCh38 primary lengths (3.1 Gb), same read
+                  model, chromosomes LPT-sharded over the ranks exactly as the command line does it
+                  (svision_amd.dist.shard_chromosomes, cli.load_rank_table); strong scaling: the job is the genome.
+
+The alignments are decoded to packed arrays and resident in HBM before the timed region.  A *step* is one collection
+window of the reference driver (10 Mb, SVision:88) through the whole hot path:
 
   device  CIGAR/segment scan of the window's alignments        (svx_cigar_scan)
   host    reads -> signatures -> clusters -> segment pairs      (parity-tested mirror of src/collection)
-  device  similarity-image rasterisation + AlexNet fp32, batches of 64 candidate images
+  device  similarity-image encoding + AlexNet fp32, batches of 64 candidate images
   host    per-site vote -> VCF body lines + scores
 
-value = candidate sites (distinct regions of the segment TSV) per second, whole job.
-With N>1 every rank owns its own chromosome-sized shard (weak scaling, no data-path
-collective; one score-range all_reduce + one record gather at the end, inside the timed
-region).  Prints ONE JSON line on rank 0.
+value = candidate sites (distinct regions of the segment TSV) per second, whole job.  No data-path collective; one
+score-range all_reduce + one record gather at the end, inside the timed region.  Prints ONE JSON line on rank 0.
+`--gpus N` without a launcher environment starts the N ranks itself (torch.distributed.run, one per GPU, RCCL).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -36,14 +41,20 @@ from svision_amd.pipeline import HelperPool, PooledHotPath  # noqa: E402
 from svision_amd.sample import Sample  # noqa: E402
 
 IMG_BYTES = 227 * 227 * 3 * 4 + 48            # 618,348 B written + 48 B read per image
-CNN_FLOP = 1_440_662_592                      # FLOP per image
+CNN_FLOP = 1_440_662_592                      # FLOP per image of the dense network
 HBM_PEAK = 8.0e12                             # MI355X_MICROARCH.md: HBM3E 8 TB/s
 F32_MFMA_PEAK = 157.3e12                      # MI355X_MICROARCH.md: FP32 matrix peak (f32-in MFMA)
-# HBM/fabric bytes per 64-image batch of the device stage, from PMC counters (rocprofv3 --pmc FETCH_SIZE and
-# --pmc WRITE_SIZE in separate passes, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md), summed over its
-# kernels: profiles/r01_pmc_traffic.md.  Offline measurement (counters cannot be read inside this process).
-PMC_TRAFFIC_PER_BATCH64 = 7.04e8
 CHR21 = 46_709_983
+# GRCh38 primary assembly, chr1..chr22, chrX, chrY (header order of a GRCh38 BAM)
+GRCH38 = (("chr1", 248956422), ("chr2", 242193529), ("chr3", 198295559), ("chr4", 190214555), ("chr5", 181538259),
+          ("chr6", 170805979), ("chr7", 159345973), ("chr8", 145138636), ("chr9", 138394717), ("chr10", 133797422),
+          ("chr11", 135086622), ("chr12", 133275309), ("chr13", 114364328), ("chr14", 107043718), ("chr15", 101991189),
+          ("chr16", 90338345), ("chr17", 83257441), ("chr18", 80373285), ("chr19", 58617616), ("chr20", 64444167),
+          ("chr21", 46709983), ("chr22", 50818468), ("chrX", 156040895), ("chrY", 57227415))
+# dense FLOP per image of the layers behind the first one (2 x MAC) and their output pixels per image
+LAYER_FLOP = {"conv2": 447_897_600, "conv3": 299_040_768, "conv4": 224_280_576, "conv5": 149_520_384, "fc": 109_092_864}
+LAYER_PIX = {"conv2": 729, "conv3": 169, "conv4": 169, "conv5": 169}
+WINDOW = 10_000_000
 
 
 def random_weights(seed=0):
@@ -63,47 +74,99 @@ def options_ns(batch):
     return types.SimpleNamespace(
         out_path=None, bam_path="<resident>", model_path=None, genome=None, sample="bench", thread_num=1, min_support=5,
         chrom=None, hash=False, qname=False, graph=False, contig=False, debug=False, min_mapq=10, min_sv_size=50,
-        max_sv_size=1000000, window_size=10000000, patition_max_distance=5000, cluster_max_distance=0.3,
+        max_sv_size=1000000, window_size=WINDOW, patition_max_distance=5000, cluster_max_distance=0.3,
         batch_size=batch, min_gt_depth=4, homo_thresh=0.8, hete_thresh=0.2, k_size=10, min_accept=50, max_hash_len=1000)
+
+
+def windows_of(name, length):
+    return [(name, pos, min(length, pos + WINDOW)) for pos in range(0, length, WINDOW)]
+
+
+def _simulate_contig(job):
+    """(name, length, coverage, seed) -> (AlignmentTable, genome bytes) of one contig (runs in a forked worker)."""
+    name, length, coverage, seed = job
+    table, genome, _svs = synth.simulate(synth.SimConfig(contigs=[(name, length)], coverage=coverage, seed=seed))
+    return table, genome[name]
+
+
+def build_workload(args, rank, world, cores):
+    """-> (samples: list of (table, fasta) per contig of this rank, windows of this rank, description dict)."""
+    if args.workload == "cfg2":
+        jobs = [("chr21", args.contig_len, args.coverage, 1 + rank)]
+        strong = False
+        total_windows = None
+    else:
+        contigs = list(GRCH38)
+        all_windows = sum(len(windows_of(n, l)) for n, l in contigs)
+        if args.steps and args.steps < all_windows:          # a prefix of every chromosome, same proportions
+            f = args.steps / all_windows
+            contigs = [(n, min(l, max(1, round(len(windows_of(n, l)) * f)) * WINDOW)) for n, l in contigs]
+        shard = sdist.shard_chromosomes([n for n, _l in contigs], [l for _n, l in contigs], world)[rank]
+        jobs = [(n, l, args.coverage, 100 + i) for i, (n, l) in enumerate(contigs) if n in shard]
+        strong = True
+        total_windows = sum(len(windows_of(n, l)) for n, l in contigs)
+    if len(jobs) > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(min(len(jobs), max(1, cores // world))) as pool:     # before the first HIP call
+            made = pool.map(_simulate_contig, jobs, chunksize=1)
+    else:
+        made = [_simulate_contig(j) for j in jobs]
+    parts = [(j[0], j[1], t, g) for j, (t, g) in zip(jobs, made)]
+    windows = [w for name, length, _t, _g in parts for w in windows_of(name, length)]
+    return parts, windows, strong, total_windows
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: run the N ranks under torch.distributed.run and pass rank 0's
+    JSON line through."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=None, help="windows to time (cfg2: per rank, default 200; wg: whole job, default all)")
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", choices=("cfg2", "wg"), default="cfg2")
     ap.add_argument("--batch", type=int, default=64, help="candidate images per CNN batch (BASELINE configs[1])")
     ap.add_argument("--contig-len", type=int, default=CHR21)
     ap.add_argument("--coverage", type=float, default=30.0)
-    ap.add_argument("--workers", type=int, default=16, help="helper processes for the Python host glue (collection, vote)")
-    ap.add_argument("--streams", type=int, default=3, help="HIP streams the per-batch graphs are replayed on")
+    ap.add_argument("--workers", type=int, default=16, help="helper processes per rank for the Python host glue (capped at cores / ranks)")
+    ap.add_argument("--streams", type=int, default=4, help="HIP streams the per-batch graphs are replayed on")
     ap.add_argument("--inflight", type=int, default=6, help="windows enqueued on the device at once")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the per-kernel timings outside the timed region")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
 
-    # order matters: the host helpers are forked before the first HIP call (forking with a live GPU context makes the
-    # driver evict / restore the queues: seconds of stall), then the device scan, then RCCL
-    rank = int(os.environ.get("RANK", "0"))
-
-    # ---- untimed set-up: synthetic sample -> packed arrays -> HBM ----
-    cfg = synth.SimConfig(contigs=[("chr21", args.contig_len)], coverage=args.coverage, seed=1 + rank)
-    table, genome, _svs = synth.simulate(cfg)
+    rank, world = sdist.env_rank()
+    cores = os.cpu_count() or 1
+    workers = max(1, min(args.workers, cores // world))
+    # ---- untimed set-up.  Order matters: everything that forks (simulation pool, CPU-baseline pool, host helpers)
+    # happens before the first HIP call (forking with a live GPU context makes the driver evict / restore the queues)
+    parts, windows, strong, total_windows = build_workload(args, rank, world, cores)
     opts = options_ns(args.batch)
-    fasta = bam.Fasta(sequences=genome)
-    pool = HelperPool(args.workers, opts, table=table, fasta=fasta)
-    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    table = bam.concat_tables([t for _n, _l, t, _g in parts]) if len(parts) > 1 else parts[0][2]
+    fasta = bam.Fasta(sequences={n: g for n, _l, _t, g in parts})
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    cpu_pool = CpuBaselinePool(cores, table, fasta, opts) if want_cpu else None
+    pool = HelperPool(workers, opts, table=table, fasta=fasta)
+    torch.cuda.set_device(sdist.local_device_index())
+    dev = torch.device("cuda", torch.cuda.current_device())
+    rank, world = sdist.init_from_env()
     sample = Sample.from_table(table, fasta, opts.min_sv_size, device=dev)
     pool.attach_scan(sample)
     net = AlexNet(random_weights(0), device=dev)
+    net.executed = torch.zeros(5, dtype=torch.int64, device=dev)     # executed conv pixels per layer + images, summed on the device
     hot = PooledHotPath(sample, opts, net, device=dev, n_streams=args.streams, max_inflight=args.inflight, pool=pool)
-    rank, world = sdist.init_from_env()
-    windows = []
-    pos = 0
-    while pos < args.contig_len:
-        windows.append(("chr21", pos, min(args.contig_len, pos + opts.window_size)))
-        pos += opts.window_size
 
     import torch.distributed as tdist
     grouped = tdist.is_available() and tdist.is_initialized()
@@ -113,8 +176,7 @@ def main():
             tdist.barrier()
         torch.cuda.synchronize()
 
-    def run(n_steps):
-        seq = [windows[i % len(windows)] for i in range(n_steps)]
+    def run(seq):
         sites = images = records = 0
         scores = []
         hot.device_events.clear()
@@ -123,101 +185,101 @@ def main():
             scores += [float(s) for s in res.scores.split()]
         return sites, images, records, scores
 
-    run(args.warmup)
+    if strong:
+        timed = list(windows)                                         # this rank's share of the job
+        steps_job = total_windows
+    else:
+        k = args.steps or 200
+        timed = [windows[i % len(windows)] for i in range(k)]
+        steps_job = k
+    if windows:
+        run([windows[i % len(windows)] for i in range(args.warmup)])
     sync_all()
+    net.executed.zero_()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    sites, images, records, scores = run(args.steps)
+    sites, images, records, scores = run(timed)
     # the single cross-shard exchange of the job: score range + record gather (dist.py)
     sdist.exchange_score_range(scores)
     sdist.gather_texts({"rank%d" % rank: "%d records" % records})
     sync_all()
     dt = time.perf_counter() - t0
 
-    totals = torch.tensor([sites, images, dt], dtype=torch.float64, device=dev)
+    dev_ms = sum(e0.elapsed_time(e1) for e0, e1, _n in hot.device_events)
+    dev_images = sum(n for _e0, _e1, n in hot.device_events)
+    executed = net.executed.cpu().numpy().astype(np.float64)         # [conv2, conv3, conv4, conv5 pixels, images]
+    totals = torch.tensor([sites, images, dt, dev_ms, dev_images] + executed.tolist(), dtype=torch.float64, device=dev)
     if grouped:
         tmax = totals.clone()
         tdist.all_reduce(totals, op=tdist.ReduceOp.SUM)
         tdist.all_reduce(tmax, op=tdist.ReduceOp.MAX)
         dt = float(tmax[2].item())
-    tot_sites, tot_images = float(totals[0].item()), float(totals[1].item())
+    tot = totals.cpu().numpy()
+    tot_sites, tot_images, sum_dev_ms, sum_dev_images = float(tot[0]), float(tot[1]), float(tot[3]), float(tot[4])
+    ex_pix, ex_images = tot[5:9], max(float(tot[9]), 1.0)
 
     B = args.batch
-    active = active_fractions(hot, net, windows[0], dev)
-    dev_ms = sum(e0.elapsed_time(e1) for e0, e1, _n in hot.device_events)
-    dev_images = sum(n for _e0, _e1, n in hot.device_events)
-    hot.close()
-    cnn_tflops = CNN_FLOP * dev_images / (dev_ms * 1e-3) / 1e12
-    ms_batch = dev_ms / max(dev_images / B, 1)
+    frac = {k: float(ex_pix[i] / (ex_images * LAYER_PIX[k])) for i, k in enumerate(("conv2", "conv3", "conv4", "conv5"))}
+    executed_flop = sum(LAYER_FLOP[k] * frac[k] for k in frac) + LAYER_FLOP["fc"]          # per image, every timed batch counted
+    dev_s = sum_dev_ms * 1e-3 / world                                 # mean device time per rank
+    executed_tflops = executed_flop * sum_dev_images / world / max(dev_s, 1e-9) / 1e12
+    ms_batch = sum_dev_ms / max(sum_dev_images / B, 1)
     line = {
         "metric": "candidate SV sites/sec (encode+CNN)",
         "value": tot_sites / dt,
         "unit": "sites/s",
         "n_gpus": world,
-        "steps": args.steps,
+        "steps": steps_job,
         "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3,
+        "ms_per_step": dt / max(steps_job, 1) * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "cfg2 stand-in: synthetic HiFi chr21 (%d bp, N(15kb,2kb) reads, %gx), step = one 10 Mb window, "
-                               "CNN batch = %d candidate images, fp32" % (args.contig_len, args.coverage, B),
-                   "batch": B, "alignments": len(table), "cigar_ops": int(table.cigar.size), "windows": len(windows),
-                   "sites_per_step": sites / args.steps, "images_per_site": images / max(sites, 1),
-                   "images_per_s": tot_images / dt, "host_workers": args.workers, "streams": args.streams, "parallelism": "one process per GPU, chromosome-sized shard per rank, "
-                   "no data-path collective (score-range all_reduce + record gather once)"},
-        "roofline": {"kernel": "device stage per batch of %d images: encode_conv1_kernel (rasterise + sparse conv1) + active-set lists + "
-                               "conv_igemm_kernel x4 (fp32 MFMA, conv2-5 on the active pixels) + pool/LRN epilogues + fc6/fc7 (hipBLASLt) + "
-                               "fc8_softmax_kernel, graph replays on %d streams" % (B, args.streams), "bound": "mfma",
-                     "achieved": cnn_tflops, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
-                     "frac": cnn_tflops * 1e12 / F32_MFMA_PEAK,
-                     "note": "achieved = ALGORITHMIC FLOP of the dense network (SURVEY 8(d): 1.44 GFLOP per image) / device time.  "
-                             "Two exact structural savings execute fewer of them, so frac can exceed 1: the sparse first layer "
-                             "(conv1's 211 MFLOP per image are never issued) and the active-set convolutions (conv2..conv5 compute "
-                             "only the outputs with a line of the image in their receptive field; the rest is the precomputed "
-                             "response to an empty image, bit-identical to the dense result).  executed_* = what the matrix "
-                             "pipe actually ran, from the active fractions of one window.",
-                     "active_fraction": active["fractions"], "executed_flop_per_image": active["executed_flop"],
-                     "executed_tflops": active["executed_flop"] * dev_images / (dev_ms * 1e-3) / 1e12,
-                     "executed_frac": active["executed_flop"] * dev_images / (dev_ms * 1e-3) / F32_MFMA_PEAK,
-                     "traffic": PMC_TRAFFIC_PER_BATCH64 * B / 64 if B == 64 else None,
-                     "traffic_unit": "bytes per batch (rocprofv3 PMC, profiles/r01_pmc_traffic.md; algorithmic minimum ~4.8e8: "
-                                     "227.6 MB weights + activations)", "ms_per_batch": ms_batch,
-                     "device_busy_frac": dev_ms * 1e-3 / dt},
-        "roofline_kernels": kernel_calibration(sample, net, dev, B),
+        "config": {"workload": ("cfg3 stand-in: synthetic whole-genome HiFi, 24 contigs of GRCh38 length (N(15kb,2kb) reads, %gx), "
+                                "chromosomes LPT-sharded over the ranks" % args.coverage) if strong else
+                               ("cfg2 stand-in: synthetic HiFi chr21 (%d bp, N(15kb,2kb) reads, %gx)" % (args.contig_len, args.coverage)),
+                   "step": "one 10 Mb collection window through scan -> collection -> encode + CNN (batches of %d candidate images, fp32) -> vote" % B,
+                   "batch": B, "alignments_rank0": len(table), "cigar_ops_rank0": int(table.cigar.size),
+                   "windows_rank0": len(windows), "sites_per_step": tot_sites / max(steps_job * (1 if strong else world), 1),
+                   "images_per_site": tot_images / max(tot_sites, 1), "images_per_s": tot_images / dt,
+                   "host_workers_per_rank": workers, "host_cores": cores, "streams": args.streams,
+                   "parallelism": "one process per GPU, chromosomes per rank, no data-path collective "
+                                  "(score-range all_reduce + record gather once)"},
+        "roofline": {"kernel": "device stage per batch of %d images (one graph replay): encode_conv1_kernel (rasterise + sparse conv1) + "
+                               "active_counts / active_lists + conv_wave_list_kernel x4 (fp32 MFMA, conv2-5 on the active pixels) + "
+                               "bias_relu_pool_lrn x2 + fc6/fc7 (hipBLASLt) + fc8_softmax_kernel; HIP events on the launch stream "
+                               "around every window of the timed region, %d streams" % (B, args.streams),
+                     "bound": "mfma", "achieved": executed_tflops, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
+                     "frac": executed_tflops * 1e12 / F32_MFMA_PEAK,
+                     "note": "achieved = FLOP the matrix pipe EXECUTED (2 x MAC of the conv2..conv5 outputs actually computed, "
+                             "counted on the device over every timed batch, + fc6..fc8) / device time.  The dense network of "
+                             "SURVEY 8(d) has 1.44 GFLOP per image: algorithmic_tflops counts that; the two exact structural savings "
+                             "(sparse first layer, active-set convolutions; bit-identical to the dense result) are the ratio "
+                             "algorithmic_speedup, not matrix-pipe utilisation.",
+                     "executed_flop_per_image": executed_flop, "active_fraction": {k: round(v, 4) for k, v in frac.items()},
+                     "algorithmic_tflops": CNN_FLOP * sum_dev_images / world / max(dev_s, 1e-9) / 1e12,
+                     "algorithmic_speedup": CNN_FLOP / executed_flop,
+                     "traffic": None,
+                     "traffic_note": "PMC counters cannot be read inside this process; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                     "the same stage are summarised in profiles/r02_pmc_traffic.md",
+                     "ms_per_batch": ms_batch, "batches": sum_dev_images / B, "device_busy_frac": dev_s / dt},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline_windows(sample, opts, windows, net)
+    if rank == 0 and not args.no_calibration:
+        line["roofline_kernels"] = kernel_calibration(hot, sample, net, dev, B, windows[0])
+    hot.close()
+    if cpu_pool is not None:
+        line["cpu_baseline"] = cpu_pool.run(windows)
     if rank == 0:
         print(json.dumps(line))
     if grouped:
         tdist.destroy_process_group()
 
 
-# dense FLOP per image of the layers behind the first one (2 x MAC)
-LAYER_FLOP = {"conv2": 447_897_600, "conv3": 299_040_768, "conv4": 224_280_576, "conv5": 149_520_384, "fc": 109_092_864}
-
-
-def active_fractions(hot, net, window, dev):
-    """Share of conv2..conv5 outputs the active-set path computes, measured on one window's records (untimed)."""
-    res = hot.collect(*window, rescan=False)
-    rec = torch.from_numpy(res.records).to(dev)
-    if not getattr(net, "active", False) or rec.shape[0] == 0:
-        return {"fractions": None, "executed_flop": float(sum(LAYER_FLOP.values()))}
-    _x, touched = kernels.encode_conv1(rec, net.conv1_hwio, net.conv1_base, touched=True)
-    counts = kernels.alexnet_active_sets(touched)[4].cpu().numpy().astype(np.float64)
-    n = rec.shape[0]
-    frac = {"conv2": counts[0] / (n * 729), "conv3": counts[1] / (n * 169), "conv4": counts[2] / (n * 169), "conv5": counts[3] / (n * 169)}
-    executed = sum(LAYER_FLOP[k] * frac[k] for k in frac) + LAYER_FLOP["fc"]
-    return {"fractions": {k: round(float(v), 4) for k, v in frac.items()}, "executed_flop": float(executed)}
-
-
-def kernel_calibration(sample, net, dev, B, reps=20):
-    """Live per-kernel timings of the hand-written kernels (HIP events on the launch stream, eager,
-    outside the timed region) at the sizes the pipeline uses them."""
-    from tests import datagen
-
+def kernel_calibration(hot, sample, net, dev, B, window, reps=20):
+    """Live per-kernel timings (HIP events on the launch stream, eager, outside the timed region) on the workload's own
+    records: the first full batch of one window, each kernel fed with the tensors the stage really hands it."""
     def timed(fn):
         fn()
         torch.cuda.synchronize()
@@ -230,24 +292,65 @@ def kernel_calibration(sample, net, dev, B, reps=20):
         return e0.elapsed_time(e1) / reps * 1e-3
 
     out = {}
-    rec = torch.from_numpy(datagen.random_records(B, seed=7, hostile=False)).to(dev)
-    img = torch.empty((B, 3, 227, 227), dtype=torch.float32, device=dev)
-    t = timed(lambda: kernels.rasterize(rec, layout="NCHW", out=img))
-    out["raster_kernel"] = {"bound": "hbm", "launch": "%d images" % B, "us": t * 1e6, "achieved": IMG_BYTES * B / t / 1e9,
-                            "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": IMG_BYTES * B / t / HBM_PEAK,
-                            "note": "dense image path (BatchGenerator API); the pipeline uses encode_conv1 instead"}
-    big = torch.from_numpy(datagen.random_records(4096, seed=8, hostile=False)).to(dev)
-    big_img = torch.empty((4096, 3, 227, 227), dtype=torch.float32, device=dev)
-    t = timed(lambda: kernels.rasterize(big, layout="NCHW", out=big_img))
-    out["raster_kernel 4096 images"] = {"bound": "hbm", "launch": "4096 images (2.5 GB written)", "us": t * 1e6,
-                                        "achieved": IMG_BYTES * 4096 / t / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                                        "frac": IMG_BYTES * 4096 / t / HBM_PEAK,
-                                        "note": "streaming regime; a bare float4 store stream reaches 5.75 TB/s on this chip"}
-    del big_img
-    t = timed(lambda: kernels.encode_conv1(rec, net.conv1_hwio, net.conv1_base))
-    out["encode_conv1_kernel"] = {"bound": "latency", "launch": "%d images" % B, "us": t * 1e6,
-                                  "note": "rasterise + sparse conv1 + relu + pool + LRN; replaces %.1f MB of image traffic and "
-                                          "13.5 GFLOP of dense conv1 per batch" % (IMG_BYTES * B / 1e6)}
+    res = hot.collect(*window, rescan=False)
+    if res.records.shape[0] < B:
+        return out
+    rec = torch.from_numpy(res.records[:B]).to(dev)
+    saved, net.executed = net.executed, None
+    bg = net.background()
+    x1, touched = kernels.encode_conv1(rec, net.conv1_hwio, net.conv1_base, touched=True)
+    out["encode_conv1_kernel"] = {"bound": "latency", "launch": "%d images" % B,
+                                  "us": timed(lambda: kernels.encode_conv1(rec, net.conv1_hwio, net.conv1_base, touched=True)) * 1e6,
+                                  "note": "rasterise + sparse conv1 + relu + pool + LRN; replaces %.1f MB of image traffic and 13.5 GFLOP "
+                                          "of dense conv1 per batch" % (IMG_BYTES * B / 1e6)}
+    l2, l3, l4, l5, counts = kernels.alexnet_active_sets(touched)
+    out["active_counts + active_lists"] = {"bound": "latency", "launch": "%d images" % B, "us": timed(lambda: kernels.alexnet_active_sets(touched)) * 1e6}
+    cnt = counts.cpu().numpy().astype(np.float64)
+    x = x1
+    for li, (name, lst, bias, relu, groups) in enumerate((("conv2", l2, None, False, 2), ("conv3", l3, net.conv3_b, True, 1),
+                                                          ("conv4", l4, net.conv4_b, True, 2), ("conv5", l5, None, False, 2))):
+        w = getattr(net, name + "_w")
+        fn = lambda x=x, w=w, lst=lst, li=li, bias=bias, relu=relu, groups=groups, name=name: kernels.conv2d_same(       # noqa: E731
+            x, w, bias, groups=groups, relu=relu, pixels=lst, pixel_count=counts[li:li + 1], background=bg[name])
+        t = timed(fn)
+        npix = B * LAYER_PIX[name]
+        computed = npix if cnt[li] * 100 >= npix * 97 else cnt[li]
+        flop = LAYER_FLOP[name] * computed / LAYER_PIX[name]
+        out["conv_wave_list_kernel %s" % name] = {"bound": "mfma", "launch": "%d of %d output pixels active (%d images), %s" % (cnt[li], npix, B, tuple(w.shape)),
+                                                   "us": t * 1e6, "achieved": flop / t / 1e12, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
+                                                   "frac": flop / t / F32_MFMA_PEAK, "note": "executed FLOP of the launch / its duration"}
+        y = fn()
+        tdense = timed(lambda x=x, w=w, bias=bias, relu=relu, groups=groups: kernels.conv2d_same(x, w, bias, groups=groups, relu=relu))
+        out["conv_wave_kernel %s (dense mode, same input)" % name] = {"bound": "mfma", "us": tdense * 1e6, "achieved": LAYER_FLOP[name] * B / tdense / 1e12,
+                                                                      "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": LAYER_FLOP[name] * B / tdense / F32_MFMA_PEAK}
+        if name in ("conv2", "conv5"):
+            b2 = getattr(net, name + "_b")
+            t = timed(lambda y=y, b2=b2, name=name: kernels.bias_relu_pool_lrn(y, b2, lrn=name == "conv2"))
+            out["bias_relu_pool_lrn_kernel %s" % name] = {"bound": "hbm", "us": t * 1e6, "achieved": (y.numel() * 4 + y.numel()) / t / 1e9,
+                                                          "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": (y.numel() * 5) / t / HBM_PEAK,
+                                                          "note": "launch-latency regime (%.1f MB)" % (y.numel() * 5 / 1e6)}
+            x = kernels.bias_relu_pool_lrn(y, b2, lrn=name == "conv2")
+        else:
+            x = y
+    h = x.reshape(B, 9216)
+    t6 = timed(lambda: torch._addmm_activation(net.fc6_b, h, net.fc6_w.t(), use_gelu=False))
+    h6 = torch._addmm_activation(net.fc6_b, h, net.fc6_w.t(), use_gelu=False)
+    t7 = timed(lambda: torch._addmm_activation(net.fc7_b, h6, net.fc7_w.t(), use_gelu=False))
+    wbytes = (net.fc6_w.numel() + net.fc7_w.numel()) * 4
+    out["fc6 + fc7 (hipBLASLt)"] = {"bound": "hbm", "us": (t6 + t7) * 1e6, "achieved": wbytes / (t6 + t7) / 1e9, "peak": HBM_PEAK / 1e9,
+                                    "unit": "GB/s", "frac": wbytes / (t6 + t7) / HBM_PEAK, "note": "218 MB of weights streamed per batch of %d" % B}
+    t = timed(lambda: net.predict_records_packed(rec))
+    out["device_stage_eager_1_stream"] = {"bound": "mfma", "launch": "%d images of the workload" % B, "us": t * 1e6}
+    dense_net = AlexNet(random_weights(0), device=dev, active=False)
+    td = timed(lambda: dense_net.predict_records_packed(rec))
+    out["device_stage_eager_1_stream_dense_convolutions"] = {
+        "bound": "mfma", "launch": "%d images" % B, "us": td * 1e6, "achieved": (CNN_FLOP - 210_830_400) * B / td / 1e12, "peak": F32_MFMA_PEAK / 1e12,
+        "unit": "TFLOP/s", "frac": (CNN_FLOP - 210_830_400) * B / td / F32_MFMA_PEAK,
+        "note": "the same stage with conv2..conv5 computed at every pixel (AlexNet(active=False)); outputs bit-identical; FLOP of "
+                "conv2..fc8 (conv1 is sparse in both)"}
+    del dense_net
+    net.executed = saved
+    # the two memory-bound kernels of the path at streaming sizes
     table = sample.table
     d_cigar, d_off, d_pos, _ = sample.device_buffers
     n = len(table)
@@ -256,96 +359,101 @@ def kernel_calibration(sample, net, dev, B, reps=20):
     alg = 4 * int(table.cigar.size) + 32 * n + 24 * int(sample.gap_off[-1])
     out["cigar_scan (4 kernels)"] = {"bound": "hbm", "launch": "%d alignments, %d ops" % (n, table.cigar.size), "us": t * 1e6,
                                      "achieved": alg / t / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": alg / t / HBM_PEAK}
-    # the dominant kernel: fp32 MFMA implicit-GEMM convolution on the four layer shapes (2 x MAC algorithmic FLOP per launch)
-    for name, cin, cout, hw, k, groups in (("conv2", 96, 256, 27, 5, 2), ("conv3", 256, 384, 13, 3, 1), ("conv4", 384, 384, 13, 3, 2),
-                                           ("conv5", 384, 256, 13, 3, 2)):
-        x = kernels.to_c8(torch.randn(B, cin, hw, hw, device=dev))
-        w = kernels.pack_conv_weights(torch.randn(k, k, cin // groups, cout, device=dev) * 0.05)
-        bias = torch.randn(cout, device=dev)
-        t = timed(lambda: kernels.conv2d_same(x, w, bias, groups=groups, relu=True))
-        flop = 2.0 * B * hw * hw * cout * (cin // groups) * k * k
-        out["conv_igemm_kernel %s" % name] = {"bound": "mfma", "launch": "%d x %d x %d x %d -> %d, %dx%d, %d group(s)" % (B, cin, hw, hw, cout, k, k, groups),
-                                               "us": t * 1e6, "achieved": flop / t / 1e12, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
-                                               "frac": flop / t / F32_MFMA_PEAK}
-    dense_net = AlexNet(random_weights(0), device=dev, active=False)
-    t = timed(lambda: dense_net.predict_records(rec))
-    out["device_stage_eager_1_stream_dense_convolutions"] = {
-        "bound": "mfma", "launch": "%d images" % B, "us": t * 1e6, "achieved": CNN_FLOP * B / t / 1e12, "peak": F32_MFMA_PEAK / 1e12,
-        "unit": "TFLOP/s", "frac": CNN_FLOP * B / t / F32_MFMA_PEAK,
-        "note": "the same stage with conv2..conv5 computed at every pixel (AlexNet(active=False)); outputs bit-identical"}
-    del dense_net
-    t = timed(lambda: net.predict_records(rec))
-    out["device_stage_eager_1_stream"] = {"bound": "mfma", "launch": "%d images" % B, "us": t * 1e6,
-                                          "achieved": CNN_FLOP * B / t / 1e12, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
-                                          "frac": CNN_FLOP * B / t / F32_MFMA_PEAK}
+    nbig = 2048
+    big = torch.from_numpy(np.resize(res.records, (nbig, 12)).astype(np.int32)).to(dev)
+    big_img = torch.empty((nbig, 3, 227, 227), dtype=torch.float32, device=dev)
+    t = timed(lambda: kernels.rasterize(big, layout="NCHW", out=big_img))
+    out["raster_kernel %d images" % nbig] = {"bound": "hbm", "launch": "%d images (%.1f GB written)" % (nbig, IMG_BYTES * nbig / 1e9), "us": t * 1e6,
+                                             "achieved": IMG_BYTES * nbig / t / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                             "frac": IMG_BYTES * nbig / t / HBM_PEAK,
+                                             "note": "dense image path (BatchGenerator API); the pipeline uses encode_conv1 instead"}
     return out
 
 
-def cpu_baseline_windows(sample, opts, windows, gpu_net, min_seconds=12.0, max_windows=3):
-    """cpu_baseline over as many windows as it takes to reach ~10-30 s of CPU work (bounded sample of the same workload)."""
-    parts, sites, seconds = [], 0.0, 0.0
-    for window in windows[:max_windows]:
-        r = cpu_baseline(sample, opts, window, gpu_net)
-        parts.append(r)
-        sites += r["_sites"]
-        seconds += r["_seconds"]
-        if seconds >= min_seconds:
-            break
-    out = {k: v for k, v in parts[0].items() if not k.startswith("_")}
-    out["value"] = sites / seconds
-    out["sample"] = "%d window(s), %.1f sites, %.1f s CPU in total; per window: %s" % (len(parts), sites, seconds, parts[0]["sample"])
-    return out
-
-
-def cpu_baseline(sample, opts, window, gpu_net):
-    """The oracle port of the same step on this box's host cores: C restatement of the scan and of
-    the rasteriser (single thread), plain PyTorch CPU fp32 AlexNet (the reference runs CPU
-    TensorFlow), the same host collection / vote code; timed on a bounded sample (one window's
-    collection, the first sites' images)."""
+# --------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle port of the same step on this box's host cores, as a pool of P = os.cpu_count() single-thread
+# processes (the reference's `-t P`, SVision:261,311), on a bounded sample of the same workload.
+def _cpu_worker(conn, table, fasta, opts):
     import io
     from oracle import cbind
+    from oracle.alexnet_torch import TorchAlexNet
     from svision_amd.collection.output_clusters import collect_pair_lines
     from svision_amd.collection.run_collection import detect_window
     from svision_amd.network.predict import Predict, SiteVoter
-    cores = os.cpu_count() or 1
-    threads = min(cores, 64)
-    torch.set_num_threads(threads)
-    params = {}
-    from oracle.alexnet_torch import TorchAlexNet
-    net = TorchAlexNet(random_weights(0), device="cpu")
-    table = sample.table
-    chrom, start, end = window
-    t0 = time.perf_counter()
-    cbind.cigar_scan(table.cigar, table.cig_off.astype(np.uint64), table.pos, opts.min_sv_size)
-    t_scan = (time.perf_counter() - t0) * (end - start) / max(table.lengths[0], 1)
-    t0 = time.perf_counter()
-    _sigs, clusters = detect_window(opts, sample, chrom, start, end)
-    lines = collect_pair_lines(clusters, opts)
-    t_collect = time.perf_counter() - t0
-    n_sites_window = len({ln.region for ln in lines})
-    # bounded sample: the first sites' images, up to ~20 s of CNN time
-    B = 128                                           # reference default batch (SVision:88)
-    recs = np.asarray([ln.record() for ln in lines], np.int32)
-    done, t_enc_cnn, outs = 0, 0.0, []
-    while done < len(lines) and t_enc_cnn < 20.0:
+    torch.set_num_threads(1)
+    net = None
+    sample = None
+    while True:
+        msg = conn.recv()
+        if msg is None:
+            return
+        chrom, start, end, part, parts, max_images = msg
         t0 = time.perf_counter()
-        x = cbind.rasterize(recs[done:done + B], "NCHW")
-        _l, cls, prob = net.predict(torch.from_numpy(x))
-        t_enc_cnn += time.perf_counter() - t0
-        outs.append((cls.numpy(), prob.numpy()))
-        done = min(len(lines), done + B)
-    t0 = time.perf_counter()
-    voter = SiteVoter(Predict(chrom, None), io.StringIO(), io.StringIO(), opts, sample)
-    voter.feed_batch([ln.label() for ln in lines[:done]], np.concatenate([o[0] for o in outs]), np.concatenate([o[1] for o in outs]))
-    voter.finish()
-    t_vote = time.perf_counter() - t0
-    frac = done / max(len(lines), 1)
-    sites = n_sites_window * frac
-    total = (t_scan + t_collect) * frac + t_enc_cnn + t_vote
-    return {"value": sites / total, "unit": "sites/s", "cores": threads, "kind": "port", "_sites": sites, "_seconds": total,
-            "sample": "first %d of %d images (%.1f sites) of window %s:%d-%d: C oracle scan+rasteriser (1 thread), torch CPU fp32 "
-                      "AlexNet batch %d on %d threads, same host collection/vote code; %.1f s CPU" %
-                      (done, len(lines), sites, chrom, start, end, B, threads, total)}
+        if sample is None:                                    # C oracle scan of the rank's alignments (once per process)
+            scan = cbind.cigar_scan(table.cigar, table.cig_off.astype(np.uint64), table.pos, opts.min_sv_size)
+            sample = Sample.with_scan(table, fasta, opts.min_sv_size, scan)
+            net = TorchAlexNet(random_weights(0), device="cpu")
+        _sigs, clusters = detect_window(opts, sample, chrom, start, end)
+        lines = collect_pair_lines(clusters, opts)
+        regions = []
+        for ln in lines:                                      # this process's share of the window's sites
+            if not regions or regions[-1] != ln.region:
+                regions.append(ln.region)
+        mine = set(regions[part::parts])
+        lines = [ln for ln in lines if ln.region in mine]
+        B = 128                                               # reference default batch (SVision:88)
+        recs = np.asarray([ln.record() for ln in lines], np.int32).reshape(-1, 12)
+        done, outs = 0, []
+        while done < len(lines) and done < max_images:
+            x = cbind.rasterize(recs[done:done + B], "NCHW")
+            _l, cls, prob = net.predict(torch.from_numpy(x))
+            outs.append((cls.numpy(), prob.numpy()))
+            done = min(len(lines), done + B)
+        sites = 0
+        if done:
+            voter = SiteVoter(Predict(chrom, None), io.StringIO(), io.StringIO(), opts, sample)
+            voter.feed_batch([ln.label() for ln in lines[:done]], np.concatenate([o[0] for o in outs]), np.concatenate([o[1] for o in outs]))
+            voter.finish()
+            sites = len({ln.region for ln in lines[:done]})
+        conn.send((sites, done, time.perf_counter() - t0))
+
+
+class CpuBaselinePool:
+    """P forked single-thread processes (forked before the first HIP call; idle until run())."""
+
+    def __init__(self, procs, table, fasta, opts):
+        import multiprocessing as mp
+        ctx = mp.get_context("fork")
+        self.conns, self.procs = [], []
+        for _ in range(procs):
+            a, b = ctx.Pipe(duplex=True)
+            p = ctx.Process(target=_cpu_worker, args=(b, table, fasta, opts), daemon=True)
+            p.start()
+            b.close()
+            self.conns.append(a)
+            self.procs.append(p)
+
+    def run(self, windows, images_per_proc=192):
+        """Every process takes 1/P of the sites of one window (round-robin over the windows) and at most `images_per_proc`
+        of their images: about 10-30 s of wall time; value = sites classified by the pool / wall time."""
+        P = len(self.conns)
+        per_win = max(1, P // max(len(windows), 1))
+        t0 = time.perf_counter()
+        for i, c in enumerate(self.conns):
+            chrom, start, end = windows[(i // per_win) % len(windows)]
+            c.send((chrom, start, end, i % per_win, per_win, images_per_proc))
+        got = [c.recv() for c in self.conns]
+        wall = time.perf_counter() - t0
+        for c in self.conns:
+            c.send(None)
+        for p in self.procs:
+            p.join(timeout=5)
+        sites, images = sum(g[0] for g in got), sum(g[1] for g in got)
+        return {"value": sites / wall, "unit": "sites/s", "cores": P, "kind": "port",
+                "sample": "pool of %d single-thread processes (the reference's -t P, SVision:261,311), each: C oracle scan of the sample "
+                          "(once), host collection of one 10 Mb window, then C oracle rasteriser + PyTorch-CPU fp32 AlexNet (batch 128, "
+                          "1 thread) + vote on its 1/%d share of that window's sites, capped at %d images: %d sites, %d images in %.1f s "
+                          "wall (slowest process %.1f s)" % (P, per_win, images_per_proc, sites, images, wall, max(g[2] for g in got))}
 
 
 if __name__ == "__main__":

@@ -35,6 +35,8 @@ extern "C" {
 #define SVX_GAP_INS       1
 #define SVX_GAP_DEL       2
 
+#define SVX_CONV_DENSE_PCT 97      /* a pixel list this full (percent) is not followed: svx_conv2d_same computes every pixel */
+
 /* "C8" activation layout of the CNN entry points: float32 [image][C/8][H][W][8] -- channel c of pixel (y, x) lives at
  * ((image * C/8 + c/8) * H*W + y*W + x) * 8 + c%8, so the 8 channels of an octet are one 32-byte sector per pixel
  * (C % 8 == 0).  It lets every MFMA operand fetch and every epilogue store of svx_conv2d_same be a 16-byte access of
@@ -118,9 +120,13 @@ int svx_encode_conv1(const int32_t* d_records, uint32_t n, const float* d_w1, co
  * independent background tensor (exactly: every operation is local).
  *   d_list2 [n*729], d_list3 / d_list4 / d_list5 [n*169]: out, permutations of all pixel ids image * H*W + y * W + x:
  *             the active ones first (ascending), then the inactive ones (ascending)
- *   d_counts [4]: out, number of active entries in the four lists;  d_ws: scratch, 16 * n bytes, 16-B aligned */
+ *   d_counts [4]: out, number of active entries in the four lists;  d_ws: scratch, 16 * n bytes, 16-B aligned
+ *   d_totals: NULL, or uint64 [5] running sums the launch ADDS to (never cleared here): [0..4) the output pixels
+ *             svx_conv2d_same computes for conv2..conv5 given these lists (all of them once a list is
+ *             SVX_CONV_DENSE_PCT full), [4] images -- the executed work of a run, for measurement */
 int svx_alexnet_active_sets(const uint32_t* d_touched, uint32_t n, int32_t* d_list2, int32_t* d_list3,
-                            int32_t* d_list4, int32_t* d_list5, uint32_t* d_counts, uint32_t* d_ws, void* stream);
+                            int32_t* d_list4, int32_t* d_list5, uint32_t* d_counts, uint32_t* d_ws,
+                            uint64_t* d_totals, void* stream);
 
 /* Fused conv epilogue: bias add + ReLU + 3x3/2 VALID max-pool (+ TF local response
  * normalisation across channels when lrn != 0), C8 float32 in and out.

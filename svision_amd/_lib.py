@@ -30,7 +30,7 @@ SYMBOLS = {
     "svx_rasterize": (ctypes.c_int, [_vp, _u32, _vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float), _vp]),
     "svx_encode_conv1": (ctypes.c_int, [_vp, _u32, _vp, _vp, _vp, ctypes.c_int, _u32, ctypes.c_float, ctypes.c_float,
                                         ctypes.c_float, _vp, _vp]),
-    "svx_alexnet_active_sets": (ctypes.c_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "svx_alexnet_active_sets": (ctypes.c_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "svx_conv2d_same": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, ctypes.c_int, _vp, _vp, _vp, _vp]),
     "svx_fc8_softmax": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _vp]),
     "svx_bias_relu_pool_lrn": (ctypes.c_int, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, ctypes.c_int, _u32,

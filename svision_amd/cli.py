@@ -175,6 +175,13 @@ def run(options, sample=None, classifier=None):
             from .pipeline import HelperPool
             pool = HelperPool(options.thread_num, options, table=table, fasta=fasta, want_tsv=True)
         _tick("open FASTA, fork helpers")
+        # one process per GPU: every device tensor of this rank (scan buffers, weights, graphs) lives on its own GPU.
+        # The process group comes up now (after the fork, before the first long phase), not when the first rank is done:
+        # a late rendezvous would time out whenever the shards finish far apart.
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.set_device(sdist.local_device_index())
+        sdist.init_from_env()
         sample = _sample.Sample.from_table(table, fasta, options.min_sv_size)
         if pool is not None:
             pool.attach_scan(sample)

@@ -276,7 +276,7 @@ void active_counts_kernel(const uint32_t* __restrict__ touched, uint32_t* __rest
 __global__ __launch_bounds__(BLOCK)
 void active_lists_kernel(const uint32_t* __restrict__ touched, const uint32_t* __restrict__ per_image, uint32_t n,
                          int32_t* __restrict__ list2, int32_t* __restrict__ list3, int32_t* __restrict__ list4,
-                         int32_t* __restrict__ list5, uint32_t* __restrict__ counts)
+                         int32_t* __restrict__ list5, uint32_t* __restrict__ counts, unsigned long long* __restrict__ totals)
 {
     __shared__ uint32_t masks[MASK_ROWS], tmp[A1], rowoff[MASK_ROWS];
     __shared__ uint32_t s_part[8][BLOCK / WAVE];
@@ -307,7 +307,15 @@ void active_lists_kernel(const uint32_t* __restrict__ touched, const uint32_t* _
             rowoff[r] = run; inoff[r] = irun;
             run += c; irun += width - c;
         }
-        if (img == n - 1) counts[t] = total;
+        if (img == n - 1) {
+            counts[t] = total;
+            if (totals) {                                    // running sums over launches (measurement: executed work)
+                const unsigned long long all = (unsigned long long)n * hw;
+                // what svx_conv2d_same will compute: every pixel once the list is SVX_CONV_DENSE_PCT full
+                atomicAdd(&totals[t], (unsigned long long)total * 100ull >= all * SVX_CONV_DENSE_PCT ? all : (unsigned long long)total);
+                if (t == 0) atomicAdd(&totals[4], (unsigned long long)n);
+            }
+        }
     }
     __syncthreads();
     for (int p = t; p < A1 * A1; p += BLOCK) {
@@ -328,14 +336,16 @@ void active_lists_kernel(const uint32_t* __restrict__ touched, const uint32_t* _
 }  // namespace
 
 extern "C" int svx_alexnet_active_sets(const uint32_t* d_touched, uint32_t n, int32_t* d_list2, int32_t* d_list3,
-                                       int32_t* d_list4, int32_t* d_list5, uint32_t* d_counts, uint32_t* d_ws, void* stream)
+                                       int32_t* d_list4, int32_t* d_list5, uint32_t* d_counts, uint32_t* d_ws,
+                                       uint64_t* d_totals, void* stream)
 {
     if (!d_counts) return SVX_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (n == 0) return hipMemsetAsync(d_counts, 0, 4 * sizeof(uint32_t), st) == hipSuccess ? SVX_OK : SVX_ELAUNCH;
     if (!d_touched || !d_list2 || !d_list3 || !d_list4 || !d_list5 || !d_ws || (reinterpret_cast<uintptr_t>(d_ws) & 15u)) return SVX_EINVAL;
     hipLaunchKernelGGL(active_counts_kernel, dim3(n), dim3(64), 0, st, d_touched, d_ws);
-    hipLaunchKernelGGL(active_lists_kernel, dim3(n), dim3(BLOCK), 0, st, d_touched, d_ws, n, d_list2, d_list3, d_list4, d_list5, d_counts);
+    hipLaunchKernelGGL(active_lists_kernel, dim3(n), dim3(BLOCK), 0, st, d_touched, d_ws, n, d_list2, d_list3, d_list4, d_list5, d_counts,
+                       reinterpret_cast<unsigned long long*>(d_totals));
     return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
 }
 

@@ -44,9 +44,6 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int THREADS = 256, WAVES = THREADS / 64;
 constexpr int FILL_PIX = 128, FILL_OCT = 8;       // background copy unit of one workgroup: 128 pixels x 8 octets (64 channels)
 constexpr unsigned OOB = 0x80000000u;             // per-lane byte offset no descriptor covers (tensors are < 2 GB)
-#ifndef SVX_CONV_DENSE_PCT
-#define SVX_CONV_DENSE_PCT 97             // a pixel list this full (percent) is not worth following: every pixel is computed
-#endif
 
 // wave tile shapes (NA x 32 channels, NB x 32 pixels), in order of preference at equal cost.  Measured on MI355X
 // (tools/ab_conv.py, tools/stage_bench.py): two small waves per SIMD cover each other's stalls better than one big wave

@@ -27,8 +27,15 @@ def env_rank():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def init_from_env():
-    """Initialise the process group when launched under torchrun (RANK/WORLD_SIZE set)."""
+def local_device_index():
+    """The GPU of this rank: LOCAL_RANK modulo the visible devices (one process per GPU)."""
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    return int(os.environ.get("LOCAL_RANK", "0")) % n if n else 0
+
+
+def init_from_env(timeout_hours=24.0):
+    """Initialise the process group when launched under torchrun (RANK/WORLD_SIZE set).  Ranks meet only once, at the
+    end of their shards, which can be hours apart (chr1 vs a rank of small contigs): the collective timeout is long."""
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     # SVX_FORCE_DIST=1 initialises the group even for a single rank (exercises the RCCL path on one GPU)
     force = os.environ.get("SVX_FORCE_DIST") == "1" and "RANK" in os.environ
@@ -36,8 +43,9 @@ def init_from_env():
         # SVX_DIST_BACKEND=gloo: several ranks sharing one GPU (1-GPU test boxes; RCCL refuses duplicate devices)
         backend = os.environ.get("SVX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
-        dist.init_process_group(backend)
+            torch.cuda.set_device(local_device_index())
+        import datetime
+        dist.init_process_group(backend, timeout=datetime.timedelta(hours=timeout_hours))
     return world()
 
 

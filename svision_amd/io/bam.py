@@ -214,6 +214,29 @@ class AlignmentTable:
         return np.where(ends >= starts, n_pos_lt_end - n_end_le_start, 0)
 
 
+def concat_tables(tables):
+    """Concatenate coordinate-sorted tables of DISJOINT reference sets (e.g. one per chromosome) into one table whose
+    references are the inputs' references in order (records stay sorted by (tid, pos))."""
+    refs, lens, names = [], [], []
+    tid, pos, flag, mapq, l_seq, nid, cigar, off = [], [], [], [], [], [], [], [np.zeros(1, np.int64)]
+    words = 0
+    for t in tables:
+        if t.seq_packed is not None:
+            raise ValueError("concat_tables does not carry read bases")
+        tid.append(np.where(t.tid >= 0, t.tid + len(refs), t.tid))
+        nid.append(t.name_id + len(names))
+        refs += t.references
+        lens += t.lengths
+        names += list(t.names)
+        pos.append(t.pos); flag.append(t.flag); mapq.append(t.mapq); l_seq.append(t.l_seq); cigar.append(t.cigar)
+        off.append(t.cig_off[1:] + words)
+        words += int(t.cig_off[-1])
+    cat = np.concatenate
+    header = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (r, n) for r, n in zip(refs, lens))
+    return AlignmentTable(refs, lens, cat(tid), cat(pos), cat(flag), cat(mapq), cat(l_seq), cat(nid), names, cat(cigar), cat(off),
+                          header_text=header)
+
+
 def read_bai(path):
     """.bai index -> per reference (first virtual offset, last virtual offset) of its records, or None when the
     reference has none (SAMv1 5.2; the pseudo-bin 37450 carries metadata, not chunks)."""

@@ -156,12 +156,15 @@ def encode_conv1(records, w1_hwio, base, lrn=True, radius=2, alpha=2e-05, beta=0
     return (y, mask) if touched else y
 
 
-def alexnet_active_sets(touched):
+def alexnet_active_sets(touched, totals=None):
     """touched int32 [n,27] (encode_conv1) -> (list2 [n*729], list3, list4, list5 [n*169], counts [4]) int32 device
     tensors: the output pixels of conv2..conv5 that can differ from the response to an empty image.
+    ``totals``: optional int64 device tensor [5] the launch adds its executed pixel counts (conv2..conv5) and image count to.
     See include/svx.h svx_alexnet_active_sets."""
     lib = _lib.load()
     _require_cuda(touched, "touched")
+    if totals is not None and (not totals.is_cuda or totals.dtype != torch.int64 or totals.numel() != 5):
+        raise _lib.SvxError("totals must be an int64 device tensor [5]")
     if touched.dtype != torch.int32 or touched.dim() != 2 or touched.shape[1] != 27:
         raise _lib.SvxError("touched must be int32 [n,27]")
     n, dev = touched.shape[0], touched.device
@@ -169,7 +172,8 @@ def alexnet_active_sets(touched):
     counts = torch.empty(4, dtype=torch.int32, device=dev)
     ws = torch.empty(max(n, 1) * 4, dtype=torch.int32, device=dev)
     rc = lib.svx_alexnet_active_sets(touched.data_ptr(), n, lists[0].data_ptr(), lists[1].data_ptr(), lists[2].data_ptr(),
-                                     lists[3].data_ptr(), counts.data_ptr(), ws.data_ptr(), _stream_ptr(dev))
+                                     lists[3].data_ptr(), counts.data_ptr(), ws.data_ptr(),
+                                     totals.data_ptr() if totals is not None else None, _stream_ptr(dev))
     _lib.check(rc, "svx_alexnet_active_sets")
     return lists[0], lists[1], lists[2], lists[3], counts
 

@@ -72,6 +72,7 @@ class AlexNet(torch.nn.Module):
         validate_params(params)
         self.active = bool(active)
         self._background = None
+        self.executed = None            # optional int64 device tensor [5]: running executed-pixel / image counts (bench)
 
         def f32(a):
             return torch.from_numpy(np.array(a, np.float32, copy=True))
@@ -105,7 +106,7 @@ class AlexNet(torch.nn.Module):
             return kernels.bias_relu_pool_lrn(x, self.conv5_b, lrn=False)
         bg = self.background()
         x, touched = kernels.encode_conv1(records, self.conv1_hwio, self.conv1_base, touched=True)
-        l2, l3, l4, l5, counts = kernels.alexnet_active_sets(touched)
+        l2, l3, l4, l5, counts = kernels.alexnet_active_sets(touched, totals=self.executed)
 
         def conv(name, x, pixels, k, bias, relu, groups):
             # active pixels computed, the others copied from the background by the workgroups behind the compute tiles

@@ -19,12 +19,13 @@ from svision_amd.pipeline import DeviceStage
 
 dev = torch.device("cuda:0")
 B = 64
+G = int(os.environ.get("GROUP", "1"))          # batches of 64 per launch
 L = int(os.environ.get("WINDOW", "6000000"))
 table, genome, _ = synth.simulate(synth.SimConfig(contigs=[("chr21", L)], coverage=30, seed=1))
 sample = Sample.from_table(table, bam.Fasta(sequences=genome), 50, device=dev)
 _s, clusters = detect_window(options_ns(B), sample, "chr21", 0, L)
 lines = collect_pair_lines(clusters, options_ns(B))
-n = (len(lines) // B) * B
+n = (len(lines) // (B * G)) * B * G
 rec = torch.from_numpy(np.asarray([ln.record() for ln in lines[:n]], np.int32)).to(dev)
 print("records", n, "batches", n // B, flush=True)
 net = AlexNet(random_weights(0), device=dev)
@@ -49,7 +50,7 @@ kernels.conv2d_same = hooked
 
 def stage_ms(n_streams, reps=4):
     """median over `reps` passes of the whole record set (each pass = n / B batches)"""
-    st = DeviceStage(net, B, dev, n_streams=n_streams)
+    st = DeviceStage(net, B * G, dev, n_streams=n_streams)
     out = torch.empty((n, 6), device=dev)
     st.run(rec, out)
     torch.cuda.synchronize()
