@@ -176,13 +176,27 @@ def main():
             tdist.barrier()
         torch.cuda.synchronize()
 
+    from svision_amd.pipeline import stitch_windows
+
     def run(seq):
+        """seq: windows in task order (a chromosome's windows contiguous).  Windows complete in any order; a run of
+        consecutive windows of one chromosome is one per-chromosome vote (sites spanning a window boundary are written once)."""
         sites = images = records = 0
         scores = []
         hot.device_events.clear()
+        done = {}
         for res in hot.run_windows(seq):
-            sites += res.n_sites; images += res.n_images; records += res.n_records
-            scores += [float(s) for s in res.scores.split()]
+            sites += res.n_sites; images += res.n_images
+            done[res.wid] = res
+        lo = 0
+        while lo < len(seq):                                           # maximal runs of ascending windows of one chromosome
+            hi = lo + 1
+            while hi < len(seq) and seq[hi][0] == seq[hi - 1][0] and seq[hi][1] == seq[hi - 1][2]:
+                hi += 1
+            for vcf_text, score_text in stitch_windows([done[w] for w in range(lo, hi)], opts, sample).values():
+                records += vcf_text.count("\n")
+                scores += [float(s) for s in score_text.split()]
+            lo = hi
         return sites, images, records, scores
 
     if strong:

@@ -340,10 +340,13 @@ def _run_pooled(options, sample, tasks, chroms, seg_dir, pred_dir, pool=None):
         hot.close()
     if os.environ.get("SVX_TIMING"):
         print("pool up %.3f, windows %.3f, close %.3f" % (_t1 - _t0, _t2 - _t1, _time.time() - _t2), flush=True)
+    from .pipeline import stitch_windows
+    texts = stitch_windows([done[w] for w in range(len(windows))], options, sample)   # per-chromosome vote: edge sites written once
     wid = 0
     for chrom in chroms:
         prefix = os.path.join(pred_dir, "%s.predict.s%s" % (chrom, options.min_support))
         logging.info("Predicting " + chrom)
+        vcf_text, score_text = texts.get(chrom, ("", ""))
         with open(prefix + ".score.txt", "w") as score_out, open(prefix + ".vcf", "w") as vcf_out, \
                 open(os.path.join(seg_dir, chrom + ".segments.all.bed"), "w") as all_bed:
             for _ in tasks[chrom]:
@@ -351,9 +354,9 @@ def _run_pooled(options, sample, tasks, chroms, seg_dir, pred_dir, pool=None):
                 with open(os.path.join(seg_dir, "%s.segments.%d.bed" % (chrom, part_of[wid])), "w") as f:
                     f.write(res.tsv)
                 all_bed.write(res.tsv)
-                vcf_out.write(res.vcf)
-                score_out.write(res.scores)
                 wid += 1
+            vcf_out.write(vcf_text)
+            score_out.write(score_text)
 
 
 def _scores_of(pred_dir, chroms, options):

@@ -30,7 +30,7 @@ def shift_left(ref_seq, ref_start, target_start, target_end):
 
 def cal_overlap_ratio(base, target, left_most, right_most):
     """Fraction of ``base``'s reference span covered by ``target`` (:49-80)."""
-    if base is target:
+    if base.same_value(target):                               # `==` on dicts upstream (:53): a duplicate record counts as itself
         return 0
     if base.ref_start < left_most or base.ref_end > right_most:
         return 1.0
@@ -50,7 +50,7 @@ def trim_segs(segs, first, last):
     left_most = first.ref_end - gap * 2
     right_most = last.ref_start + gap * 2
     for seg in segs:
-        if seg is first:
+        if seg.same_value(first):                             # dict `==` upstream (:102,120,126)
             if seg.ref_start < left_most:
                 seg.q_start += left_most - seg.ref_start
                 seg.ref_start = left_most
@@ -59,10 +59,10 @@ def trim_segs(segs, first, last):
                 seg.ref_start = left_most
                 seg.q_end += grow
                 for other in segs:
-                    if other is not first:
+                    if not other.same_value(first):
                         other.q_start += grow
                         other.q_end += grow
-        elif seg is last:
+        elif seg.same_value(last):
             if seg.ref_end > right_most:
                 seg.q_end -= seg.ref_end - right_most
                 seg.ref_end = right_most
@@ -85,7 +85,7 @@ def _signature(chrom, qname, sig_type, first_bkp, segs, helpers, trim_first, tri
     order, extreme coordinates, trim, Signature."""
     bkps = [first_bkp]
     for seg in segs:
-        if any(seg is h for h in helpers):
+        if any(seg.same_value(h) for h in helpers):           # `align in help_aligns` (:225): by value
             bkps.append([seg.ref_start, seg.ref_end, seg.ref_end - seg.ref_start])
     left = min(b[0] for b in bkps)
     right = max(b[1] for b in bkps)
@@ -244,6 +244,7 @@ def analyze_between_aligns(primary, supplementary, table, options, sample=None):
     if not options.contig and len(supplementary) > 4:
         return [], []
     flag, pos = table.flag, table.pos
+    Seg.table = table
     p_rev = bool(flag[primary] & 0x10)
     qlen = int(table.l_seq[primary])                       # supplementary records inherit the primary's SEQ
     majors, minors, same_strand = [], [], []
@@ -328,7 +329,7 @@ def analyze_inside_align(seg, gaps, options=None, sample=None):
     vrp = seg.q_start
 
     def piece(q0, q1, r0, r1):
-        out.append(Seg(q0, q1, r0, r1, seg.ref_id, False, seg.is_supplementary, "main", seg.qual, seg.aln))
+        out.append(Seg(q0, q1, r0, r1, seg.ref_id, False, seg.is_supplementary, "main", seg.qual, seg.aln, derived=True))
 
     first_ref = int(gaps[0]["ref_pos"])
     m = first_ref - seg.ref_start

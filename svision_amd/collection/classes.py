@@ -13,10 +13,11 @@ comparison is used.
 class Seg:
     """One aligned piece of a read in read/reference coordinates."""
     __slots__ = ("q_start", "q_end", "ref_start", "ref_end", "ref_id", "is_reverse",
-                 "is_supplementary", "type", "qual", "aln", "read_seq")
+                 "is_supplementary", "type", "qual", "aln", "read_seq", "derived")
+    table = None                  # AlignmentTable the `aln` indices point into (set by analyze_between_aligns)
 
     def __init__(self, q_start, q_end, ref_start, ref_end, ref_id, is_reverse,
-                 is_supplementary=False, type=None, qual=0, aln=-1):
+                 is_supplementary=False, type=None, qual=0, aln=-1, derived=False):
         self.q_start, self.q_end = q_start, q_end
         self.ref_start, self.ref_end = ref_start, ref_end
         self.ref_id = ref_id
@@ -26,12 +27,32 @@ class Seg:
         self.qual = qual
         self.aln = aln            # index of the source alignment in the AlignmentTable (-1: synthetic)
         self.read_seq = None      # bases of this piece of the read (--hash only)
+        self.derived = derived    # piece cut out of an alignment (upstream: cigarstring '') rather than a whole record
 
     def copy(self):
         c = Seg(self.q_start, self.q_end, self.ref_start, self.ref_end, self.ref_id, self.is_reverse,
-                self.is_supplementary, self.type, self.qual, self.aln)
+                self.is_supplementary, self.type, self.qual, self.aln, self.derived)
         c.read_seq = self.read_seq
         return c
+
+    def same_value(self, o):
+        """Upstream segments are dicts and are compared BY VALUE (`==`, `in`: analyze_reads.py:53,102,126,225,...), which
+        matters when a BAM holds the same record twice: all fields equal, including the `type` key being set or not
+        (None here), the CIGAR string of whole records ('' for pieces cut out of one) and, implicitly, the read."""
+        if self is o:
+            return True
+        if (self.q_start, self.q_end, self.ref_start, self.ref_end, self.ref_id, self.is_reverse, self.is_supplementary,
+                self.type, self.qual, self.derived, self.aln < 0) != \
+                (o.q_start, o.q_end, o.ref_start, o.ref_end, o.ref_id, o.is_reverse, o.is_supplementary,
+                 o.type, o.qual, o.derived, o.aln < 0):
+            return False
+        if self.derived or self.aln < 0 or self.aln == o.aln:
+            return True
+        t = Seg.table
+        if t is None:
+            return False
+        a, b = t.cigar[t.cig_off[self.aln]:t.cig_off[self.aln + 1]], t.cigar[t.cig_off[o.aln]:t.cig_off[o.aln + 1]]
+        return a.size == b.size and bool((a == b).all())
 
     def __repr__(self):
         return "Seg(q=%d-%d ref=%d-%d rev=%s %s)" % (self.q_start, self.q_end, self.ref_start, self.ref_end,

@@ -97,51 +97,103 @@ class Predict:
 class SiteVoter:
     """The per-image bookkeeping of predict.py:213-300: consumes (label, class, softmax row) in
     TSV order, groups by region, and emits one site through write_results_to_vcf at every
-    region change and at the end."""
+    region change and at the end.
 
-    def __init__(self, predictor, vcf_out, score_out, options, sample):
+    ``hold_edges``: the voter sees ONE collection window of a chromosome.  The reference votes over the concatenation of
+    the windows' TSVs (SVision:284-288 -> predict.py:235-247), where a region string that ends window k and opens
+    window k+1 (reads overlapping the boundary are collected by both, run_collection.py:26) is a single site.  So the
+    first and the last site of the window are not written: their accepted (label, class, score) items are kept in
+    ``head`` / ``tail`` and replayed, in window order, through the chromosome's own voter (:class:`ChromosomeVote`)."""
+
+    def __init__(self, predictor, vcf_out, score_out, options, sample, hold_edges=False):
         self.predictor, self.vcf_out, self.score_out = predictor, vcf_out, score_out
         self.options, self.sample = options, sample
         self.site = _SiteState()
         self.n_sites = 0
+        self.hold_edges, self.head, self.tail, self._seen_first = hold_edges, None, None, False
 
     def feed_batch(self, labels, classes, probs):
-        site = self.site
         classes = np.asarray(classes)
         probs = np.asarray(probs)
         # round(probs[i][cls], 2) of predict.py:270 for the whole batch at once (np.float32.__round__ is np.round)
         scores = np.round(probs[np.arange(len(labels)), classes[:len(labels)].astype(np.int64)], 2) if len(labels) else probs[:0, 0]
-        for i, label in enumerate(labels):
+        self.feed_items(zip(labels, classes, scores))
+
+    def feed_items(self, items):
+        site = self.site
+        for label, cls, score in items:
             if "complement" in label:
                 continue
             f = label.split("svision")
             read_num, region, read_name = f[0], f[1], f[2]
-            cls = int(classes[i])
+            cls = int(cls)
             if f[7] == "True" and cls == 2:                           # :229-231 forward pairs cannot be INV
                 continue
             if region != site.region:
                 if site.region != "":
                     self._flush(site)
                 site = self.site = _SiteState(region)
+            if self.hold_edges:
+                site.items.append((label, cls, score))
             rid = read_num.replace("m", "")
             site.read_names[rid] = read_name
             site.sig_types.append(f[3])
-            site.predict_scores.append(scores[i])
+            site.predict_scores.append(score)
             site.sig_scores[rid] = f[6]
             site.mechanisms[rid] = f[8]
             if "m" not in read_num and cls in (0, 1):                 # :278-280 only main x main pairs call INS/DEL
                 continue
             site.reads.setdefault(rid, {})[cls] = [int(f[4]), int(f[5]), int(f[9])]
 
+    def close_site(self):
+        """Write the open site, if any (the next lines belong to other sites)."""
+        if self.site.region != "":
+            self._flush(self.site)
+        self.site = _SiteState()
+
     def finish(self):
-        self._flush(self.site)
+        if self.hold_edges:
+            if self.site.region != "":
+                if self._seen_first:
+                    self.tail = self.site.items                       # last site of the window: may continue in the next one
+                else:
+                    self.head = self.site.items                       # the window's only site: first and last at once
+                    self.n_sites += 1
+        else:
+            self._flush(self.site)
         self.site = _SiteState()
 
     def _flush(self, site):
         self.n_sites += 1 if site.region != "" else 0
+        if self.hold_edges and not self._seen_first and site.region != "":
+            self._seen_first, self.head = True, site.items            # first site of the window: may continue the previous one
+            return
         write_results_to_vcf(self.vcf_out, self.score_out, self.predictor.get_region_potential_svtypes(site.reads),
                              site.region, site.read_names, site.sig_types, site.sig_scores, site.predict_scores,
                              site.mechanisms, self.options, self.sample)
+
+
+class ChromosomeVote:
+    """One chromosome's vote over per-window results (SiteVoter(hold_edges=True)) delivered in task order: interior
+    sites were written by the window's own voter; the edge sites are replayed here, so a site that spans a window
+    boundary is written once, exactly as a vote over the concatenated TSV writes it."""
+
+    def __init__(self, chrom, vcf_out, score_out, options, sample):
+        self.vcf_out, self.score_out = vcf_out, score_out
+        self.voter = SiteVoter(Predict(chrom, None), vcf_out, score_out, options, sample)
+
+    def add(self, head, vcf_text, score_text, tail):
+        if head:
+            self.voter.feed_items(head)
+        if vcf_text or score_text or tail:
+            self.voter.close_site()
+            self.vcf_out.write(vcf_text)
+            self.score_out.write(score_text)
+            if tail:
+                self.voter.feed_items(tail)
+
+    def finish(self):
+        self.voter.close_site()
 
 
 class _SiteState:
@@ -155,3 +207,4 @@ class _SiteState:
         self.mechanisms = {}
         self.sig_types = []
         self.predict_scores = []
+        self.items = []                  # accepted (label, class, score) of the site (SiteVoter(hold_edges=True) only)

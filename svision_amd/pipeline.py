@@ -36,7 +36,7 @@ _PAD_REC = parse_data_fields(PAD_DATA.split("_"))
 
 class WindowResult:
     __slots__ = ("chrom", "start", "end", "lines", "n_images", "packed", "vcf", "scores", "n_sites", "n_records",
-                 "records", "done_event", "t_device", "wid", "tsv")
+                 "records", "done_event", "t_device", "wid", "tsv", "head", "tail")
 
 
 def _collect_lines(sample, options, chrom, start, end):
@@ -52,15 +52,40 @@ def _collect_lines(sample, options, chrom, start, end):
 
 
 def _vote(sample, options, chrom, lines, classes, probs):
+    """Vote of ONE window: -> (VCF text, score text of its interior sites, n_sites, head, tail).  The first and the last
+    site are returned unwritten (predict.SiteVoter(hold_edges=True)): a site can span the window boundary, and the
+    chromosome's :class:`~svision_amd.network.predict.ChromosomeVote` writes it once, as the reference's vote over the
+    concatenated TSV does (predict.py:235-247)."""
     vcf, score = io.StringIO(), io.StringIO()
-    n_sites = 0
+    n_sites, head, tail = 0, None, None
     if lines:
-        voter = SiteVoter(Predict(chrom, None), vcf, score, options, sample)
+        voter = SiteVoter(Predict(chrom, None), vcf, score, options, sample, hold_edges=True)
         voter.feed_batch([ln.label() for ln in lines], classes, probs)
         voter.finish()
+        head, tail = voter.head, voter.tail
         # candidate sites = distinct region keys of the segment TSV (SURVEY 8(d)), whatever the CNN says
         n_sites = len({ln.region for ln in lines})
-    return vcf.getvalue(), score.getvalue(), n_sites
+    return vcf.getvalue(), score.getvalue(), n_sites, head, tail
+
+
+def stitch_windows(results, options, sample):
+    """WindowResults of any number of chromosomes in task order -> {chrom: (VCF body text, score text)}: the
+    per-chromosome vote over the windows' held-back edge sites and their interior texts."""
+    from .network.predict import ChromosomeVote
+    out, cur, bufs = {}, None, None
+    for res in results:
+        if res.chrom not in out:
+            if cur is not None:
+                cur.finish()
+            bufs = (io.StringIO(), io.StringIO())
+            out[res.chrom] = bufs
+            cur = ChromosomeVote(res.chrom, bufs[0], bufs[1], options, sample)
+        elif out[res.chrom] is not bufs:
+            raise ValueError("windows of %s are not contiguous in task order" % res.chrom)
+        cur.add(res.head, res.vcf, res.scores, res.tail)
+    if cur is not None:
+        cur.finish()
+    return {c: (v.getvalue(), sc.getvalue()) for c, (v, sc) in out.items()}
 
 
 class DeviceStage:
@@ -171,7 +196,7 @@ class HotPath:
 
     def finish(self, res):
         classes, probs = self.fetch_predictions(res)
-        res.vcf, res.scores, res.n_sites = _vote(self.sample, self.options, res.chrom, res.lines, classes, probs)
+        res.vcf, res.scores, res.n_sites, res.head, res.tail = _vote(self.sample, self.options, res.chrom, res.lines, classes, probs)
         res.n_records = res.vcf.count("\n")
         return res
 
@@ -194,7 +219,7 @@ _POOL_STATE = {}
 def _worker_main(conn):
     """Helper process: never touches the GPU.  Protocol on the duplex pipe:
        owner -> ("win", wid, chrom, start, end, scan of the window's rows or None)   helper -> ("rec", wid, records int32[n,12])
-       owner -> ("pred", wid, classes, probs)      helper -> ("done", wid, vcf, scores, n_sites, n_images, tsv)
+       owner -> ("pred", wid, classes, probs)      helper -> ("done", wid, vcf, scores, n_sites, n_images, tsv, head, tail)
        owner -> ("scan", min_sv, gaps.npy, gap_off.npy, stats.npy)   (HelperPool.attach_scan: helpers forked before the scan)
        owner -> ("stop",)"""
     sample, options = _POOL_STATE["sample"], _POOL_STATE["options"]
@@ -220,9 +245,9 @@ def _worker_main(conn):
         elif msg[0] == "pred":
             _t, wid, classes, probs = msg
             chrom, lines = held.pop(wid)
-            vcf, scores, n_sites = _vote(sample, options, chrom, lines, classes, probs)
+            vcf, scores, n_sites, head, tail = _vote(sample, options, chrom, lines, classes, probs)
             tsv = "".join(ln.text() for ln in lines) if _POOL_STATE.get("want_tsv") else None
-            conn.send(("done", wid, vcf, scores, n_sites, len(lines), tsv))
+            conn.send(("done", wid, vcf, scores, n_sites, len(lines), tsv, head, tail))
 
 
 class HelperPool:
@@ -330,11 +355,12 @@ class PooledHotPath(HotPath):
                     res.t_device = None
                     ready.append((ci, res))
                 else:
-                    _t, wid, vcf, scores, n_sites, n_images, tsv = msg
+                    _t, wid, vcf, scores, n_sites, n_images, tsv, head, tail = msg
                     res = WindowResult()
                     res.chrom, res.start, res.end = windows[wid]
                     res.wid, res.tsv = wid, tsv
                     res.vcf, res.scores, res.n_sites, res.n_images = vcf, scores, n_sites, n_images
+                    res.head, res.tail = head, tail
                     res.n_records = vcf.count("\n")
                     del busy[ci]
                     idle.append(ci)

@@ -152,11 +152,11 @@ def _block_bases(rng, ref_bases, ops, lens):
     return np.concatenate(out) if out else np.empty(0, np.uint8)
 
 
-def simulate(cfg, with_genome=True, with_seq=False):
+def simulate(cfg, with_genome=True, with_seq=False, svs=None):
     """-> (AlignmentTable, genome dict or None, svs dict).  ``with_seq``: also synthesise the read bases
     (primary records carry SEQ, as minimap2 writes them; needed for --hash only)."""
     rng = np.random.default_rng(cfg.seed + 2)
-    svs = plant_svs(cfg)
+    svs = plant_svs(cfg) if svs is None else svs          # svs: {contig: [dict(type,pos,len,src,gt)]} planted by hand
     genome = make_genome(cfg) if (with_genome or with_seq) else None
     recs = []          # (tid, pos, flag, mapq, l_seq, name_id, ops, lens[, seq])
     names = []

@@ -40,9 +40,9 @@ def oracle_scan(table, min_sv):
     return cbind.cigar_scan(table.cigar, table.cig_off.astype(np.uint64), table.pos, min_sv)
 
 
-def golden_sample(min_sv=50, device=None):
-    table = bam.read_bam(os.path.join(GOLDEN, "collect_small.bam"))
-    fasta = load_golden_fasta()
+def golden_sample(min_sv=50, device=None, name="collect_small"):
+    table = bam.read_bam(os.path.join(GOLDEN, name + ".bam"))
+    fasta = load_golden_fasta(name + ".fa.gz")
     if device is None:
         return Sample.with_scan(table, fasta, min_sv, oracle_scan(table, min_sv))
     return Sample.from_table(table, fasta, min_sv, device)

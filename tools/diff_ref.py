@@ -41,6 +41,13 @@ def one_case(seed):
                           het_frac=float(rng.choice([0.0, 0.5, 1.0])), seed=int(seed), sv_mix=MIXES[int(rng.integers(0, len(MIXES)))])
     use_hash = bool(rng.random() < 0.2)
     table, genome, _svs = synth.simulate(cfg, with_seq=use_hash)
+    if os.environ.get("DUP_RECORDS") and not use_hash:
+        # duplicate some records verbatim (value-equal segments of one read: analyze_reads.py:225 compares dicts by value)
+        rows = np.arange(len(table))
+        pick = rng.random(len(table)) < float(os.environ["DUP_RECORDS"])
+        if os.environ.get("DUP_ONLY_SUPP"):
+            pick &= (table.flag & 0x800) != 0
+        table = table.subset(np.sort(np.concatenate([rows, rows[pick]]), kind="stable"))
     over = dict(hash=use_hash, min_support=int(rng.choice([1, 2, 3, 5, 8])), min_mapq=int(rng.choice([0, 10, 20, 40])),
                 min_sv_size=int(rng.choice([30, 50, 100])), max_sv_size=int(rng.choice([3000, 1000000])),
                 patition_max_distance=int(rng.choice([500, 5000])), cluster_max_distance=float(rng.choice([0.1, 0.3, 0.6])),
