@@ -167,6 +167,21 @@ int svx_conv2d_same(const float* d_in, const float* d_w_packed, const float* d_b
                     uint32_t groups, int relu, const int32_t* d_pixels, const uint32_t* d_pixel_count,
                     const float* d_background, void* stream);
 
+/* Pairwise signature distances of the clustering step, all partitions of a window in one launch (fp64).
+ * Replaces the Python-callback pdist inside linkage(data, method="average", metric=span_position_distance)
+ * (reference src/collection/cluster_signatures.py:114 with the metric of :132-141):
+ *   d(a, b) = min(|s_a - s_b|, |e_a - e_b|, |floor((s_a+e_a)/2) - floor((s_b+e_b)/2)|) / normalizer
+ *             + |span_a - span_b| / max(span_a, span_b)          (NaN when both spans are 0, as NumPy's 0/0)
+ *   d_start, d_end  [part_off[n_parts]] signature tstart / tend as doubles, partitions concatenated
+ *   d_part_off      [n_parts + 1] first signature of every partition
+ *   d_out_off       [n_parts + 1] first output element of every partition; partition p of n signatures owns
+ *                   n (n - 1) / 2 doubles in scipy's condensed (pdist) order: (0,1), (0,2), ..., (1,2), ...
+ *   total_pairs     = d_out_off[n_parts] (host copy, sizes the grid)
+ *   d_out           [total_pairs] */
+int svx_span_position_distance(const double* d_start, const double* d_end, const uint64_t* d_part_off,
+                               uint32_t n_parts, const uint64_t* d_out_off, uint64_t total_pairs,
+                               double normalizer, double* d_out, void* stream);
+
 /* ---- host side: native BGZF/BAM ingestion (no device work) -------------------------------------------
  * Replaces the per-record pysam iteration of the reference (aln_file.fetch at
  * src/collection/run_collection.py:23-26, field reads at src/collection/collect_signatures.py:128-155):

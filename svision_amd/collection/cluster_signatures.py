@@ -1,12 +1,15 @@
 """Partition + hierarchical clustering of signatures into candidate SV sites.
 
-Host-side mirror of the reference's ``src/collection/cluster_signatures.py``:
+Mirror of the reference's ``src/collection/cluster_signatures.py``:
 ``signature_partition`` :51-66, ``cluster_partitions`` :68-130,
 ``span_position_distance`` :132-141.  The O(n^2) Python-callback ``pdist`` of the
-reference is replaced by the same IEEE-double arithmetic evaluated with NumPy on
-the condensed index pairs; the condensed matrix then goes through the very same
-SciPy ``linkage(method="average")`` / ``fcluster(criterion="distance")`` calls,
-so merge order, labels and therefore site coordinates are unchanged.
+reference is replaced by the same IEEE-double arithmetic: on the device
+(``svx_span_position_distance``, the condensed matrices of all partitions of a window in
+one launch) in the process that owns the GPU, with NumPy on the condensed index pairs in
+the forked host helpers (which never touch the GPU); both are bit-identical to the
+callback.  The condensed matrix then goes through the very same SciPy
+``linkage(method="average")`` / ``fcluster(criterion="distance")`` calls, so merge order,
+labels and therefore site coordinates are unchanged.
 """
 import logging
 
@@ -50,17 +53,40 @@ def span_position_distance_condensed(starts, ends, normalizer=1000):
     return pos + spd
 
 
+def condensed_distances(parts, sample):
+    """[condensed span_position_distance matrix (float64) of every partition in ``parts``] -- one device launch for
+    all of them when the sample lives on a GPU in this process, NumPy otherwise."""
+    if not parts:
+        return []
+    if getattr(sample, "device_buffers", None) is not None:
+        import torch
+        from .. import kernels
+        dev = sample.device_buffers[0].device
+        sizes = np.array([len(p) for p in parts], np.int64)
+        off = np.zeros(sizes.size + 1, np.int64)
+        off[1:] = np.cumsum(sizes)
+        starts = torch.tensor([s.tstart for p in parts for s in p], dtype=torch.float64, device=dev)
+        ends = torch.tensor([s.tend for p in parts for s in p], dtype=torch.float64, device=dev)
+        out, out_off = kernels.span_position_distance(starts, ends, off)
+        host = out.cpu().numpy()
+        return [host[int(out_off[i]):int(out_off[i + 1])] for i in range(len(parts))]
+    return [span_position_distance_condensed([s.tstart for s in p], [s.tend for s in p]) for p in parts]
+
+
 def cluster_partitions(partitions, chrom, sample, options):
     clusters = []
+    kept = []
     for part in partitions:
         if len(part) > 100000:                                # :80-85
             logging.warning("Partition size large than 100,000, ranging from %s:%d-%d", chrom, part[0].tstart, part[-1].tstart)
             continue
+        kept.append(part)
+    dists = iter(condensed_distances([p for p in kept if len(p) > 1], sample))
+    for part in kept:
         if len(part) == 1:
             groups = [part]
         else:
-            y = span_position_distance_condensed([s.tstart for s in part], [s.tend for s in part])
-            z = linkage(y, method="average")
+            z = linkage(next(dists), method="average")
             labels = fcluster(z, options.cluster_max_distance, criterion="distance")
             groups = [[] for _ in range(int(labels.max()))]
             for sig, lab in zip(part, labels):

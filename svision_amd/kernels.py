@@ -226,3 +226,30 @@ def fc8_softmax(x, w_out_in, bias, out=None):
     rc = lib.svx_fc8_softmax(x.data_ptr(), w_out_in.data_ptr(), bias.data_ptr(), out.data_ptr(), n, _stream_ptr(x.device))
     _lib.check(rc, "svx_fc8_softmax")
     return out
+
+
+def span_position_distance(starts, ends, part_off, normalizer=1000.0):
+    """Condensed span_position_distance matrices of several partitions in one launch.
+    starts / ends: float64 device tensors [N] (partitions concatenated); part_off: int sequence [P+1].
+    -> (float64 device tensor [sum n_p (n_p - 1) / 2] in scipy pdist order, out_off numpy uint64 [P+1]).
+    See include/svx.h svx_span_position_distance."""
+    lib = _lib.load()
+    _require_cuda(starts, "starts")
+    _require_cuda(ends, "ends")
+    if starts.dtype != torch.float64 or ends.dtype != torch.float64 or starts.numel() != ends.numel():
+        raise _lib.SvxError("starts / ends must be float64 tensors of one length")
+    part = np.ascontiguousarray(part_off, np.uint64)
+    if part.ndim != 1 or part.size < 1 or int(part[-1]) != starts.numel() or np.any(np.diff(part.astype(np.int64)) < 0):
+        raise _lib.SvxError("part_off must be ascending and end at the number of signatures")
+    sizes = np.diff(part.astype(np.int64))
+    out_off = np.zeros(part.size, np.uint64)
+    out_off[1:] = np.cumsum(sizes * (sizes - 1) // 2)
+    total = int(out_off[-1])
+    out = torch.empty(total, dtype=torch.float64, device=starts.device)
+    if total:
+        d_part = torch.from_numpy(part.view(np.int64)).to(starts.device)
+        d_off = torch.from_numpy(out_off.view(np.int64)).to(starts.device)
+        rc = lib.svx_span_position_distance(starts.data_ptr(), ends.data_ptr(), d_part.data_ptr(), part.size - 1, d_off.data_ptr(), total,
+                                            float(normalizer), out.data_ptr(), _stream_ptr(starts.device))
+        _lib.check(rc, "svx_span_position_distance")
+    return out, out_off

@@ -223,6 +223,8 @@ def _worker_main(conn):
        owner -> ("scan", min_sv, gaps.npy, gap_off.npy, stats.npy)   (HelperPool.attach_scan: helpers forked before the scan)
        owner -> ("stop",)"""
     sample, options = _POOL_STATE["sample"], _POOL_STATE["options"]
+    if sample is not None:
+        sample.device_buffers = None          # a helper forked from a live owner: its copy of the Sample is host-only
     held = {}
     while True:
         msg = conn.recv()

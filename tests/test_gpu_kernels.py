@@ -331,3 +331,55 @@ def test_conv_with_pixel_list_and_background(fill):
         assert torch.equal(got, want)
         if fill == 0.0:
             assert int(counts[li]) == 0
+
+
+def _callback_distance(a, b):
+    """reference cluster_signatures.py:132-141 on double rows, as scipy's pdist hands them to the callback"""
+    span1, span2 = a[1] - a[0], b[1] - b[0]
+    c1, c2 = (a[0] + a[1]) // 2, (b[0] + b[1]) // 2
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return min(abs(a[0] - b[0]), abs(a[1] - b[1]), abs(c1 - c2)) / a[2] + abs(span1 - span2) / max(span1, span2)
+
+
+def test_span_position_distance_matches_the_reference_callback():
+    """svx_span_position_distance (fp64) == the Python callback of the reference, bit for bit: golden partitions (the
+    signatures of the golden sample, partitioned by the product), hostile rows (zero / negative / equal spans, odd sums,
+    huge coordinates), several partitions per launch, and a 10^4-signature partition (5 x 10^7 pairs)."""
+    from scipy.spatial.distance import pdist
+    from svision_amd.collection.cluster_signatures import signature_partition, span_position_distance_condensed
+    from svision_amd.collection.collect_signatures import analyze_alignments
+    from tests import helpers
+    rng = np.random.default_rng(5)
+    parts = []
+    sample = helpers.golden_sample(50, device=DEV)
+    opts = helpers.default_options(min_support=3)
+    for chrom, length in zip(sample.table.references, sample.table.lengths):
+        sigs = analyze_alignments(sample.table.fetch(sample.table.get_tid(chrom), 0, length), sample, opts)
+        parts += [np.array([[s.tstart, s.tend] for s in p], np.float64) for p in signature_partition(sigs, opts) if len(p) > 1]
+    assert len(parts) > 10
+    parts.append(np.array([[5, 5], [7, 7], [5, 5], [0, 11], [11, 0], [3, 10], [2, 9], [1e15, 1e15 + 3], [-7, 8], [-8, 7]], np.float64))
+    parts.append(np.sort(rng.integers(0, 250_000_000, (300, 2)), axis=1).astype(np.float64))
+    parts.append(np.array([[1, 2], [1, 2]], np.float64))
+    big = np.cumsum(rng.integers(0, 40, 10_000))[:, None] + np.array([[0, 0]]) + np.stack([np.zeros(10_000), rng.integers(0, 3000, 10_000)], 1)
+    parts.append(big.astype(np.float64))
+    off = np.zeros(len(parts) + 1, np.int64)
+    off[1:] = np.cumsum([len(p) for p in parts])
+    flat = np.concatenate(parts)
+    out, out_off = kernels.span_position_distance(_dev(flat[:, 0].copy()), _dev(flat[:, 1].copy()), off)
+    out = out.cpu().numpy()
+    for i, p in enumerate(parts):
+        got = out[int(out_off[i]):int(out_off[i + 1])]
+        assert got.size == len(p) * (len(p) - 1) // 2
+        want_np = span_position_distance_condensed(p[:, 0], p[:, 1])
+        assert np.array_equal(got, want_np, equal_nan=True)
+        if len(p) <= 300:                                      # the callback itself, through scipy's pdist
+            data = np.concatenate([p, np.full((len(p), 1), 1000.0)], axis=1)
+            assert np.array_equal(got, pdist(data, metric=_callback_distance), equal_nan=True)
+        else:                                                  # 5 x 10^7 pairs: sampled against the callback
+            n = len(p)
+            for k in rng.integers(0, got.size, 20_000):
+                i0 = int(n - 2 - np.floor(np.sqrt(-8.0 * k + 4.0 * n * (n - 1) - 7) / 2.0 - 0.5))
+                j0 = int(k + i0 + 1 - n * (n - 1) // 2 + (n - i0) * ((n - i0) - 1) // 2)
+                want = _callback_distance(np.array([p[i0, 0], p[i0, 1], 1000.0]), np.array([p[j0, 0], p[j0, 1], 1000.0]))
+                assert got[k] == want or (np.isnan(got[k]) and np.isnan(want))
+    assert np.isnan(out[int(out_off[len(parts) - 4])])         # hostile partition: (5,5) vs (7,7): 0/0
