@@ -182,6 +182,33 @@ int svx_span_position_distance(const double* d_start, const double* d_end, const
                                uint32_t n_parts, const uint64_t* d_out_off, uint64_t total_pairs,
                                double normalizer, double* d_out, void* stream);
 
+/* k-mer seed-and-extend of the --hash re-aligner, a batch of independent jobs per launch (integer-exact).
+ * Replaces the two HashAligner.run passes of hashplot_unmapped (reference src/segmentplot/run_hash_lineplot.py:70-78:
+ * makePairwiseAlignment, extendKmersForward / extendKmersReverse, src/segmentplot/hash_aligner.py:145-239, :37-99) up to
+ * the raw hit lists; the self-repeat filter, the collinear merge and select_longest stay on the host.
+ * Job = (x: the unmapped read piece, y: its reference window), bases packed one per byte as 4-bit symbols:
+ * 0..4 = A C G T N, 5..9 = a c g t n, 10..14 = R Y K M S (upstream's k-mers are raw strings: a symbol matches only
+ * itself, only upper-case ACGT complement to something else than N, only 'N' stops an extension); a sequence with
+ * any other character must be sent down the host path.  For every job the launch writes, in the reference's loop order
+ * (y position ascending, then the k-mer's position list: forward positions ascending, then reverse-strand ones):
+ *   list A  hits of y against itself for the k-mers of y that occur once among y's k-mers of both strands
+ *   list B  hits of x (both strands) on y for the k-mers of y that are not "avoided" (occur once in y)
+ * each hit = int32[4] {y position, x position (forward) or position in the reverse complement, match length, forward}
+ * with length >= window; d_counts[2 j], d_counts[2 j + 1] = the numbers of hits of job j (they may exceed hit_cap:
+ * the lists are then truncated and the caller must redo the job on the host).
+ *   d_table  scratch, 16 bytes per slot, sum of table_slots slots; contents ignored
+ * Requires repeat_thresh = 2 and mismatchNum = 0 (what hashplot_unmapped passes), 2 <= k <= 13, x_len <= max_x_len <= 2048. */
+typedef struct SvxHashJob {
+    uint64_t x_off, y_off;       /* byte offsets of the two sequences in d_bases                      */
+    uint32_t x_len, y_len;
+    uint64_t table_off;          /* first scratch slot of the job                                        */
+    uint32_t table_slots;        /* power of two >= 8 * y_len                                            */
+    uint32_t hit_cap;            /* capacity of each of the job's two hit lists                         */
+    uint64_t hit_off;            /* first hit record of the job: list A at hit_off, list B at + hit_cap */
+} SvxHashJob;
+int svx_hash_seeds(const uint8_t* d_bases, const SvxHashJob* d_jobs, uint32_t n_jobs, uint64_t* d_table,
+                   int32_t* d_hits, uint32_t* d_counts, uint32_t k, uint32_t window, uint32_t max_x_len, void* stream);
+
 /* ---- host side: native BGZF/BAM ingestion (no device work) -------------------------------------------
  * Replaces the per-record pysam iteration of the reference (aln_file.fetch at
  * src/collection/run_collection.py:23-26, field reads at src/collection/collect_signatures.py:128-155):

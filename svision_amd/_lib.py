@@ -36,6 +36,7 @@ SYMBOLS = {
     "svx_bias_relu_pool_lrn": (ctypes.c_int, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, ctypes.c_int, _u32,
                                               ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),
     "svx_span_position_distance": (ctypes.c_int, [_vp, _vp, _vp, _u32, _vp, _u64, ctypes.c_double, _vp, _vp]),
+    "svx_hash_seeds": (ctypes.c_int, [_vp, _vp, _u32, _vp, _vp, _vp, _u32, _u32, _u32, _vp]),
     "svx_bam_open": (_vp, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
     "svx_bam_open_range": (_vp, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, _u64, _u64]),
     "svx_bam_error": (ctypes.c_char_p, []),

@@ -253,3 +253,58 @@ def span_position_distance(starts, ends, part_off, normalizer=1000.0):
                                             float(normalizer), out.data_ptr(), _stream_ptr(starts.device))
         _lib.check(rc, "svx_span_position_distance")
     return out, out_off
+
+
+HASH_MAX_X = 2048
+_BASE_CODE = np.full(256, 255, np.uint8)
+for _i, _c in enumerate(b"ACGTNacgtnRYKMS"):
+    _BASE_CODE[_c] = _i
+HASH_JOB_DTYPE = np.dtype([("x_off", "<u8"), ("y_off", "<u8"), ("x_len", "<u4"), ("y_len", "<u4"), ("table_off", "<u8"),
+                           ("table_slots", "<u4"), ("hit_cap", "<u4"), ("hit_off", "<u8")])
+
+
+def pack_bases(seq):
+    """str / bytes over ACGTN, acgtn (soft-masked references) and RYKMS -> uint8 symbols 0..14, or None when another
+    character occurs (those jobs take the host path, whose k-mers are the raw strings)."""
+    raw = np.frombuffer(seq.encode() if isinstance(seq, str) else bytes(seq), np.uint8)
+    codes = _BASE_CODE[raw]
+    return None if (codes == 255).any() else codes
+
+
+def hash_seeds(jobs, k, window, device):
+    """jobs: list of (x_codes, y_codes) uint8 arrays (pack_bases) -> list of (hits_a, hits_b) int32 arrays [n,4]
+    = {y position, x position or position in x's reverse complement, match length, forward}, or None for a job whose
+    hit lists overflowed.  One launch for the whole batch.  See include/svx.h svx_hash_seeds."""
+    lib = _lib.load()
+    if not jobs:
+        return []
+    dev = torch.device(device)
+    desc = np.zeros(len(jobs), HASH_JOB_DTYPE)
+    parts, off, slots, hit_off = [], 0, 0, 0
+    for j, (x, y) in enumerate(jobs):
+        if len(x) > HASH_MAX_X:
+            raise _lib.SvxError("hash_seeds: piece longer than %d bases" % HASH_MAX_X)
+        t = 1
+        while t < 8 * max(len(y), 1):
+            t <<= 1
+        cap = 4 * len(y) + 64
+        desc[j] = (off, off + len(x), len(x), len(y), slots, t, cap, hit_off)
+        parts += [x, y]
+        off += len(x) + len(y)
+        slots += t
+        hit_off += 2 * cap
+    d_bases = torch.from_numpy(np.concatenate(parts + [np.zeros(16, np.uint8)])).to(dev)
+    d_jobs = torch.from_numpy(desc.view(np.uint8).copy()).to(dev)
+    d_table = torch.empty(slots * 2, dtype=torch.int64, device=dev)
+    d_hits = torch.empty(hit_off * 4, dtype=torch.int32, device=dev)
+    d_counts = torch.empty(2 * len(jobs), dtype=torch.int32, device=dev)
+    rc = lib.svx_hash_seeds(d_bases.data_ptr(), d_jobs.data_ptr(), len(jobs), d_table.data_ptr(), d_hits.data_ptr(), d_counts.data_ptr(),
+                            int(k), int(window), HASH_MAX_X, _stream_ptr(dev))
+    _lib.check(rc, "svx_hash_seeds")
+    counts = d_counts.cpu().numpy().astype(np.int64)
+    hits = d_hits.cpu().numpy().reshape(-1, 4)
+    out = []
+    for j in range(len(jobs)):
+        na, nb, cap, ho = int(counts[2 * j]), int(counts[2 * j + 1]), int(desc[j]["hit_cap"]), int(desc[j]["hit_off"])
+        out.append(None if na > cap or nb > cap else (hits[ho:ho + na], hits[ho + cap:ho + cap + nb]))
+    return out

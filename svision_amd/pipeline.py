@@ -223,6 +223,8 @@ def _worker_main(conn):
        owner -> ("scan", min_sv, gaps.npy, gap_off.npy, stats.npy)   (HelperPool.attach_scan: helpers forked before the scan)
        owner -> ("stop",)"""
     sample, options = _POOL_STATE["sample"], _POOL_STATE["options"]
+    from .segmentplot import run_hash_lineplot
+    run_hash_lineplot.DEVICE = None           # helpers never touch the GPU
     if sample is not None:
         sample.device_buffers = None          # a helper forked from a live owner: its copy of the Sample is host-only
     held = {}

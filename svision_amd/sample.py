@@ -37,6 +37,8 @@ class Sample:
         d_pos = torch.from_numpy(table.pos).to(dev)
         res = kernels.cigar_scan(d_cigar, d_off, d_pos, min_sv)
         gaps, gap_off, stats = res.to_host()
+        from .segmentplot import run_hash_lineplot
+        run_hash_lineplot.DEVICE = dev                       # this process owns a GPU: --hash re-alignment seeds on the device
         return cls(table, fasta, gaps, gap_off, stats, min_sv, device_buffers=(d_cigar, d_off, d_pos, res))
 
     @classmethod
