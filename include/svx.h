@@ -140,6 +140,19 @@ int svx_bias_relu_pool_lrn(const float* d_x, const float* d_bias, float* d_y, ui
                            uint32_t height, uint32_t width, int lrn, uint32_t radius, float alpha, float beta,
                            float k, void* stream);
 
+/* Fully connected layer with bias (+ ReLU) on the fp32 matrix cores: out[m][n] = act(bias[n] + sum_k x[m][k] * W[n][k]).
+ * Replaces tf.nn.xw_plus_b + relu of fc6 / fc7 (reference src/network/alexnet.py:49-55 via :141-155).
+ *   d_x        float32 [m][k] row major
+ *   d_w_packed float32 [n/32][k/8][32][8]: packed[b][q][l][j] = W[32 b + l][8 q + j], W = the checkpoint's
+ *              [k][n] tensor transposed -- packed once per model (a wave's weight loads are one contiguous stream)
+ *   d_out      float32 [m][n]
+ *   d_ws       scratch of svx_fc_ws_bytes(m, n, k) bytes (split-K partial sums, added in fixed order: results are
+ *              bit-reproducible), 16-byte aligned
+ * Requires n % 32 == 0, k % 8 == 0, k >= 192, 16-byte aligned pointers, tensors below 2 GB. */
+size_t svx_fc_ws_bytes(uint32_t m, uint32_t n, uint32_t k);
+int svx_fc_bias_act(const float* d_x, const float* d_w_packed, const float* d_bias, float* d_out, float* d_ws,
+                    uint32_t m, uint32_t n, uint32_t k, int relu, void* stream);
+
 /* fc8 + softmax + argmax in one launch: logits = x @ W^T + b (tf xw_plus_b, src/network/alexnet.py:58,148),
  * tf.nn.softmax and tf.argmax as fetched at src/network/predict.py:209.
  *   d_x [n][4096] fc7 activations, d_w [5][4096] (fc8/weights transposed), d_bias [5]

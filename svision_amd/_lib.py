@@ -32,6 +32,8 @@ SYMBOLS = {
                                         ctypes.c_float, _vp, _vp]),
     "svx_alexnet_active_sets": (ctypes.c_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "svx_conv2d_same": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, ctypes.c_int, _vp, _vp, _vp, _vp]),
+    "svx_fc_ws_bytes": (_sz, [_u32, _u32, _u32]),
+    "svx_fc_bias_act": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, ctypes.c_int, _vp]),
     "svx_fc8_softmax": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _vp]),
     "svx_bias_relu_pool_lrn": (ctypes.c_int, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, ctypes.c_int, _u32,
                                               ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),

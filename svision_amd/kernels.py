@@ -212,6 +212,37 @@ def conv2d_same(x, w_packed, bias=None, groups=1, relu=False, pixels=None, pixel
     return y
 
 
+def pack_fc_weights(w_out_in):
+    """fc weights [out,in] -> [out/32, in/8, 32, 8] (svx_fc_bias_act's d_w_packed)."""
+    n, k = w_out_in.shape
+    if n % 32 or k % 8:
+        raise _lib.SvxError("fc weights need out % 32 == 0 and in % 8 == 0")
+    return w_out_in.reshape(n // 32, 32, k // 8, 8).permute(0, 2, 1, 3).contiguous()
+
+
+def fc_bias_act(x, w_packed, bias, relu=True, out=None, ws=None):
+    """x float32 [m,k], w_packed [n/32,k/8,32,8] (:func:`pack_fc_weights`), bias [n] -> act(x @ W^T + bias) [m,n] on the
+    fp32 matrix cores (split-K wave tiles + ordered reduction).  See include/svx.h svx_fc_bias_act."""
+    lib = _lib.load()
+    for t, nm in ((x, "x"), (w_packed, "w_packed"), (bias, "bias")):
+        _require_cuda(t, nm)
+    if x.dtype != torch.float32 or x.dim() != 2 or w_packed.dim() != 4 or w_packed.shape[2:] != (32, 8) or w_packed.shape[1] * 8 != x.shape[1]:
+        raise _lib.SvxError("x must be float32 [m,k] and w packed [n/32,k/8,32,8]")
+    m, k = x.shape
+    n = w_packed.shape[0] * 32
+    if bias.numel() != n:
+        raise _lib.SvxError("bias must have n entries")
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    need = lib.svx_fc_ws_bytes(m, n, k)
+    if ws is None or ws.numel() * ws.element_size() < need:
+        ws = torch.empty(max(need, 16) // 4, dtype=torch.float32, device=x.device)
+    rc = lib.svx_fc_bias_act(x.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), out.data_ptr(), ws.data_ptr(), m, n, k, 1 if relu else 0,
+                             _stream_ptr(x.device))
+    _lib.check(rc, "svx_fc_bias_act")
+    return out
+
+
 def fc8_softmax(x, w_out_in, bias, out=None):
     """x float32 [n,4096], w float32 [5,4096], bias [5] -> packed float32 [n,12] = softmax[5], class, logits[5], 0.
     See include/svx.h svx_fc8_softmax."""

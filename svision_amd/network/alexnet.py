@@ -12,14 +12,14 @@ layer are one kernel.
     svx_alexnet_active_sets   which outputs of conv2..conv5 can differ from the response to an empty image
     svx_conv2d_same           conv2..conv5 on the fp32 matrix cores, active pixels only (list mode), bias+relu fused
     svx_bias_relu_pool_lrn    conv2 / conv5 epilogues
-    hipBLASLt (torch)         fc6 / fc7 with bias + relu epilogue
+    svx_fc_bias_act           fc6 / fc7 (+ bias + relu) as a weight stream feeding fp32 MFMAs, split-K, ordered reduce
     svx_fc8_softmax           fc8 + softmax + argmax + packing
 
 Parameters keep the checkpoint's names and layouts (``convN/weights`` HWIO,
 ``fcN/weights`` [in,out]) at the ``-m`` boundary and are re-laid out once for the device:
 conv2..5 weights packed for svx_conv2d_same (kernels.pack_conv_weights), fc6 rows
 permuted from the reference's NHWC flatten ((h*6+w)*256+c) to the C8 flatten of pool5
-(((c/8)*36 + h*6+w)*8 + c%8), fc weights stored [out,in].  Activations between the kernels
+(((c/8)*36 + h*6+w)*8 + c%8), fc6 / fc7 weights packed for svx_fc_bias_act, fc8 stored [out,in].  Activations between the kernels
 are in the C8 layout of include/svx.h.  There is no CPU or library fallback: the plain
 PyTorch restatement used as a cross-check lives in oracle/alexnet_torch.py (tests only).
 """
@@ -90,7 +90,8 @@ class AlexNet(torch.nn.Module):
             if name == "fc6":
                 # rows (h,w,c) of the reference's NHWC flatten -> (c/8, h, w, c%8): pool5 is flattened in C8
                 w = w.reshape(6, 6, 32, 8, nout).transpose(2, 0, 1, 3, 4).reshape(nin, nout)
-            self.register_buffer(f"{name}_w", torch.from_numpy(np.ascontiguousarray(w.T)).to(device))       # [out,in]
+            wt = torch.from_numpy(np.ascontiguousarray(w.T))                                              # [out,in]
+            self.register_buffer(f"{name}_w", (kernels.pack_fc_weights(wt) if name != "fc8" else wt).to(device))
             self.register_buffer(f"{name}_b", f32(params[f"{name}/biases"]).to(device))
 
     def _convs(self, records):
@@ -151,8 +152,8 @@ class AlexNet(torch.nn.Module):
         from .. import kernels
         x = self._convs(records)
         x = x.reshape(x.shape[0], 9216)
-        x = torch._addmm_activation(self.fc6_b, x, self.fc6_w.t(), use_gelu=False)       # bias + ReLU in the hipBLASLt epilogue
-        x = torch._addmm_activation(self.fc7_b, x, self.fc7_w.t(), use_gelu=False)
+        x = kernels.fc_bias_act(x, self.fc6_w, self.fc6_b, relu=True)
+        x = kernels.fc_bias_act(x, self.fc7_w, self.fc7_b, relu=True)
         return kernels.fc8_softmax(x, self.fc8_w, self.fc8_b, out=out)
 
     @torch.no_grad()

@@ -383,3 +383,27 @@ def test_span_position_distance_matches_the_reference_callback():
                 want = _callback_distance(np.array([p[i0, 0], p[i0, 1], 1000.0]), np.array([p[j0, 0], p[j0, 1], 1000.0]))
                 assert got[k] == want or (np.isnan(got[k]) and np.isnan(want))
     assert np.isnan(out[int(out_off[len(parts) - 4])])         # hostile partition: (5,5) vs (7,7): 0/0
+
+
+@pytest.mark.parametrize("m,n,k", [(64, 4096, 9216), (64, 4096, 4096), (1, 64, 192), (37, 96, 1000), (130, 128, 2048), (256, 4096, 4096)])
+def test_fc_bias_act_matches_fp64_reference(m, n, k):
+    """fp32 MFMA split-K fc vs an fp64 matmul (tolerance 2e-5 of the output scale: f32 round-off over k <= 9216), ReLU and
+    linear, ragged batch sizes (rows past m must not leak), and bit-reproducibility of the ordered reduction."""
+    rng = np.random.default_rng(m + n + k)
+    x = _dev(rng.standard_normal((m, k)).astype(np.float32))
+    w = _dev((rng.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32))
+    b = _dev(rng.standard_normal(n).astype(np.float32))
+    want = x.double() @ w.double().t() + b.double()
+    wp = kernels.pack_fc_weights(w)
+    got = kernels.fc_bias_act(x, wp, b, relu=False)
+    scale = float(want.abs().max())
+    assert float((got.double() - want).abs().max()) < 2e-5 * scale
+    got_relu = kernels.fc_bias_act(x, wp, b, relu=True)
+    assert torch.equal(got_relu, got.clamp_min(0))
+    assert torch.equal(kernels.fc_bias_act(x, wp, b, relu=False), got)
+    probe = torch.zeros(m, k, device=DEV)                       # one-hot probe: transposition / packing mix-ups
+    probe[m - 1, k - 3] = 2.0
+    hot = kernels.fc_bias_act(probe, wp, torch.zeros(n, device=DEV), relu=False)
+    ref = torch.zeros(m, n, device=DEV)
+    ref[m - 1] = 2.0 * w[:, k - 3]
+    assert torch.equal(hot, ref)
