@@ -47,6 +47,17 @@ def hooked(x, w, bias=None, groups=1, **kw):
 
 kernels.conv2d_same = hooked
 
+if os.environ.get("FC") == "blaslt":             # A/B: the vendor GEMM instead of svx_fc_bias_act (same box, same run)
+    _unpacked = {}
+
+    def fc_lt(x, w_packed, bias, relu=True, out=None, ws=None):
+        key = w_packed.data_ptr()
+        if key not in _unpacked:
+            nb, kq = w_packed.shape[0], w_packed.shape[1]
+            _unpacked[key] = w_packed.permute(0, 2, 1, 3).reshape(nb * 32, kq * 8).contiguous()
+        return torch._addmm_activation(bias, x, _unpacked[key].t(), use_gelu=False)
+    kernels.fc_bias_act = fc_lt
+
 
 def stage_ms(n_streams, reps=4):
     """median over `reps` passes of the whole record set (each pass = n / B batches)"""
