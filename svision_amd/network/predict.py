@@ -105,12 +105,16 @@ class SiteVoter:
     first and the last site of the window are not written: their accepted (label, class, score) items are kept in
     ``head`` / ``tail`` and replayed, in window order, through the chromosome's own voter (:class:`ChromosomeVote`)."""
 
-    def __init__(self, predictor, vcf_out, score_out, options, sample, hold_edges=False):
+    def __init__(self, predictor, vcf_out, score_out, options, sample, hold_edges=False, hold_range=None):
         self.predictor, self.vcf_out, self.score_out = predictor, vcf_out, score_out
         self.options, self.sample = options, sample
         self.site = _SiteState()
         self.n_sites = 0
         self.hold_edges, self.head, self.tail, self._seen_first = hold_edges, None, None, False
+        # hold_range = (lo, hi): an edge site is only held back when it can reach into the neighbouring window -- the
+        # first site when its start is <= lo, the last one when its end is >= hi (pipeline._vote derives both from the
+        # longest alignment of the sample); any other edge site is written at once like an interior one
+        self.hold_range = hold_range
 
     def feed_batch(self, labels, classes, probs):
         classes = np.asarray(classes)
@@ -151,23 +155,36 @@ class SiteVoter:
             self._flush(self.site)
         self.site = _SiteState()
 
+    @staticmethod
+    def _span(region):
+        f = region.split("+")
+        return int(f[1]), int(f[2])
+
     def finish(self):
-        if self.hold_edges:
-            if self.site.region != "":
-                if self._seen_first:
+        if self.hold_edges and self.site.region != "":
+            lo, hi = self.hold_range if self.hold_range is not None else (float("inf"), float("-inf"))
+            start, end = self._span(self.site.region)
+            if self._seen_first:
+                if end >= hi:
                     self.tail = self.site.items                       # last site of the window: may continue in the next one
                 else:
-                    self.head = self.site.items                       # the window's only site: first and last at once
-                    self.n_sites += 1
-        else:
+                    self._flush(self.site)
+            elif start <= lo or end >= hi:
+                self.head = self.site.items                           # the window's only site: first and last at once
+                self.n_sites += 1
+            else:
+                self._flush(self.site)
+        elif not self.hold_edges:
             self._flush(self.site)
         self.site = _SiteState()
 
     def _flush(self, site):
         self.n_sites += 1 if site.region != "" else 0
         if self.hold_edges and not self._seen_first and site.region != "":
-            self._seen_first, self.head = True, site.items            # first site of the window: may continue the previous one
-            return
+            self._seen_first = True
+            if self.hold_range is None or self._span(site.region)[0] <= self.hold_range[0]:
+                self.head = site.items                                # first site of the window: may continue the previous one
+                return
         write_results_to_vcf(self.vcf_out, self.score_out, self.predictor.get_region_potential_svtypes(site.reads),
                              site.region, site.read_names, site.sig_types, site.sig_scores, site.predict_scores,
                              site.mechanisms, self.options, self.sample)

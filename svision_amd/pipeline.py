@@ -51,15 +51,32 @@ def _collect_lines(sample, options, chrom, start, end):
         return []
 
 
-def _vote(sample, options, chrom, lines, classes, probs):
-    """Vote of ONE window: -> (VCF text, score text of its interior sites, n_sites, head, tail).  The first and the last
-    site are returned unwritten (predict.SiteVoter(hold_edges=True)): a site can span the window boundary, and the
-    chromosome's :class:`~svision_amd.network.predict.ChromosomeVote` writes it once, as the reference's vote over the
-    concatenated TSV does (predict.py:235-247)."""
+def edge_margin(sample):
+    """A site farther than this from a window boundary cannot be collected by the neighbouring window as well: a
+    cluster reported by a window is built from records that overlap that window, and a signature's coordinates stay
+    within the reference span of its records plus one read length (inserted / re-placed pieces)."""
+    m = getattr(sample, "_edge_margin", None)
+    if m is None:
+        t = sample.table
+        m = sample._edge_margin = (int(t.ref_span.max()) + int(t.l_seq.max()) + 1000) if len(t) else 0
+    return m
+
+
+def _vote(sample, options, chrom, lines, classes, probs, start=None, end=None):
+    """Vote of ONE window [start, end): -> (VCF text, score text of its interior sites, n_sites, head, tail).  The first /
+    last site is returned unwritten (predict.SiteVoter(hold_edges=True)) when it lies within :func:`edge_margin` of the
+    window's start / end and a neighbouring window exists: such a site can span the boundary, and the chromosome's
+    :class:`~svision_amd.network.predict.ChromosomeVote` writes it once, as the reference's vote over the concatenated
+    TSV does (predict.py:235-247)."""
     vcf, score = io.StringIO(), io.StringIO()
     n_sites, head, tail = 0, None, None
     if lines:
-        voter = SiteVoter(Predict(chrom, None), vcf, score, options, sample, hold_edges=True)
+        hold = None
+        if start is not None:
+            m = edge_margin(sample)
+            clen = sample.table.lengths[sample.table.get_tid(chrom)]
+            hold = (start + m if start > 0 else float("-inf"), end - m if end < clen else float("inf"))
+        voter = SiteVoter(Predict(chrom, None), vcf, score, options, sample, hold_edges=True, hold_range=hold)
         voter.feed_batch([ln.label() for ln in lines], classes, probs)
         voter.finish()
         head, tail = voter.head, voter.tail
@@ -196,7 +213,7 @@ class HotPath:
 
     def finish(self, res):
         classes, probs = self.fetch_predictions(res)
-        res.vcf, res.scores, res.n_sites, res.head, res.tail = _vote(self.sample, self.options, res.chrom, res.lines, classes, probs)
+        res.vcf, res.scores, res.n_sites, res.head, res.tail = _vote(self.sample, self.options, res.chrom, res.lines, classes, probs, res.start, res.end)
         res.n_records = res.vcf.count("\n")
         return res
 
@@ -243,13 +260,13 @@ def _worker_main(conn):
             if scan is not None:
                 sample.apply_window_scan(*scan)
             lines = _collect_lines(sample, options, chrom, start, end)
-            held[wid] = (chrom, lines)
+            held[wid] = (chrom, lines, start, end)
             recs = np.asarray([ln.record() for ln in lines], np.int32).reshape(-1, 12)
             conn.send(("rec", wid, recs))
         elif msg[0] == "pred":
             _t, wid, classes, probs = msg
-            chrom, lines = held.pop(wid)
-            vcf, scores, n_sites, head, tail = _vote(sample, options, chrom, lines, classes, probs)
+            chrom, lines, start, end = held.pop(wid)
+            vcf, scores, n_sites, head, tail = _vote(sample, options, chrom, lines, classes, probs, start, end)
             tsv = "".join(ln.text() for ln in lines) if _POOL_STATE.get("want_tsv") else None
             conn.send(("done", wid, vcf, scores, n_sites, len(lines), tsv, head, tail))
 
