@@ -183,7 +183,7 @@ def main():
         consecutive windows of one chromosome is one per-chromosome vote (sites spanning a window boundary are written once)."""
         sites = images = records = 0
         scores = []
-        hot.device_events.clear()
+        hot.reset_timing()
         done = {}
         for res in hot.run_windows(seq):
             sites += res.n_sites; images += res.n_images
@@ -219,8 +219,8 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
 
-    dev_ms = sum(e0.elapsed_time(e1) for e0, e1, _n in hot.device_events)
-    dev_images = sum(n for _e0, _e1, n in hot.device_events)
+    dev_ms = hot.device_busy_ms()            # time with at least one batch in flight (HIP events on the batches' streams)
+    dev_images = hot.device_images
     executed = net.executed.cpu().numpy().astype(np.float64)         # [conv2, conv3, conv4, conv5 pixels, images]
     totals = torch.tensor([sites, images, dt, dev_ms, dev_images] + executed.tolist(), dtype=torch.float64, device=dev)
     if grouped:
@@ -263,8 +263,8 @@ def main():
                                   "(score-range all_reduce + record gather once)"},
         "roofline": {"kernel": "device stage per batch of %d images (one graph replay): encode_conv1_kernel (rasterise + sparse conv1) + "
                                "active_counts / active_lists + conv_wave_list_kernel x4 (fp32 MFMA, conv2-5 on the active pixels) + "
-                               "bias_relu_pool_lrn x2 + fc_splitk / fc_reduce x2 (fc6, fc7) + fc8_softmax_kernel; HIP events on the launch stream "
-                               "around every window of the timed region, %d streams" % (B, args.streams),
+                               "bias_relu_pool_lrn x2 + fc_splitk / fc_reduce x2 (fc6, fc7) + fc8_softmax_kernel; HIP events on the batch's stream "
+                               "around every batch of the timed region, device time = union of the intervals, %d streams" % (B, args.streams),
                      "bound": "mfma", "achieved": executed_tflops, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                      "frac": executed_tflops * 1e12 / F32_MFMA_PEAK,
                      "note": "achieved = FLOP the matrix pipe EXECUTED (2 x MAC of the conv2..conv5 outputs actually computed, "

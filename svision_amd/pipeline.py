@@ -132,29 +132,56 @@ class DeviceStage:
     def _body(self, rec, out):
         self.net.predict_records_packed(rec, out=out)        # no image tensor: encoding is fused into the first layer
 
-    def run(self, d_rec, out):
+    def run(self, d_rec, out, after=None, timing=None):
         """d_rec: int32 [n_padded,12] on the device (n_padded % batch == 0); out: float32 [n_padded,6].
-        Enqueues everything asynchronously; the caller's current stream waits for the side streams."""
+        Enqueues everything asynchronously.
+
+        ``after is None``: the side streams wait for the caller's current stream and that stream waits for them
+        afterwards (simple, but consecutive calls are separated by a full drain of all streams).
+        ``after`` = an event behind which ``d_rec`` is valid: the side streams wait for it only, nothing waits for them;
+        returned are the events (one per stream used) behind which ``out`` is complete -- consecutive calls flow into
+        each other, batch after batch, with no drain between two windows.  ``timing``: list that receives one
+        (start, end) event pair per batch, recorded on the batch's stream."""
         main = torch.cuda.current_stream(self.device)
         used = set()
         b = self.batch
-        for i, lo in enumerate(range(0, d_rec.shape[0], b)):
-            k = i % len(self.streams)
+        n_streams = len(self.streams)
+        for lo in range(0, d_rec.shape[0], b):
+            k = self._next = (getattr(self, "_next", -1) + 1) % n_streams     # round-robin continues across calls
             s = self.streams[k]
             rec, o, graph = self.slots[k]
             if k not in used:
-                s.wait_stream(main)
+                if after is None:
+                    s.wait_stream(main)
+                else:
+                    s.wait_event(after)
                 used.add(k)
             with torch.cuda.stream(s):
+                if timing is not None:
+                    t0 = torch.cuda.Event(enable_timing=True)
+                    t0.record()
                 rec.copy_(d_rec[lo:lo + b], non_blocking=True)
                 if graph is not None:
                     graph.replay()
                 else:
                     self._body(rec, o)
                 out[lo:lo + b].copy_(o[:, :6], non_blocking=True)
+                if timing is not None:
+                    t1 = torch.cuda.Event(enable_timing=True)
+                    t1.record()
+                    timing.append((t0, t1))
+        if after is None:
+            for k in used:
+                main.wait_stream(self.streams[k])
+            return out
+        done = []
         for k in used:
-            main.wait_stream(self.streams[k])
-        return out
+            ev = torch.cuda.Event()
+            ev.record(self.streams[k])
+            done.append(ev)
+            d_rec.record_stream(self.streams[k])
+            out.record_stream(self.streams[k])
+        return done
 
 
 class HotPath:
@@ -166,7 +193,9 @@ class HotPath:
         self.device = torch.device(device)
         self.batch = options.batch_size
         self.stage = DeviceStage(net, self.batch, self.device, n_streams, use_graph)
-        self.device_events = []          # (start, end, n_images_padded) per window, on the launch stream
+        self.batch_events = []           # (start, end) event pair of every batch, on the batch's stream
+        self.device_images = 0           # images (padding included) launched since reset_timing()
+        self._t_ref = None
 
     def collect(self, chrom, start, end, rescan=True):
         res = WindowResult()
@@ -185,8 +214,18 @@ class HotPath:
         res.records = np.empty((0, 12), np.int32)
         return res
 
+    def _pinned(self, rows):
+        """A pinned host buffer of at least ``rows`` x 6 floats from a small free list (hipHostMalloc is slow)."""
+        pool = self.__dict__.setdefault("_pinned_free", [])
+        for i, buf in enumerate(pool):
+            if buf.shape[0] >= rows:
+                return pool.pop(i)
+        return torch.empty((max(rows, 4096), 6), dtype=torch.float32, pin_memory=True)
+
     def launch(self, res):
-        """Enqueue encode + CNN for the window's records; returns immediately."""
+        """Enqueue encode + CNN for the window's records and the copy of the packed predictions to pinned host memory on
+        a stream of its own; returns immediately.  Nothing here -- and nothing in :meth:`fetch_predictions` -- synchronises
+        with the launch stream: a blocking read-back there would wait for every window queued behind this one."""
         n = res.n_images
         res.t_device = None
         if n == 0:
@@ -195,19 +234,50 @@ class HotPath:
         recs = np.concatenate([res.records, np.tile(np.asarray(_PAD_REC, np.int32), (pad, 1))]) if pad else res.records
         d_rec = torch.from_numpy(np.ascontiguousarray(recs)).to(self.device, non_blocking=True)
         out = torch.empty((n + pad, 6), dtype=torch.float32, device=self.device)
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        self.stage.run(d_rec, out)
-        e1.record()
-        res.packed, res.done_event, res.t_device = out, e1, (e0, e1)
-        self.device_events.append((e0, e1, n + pad))
+        up = torch.cuda.Event(enable_timing=True)
+        up.record()                                                   # behind the upload of the records
+        if getattr(self, "_t_ref", None) is None:
+            self._t_ref = up                                          # time origin of batch_events
+        done = self.stage.run(d_rec, out, after=up, timing=self.batch_events)
+        if getattr(self, "_d2h", None) is None:
+            self._d2h = torch.cuda.Stream(device=self.device)
+        host = self._pinned(n + pad)
+        e2 = torch.cuda.Event()
+        with torch.cuda.stream(self._d2h):
+            for ev in done:
+                self._d2h.wait_event(ev)
+            host[:n + pad].copy_(out, non_blocking=True)
+            e2.record()
+        out.record_stream(self._d2h)
+        res.packed, res.done_event, res.t_device = host, e2, None
+        self.device_images += n + pad
         return res
+
+    def device_busy_ms(self):
+        """Milliseconds during which at least one batch was in flight on the device since the last reset_timing()
+        (union of the per-batch [start, end] intervals recorded on the streams; call after a synchronize)."""
+        if not self.batch_events:
+            return 0.0
+        ref = self._t_ref
+        iv = sorted((ref.elapsed_time(a), ref.elapsed_time(b)) for a, b in self.batch_events)
+        busy, cur_lo, cur_hi = 0.0, iv[0][0], iv[0][1]
+        for lo, hi in iv[1:]:
+            if lo > cur_hi:
+                busy += cur_hi - cur_lo
+                cur_lo, cur_hi = lo, hi
+            else:
+                cur_hi = max(cur_hi, hi)
+        return busy + (cur_hi - cur_lo)
+
+    def reset_timing(self):
+        self.batch_events, self.device_images, self._t_ref = [], 0, None
 
     def fetch_predictions(self, res):
         if res.n_images == 0:
             return np.empty(0, np.int64), np.empty((0, 5), np.float32)
-        packed = res.packed.cpu().numpy()[:res.n_images]
+        res.done_event.synchronize()                                  # the copy stream's event: normally already complete
+        packed = res.packed[:res.n_images].numpy().copy()
+        self._pinned_free.append(res.packed)
         res.packed = None
         return packed[:, 5].astype(np.int64), packed[:, :5]
 

@@ -69,8 +69,13 @@ class Sample:
             return 0
         d_cigar, d_off, d_pos, _ = self.device_buffers
         cap = int(self.gap_off[hi] - self.gap_off[lo])
-        res = kernels.cigar_scan(d_cigar, d_off[lo:hi + 1], d_pos[lo:hi], self.min_sv, gaps_cap=max(cap, 16))
-        gaps, gap_off, stats = res.to_host()
+        # own stream: the result is read back synchronously, and on the default stream that read-back would wait for every
+        # CNN batch queued before it (the pipeline's side streams join the default stream after each window)
+        if getattr(self, "_scan_stream", None) is None:
+            self._scan_stream = torch.cuda.Stream(device=d_cigar.device)
+        with torch.cuda.stream(self._scan_stream):
+            res = kernels.cigar_scan(d_cigar, d_off[lo:hi + 1], d_pos[lo:hi], self.min_sv, gaps_cap=max(cap, 16))
+            gaps, gap_off, stats = res.to_host()
         if int(gap_off[-1]) != cap or not np.array_equal(gap_off.astype(np.int64) + self.gap_off[lo], self.gap_off[lo:hi + 1]):
             raise RuntimeError("window rescan disagrees with the resident scan")
         gaps = gaps.copy()
