@@ -56,6 +56,9 @@ typedef struct SvxGap {
 
 int         svx_version(void);
 const char* svx_strerror(int code);
+/* host: crc32c (Castagnoli) of a buffer -- the tensor / block checksums of the -m checkpoint (predict.py:181-184's
+ * Saver().restore verifies them inside TensorFlow) */
+uint32_t    svx_crc32c(const void* data, size_t n);
 
 /* Bytes of device scratch svx_cigar_scan needs for n_aln alignments. */
 size_t svx_cigar_scan_ws_bytes(uint32_t n_aln);

@@ -518,7 +518,18 @@ class Fasta:
         self._map = mmap.mmap(self._file.fileno(), 0, access=mmap.ACCESS_READ)
         mm = self._map
         fai = path + ".fai"
-        if os.path.exists(fai) and os.path.getmtime(fai) >= os.path.getmtime(path):
+        compressed = mm[:2] == b"\x1f\x8b"
+        if compressed:
+            # gzip / bgzip FASTA (pysam.FastaFile reads bgzip): inflate once into memory and index the text; the .fai of a
+            # bgzip file describes the uncompressed text, so it stays valid.  (Random access through a .gzi is not needed:
+            # every contig a rank works on is read in full anyway.)
+            import gzip
+            with gzip.open(path, "rb") as gz:
+                mm = self._map = gz.read()
+            size = len(mm)
+            if size == 0:
+                return
+        if os.path.exists(fai) and (compressed or os.path.getmtime(fai) >= os.path.getmtime(path)):
             with open(fai) as f:                       # name, length, offset, bases per line, bytes per line (faidx)
                 for line in f:
                     p = line.rstrip("\n").split("\t")

@@ -108,11 +108,27 @@ def _mask_crc(c):
     return (((c >> 15) | (c << 17)) + 0xA282EAD8) & 0xFFFFFFFF
 
 
+def _crc32c_fast(buf):
+    """crc32c through libsvx.so (slicing-by-8) when it is built, the Python loop otherwise (index blocks are tiny)."""
+    try:
+        from .. import _lib
+        lib = _lib.load()
+    except Exception:                                         # noqa: BLE001 -- library not built: CPU-only tooling
+        return _crc32c(bytes(buf))
+    a = np.ascontiguousarray(np.frombuffer(buf, np.uint8))
+    return int(lib.svx_crc32c(a.ctypes.data, a.size))
+
+
 # ---------------------------------------------------------------- SSTable
 def _read_block(data, off, size):
     if data[off + size] != 0:
         raise ValueError("compressed SSTable blocks are not supported (type %d)" % data[off + size])
     blk = data[off:off + size]
+    if len(data) < off + size + 5:
+        raise ValueError("truncated SSTable block")
+    stored = struct.unpack_from("<I", data, off + size + 1)[0]
+    if stored != _mask_crc(_crc32c(data[off:off + size + 1])):
+        raise ValueError("corrupt checkpoint index: block checksum mismatch at offset %d" % off)
     n_restarts = struct.unpack_from("<I", blk, size - 4)[0]
     end = size - 4 - 4 * n_restarts
     entries, key, p = [], b"", 0
@@ -150,7 +166,7 @@ def read_index(prefix):
             else:
                 out[key.decode()] = {"dtype": msg.get(1, [0])[0], "shape": _parse_shape(msg.get(2, [b""])[0]),
                                      "shard_id": msg.get(3, [0])[0], "offset": msg.get(4, [0])[0],
-                                     "size": msg.get(5, [0])[0]}
+                                     "size": msg.get(5, [0])[0], "crc32c": msg.get(6, [0])[0]}
     return out
 
 
@@ -174,8 +190,13 @@ def read_checkpoint(prefix, names=None):
         if sid not in shards:
             path = "%s.data-%05d-of-%05d" % (prefix, sid, header["num_shards"])
             shards[sid] = np.memmap(path, dtype=np.uint8, mode="r")
-        raw = shards[sid][e["offset"]:e["offset"] + e["size"]]
-        arr = np.frombuffer(raw.tobytes(), dtype=_DTYPES[e["dtype"]]).reshape(e["shape"])
+        if e["offset"] + e["size"] > shards[sid].size:
+            raise ValueError("checkpoint shard %d is truncated: tensor %s needs bytes %d..%d of %d"
+                             % (sid, name, e["offset"], e["offset"] + e["size"], shards[sid].size))
+        raw = shards[sid][e["offset"]:e["offset"] + e["size"]].tobytes()
+        if e.get("crc32c") and e["crc32c"] != _mask_crc(_crc32c_fast(raw)):      # 0 = not recorded (own writer without crc_tensors)
+            raise ValueError("corrupt checkpoint: checksum mismatch in tensor %s" % name)
+        arr = np.frombuffer(raw, dtype=_DTYPES[e["dtype"]]).reshape(e["shape"])
         out[name] = arr
     if names is not None:
         missing = [n for n in names if n not in out]

@@ -272,3 +272,23 @@ def test_unmapped_and_secondary_records(tmp_path, oracle_lib):
     scan = cbind.cigar_scan(a.cigar, a.cig_off.astype(np.uint64), a.pos, 50)
     lines = collect_pair_lines(detect_window(opts, Sample.with_scan(a, fasta, 50, scan), "c1", 0, 200_000)[1], opts)
     assert len(lines) > 10
+
+
+def test_fasta_gzip_and_bgzip(tmp_path):
+    """pysam.FastaFile reads bgzip-compressed references; a plain-gzip or bgzip FASTA gives the same answers as the text file."""
+    import gzip
+    from tests import helpers
+    fa = helpers.load_golden_fasta()
+    plain = str(tmp_path / "g.fa")
+    bam.write_fasta(plain, {n: fa._seq[n] for n in fa.references})
+    raw = open(plain, "rb").read()
+    gz, bgz = str(tmp_path / "g.fa.gz"), str(tmp_path / "b.fa.gz")
+    open(gz, "wb").write(gzip.compress(raw))
+    open(bgz, "wb").write(bam.bgzf_compress(raw))
+    a = bam.Fasta(plain)
+    for path in (gz, bgz):
+        b = bam.Fasta(path)
+        assert b.references == a.references
+        for name in a.references:
+            assert b.get_reference_length(name) == a.get_reference_length(name)
+            assert b.fetch(name, 1234, 2345) == a.fetch(name, 1234, 2345)

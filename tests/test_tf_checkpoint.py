@@ -52,3 +52,33 @@ def test_alexnet_requires_all_tensors():
     params["conv2/weights"] = np.zeros((5, 5, 96, 256), np.float32)      # ungrouped shape is wrong
     with pytest.raises(ValueError):
         AlexNet(params, device="cpu")
+
+
+def test_checksums_are_verified_on_read(tmp_path):
+    """A flipped byte in a tensor or in the index, or a truncated data shard, is an error -- not wrong weights."""
+    from svision_amd import _lib
+    lib = _lib.load()
+    buf = np.frombuffer(b"123456789" * 1000 + b"xyz", np.uint8)
+    assert lib.svx_crc32c(buf.ctypes.data, buf.size) == ck._crc32c(buf.tobytes())          # native slicing-by-8 == table loop
+    assert lib.svx_crc32c(np.zeros(32, np.uint8).ctypes.data, 32) == 0x8A9136AA
+    rng = np.random.default_rng(1)
+    tensors = {"conv1/weights": rng.standard_normal((11, 11, 3, 96)).astype(np.float32), "conv1/biases": rng.standard_normal(96).astype(np.float32)}
+    prefix = str(tmp_path / "m.ckpt")
+    ck.write_checkpoint(prefix, tensors, crc_tensors=True)
+    assert np.array_equal(ck.read_checkpoint(prefix)["conv1/weights"], tensors["conv1/weights"])
+    shard = prefix + ".data-00000-of-00001"
+    raw = bytearray(open(shard, "rb").read())
+    raw[1000] ^= 0x40
+    open(shard, "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="checksum mismatch in tensor"):
+        ck.read_checkpoint(prefix)
+    raw[1000] ^= 0x40
+    open(shard, "wb").write(bytes(raw[:-100]))
+    with pytest.raises(ValueError, match="truncated"):
+        ck.read_checkpoint(prefix)
+    open(shard, "wb").write(bytes(raw))
+    idx = bytearray(open(prefix + ".index", "rb").read())
+    idx[10] ^= 0x01
+    open(prefix + ".index", "wb").write(bytes(idx))
+    with pytest.raises(ValueError, match="block checksum"):
+        ck.read_checkpoint(prefix)
