@@ -141,6 +141,7 @@ def main():
     ap.add_argument("--workers", type=int, default=16, help="helper processes per rank for the Python host glue (capped at cores / ranks)")
     ap.add_argument("--streams", type=int, default=4, help="HIP streams the per-batch graphs are replayed on")
     ap.add_argument("--inflight", type=int, default=6, help="windows enqueued on the device at once")
+    ap.add_argument("--launch-batches", type=int, default=2, help="batches of --batch images per device launch (graph replay)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-calibration", action="store_true", help="skip the per-kernel timings outside the timed region")
     args = ap.parse_args()
@@ -166,7 +167,7 @@ def main():
     pool.attach_scan(sample)
     net = AlexNet(random_weights(0), device=dev)
     net.executed = torch.zeros(5, dtype=torch.int64, device=dev)     # executed conv pixels per layer + images, summed on the device
-    hot = PooledHotPath(sample, opts, net, device=dev, n_streams=args.streams, max_inflight=args.inflight, pool=pool)
+    hot = PooledHotPath(sample, opts, net, device=dev, n_streams=args.streams, max_inflight=args.inflight, launch_batches=args.launch_batches, pool=pool)
 
     import torch.distributed as tdist
     grouped = tdist.is_available() and tdist.is_initialized()
@@ -218,6 +219,8 @@ def main():
     sdist.gather_texts({"rank%d" % rank: "%d records" % records})
     sync_all()
     dt = time.perf_counter() - t0
+    if os.environ.get("SVX_TIMING") and rank == 0:
+        print("owner thread seconds over %.3f s: %s" % (dt, {k: round(v, 3) for k, v in getattr(hot, "owner_profile", {}).items()}), file=sys.stderr)
 
     dev_ms = hot.device_busy_ms()            # time with at least one batch in flight (HIP events on the batches' streams)
     dev_images = hot.device_images
@@ -258,13 +261,13 @@ def main():
                    "batch": B, "alignments_rank0": len(table), "cigar_ops_rank0": int(table.cigar.size),
                    "windows_rank0": len(windows), "sites_per_step": tot_sites / max(steps_job * (1 if strong else world), 1),
                    "images_per_site": tot_images / max(tot_sites, 1), "images_per_s": tot_images / dt,
-                   "host_workers_per_rank": workers, "host_cores": cores, "streams": args.streams,
+                   "host_workers_per_rank": workers, "host_cores": cores, "streams": args.streams, "batches_per_launch": args.launch_batches,
                    "parallelism": "one process per GPU, chromosomes per rank, no data-path collective "
                                   "(score-range all_reduce + record gather once)"},
-        "roofline": {"kernel": "device stage per batch of %d images (one graph replay): encode_conv1_kernel (rasterise + sparse conv1) + "
+        "roofline": {"kernel": "device stage per batch of %d images (a graph replay carries --launch-batches of them): encode_conv1_kernel (rasterise + sparse conv1) + "
                                "active_counts / active_lists + conv_wave_list_kernel x4 (fp32 MFMA, conv2-5 on the active pixels) + "
-                               "bias_relu_pool_lrn x2 + fc_splitk / fc_reduce x2 (fc6, fc7) + fc8_softmax_kernel; HIP events on the batch's stream "
-                               "around every batch of the timed region, device time = union of the intervals, %d streams" % (B, args.streams),
+                               "bias_relu_pool_lrn x2 + fc_splitk / fc_reduce x2 (fc6, fc7) + fc8_softmax_kernel; HIP events on the launch's stream "
+                               "around every launch of the timed region, device time = union of the intervals, %d streams" % (B, args.streams),
                      "bound": "mfma", "achieved": executed_tflops, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                      "frac": executed_tflops * 1e12 / F32_MFMA_PEAK,
                      "note": "achieved = FLOP the matrix pipe EXECUTED (2 x MAC of the conv2..conv5 outputs actually computed, "

@@ -106,28 +106,38 @@ def stitch_windows(results, options, sample):
 
 
 class DeviceStage:
-    """records [n,12] -> (softmax[5], class) per image, in batches of ``batch`` images, each batch a
-    replay of one captured graph: svx_encode_conv1 -> active sets -> conv2..5 -> fc6/7 -> svx_fc8_softmax."""
+    """records [n,12] -> (softmax[5], class) per image, each launch a replay of one captured graph:
+    svx_encode_conv1 -> active sets -> conv2..5 -> fc6/7 -> svx_fc8_softmax.
 
-    def __init__(self, net, batch, device, n_streams=2, use_graph=True):
+    ``batch`` is the reference's batch (the padding granule of BatchGenerator, create_batch.py:54-59); a launch carries
+    ``launch_batches`` of them while that many are left and single batches otherwise.  Every image is independent of its
+    neighbours in every kernel (fixed k order per output element, tests/test_gpu_pipeline.py), so the grouping changes no
+    result; it halves the fc6 / fc7 weight traffic per image (218 MB per launch whatever its size) and the share of
+    partly filled tile rounds of the convolutions."""
+
+    def __init__(self, net, batch, device, n_streams=2, use_graph=True, launch_batches=2):
         self.net, self.batch, self.device = net, batch, torch.device(device)
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
         self.use_graph = use_graph
-        self.slots = []
+        self.sizes = sorted({batch * max(1, int(launch_batches)), batch}, reverse=True)
+        self.slots = []                                       # per stream: {images per launch: (records, packed out, graph)}
         for s in self.streams:
-            rec = torch.zeros((batch, 12), dtype=torch.int32, device=self.device)
-            rec[:] = torch.tensor(_PAD_REC, dtype=torch.int32, device=self.device)
-            out = torch.empty((batch, 12), dtype=torch.float32, device=self.device)   # softmax[5], class, logits[5], 0
-            graph = None
-            with torch.cuda.stream(s):
-                for _ in range(2):                           # warm hipBLASLt (and the model's background tensors) before capture
-                    self._body(rec, out)
-            s.synchronize()
-            if use_graph:
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=s):
-                    self._body(rec, out)
-            self.slots.append((rec, out, graph))
+            slot = {}
+            for size in self.sizes:
+                rec = torch.zeros((size, 12), dtype=torch.int32, device=self.device)
+                rec[:] = torch.tensor(_PAD_REC, dtype=torch.int32, device=self.device)
+                out = torch.empty((size, 12), dtype=torch.float32, device=self.device)   # softmax[5], class, logits[5], 0
+                graph = None
+                with torch.cuda.stream(s):
+                    for _ in range(2):                       # the model's background tensors and the allocator's blocks before capture
+                        self._body(rec, out)
+                s.synchronize()
+                if use_graph:
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph, stream=s):
+                        self._body(rec, out)
+                slot[size] = (rec, out, graph)
+            self.slots.append(slot)
 
     def _body(self, rec, out):
         self.net.predict_records_packed(rec, out=out)        # no image tensor: encoding is fused into the first layer
@@ -140,16 +150,17 @@ class DeviceStage:
         afterwards (simple, but consecutive calls are separated by a full drain of all streams).
         ``after`` = an event behind which ``d_rec`` is valid: the side streams wait for it only, nothing waits for them;
         returned are the events (one per stream used) behind which ``out`` is complete -- consecutive calls flow into
-        each other, batch after batch, with no drain between two windows.  ``timing``: list that receives one
-        (start, end) event pair per batch, recorded on the batch's stream."""
+        each other, launch after launch, with no drain between two windows.  ``timing``: list that receives one
+        (start, end, images) triple per launch, the events recorded on the launch's stream."""
         main = torch.cuda.current_stream(self.device)
         used = set()
-        b = self.batch
         n_streams = len(self.streams)
-        for lo in range(0, d_rec.shape[0], b):
+        lo, n = 0, int(d_rec.shape[0])
+        while lo < n:
+            b = next(size for size in self.sizes if size <= n - lo)
             k = self._next = (getattr(self, "_next", -1) + 1) % n_streams     # round-robin continues across calls
             s = self.streams[k]
-            rec, o, graph = self.slots[k]
+            rec, o, graph = self.slots[k][b]
             if k not in used:
                 if after is None:
                     s.wait_stream(main)
@@ -169,7 +180,8 @@ class DeviceStage:
                 if timing is not None:
                     t1 = torch.cuda.Event(enable_timing=True)
                     t1.record()
-                    timing.append((t0, t1))
+                    timing.append((t0, t1, b))
+            lo += b
         if after is None:
             for k in used:
                 main.wait_stream(self.streams[k])
@@ -188,11 +200,11 @@ class HotPath:
     """Single-process form: collect -> device -> vote, with the device work of window k overlapped
     with the host collection of window k+1."""
 
-    def __init__(self, sample, options, net, device="cuda", n_streams=2, use_graph=True):
+    def __init__(self, sample, options, net, device="cuda", n_streams=2, use_graph=True, launch_batches=2):
         self.sample, self.options, self.net = sample, options, net
         self.device = torch.device(device)
         self.batch = options.batch_size
-        self.stage = DeviceStage(net, self.batch, self.device, n_streams, use_graph)
+        self.stage = DeviceStage(net, self.batch, self.device, n_streams, use_graph, launch_batches)
         self.batch_events = []           # (start, end) event pair of every batch, on the batch's stream
         self.device_images = 0           # images (padding included) launched since reset_timing()
         self._t_ref = None
@@ -259,7 +271,7 @@ class HotPath:
         if not self.batch_events:
             return 0.0
         ref = self._t_ref
-        iv = sorted((ref.elapsed_time(a), ref.elapsed_time(b)) for a, b in self.batch_events)
+        iv = sorted((ref.elapsed_time(ev[0]), ref.elapsed_time(ev[1])) for ev in self.batch_events)
         busy, cur_lo, cur_hi = 0.0, iv[0][0], iv[0][1]
         for lo, hi in iv[1:]:
             if lo > cur_hi:
@@ -393,9 +405,9 @@ class HelperPool:
 class PooledHotPath(HotPath):
     """Owner process = device feeder; the helpers of a :class:`HelperPool` do the Python glue."""
 
-    def __init__(self, sample, options, net, device="cuda", n_workers=8, n_streams=2, use_graph=True, max_inflight=3,
+    def __init__(self, sample, options, net, device="cuda", n_workers=8, n_streams=2, use_graph=True, max_inflight=3, launch_batches=2,
                  want_tsv=False, pool=None):
-        super().__init__(sample, options, net, device, n_streams, use_graph)
+        super().__init__(sample, options, net, device, n_streams, use_graph, launch_batches)
         self.pool = pool if pool is not None else HelperPool(n_workers, options, sample=sample, want_tsv=want_tsv)
         self.conns, self.procs = self.pool.conns, self.pool.procs
         self.max_inflight = max_inflight
@@ -412,26 +424,44 @@ class PooledHotPath(HotPath):
         busy = {}                     # conn index -> wid
         ready = collections.deque()   # (conn index, WindowResult with records) waiting for the device
         inflight = collections.deque()  # (conn index, WindowResult) enqueued on the device
+        scans = collections.deque()     # handles of the window scans enqueued ahead (Sample.rescan_window_async)
         remaining = len(windows)
+        import time as _time
+        prof = self.owner_profile = {"scan+send": 0.0, "launch": 0.0, "fetch+send": 0.0, "wait": 0.0, "recv": 0.0}     # owner-thread seconds
+        clock = _time.perf_counter
         while remaining:
+            t = clock()
             while idle and nxt < len(windows):
                 ci = idle.pop()
                 chrom, start, end = windows[nxt]
                 scan = None
                 if rescan:                                            # device scan of the window's block: the helper collects on ITS result
-                    scan = self.sample.last_window_scan if self.sample.rescan_window(chrom, start, end) else None
+                    ta = clock()
+                    while len(scans) < 4 and nxt + len(scans) < len(windows):        # enqueued a few windows ahead, read back here
+                        scans.append(self.sample.rescan_window_async(*windows[nxt + len(scans)]))
+                    tb = clock(); prof["scan.enqueue"] = prof.get("scan.enqueue", 0.0) + tb - ta
+                    hd = scans.popleft()
+                    if hd is not None:
+                        hd[5].synchronize()
+                    tc = clock(); prof["scan.sync"] = prof.get("scan.sync", 0.0) + tc - tb
+                    scan = self.sample.last_window_scan if self.sample.finish_rescan(hd) else None
+                    td = clock(); prof["scan.apply"] = prof.get("scan.apply", 0.0) + td - tc
                 self.conns[ci].send(("win", nxt, chrom, start, end, scan))
                 busy[ci] = nxt
                 nxt += 1
+            t1 = clock(); prof["scan+send"] += t1 - t
             while ready and len(inflight) < self.max_inflight:
                 ci, res = ready.popleft()
                 inflight.append((ci, self.launch(res)))
+            t2 = clock(); prof["launch"] += t2 - t1
             while inflight and (inflight[0][1].n_images == 0 or inflight[0][1].done_event.query()):
                 ci, res = inflight.popleft()
                 classes, probs = self.fetch_predictions(res)
                 self.conns[ci].send(("pred", busy[ci], classes, probs))
+            t3 = clock(); prof["fetch+send"] += t3 - t2
             waiting = [self.conns[ci] for ci in busy]
             got = mpc.wait(waiting, timeout=0.0005 if inflight else 0.05)
+            t4 = clock(); prof["wait"] += t4 - t3
             if not got and not inflight and not ready:
                 dead = [ci for ci in busy if not self.procs[ci].is_alive()]
                 if dead:

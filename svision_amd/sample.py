@@ -58,6 +58,14 @@ class Sample:
         """Re-run the device scan for the block of rows whose start lies in [start, end) of
         ``chrom`` and refresh the host copies (streaming use: each window's rows are scanned
         when the window is processed).  Rows form a partition of the table over windows."""
+        return self.finish_rescan(self.rescan_window_async(chrom, start, end))
+
+    def rescan_window_async(self, chrom, start, end):
+        """Enqueue the scan of a window's rows and the copy of its result to pinned host memory on the (high priority)
+        scan stream; returns a handle for :meth:`finish_rescan`, or None for a window without rows.  Issued a few windows
+        ahead by the pipeline: a blocking read-back right after the launch waited 12 ms per window behind the queued CNN
+        batches (a tiny kernel arriving behind ~40 queued graph replays is dispatched late, whatever its stream), which
+        made the GPU-owning thread -- not the device -- the limit of the whole pipeline."""
         import torch
         from . import kernels
         table = self.table
@@ -66,19 +74,47 @@ class Sample:
         lo = int(b[tid]) + int(np.searchsorted(table.pos[b[tid]:b[tid + 1]], start, side="left"))
         hi = int(b[tid]) + int(np.searchsorted(table.pos[b[tid]:b[tid + 1]], end, side="left"))
         if hi <= lo:
-            return 0
+            return None
         d_cigar, d_off, d_pos, _ = self.device_buffers
+        n = hi - lo
         cap = int(self.gap_off[hi] - self.gap_off[lo])
-        # own stream: the result is read back synchronously, and on the default stream that read-back would wait for every
-        # CNN batch queued before it (the pipeline's side streams join the default stream after each window)
+        capd = max(cap, 16)
         if getattr(self, "_scan_stream", None) is None:
-            self._scan_stream = torch.cuda.Stream(device=d_cigar.device)
+            self._scan_stream = torch.cuda.Stream(device=d_cigar.device, priority=-1)
+            self._scan_pinned = []
+        need = (n + 1) + capd * 6 + n * 4
+        host = None
+        for i, buf in enumerate(self._scan_pinned):
+            if buf.numel() >= need:
+                host = self._scan_pinned.pop(i)
+                break
+        if host is None:
+            host = torch.empty(max(need, 1 << 20), dtype=torch.int32, pin_memory=True)
         with torch.cuda.stream(self._scan_stream):
-            res = kernels.cigar_scan(d_cigar, d_off[lo:hi + 1], d_pos[lo:hi], self.min_sv, gaps_cap=max(cap, 16))
-            gaps, gap_off, stats = res.to_host()
+            res = kernels.cigar_scan(d_cigar, d_off[lo:hi + 1], d_pos[lo:hi], self.min_sv, gaps_cap=capd)
+            host[:n + 1].copy_(res.gap_off, non_blocking=True)
+            host[n + 1:n + 1 + capd * 6].copy_(res.gaps[:capd * 6], non_blocking=True)
+            host[n + 1 + capd * 6:need].copy_(res.stats.view(-1), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        return (lo, hi, cap, capd, host, ev, res)
+
+    def finish_rescan(self, handle):
+        """Wait for an enqueued window scan, check it against the resident scan and install it; -> number of rows."""
+        from . import kernels
+        if handle is None:
+            self.last_window_scan = None
+            return 0
+        lo, hi, cap, capd, host, ev, _res = handle
+        ev.synchronize()
+        n = hi - lo
+        h = host.numpy()
+        gap_off = h[:n + 1].view(np.uint32).copy()
+        gaps = h[n + 1:n + 1 + cap * 6].copy().view(kernels.GAP_DTYPE) if cap else np.empty(0, kernels.GAP_DTYPE)
+        stats = h[n + 1 + capd * 6:n + 1 + capd * 6 + n * 4].reshape(n, 4).copy()
+        self._scan_pinned.append(host)
         if int(gap_off[-1]) != cap or not np.array_equal(gap_off.astype(np.int64) + self.gap_off[lo], self.gap_off[lo:hi + 1]):
             raise RuntimeError("window rescan disagrees with the resident scan")
-        gaps = gaps.copy()
         gaps["aln"] += lo
         self.apply_window_scan(lo, hi, gaps, stats)
         self.last_window_scan = (lo, hi, gaps, stats)           # what a helper process needs to follow (apply_window_scan)

@@ -61,7 +61,7 @@ if os.environ.get("FC") == "blaslt":             # A/B: the vendor GEMM instead 
 
 def stage_ms(n_streams, reps=4):
     """median over `reps` passes of the whole record set (each pass = n / B batches)"""
-    st = DeviceStage(net, B * G, dev, n_streams=n_streams)
+    st = DeviceStage(net, B, dev, n_streams=n_streams, launch_batches=G)
     out = torch.empty((n, 6), device=dev)
     st.run(rec, out)
     torch.cuda.synchronize()
