@@ -137,7 +137,7 @@ int svx_alexnet_active_sets(const uint32_t* d_touched, uint32_t n, int32_t* d_li
  * tf.nn.bias_add + relu (src/network/alexnet.py:132-135), max_pool (:158-161), lrn (:164-166)
  * as composed at alexnet.py:29-31, :34-36, :45-46.
  *   d_x   C8 [n][channels/8][height][width][8]  raw convolution output (no bias); channels % 8 == 0
- *   d_y   C8 [n][channels/8][(height-3)/2+1][(width-3)/2+1][8]
+ *   d_y   C8 [n][channels/8][(height-3)/2+1][(width-3)/2+1][8]          (d_x, d_bias, d_y 16-byte aligned)
  *   LRN:  y = p / (k + alpha * sum_{|j-c| <= radius} p_j^2)^beta   (alpha NOT divided by the window) */
 int svx_bias_relu_pool_lrn(const float* d_x, const float* d_bias, float* d_y, uint32_t n, uint32_t channels,
                            uint32_t height, uint32_t width, int lrn, uint32_t radius, float alpha, float beta,

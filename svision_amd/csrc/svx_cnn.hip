@@ -23,9 +23,13 @@ __device__ inline float lrn_scale(float v, float x, float beta)
     return v / powf(x, beta);
 }
 
+__device__ inline float4 max4(float4 a, float4 b) { return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)); }
+
 // relu(max(window) + bias) == max(relu(x + bias)) : + and relu are monotonic.
-// C8 layout in and out ([image][C/8][H][W][8], include/svx.h): consecutive lanes walk the 8 channels of an octet, then
-// the pooled pixels of the row, so every load and store instruction touches whole 32-byte sectors.
+// C8 layout in and out ([image][C/8][H][W][8], include/svx.h): a lane owns four channels (half an octet) of one pooled
+// pixel -- nine 16-byte loads, one 16-byte store -- and consecutive lanes walk the two halves of the octet, then the
+// pooled pixels of the row: every load and store instruction touches whole 32-byte sectors (with one channel per lane
+// the kernel issued four times the loads and ran at a third of the HBM rate).
 __global__ __launch_bounds__(BLOCK)
 void bias_relu_pool_lrn_kernel(const float* __restrict__ x, const float* __restrict__ bias, float* __restrict__ y,
                                int C, int H, int W, int OH, int OW, int lrn, int radius, float alpha, float beta, float k)
@@ -35,32 +39,38 @@ void bias_relu_pool_lrn_kernel(const float* __restrict__ x, const float* __restr
     const int oy = blockIdx.x - b * OH;
     const int CP = C + 1, HW = H * W;
     const float* xb = x + ((size_t)b * (C / 8) * HW + (size_t)(2 * oy) * W) * 8;
-    const int n = C * OW;
+    const int n = (C / 4) * OW;
     for (int idx = threadIdx.x; idx < n; idx += BLOCK) {
-        const int c8 = idx & 7, rest = idx >> 3;
+        const int h = idx & 1, rest = idx >> 1;
         const int oct = rest / OW, ox = rest - oct * OW;
-        const float* p = xb + ((size_t)oct * HW + 2 * ox) * 8 + c8;
-        float m = p[0];
-        m = fmaxf(m, p[8]); m = fmaxf(m, p[16]);
-        m = fmaxf(m, p[W * 8]); m = fmaxf(m, p[W * 8 + 8]); m = fmaxf(m, p[W * 8 + 16]);
-        m = fmaxf(m, p[2 * W * 8]); m = fmaxf(m, p[2 * W * 8 + 8]); m = fmaxf(m, p[2 * W * 8 + 16]);
-        const int c = oct * 8 + c8;
-        pooled[ox * CP + c] = fmaxf(m + bias[c], 0.0f);
+        const float4* p = reinterpret_cast<const float4*>(xb + ((size_t)oct * HW + 2 * ox) * 8 + 4 * h);   // pixel = 2 float4
+        float4 m = p[0];
+        m = max4(m, p[2]); m = max4(m, p[4]);
+        m = max4(m, p[2 * W]); m = max4(m, p[2 * W + 2]); m = max4(m, p[2 * W + 4]);
+        m = max4(m, p[4 * W]); m = max4(m, p[4 * W + 2]); m = max4(m, p[4 * W + 4]);
+        const int c = oct * 8 + 4 * h;
+        const float4 bv = *reinterpret_cast<const float4*>(bias + c);
+        float* q = pooled + ox * CP + c;
+        q[0] = fmaxf(m.x + bv.x, 0.0f); q[1] = fmaxf(m.y + bv.y, 0.0f); q[2] = fmaxf(m.z + bv.z, 0.0f); q[3] = fmaxf(m.w + bv.w, 0.0f);
     }
     __syncthreads();
     float* yb = y + ((size_t)b * (C / 8) * OH * OW + (size_t)oy * OW) * 8;
     for (int idx = threadIdx.x; idx < n; idx += BLOCK) {
-        const int c8 = idx & 7, rest = idx >> 3;
+        const int h = idx & 1, rest = idx >> 1;
         const int oct = rest / OW, ox = rest - oct * OW;
-        const int c = oct * 8 + c8;
-        float v = pooled[ox * CP + c];
+        const int c = oct * 8 + 4 * h;
+        const float* q = pooled + ox * CP;
+        float v[4] = {q[c], q[c + 1], q[c + 2], q[c + 3]};
         if (lrn) {
-            float s = 0.0f;
-            const int lo = max(0, c - radius), hi = min(C - 1, c + radius);
-            for (int j = lo; j <= hi; ++j) { const float q = pooled[ox * CP + j]; s += q * q; }
-            v = lrn_scale(v, k + alpha * s, beta);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float s = 0.0f;                               // ascending channel order, as tf.nn.lrn's window sum
+                const int lo = max(0, c + i - radius), hi = min(C - 1, c + i + radius);
+                for (int j = lo; j <= hi; ++j) s += q[j] * q[j];
+                v[i] = lrn_scale(v[i], k + alpha * s, beta);
+            }
         }
-        yb[((size_t)oct * OH * OW + ox) * 8 + c8] = v;
+        *reinterpret_cast<float4*>(yb + ((size_t)oct * OH * OW + ox) * 8 + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 
@@ -85,6 +95,13 @@ __device__ inline unsigned window_mask(const unsigned* row_words, int c0)
     return m & 0x7FFu;
 }
 
+#ifdef SVX_ENC_PROFILE
+__device__ unsigned long long svx_enc_prof[8];
+#define ENC_MARK(i_) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&svx_enc_prof[i_], t_ - t_prev); t_prev = t_; } } while (0)
+#else
+#define ENC_MARK(i_) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(ENC_BLOCK)
 void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __restrict__ w1, const float* __restrict__ base,
                          float* __restrict__ y, int lrn, int radius, float alpha, float beta, float kk,
@@ -102,7 +119,11 @@ void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __res
 
     const int img = blockIdx.x / P1;
     const int oyp = blockIdx.x - img * P1;
+#ifdef SVX_ENC_PROFILE
+    unsigned long long t_prev = wall_clock64();
+#endif
     draw_planes<ENC_BLOCK>(records + (size_t)img * 12, bits, colcnt, colmask);
+    ENC_MARK(0);
 
     const int tid = threadIdx.x;
     if (tid < 3 * ROW_WORDS) {
@@ -143,6 +164,7 @@ void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __res
         if (window_mask(rowany[win / 3], 4 * (2 * oxp + win % 3)) != 0) queue[atomicAdd(&n_queue, 1)] = (unsigned short)tid;
     }
     __syncthreads();
+    ENC_MARK(1);
     const int n_items = n_queue * C1_GROUPS;
     for (int item = tid; item < n_items; item += ENC_BLOCK) {
         const int g = item % C1_GROUPS, pw = queue[item / C1_GROUPS];
@@ -176,6 +198,7 @@ void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __res
             if (acc[j] > 0.0f) atomicMax(&pooled_bits[oxp * C1P + 8 * g + j], __float_as_uint(acc[j]));
     }
     __syncthreads();
+    ENC_MARK(2);
     const float* pooled = reinterpret_cast<const float*>(pooled_bits);
     // C8 output [image][12 octets][27][27][8]: consecutive lanes -> the 8 channels of an octet, then consecutive ox
     // (one contiguous 864-byte run per octet and row)
@@ -193,9 +216,22 @@ void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __res
         }
         yb[((size_t)oct * P1 * P1 + ox) * 8 + c8] = v;
     }
+    ENC_MARK(3);
+#ifdef SVX_ENC_PROFILE
+    if (threadIdx.x == 0) { atomicAdd(&svx_enc_prof[4], 1ull); atomicAdd(&svx_enc_prof[5], (unsigned long long)n_queue); }
+#endif
 }
 
 }  // namespace
+
+#ifdef SVX_ENC_PROFILE
+extern "C" int svx_debug_enc_prof(unsigned long long* out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(svx_enc_prof), sizeof(svx_enc_prof)) != hipSuccess) return SVX_ELAUNCH;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(svx_enc_prof), z, sizeof(z)) != hipSuccess) return SVX_ELAUNCH; }
+    return SVX_OK;
+}
+#endif
 
 extern "C" int svx_encode_conv1(const int32_t* d_records, uint32_t n, const float* d_w1, const float* d_base, float* d_y,
                                 int lrn, uint32_t radius, float alpha, float beta, float k, uint32_t* d_touched, void* stream)
@@ -401,6 +437,7 @@ extern "C" int svx_bias_relu_pool_lrn(const float* d_x, const float* d_bias, flo
 {
     if (n == 0) return SVX_OK;
     if (!d_x || !d_bias || !d_y || channels == 0 || channels % 8 || height < 3 || width < 3) return SVX_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(d_x) | reinterpret_cast<uintptr_t>(d_bias) | reinterpret_cast<uintptr_t>(d_y)) & 15u) return SVX_EINVAL;
     const int OH = (int)(height - 3) / 2 + 1, OW = (int)(width - 3) / 2 + 1;
     const size_t lds = (size_t)(channels + 1) * OW * sizeof(float);
     if (lds > 64 * 1024) return SVX_EINVAL;

@@ -28,6 +28,28 @@ __device__ __forceinline__ v4f buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned v
     return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0));
 }
 
+#ifndef SVX_FC_RING_A
+#define SVX_FC_RING_A 6
+#endif
+
+template <int U> struct StageIndex { static constexpr int value = U; };
+
+// stage(0) .. stage(N - 1) with compile-time indices
+template <int N, int U = 0, typename F>
+__device__ __forceinline__ void svx_unroll_stages(F& f)
+{
+    if constexpr (U < N) { f(StageIndex<U>{}); svx_unroll_stages<N, U + 1>(f); }
+}
+
+// the first `left` (< N) stages: no exits inside the unrolled body above (see svx_conv.hip)
+template <int N, int U = 0, typename F>
+__device__ __forceinline__ void svx_tail_stages(F& f, int left)
+{
+    if constexpr (U < N - 1) {
+        if (left > U) { f(StageIndex<U>{}); svx_tail_stages<N, U + 1>(f, left); }
+    }
+}
+
 struct FcArgs { const float* x; const float* w; float* part; int M, N, K, splits; };
 
 template <int NA, int NB>
@@ -57,40 +79,52 @@ void fc_splitk_kernel(const FcArgs a)
         for (int t = 0; t < NB; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.0f;
-    constexpr int R = 3, L = NA + NB, MF = 4 * NA * NB;
-    v4f ra[R][NA], rb[R][NB];
-    unsigned soff_a = 0, soff_b = 0;
-    auto load_one = [&](int slot, int q) {
-        if (q < NA) ra[slot][q] = buf_load4(rs_w, voff_a[q], soff_a);
-        else        rb[slot][q - NA] = buf_load4(rs_x, voff_b[q - NA], soff_b);
+    // Two rings: the weights are a once-only HBM stream (latency ~2 us: a wave keeps RA - 1 octets = 5 KB of them in
+    // flight; at the two octets of the activations' ring ~1000 waves held 2 MB in flight and the stream ran at 3 TB/s),
+    // the activations come out of L2 (RB - 1 = 2 octets ahead, as in svx_conv.hip).  RA is a multiple of RB: the body is
+    // unrolled RA stages so that every ring slot is a compile-time register.
+    constexpr int RA = SVX_FC_RING_A, RB = 3, MF = 4 * NA * NB, L = NA + NB;
+    static_assert(RA % RB == 0, "weight ring must be a multiple of the activation ring");
+    v4f ra[RA][NA], rb[RB][NB];
+    unsigned soff_a = 0, soff_b = 0;                      // of the NEXT octet each ring loads
+    auto load_a = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) ra[slot][i] = buf_load4(rs_w, voff_a[i], soff_a);
+        soff_a += 1024u;
     };
-    auto stage = [&](int ls, int cs, bool loads) {
+    auto load_b1 = [&](int slot, int t) { rb[slot][t] = buf_load4(rs_x, voff_b[t], soff_b); };
+    // stage u (0 <= u < RA, compile time): MFMAs of the octet in slots (u % RA, u % RB); the weight load for the octet
+    // RA - 1 later and the activation loads for the octet RB - 1 later are spread between them
+    auto stage = [&](auto u_) {
+        constexpr int u = decltype(u_)::value;
+        constexpr int sa = u % RA, sb = u % RB, la = (u + RA - 1) % RA, lb = (u + RB - 1) % RB;
 #pragma unroll
         for (int m = 0; m < MF; ++m) {
-            if (loads) {
+            if (m == 0) load_a(la);
 #pragma unroll
-                for (int q = 0; q < L; ++q)
-                    if (q * MF / L == m) load_one(ls, q);
-            }
+            for (int t = 0; t < NB; ++t)
+                if ((t + 1) * MF / L == m) load_b1(lb, t);
             const int j = m / (NA * NB), r = m - j * (NA * NB);
             const int i = r / NB, t = r - i * NB;
-            acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[cs][i][j], rb[cs][t][j], acc[i][t], 0, 0, 0);
+            acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[sa][i][j], rb[sb][t][j], acc[i][t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (loads) { soff_a += 1024u; soff_b += 32u; }
+        soff_b += 32u;
     };
     const int Q = q1 - q0;
+    // prologue (a split shorter than the rings reads a neighbour's weights / x columns: valid memory or zeros, never used)
 #pragma unroll
-    for (int p = 0; p < R - 1; ++p) {                      // prologue: two octets ahead (a split shorter than that reads
-#pragma unroll                                             // a neighbour's weights / x columns: valid memory, never used)
-        for (int q = 0; q < L; ++q) load_one(p, q);
-        soff_a += 1024u; soff_b += 32u;
+    for (int p = 0; p < RA - 1; ++p) load_a(p);
+#pragma unroll
+    for (int p = 0; p < RB - 1; ++p) {
+#pragma unroll
+        for (int t = 0; t < NB; ++t) load_b1(p, t);
+        soff_b += 32u;
     }
     __builtin_amdgcn_sched_barrier(0);
-    const int Q3 = Q - Q % R;
-    for (int q = 0; q < Q3; q += R) { stage(2, 0, true); stage(0, 1, true); stage(1, 2, true); }
-    if (Q - Q3 >= 1) stage(2, 0, true);
-    if (Q - Q3 >= 2) stage(0, 1, true);
+    const int QU = Q - Q % RA;
+    for (int q = 0; q < QU; q += RA) svx_unroll_stages<RA>(stage);
+    svx_tail_stages<RA>(stage, Q - QU);
     // partial sums: part[s][m][n]; lane holds image m = lo of the tile column, neurons 8u + 4hi + (0..3) of the 32-block
 #pragma unroll
     for (int i = 0; i < NA; ++i)
@@ -118,11 +152,22 @@ void fc_reduce_kernel(const float* __restrict__ part, const float* __restrict__ 
     reinterpret_cast<float4*>(out)[e] = v;
 }
 
+// wave tile: 32 neurons x 64 images up to one batch of 64; 64 x 64 (four independent accumulator chains, a quarter fewer
+// operand loads per MFMA) from two batches on, where it is 10 % faster on fc6 (tools/ab_fc.py)
+int fc_na(uint32_t m, uint32_t n)
+{
+    int na = (m > 64 && n % 64 == 0) ? 2 : 1;
+#ifdef SVX_CONV_EXPERIMENT
+    if (const char* e = getenv("SVX_FC_NA")) if (atoi(e) == 1 || (atoi(e) == 2 && m > 32 && n % 64 == 0)) na = atoi(e);
+#endif
+    return na;
+}
+
 int fc_splits(uint32_t m, uint32_t n, uint32_t k)
 {
-    // about one wave per SIMD (1024 on MI355X), each of >= 24 octets: measured best at M = 64 and M = 128 (tools/ab_fc.py:
-    // 8 / 4 splits; 16 / 8 cost 10-20 % more in partial-sum traffic and prologues)
-    const int tiles = (int)(n / 32) * (int)((m + 63) / 64);
+    // about one wave per SIMD (1024 on MI355X), each of >= 24 octets: measured best at M = 64 and M = 128 (tools/ab_fc.py;
+    // twice as many cost 10-20 % more in partial-sum traffic and prologues, fewer leave SIMDs without a wave)
+    const int tiles = (int)(n / (32 * fc_na(m, n))) * (int)((m + 63) / 64);
     int s = (1024 + tiles - 1) / tiles;
     const int max_s = (int)(k / 8) / 24;
     if (s > max_s) s = max_s;
@@ -150,15 +195,12 @@ extern "C" int svx_fc_bias_act(const float* d_x, const float* d_w_packed, const 
     hipStream_t st = static_cast<hipStream_t>(stream);
     FcArgs a{d_x, d_w_packed, d_ws, (int)m, (int)n, (int)k, fc_splits(m, n, k)};
     const int m_tiles = (int)((m + 63) / 64);
-    const int waves = m_tiles * a.splits * (int)(n / 32);
-    int na = 1;
-#ifdef SVX_CONV_EXPERIMENT
-    if (const char* e = getenv("SVX_FC_NA")) na = atoi(e);
-#endif
-    if (na == 2 && m > 32 && n % 64 == 0) {
-        hipLaunchKernelGGL((fc_splitk_kernel<2, 2>), dim3((waves / 2 + WAVES - 1) / WAVES), dim3(THREADS), 0, st, a);
-    } else if (m <= 32) hipLaunchKernelGGL((fc_splitk_kernel<1, 1>), dim3((waves + WAVES - 1) / WAVES), dim3(THREADS), 0, st, a);
-    else         hipLaunchKernelGGL((fc_splitk_kernel<1, 2>), dim3((waves + WAVES - 1) / WAVES), dim3(THREADS), 0, st, a);
+    const int na = fc_na(m, n);
+    const int waves = m_tiles * a.splits * (int)(n / (32 * na));
+    const dim3 grid((unsigned)((waves + WAVES - 1) / WAVES));
+    if (na == 2)      hipLaunchKernelGGL((fc_splitk_kernel<2, 2>), grid, dim3(THREADS), 0, st, a);
+    else if (m <= 32) hipLaunchKernelGGL((fc_splitk_kernel<1, 1>), grid, dim3(THREADS), 0, st, a);
+    else              hipLaunchKernelGGL((fc_splitk_kernel<1, 2>), grid, dim3(THREADS), 0, st, a);
     const int mn4 = (int)((uint64_t)m * n / 4);
     hipLaunchKernelGGL(fc_reduce_kernel, dim3((mn4 + THREADS - 1) / THREADS), dim3(THREADS), 0, st, d_ws, d_bias, d_out, mn4, (int)(n / 4), a.splits, relu);
     return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;

@@ -33,7 +33,7 @@ for m in (64, 128):
         t_lt = timed(lambda: torch._addmm_activation(b, x, w.t(), use_gelu=False))
         row = ["%s m=%d hipBLASLt %.1f us" % (name, m, t_lt)]
         for na in (1, 2):
-            for s in (4, 8, 12, 16, 21, 32):
+            for s in [int(v) for v in os.environ.get("SPLITS", "4,8,12,16,21,32").split(",")]:
                 os.environ["SVX_FC_SPLITS"], os.environ["SVX_FC_NA"] = str(s), str(na)
                 t = timed(lambda: kernels.fc_bias_act(x, wp, b, relu=True, ws=ws))
                 row.append("na%d s%d %.1f" % (na, s, t))

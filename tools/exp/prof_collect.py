@@ -27,4 +27,4 @@ for w in wins[1:4]:
     lines = _collect_lines(sample, opts, *w)
     recs = np.asarray([ln.record() for ln in lines], np.int32).reshape(-1, 12)
 pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+pstats.Stats(pr).sort_stats(os.environ.get("SORT", "cumulative")).print_stats(40)
