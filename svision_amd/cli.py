@@ -124,12 +124,12 @@ def load_rank_table(options, rank, ws):
     records, and only that range is read and inflated (upstream: AlignmentFile.fetch(chrom), run_collection.py:26)."""
     index = next((c for c in (options.bam_path + ".bai", os.path.splitext(options.bam_path)[0] + ".bai") if os.path.exists(c)), None)
     if ws == 1 or index is None:
-        return read_bam(options.bam_path, with_seq=bool(options.hash))
+        return read_bam(options.bam_path, with_seq=bool(options.hash or options.graph))
     head = read_bam(options.bam_path, tids=[], index=index)
     tasks = build_tasks(options, head.references, head.lengths, Fasta(options.genome).references)
     length_of = dict(zip(head.references, head.lengths))
     shard = sdist.shard_chromosomes(list(tasks), [length_of.get(c, 1) for c in tasks], ws)[rank]
-    table = read_bam(options.bam_path, with_seq=bool(options.hash), tids=[head.references.index(c) for c in shard], index=index)
+    table = read_bam(options.bam_path, with_seq=bool(options.hash or options.graph), tids=[head.references.index(c) for c in shard], index=index)
     logging.info("rank %d/%d: %d records of %s decoded through %s", rank, ws, len(table), ",".join(shard) or "-", index)
     return table
 
@@ -142,10 +142,11 @@ def run(options, sample=None, classifier=None):
     from .network.predict import Predict
 
     rank, ws = sdist.env_rank()              # the process group comes up after the host helpers are forked (below)
-    if options.graph:
-        raise SystemExit("--graph (GFA output) is outside the MI355X hot path of this build (SURVEY 8(f))")
     work_dir = options.out_path
     os.makedirs(work_dir, exist_ok=True)
+    graph_dir = os.path.join(work_dir, "graphs")
+    if options.graph:                        # SVision:253-256; before the helpers are forked: they write the per-read graphs
+        os.makedirs(graph_dir, exist_ok=True)
     fmt = logging.Formatter("%(asctime)s [%(levelname)-7.7s]  %(message)s")
     root = logging.getLogger()
     root.setLevel(logging.INFO)
@@ -259,6 +260,16 @@ def run(options, sample=None, classifier=None):
     if rank == 0:
         options.source_version = REFERENCE_VERSION
         merge_split_vcfs(pred_dir, merged_path, max_score, min_score, chroms, options, fasta=fasta)
+        if options.graph:                    # SVision:341-359: graph VCF + summaries; the plain VCF and the per-site folders go
+            from .collection.graph import annotate_vcf_with_graphs
+            logging.info("\n****************** Step3 Computing graphs ******************")
+            annotate_vcf_with_graphs(graph_dir, merged_path, options)
+            for name in os.listdir(graph_dir):
+                if os.path.isdir(os.path.join(graph_dir, name)):
+                    shutil.rmtree(os.path.join(graph_dir, name))
+            os.remove(merged_path)
+            merged_path = os.path.join(options.out_path, "%s.svision.s%s.graph.vcf" % (options.sample, options.min_support))
+            logging.info("[Graph creation finished] Generate graphs")
         logging.info("[All steps finished] Total Cost time: %ss", (datetime.datetime.now() - t0).seconds)
     _tick("exchange + merge")
     if ws > 1:

@@ -248,7 +248,8 @@ def analyze_between_aligns(primary, supplementary, table, options, sample=None):
     p_rev = bool(flag[primary] & 0x10)
     qlen = int(table.l_seq[primary])                       # supplementary records inherit the primary's SEQ
     majors, minors, same_strand = [], [], []
-    whole_seq = table.query_sequence(primary) if options.hash else None
+    keep_seq = options.hash or getattr(options, "graph", False)           # the bases of every segment (--hash re-aligns them, --graph prints them)
+    whole_seq = table.query_sequence(primary) if keep_seq else None
     for a in [primary] + list(supplementary):
         a_rev = bool(flag[a] & 0x10)
         lead, trail = int(table.lead_clip[a]), int(table.trail_clip[a])
@@ -259,7 +260,7 @@ def analyze_between_aligns(primary, supplementary, table, options, sample=None):
         r0 = int(pos[a])
         seg = Seg(q_start, q_end, r0, r0 + int(table.ref_span[a]), int(table.tid[a]), a_rev != p_rev,
                   bool(flag[a] & 0x800), qual=int(table.mapq[a]), aln=int(a))
-        if options.hash:
+        if keep_seq:
             seg.read_seq = whole_seq[q_start:q_end]           # :667 (TypeError on SEQ '*', as upstream)
         if seg.is_reverse:
             seg.type = "other"
@@ -330,6 +331,8 @@ def analyze_inside_align(seg, gaps, options=None, sample=None):
 
     def piece(q0, q1, r0, r1):
         out.append(Seg(q0, q1, r0, r1, seg.ref_id, False, seg.is_supplementary, "main", seg.qual, seg.aln, derived=True))
+        if seg.read_seq is not None:                          # :943 the piece's own bases (read by --graph)
+            out[-1].read_seq = seg.read_seq[q0 - seg.q_start:q1 - seg.q_start]
 
     first_ref = int(gaps[0]["ref_pos"])
     m = first_ref - seg.ref_start

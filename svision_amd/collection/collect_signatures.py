@@ -13,6 +13,7 @@ import numpy as np
 
 from .analyze_reads import analyze_between_aligns, analyze_gap, analyze_inside_align
 from .classes import by_read_pos
+from .graph import build_graph
 
 
 def analyze_alignments(rows, sample, options, part_num=0):
@@ -79,9 +80,18 @@ def analyze_alignments(rows, sample, options, part_num=0):
         if n < 2:
             continue
 
-        def emit(cur, nxt, helpers=()):
-            sig = analyze_gap(cur.copy(), nxt.copy(), chrom_of, fetch_ref, options, qname, helpers)
+        want_graph = getattr(options, "graph", False)
+        whole_seq = table.query_sequence(primary) if want_graph else None
+
+        def emit(cur, nxt, helpers=(), next_is_last=True):
+            cur, nxt = cur.copy(), nxt.copy()
+            graph = None
+            if want_graph:                                    # before analyze_gap shifts / trims anything (:236-237, :298-302)
+                graph = build_graph(cur, nxt, helpers, options.min_sv_size, whole_seq, chrom_of, sample.fetch_ref_str, qname,
+                                    next_is_last)
+            sig = analyze_gap(cur, nxt, chrom_of, fetch_ref, options, qname, helpers)
             if sig is not None:
+                sig.set_graph(graph)
                 signatures.append(sig)
 
         if n == 2:
@@ -92,7 +102,7 @@ def analyze_alignments(rows, sample, options, part_num=0):
         if segs[-1].is_reverse:                               # :263-274
             emit(segs[-2], segs[-1])
         main_idx = [i for i, s in enumerate(segs) if s.type == "main"]
-        for i, j in zip(main_idx[:-1], main_idx[1:]):         # :287-308
+        for p, (i, j) in enumerate(zip(main_idx[:-1], main_idx[1:])):         # :287-308
             if segs[j].q_start - segs[i].q_end >= -25:
-                emit(segs[i], segs[j], segs[i + 1:j])
+                emit(segs[i], segs[j], segs[i + 1:j], p == len(main_idx) - 2)
     return signatures

@@ -8,6 +8,8 @@ rasteriser can consume a packed int32 array without re-parsing text.
 """
 import os
 
+from .graph import write_cluster_graphs
+
 from ..segmentplot.classes import cord_to_segments
 
 
@@ -105,6 +107,8 @@ def collect_pair_lines(clusters, options):
             continue
         if cl.read_num >= options.min_support:
             out.extend(proc_one_cluster(cl, options)[1])
+            if getattr(options, "graph", False) is True:      # :57-67
+                write_cluster_graphs(cl, options)
     return out
 
 

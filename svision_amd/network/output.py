@@ -101,6 +101,11 @@ VCF_HEADER = """##CHROM=<CHROM=XXX,Description="Chromosome ID">
 ##INFO=<ID=SUPPORT,Number=1,Type=Integer,Description="SV support number in this region">
 ##INFO=<ID=READS,Number=.,Type=String,Description="SV support read names in this region">
 """
+VCF_GRAPH_INFO = """##INFO=<ID=GraphID,Number=1,Type=String,Description="The corresponding graph id of isomorphic CSV graph structures">
+##INFO=<ID=GFA_FILE_PREFIX,Number=1,Type=String,Description="File name of CSV corresponding GFA file">
+##INFO=<ID=GFA_S,Number=1,Type=String,Description="Nodes contained in a CSV graph represented based on GFA format">
+##INFO=<ID=GFA_L,Number=1,Type=String,Description="Links contained in a CSV graph represented based on GFA format">
+"""                                                             # --graph only (:292-296)
 VCF_FORMAT = """##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">
 ##FORMAT=<ID=DR,Number=1,Type=Integer,Description="high-quality reference reads">
 ##FORMAT=<ID=DV,Number=1,Type=Integer,Description="high-quality variant reads">
@@ -142,6 +147,8 @@ def merge_split_vcfs(in_dir, merged_vcf_path, max_score, min_score, spec_chroms,
         for chrom in fasta.references:
             out.write("##contig=<ID=%s,length=%d>\n" % (chrom, fasta.get_reference_length(chrom)))
         out.write(VCF_HEADER)
+        if getattr(options, "graph", False):
+            out.write(VCF_GRAPH_INFO)
         out.write(VCF_FORMAT)
         out.write("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t%s\n" % options.sample)
         id_num = -1

@@ -159,4 +159,4 @@ def resolve(sample_or_path, options):
     reg = _CACHE.get(("registered", sample_or_path))
     if reg is not None:
         return reg
-    return Sample.open(sample_or_path, options.genome, options.min_sv_size, with_seq=bool(options.hash))
+    return Sample.open(sample_or_path, options.genome, options.min_sv_size, with_seq=bool(options.hash or getattr(options, "graph", False)))

@@ -172,6 +172,49 @@ class FastaFile:
         return len(self._seqs[chrom])
 
 
+class _VariantRecord:
+    """One body line of a VCF as pysam.VariantRecord shows it to graph.py:545-582."""
+
+    def __init__(self, line):
+        self._line = line.rstrip("\n")
+        c = self._line.split("\t")
+        self.contig = c[0]
+        self.start = int(c[1]) - 1
+        info = dict(kv.split("=", 1) for kv in c[7].split(";") if "=" in kv)
+        self.stop = int(info["END"])                           # htslib: rlen from INFO/END
+        self.info = {"SVTYPE": info["SVTYPE"], "SUPPORT": int(info["SUPPORT"])}
+        if "READS" in info:                                    # written with --qname only (output.py:580)
+            self.info["READS"] = tuple(info["READS"].split(","))
+
+    def __str__(self):
+        return self._line + "\n"                               # htslib prints back the fields it parsed, in their order
+
+
+class _VariantHeader:
+    def __init__(self, lines):
+        self._lines = list(lines)
+        if not any(l.startswith("##FILTER=<ID=PASS,") for l in self._lines):    # htslib defines PASS right after ##fileformat
+            self._lines.insert(1, '##FILTER=<ID=PASS,Description="All filters passed">\n')
+
+    def __str__(self):
+        return "".join(self._lines)
+
+
+class VariantFile:
+    """pysam.VariantFile(path) for reading: .header (str()) and iteration over records.  Assumed third-party
+    behaviour (pysam / htslib are not in this image): the text of header and records round-trips unchanged -- true for
+    the reference's own VCF writer, whose INFO / FORMAT fields are all declared -- plus the PASS filter line."""
+
+    def __init__(self, path, mode="r"):
+        with open(path) as f:
+            lines = f.readlines()
+        self.header = _VariantHeader([l for l in lines if l.startswith("#")])
+        self._records = [_VariantRecord(l) for l in lines if not l.startswith("#") and l.strip()]
+
+    def __iter__(self):
+        return iter(self._records)
+
+
 class _Shape(list):
     def as_list(self):
         return list(self)
@@ -224,6 +267,7 @@ def install_stubs():
     pysam.AlignedSegment = AlignedSegment
     pysam.AlignmentFile = AlignmentFile
     pysam.FastaFile = FastaFile
+    pysam.VariantFile = VariantFile
     cv2 = types.ModuleType("cv2")
     cv2.line = lambda img, p1, p2, color, thickness=1: encode_ref.cv_line(img, p1, p2, color)
     cv2.resize = lambda img, size: img

@@ -260,3 +260,44 @@ def test_hash_mode_with_helper_processes(checkpoint, tmp_path):
     with open(os.path.join(helpers.GOLDEN, "hash_collect.expected.json")) as f:
         want = [w for w in json.load(f)["windows"] if w["hash"]][0]
     assert open(os.path.join(out, "segments", "chrH.segments.all.bed")).read() == want["tsv"]
+
+
+@pytest.mark.gpu
+def test_cli_graph_mode_on_device(checkpoint, tmp_path):
+    """--graph --qname end to end on the device path, one process and ``-t 3``: the per-read graphs come out of the
+    collection as the reference writes them (fixture), step 3 leaves the graph VCF (the plain VCF's records, each with its
+    GraphID / GFA_* fields), the per-record graphs and the two summaries, and removes the per-site folders and the plain VCF."""
+    import gzip
+    import json
+    from svision_amd.io import bam
+    prefix, _params = checkpoint
+    fasta = helpers.load_golden_fasta("graph_small.fa.gz")
+    fa = str(tmp_path / "genome.fa")
+    bam.write_fasta(fa, {n: fasta._seq[n] for n in fasta.references})
+    with gzip.open(os.path.join(helpers.GOLDEN, "graph_small.expected.json.gz"), "rt") as f:
+        want = json.load(f)
+    args = ["-b", os.path.join(helpers.GOLDEN, "graph_small.bam"), "-m", prefix, "-g", fa, "-n", "HGg", "-s", "3",
+            "--window_size", str(want["window"]), "--batch_size", "64", "--qname", "--debug"]
+    plain = cli.run(cli.parse_arguments(["-o", str(tmp_path / "plain")] + args))
+    body = [l for l in open(plain).read().splitlines() if not l.startswith("#")]
+    outs = {}
+    for tag, extra in (("one", []), ("three", ["-t", "3"])):
+        out = str(tmp_path / tag)
+        if extra:
+            r = run_cli_fresh(["-o", out, "--graph"] + extra + args)
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        else:
+            assert cli.run(cli.parse_arguments(["-o", out, "--graph"] + args)).endswith("HGg.svision.s3.graph.vcf")
+        assert not os.path.exists(os.path.join(out, "HGg.svision.s3.vcf"))
+        got = [l for l in open(os.path.join(out, "HGg.svision.s3.graph.vcf")).read().splitlines() if not l.startswith("#")]
+        assert len(got) == len(body) >= 1                  # (random weights: few calls; the complex ones are covered on the CPU, test_graph_golden)
+        for a, b in zip(got, body):
+            ca, cb = a.split("\t"), b.split("\t")
+            assert ca[:7] == cb[:7] and ca[8:] == cb[8:] and ca[7].startswith(cb[7] + ";GraphID=")
+            assert ("GraphID=-1;GFA_ID=.;GFA_S=.;GFA_L=." in ca[7]) == ("CSV" not in b)
+        left = sorted(os.listdir(os.path.join(out, "graphs")))
+        assert all(n.endswith(".gfa") for n in left) and len(left) == sum("CSV" in b for b in body)
+        assert os.path.exists(os.path.join(out, "HGg.graph_exactly_match.txt")) and os.path.exists(os.path.join(out, "HGg.graph_symmetry_match.txt"))
+        assert open(os.path.join(out, "segments", "chrG.segments.all.bed")).read() == "".join(w["tsv"] for w in want["windows"])
+        outs[tag] = {n: open(os.path.join(out, n)).read() for n in ("HGg.svision.s3.graph.vcf", "HGg.graph_exactly_match.txt")}
+    assert outs["one"] == outs["three"]
