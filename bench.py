@@ -138,8 +138,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="candidate images per CNN batch (BASELINE configs[1])")
     ap.add_argument("--contig-len", type=int, default=CHR21)
     ap.add_argument("--coverage", type=float, default=30.0)
-    ap.add_argument("--workers", type=int, default=16, help="helper processes per rank for the Python host glue (capped at cores / ranks)")
-    ap.add_argument("--streams", type=int, default=4, help="HIP streams the per-batch graphs are replayed on")
+    ap.add_argument("--workers", type=int, default=8, help="helper processes per rank for the Python host glue (capped at cores / ranks)")
+    ap.add_argument("--streams", type=int, default=3, help="HIP streams the per-batch graphs are replayed on")
     ap.add_argument("--inflight", type=int, default=6, help="windows enqueued on the device at once")
     ap.add_argument("--launch-batches", type=int, default=2, help="batches of --batch images per device launch (graph replay)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -57,6 +57,9 @@ class SvxError(RuntimeError):
 _lib = None
 
 
+ABI_VERSION = 200                     # SVX_VERSION of include/svx.h this binding was written against
+
+
 def load():
     """Return the loaded library, binding all prototypes on first use."""
     global _lib
@@ -70,6 +73,8 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        if lib.svx_version() != ABI_VERSION:
+            raise SvxError(f"{LIB_PATH} reports ABI {lib.svx_version()}, this package binds {ABI_VERSION}: rebuild it (make -C svision_amd/csrc)")
         _lib = lib
     return _lib
 

@@ -1,0 +1,49 @@
+"""Compiles the per-read host modules of the collection step with Cython, in place (``python -m svision_amd.build_host``).
+
+The reference's collection is interpreted Python and so is this package's mirror of it (SURVEY 8(a'): same functions, same
+order of operations).  The six modules below are where a 10 Mb window spends its ~90 ms of host time; compiled as they
+are -- pure-Python mode, no type annotations, no semantic change -- they take 1.5x less (tools/exp/prof_collect.py), and an
+extension module next to its ``.py`` source is what ``import`` picks up.  Without the build the ``.py`` files run: same
+results, slower.  Outputs (``*.so``, generated ``*.c``) are git-ignored; the ``.so`` files travel with the snapshot like
+``libsvx.so``."""
+import os
+import sys
+
+MODULES = ["collection/analyze_reads.py", "collection/collect_signatures.py", "collection/classes.py",
+           "collection/output_clusters.py", "collection/cluster_signatures.py", "collection/graph.py",
+           "segmentplot/classes.py", "network/predict.py"]
+
+
+def build(quiet=True):
+    import shutil
+    import tempfile
+    from setuptools import setup
+    from Cython.Build import cythonize
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    cwd = os.getcwd()
+    os.chdir(root)
+    tmp = tempfile.mkdtemp(prefix="svx_host_build_")
+    os.environ["CFLAGS"] = (os.environ.get("CFLAGS", "") + " -g0 -O2").strip()           # no debug info: 8 x 0.1 MB instead of 8 x 1 MB
+    try:
+        ext = cythonize([os.path.join("svision_amd", m) for m in MODULES], language_level=3, quiet=quiet, build_dir=tmp,
+                        compiler_directives={"binding": True, "embedsignature": True})
+        setup(name="svision_amd_host", ext_modules=ext,
+              script_args=["build_ext", "--inplace", "--build-temp", tmp, "--build-lib", tmp] + (["-q"] if quiet else []))
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def clean():
+    here = os.path.dirname(os.path.abspath(__file__))
+    for m in MODULES:
+        base = os.path.join(here, m[:-3])
+        d = os.path.dirname(base)
+        for name in os.listdir(d):
+            if name.startswith(os.path.basename(base) + ".") and (name.endswith(".so") or name.endswith(".c")):
+                os.remove(os.path.join(d, name))
+
+
+if __name__ == "__main__":
+    clean() if sys.argv[1:] == ["clean"] else build(quiet="-v" not in sys.argv)

@@ -294,7 +294,7 @@ def _run_streaming(options, sample, tasks, chroms, seg_dir, pred_dir):
     import time as _time
     _t0 = _time.time()
     net = load_network(options.model_path)
-    hot = HotPath(sample, options, net, n_streams=4)
+    hot = HotPath(sample, options, net, n_streams=3)
     _t1 = _time.time()
     for chrom in chroms:
         prefix = os.path.join(pred_dir, "%s.predict.s%s" % (chrom, options.min_support))
@@ -340,7 +340,7 @@ def _run_pooled(options, sample, tasks, chroms, seg_dir, pred_dir, pool=None):
     part_of = [part for chrom in chroms for part in range(len(tasks[chrom]))]
     import time as _time
     _t0 = _time.time()
-    hot = PooledHotPath(sample, options, net, n_workers=options.thread_num, n_streams=4, max_inflight=6, want_tsv=True, pool=pool)
+    hot = PooledHotPath(sample, options, net, n_workers=options.thread_num, n_streams=3, max_inflight=6, want_tsv=True, pool=pool)
     _t1 = _time.time()
     done = {}
     try:

@@ -175,6 +175,9 @@ void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __res
         const float4 b1 = reinterpret_cast<const float4*>(base)[2 * g + 1];
         float acc[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
         {
+            // (A two-deep software pipeline of the weight-row loads -- request a tap's rows, add the previous tap's -- was
+            // measured and is not faster: the phase is bound by the 66 dependent LDS mask reads per item and by the four
+            // workgroups sharing a CU, not by the L2 latency of the rows; tools/exp/enc_prof.py.)
             for (int ky = 0; ky < 11; ++ky) {
                 const int r = 4 * oy + ky;
 #pragma unroll

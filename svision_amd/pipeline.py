@@ -326,7 +326,15 @@ def _worker_main(conn):
     run_hash_lineplot.DEVICE = None           # helpers never touch the GPU
     if sample is not None:
         sample.device_buffers = None          # a helper forked from a live owner: its copy of the Sample is host-only
+    # The cyclic collector finds nothing to free here (segments, signatures and lines die by reference count) but its
+    # young-generation passes cost 20 % of a window and a full pass over the alignment table's objects ~70 ms: it runs
+    # by hand, rarely.
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     held = {}
+    n_done = 0
     while True:
         msg = conn.recv()
         if msg[0] == "stop":
@@ -351,6 +359,9 @@ def _worker_main(conn):
             vcf, scores, n_sites, head, tail = _vote(sample, options, chrom, lines, classes, probs, start, end)
             tsv = "".join(ln.text() for ln in lines) if _POOL_STATE.get("want_tsv") else None
             conn.send(("done", wid, vcf, scores, n_sites, len(lines), tsv, head, tail))
+            n_done += 1
+            if n_done % 128 == 0:
+                gc.collect()
 
 
 class HelperPool:
