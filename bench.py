@@ -284,7 +284,7 @@ def main():
                      "ms_per_batch": ms_batch, "batches": sum_dev_images / B, "device_busy_frac": dev_s / dt},
     }
     if rank == 0 and not args.no_calibration:
-        line["roofline_kernels"] = kernel_calibration(hot, sample, net, dev, B, windows[0])
+        line["roofline_kernels"] = kernel_calibration(hot, sample, net, dev, B * max(1, args.launch_batches), windows[0])
     hot.close()
     if cpu_pool is not None:
         line["cpu_baseline"] = cpu_pool.run(windows)
@@ -296,7 +296,8 @@ def main():
 
 def kernel_calibration(hot, sample, net, dev, B, window, reps=20):
     """Live per-kernel timings (HIP events on the launch stream, eager, outside the timed region) on the workload's own
-    records: the first full batch of one window, each kernel fed with the tensors the stage really hands it."""
+    records: the first full launch (B = batch x batches per launch images) of one window, each kernel fed with the tensors
+    the stage really hands it."""
     def timed(fn):
         fn()
         torch.cuda.synchronize()
@@ -318,8 +319,8 @@ def kernel_calibration(hot, sample, net, dev, B, window, reps=20):
     x1, touched = kernels.encode_conv1(rec, net.conv1_hwio, net.conv1_base, touched=True)
     out["encode_conv1_kernel"] = {"bound": "latency", "launch": "%d images" % B,
                                   "us": timed(lambda: kernels.encode_conv1(rec, net.conv1_hwio, net.conv1_base, touched=True)) * 1e6,
-                                  "note": "rasterise + sparse conv1 + relu + pool + LRN; replaces %.1f MB of image traffic and 13.5 GFLOP "
-                                          "of dense conv1 per batch" % (IMG_BYTES * B / 1e6)}
+                                  "note": "rasterise + sparse conv1 + relu + pool + LRN; replaces %.1f MB of image traffic and %.1f GFLOP "
+                                          "of dense conv1 per launch" % (IMG_BYTES * B / 1e6, 210_830_400 * B / 1e9)}
     l2, l3, l4, l5, counts = kernels.alexnet_active_sets(touched)
     out["active_counts + active_lists"] = {"bound": "latency", "launch": "%d images" % B, "us": timed(lambda: kernels.alexnet_active_sets(touched)) * 1e6}
     cnt = counts.cpu().numpy().astype(np.float64)
@@ -356,10 +357,11 @@ def kernel_calibration(hot, sample, net, dev, B, window, reps=20):
     wbytes = (net.fc6_w.numel() + net.fc7_w.numel()) * 4
     fc_flop = 2.0 * B * (9216 * 4096 + 4096 * 4096)
     out["fc_splitk_kernel + fc_reduce_kernel (fc6, fc7)"] = {
-        "bound": "hbm", "us": (t6 + t7) * 1e6, "achieved": wbytes / (t6 + t7) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-        "frac": wbytes / (t6 + t7) / HBM_PEAK,
-        "note": "218 MB of weights streamed per batch of %d; the same launches run %.1f TFLOP/s of fp32 MFMA (%.2f of the peak): "
-                "the layers are balanced between the two limits at this batch" % (B, fc_flop / (t6 + t7) / 1e12, fc_flop / (t6 + t7) / F32_MFMA_PEAK)}
+        "bound": "mfma", "us": (t6 + t7) * 1e6, "achieved": fc_flop / (t6 + t7) / 1e12, "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s",
+        "frac": fc_flop / (t6 + t7) / F32_MFMA_PEAK,
+        "note": "fp32 MFMA over a 218 MB weight stream: %.0f GB/s of weights (%.2f of the HBM peak) at this launch size (%d images); "
+                "at one batch of 64 the two limits are balanced, from two batches on the matrix pipe is the bound"
+                % (wbytes / (t6 + t7) / 1e9, wbytes / (t6 + t7) / HBM_PEAK, B)}
     t = timed(lambda: net.predict_records_packed(rec))
     out["device_stage_eager_1_stream"] = {"bound": "mfma", "launch": "%d images of the workload" % B, "us": t * 1e6}
     dense_net = AlexNet(random_weights(0), device=dev, active=False)
