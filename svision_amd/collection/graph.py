@@ -237,8 +237,7 @@ def graph_features(graph):
 def write_cluster_graphs(cluster, options):
     """One ``.gfa`` per signature of a reported cluster (output_clusters.py:57-67)."""
     path = os.path.join(options.out_path, "graphs", "%s-%d-%d" % (cluster.contig, int(cluster.cstart), int(cluster.cend)))
-    if not os.path.exists(path):
-        os.mkdir(path)
+    os.makedirs(path, exist_ok=True)                          # two windows (two helper processes) can report the same boundary cluster
     for sig in cluster.get_signatures():
         write_gfa(sig.graph, os.path.join(path, "%s.gfa" % sig.graph.qname.replace("/", "_")))
 

@@ -156,6 +156,8 @@ class DeviceStage:
         used = set()
         n_streams = len(self.streams)
         lo, n = 0, int(d_rec.shape[0])
+        if n % self.batch:
+            raise ValueError("DeviceStage.run: %d records are not a multiple of the batch (%d); pad with the reference's pad record" % (n, self.batch))
         while lo < n:
             b = next(size for size in self.sizes if size <= n - lo)
             k = self._next = (getattr(self, "_next", -1) + 1) % n_streams     # round-robin continues across calls

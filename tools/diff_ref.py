@@ -40,7 +40,8 @@ def one_case(seed):
                           sv_max=int(rng.choice([800, 4000, 20000])), inline_max=int(rng.choice([300, 1500, 4000])),
                           het_frac=float(rng.choice([0.0, 0.5, 1.0])), seed=int(seed), sv_mix=MIXES[int(rng.integers(0, len(MIXES)))])
     use_hash = bool(rng.random() < 0.2)
-    table, genome, _svs = synth.simulate(cfg, with_seq=use_hash)
+    use_graph = bool(rng.random() < float(os.environ.get("GRAPH_FRAC", "0.25")))      # --graph: per-read .gfa trees compared as well
+    table, genome, _svs = synth.simulate(cfg, with_seq=use_hash or use_graph)
     if os.environ.get("DUP_RECORDS") and not use_hash:
         # duplicate some records verbatim (value-equal segments of one read: analyze_reads.py:225 compares dicts by value)
         rows = np.arange(len(table))
@@ -48,7 +49,7 @@ def one_case(seed):
         if os.environ.get("DUP_ONLY_SUPP"):
             pick &= (table.flag & 0x800) != 0
         table = table.subset(np.sort(np.concatenate([rows, rows[pick]]), kind="stable"))
-    over = dict(hash=use_hash, min_support=int(rng.choice([1, 2, 3, 5, 8])), min_mapq=int(rng.choice([0, 10, 20, 40])),
+    over = dict(hash=use_hash, graph=use_graph, min_support=int(rng.choice([1, 2, 3, 5, 8])), min_mapq=int(rng.choice([0, 10, 20, 40])),
                 min_sv_size=int(rng.choice([30, 50, 100])), max_sv_size=int(rng.choice([3000, 1000000])),
                 patition_max_distance=int(rng.choice([500, 5000])), cluster_max_distance=float(rng.choice([0.1, 0.3, 0.6])),
                 contig=bool(rng.random() < 0.15), qname=bool(rng.random() < 0.2))
@@ -63,6 +64,19 @@ def one_case(seed):
         refdriver.FASTAS[genome_path] = genome
         refdriver.DATASETS["sample.bam"] = table
         os.mkdir(os.path.join(out, "segments"))
+        gdir = os.path.join(out, "graphs")
+
+        def graph_tree():
+            tree = {}
+            if os.path.exists(gdir):
+                for d, _dirs, files in os.walk(gdir):
+                    for name in files:
+                        with open(os.path.join(d, name)) as f:
+                            tree[os.path.relpath(os.path.join(d, name), gdir)] = f.read()
+                shutil.rmtree(gdir)
+            os.mkdir(gdir)
+            return tree
+        graph_tree()
         ropts = refdriver.default_options(out_path=out, genome=genome_path, bam_path="sample.bam", window_size=window, **over)
         popts = helpers.default_options(out_path=out, genome=genome_path, bam_path="sample.bam", window_size=window, **over)
         fasta = bam.Fasta(sequences=genome)
@@ -77,6 +91,7 @@ def one_case(seed):
                 want = open(path).read() if os.path.exists(path) else None
                 if os.path.exists(path):
                     os.remove(path)
+                want_graphs = graph_tree()
                 sample = Sample.with_scan(table, fasta, over["min_sv_size"], scan)
                 try:                                         # run_detect's catch-all: a failing window writes nothing
                     _sigs, clusters = detect_window(popts, sample, chrom, pos, end, part)
@@ -85,6 +100,11 @@ def one_case(seed):
                     got = ""
                     if err is None:
                         return "PRODUCT-ONLY EXCEPTION seed %d %s:%d-%d: %r" % (seed, chrom, pos, end, exc), n_lines
+                got_graphs = graph_tree()
+                if use_graph and err is None and want_graphs != got_graphs:
+                    diff = sorted(k for k in set(want_graphs) | set(got_graphs) if want_graphs.get(k) != got_graphs.get(k))
+                    return "GRAPH MISMATCH seed %d %s:%d-%d opts %s: %d of %d files differ, first %s" % (
+                        seed, chrom, pos, end, over, len(diff), len(want_graphs), diff[:3]), n_lines
                 if (want or "") != got:
                     return "MISMATCH seed %d %s:%d-%d part %d opts %s cfg %s (ref err %r): want %d lines, got %d" % (
                         seed, chrom, pos, end, part, over, cfg, err, (want or "").count("\n"), got.count("\n")), n_lines
