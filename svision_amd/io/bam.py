@@ -166,6 +166,7 @@ class AlignmentTable:
         self.lead_clip = np.ascontiguousarray(stats[:, 1])
         self.trail_clip = np.ascontiguousarray(stats[:, 2])
         self._ref_end = None
+        self._max_span = None
 
     def ref_end(self):
         """htslib bam_endpos: pos + reference span, or pos + 1 for spanless/unmapped records."""
@@ -192,9 +193,17 @@ class AlignmentTable:
         if lo == hi:
             return np.empty(0, np.int64)
         pos = self.pos[lo:hi]
-        stop = lo + int(np.searchsorted(pos, end, side="left"))      # pos < end
-        idx = np.arange(lo, stop, dtype=np.int64)
-        return idx[self.ref_end()[lo:stop] > start]
+        info = np.iinfo(pos.dtype)
+
+        def key(v):                                                  # a needle of the array's own type: no converted copy of `pos`
+            return pos.dtype.type(min(max(int(v), info.min), info.max))
+        stop = lo + int(np.searchsorted(pos, key(end), side="left"))      # pos < end
+        ref_end = self.ref_end()
+        if getattr(self, "_max_span", None) is None:                 # no record reaches farther than this behind its start
+            self._max_span = int((ref_end - self.pos).max()) if len(self.pos) else 0
+        first = lo + int(np.searchsorted(pos, key(start - self._max_span), side="left"))
+        idx = np.arange(first, stop, dtype=np.int64)
+        return idx[ref_end[first:stop] > start]
 
     def count_overlaps(self, tid, starts, ends):
         """Vectorised number of records overlapping each [start, end): the per-cluster

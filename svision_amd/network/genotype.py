@@ -19,7 +19,8 @@ def genotyper(candidate, support_reads, options, sample):
     if rows.size:
         names = table.name_id[rows]
         alt_ids = table.ids_of(alt)
-        usable = ~np.isin(names, alt_ids)
+        # (np.isin sorts both sides: ~90 us per call for a few hundred names against a few dozen ids)
+        usable = ~(names[:, None] == alt_ids[None, :]).any(axis=1) if alt_ids.size <= 64 else ~np.isin(names, alt_ids)
         usable &= ((table.flag[rows] & (0x4 | 0x100)) == 0) & (table.mapq[rows] >= options.min_mapq)
         rows = rows[usable][:500]                             # aln_no < 500 (:33-43)
     if rows.size == 0:
@@ -37,7 +38,7 @@ def genotyper(candidate, support_reads, options, sample):
         ref_names = table.name_id[rows][hit]
     else:
         ref_names = table.name_id[rows]
-    ref_no = int(np.unique(ref_names).size)
+    ref_no = len(set(ref_names.tolist()))
     gt = "./."
     if len(svtype) != 1:
         return gt, ref_no, alt_no

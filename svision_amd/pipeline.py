@@ -442,6 +442,7 @@ class PooledHotPath(HotPath):
         import time as _time
         prof = self.owner_profile = {"scan+send": 0.0, "launch": 0.0, "fetch+send": 0.0, "wait": 0.0, "recv": 0.0}     # owner-thread seconds
         clock = _time.perf_counter
+        t_loop = clock()
         while remaining:
             t = clock()
             while idle and nxt < len(windows):
@@ -465,12 +466,14 @@ class PooledHotPath(HotPath):
             t1 = clock(); prof["scan+send"] += t1 - t
             while ready and len(inflight) < self.max_inflight:
                 ci, res = ready.popleft()
+                prof.setdefault("first_launch_at", clock() - t_loop)
                 inflight.append((ci, self.launch(res)))
             t2 = clock(); prof["launch"] += t2 - t1
             while inflight and (inflight[0][1].n_images == 0 or inflight[0][1].done_event.query()):
                 ci, res = inflight.popleft()
                 classes, probs = self.fetch_predictions(res)
                 self.conns[ci].send(("pred", busy[ci], classes, probs))
+                prof["last_fetch_at"] = clock() - t_loop
             t3 = clock(); prof["fetch+send"] += t3 - t2
             waiting = [self.conns[ci] for ci in busy]
             got = mpc.wait(waiting, timeout=0.0005 if inflight else 0.05)
@@ -499,4 +502,5 @@ class PooledHotPath(HotPath):
                     del busy[ci]
                     idle.append(ci)
                     remaining -= 1
+                    prof["last_done_at"] = clock() - t_loop
                     yield res

@@ -128,6 +128,7 @@ class Sample:
         table.ref_span[lo:hi], table.lead_clip[lo:hi], table.trail_clip[lo:hi] = stats[:, 0], stats[:, 1], stats[:, 2]
         if changed:
             table._ref_end = None                               # reference ends (and their sorted copies) are derived from ref_span
+            table._max_span = None
 
     # -- accessors used by the collection step ----------------------------------------
     def gaps_of(self, aln):
