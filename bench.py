@@ -83,16 +83,21 @@ def windows_of(name, length):
 
 
 def _simulate_contig(job):
-    """(name, length, coverage, seed) -> (AlignmentTable, genome bytes) of one contig (runs in a forked worker)."""
-    name, length, coverage, seed = job
-    table, genome, _svs = synth.simulate(synth.SimConfig(contigs=[(name, length)], coverage=coverage, seed=seed))
+    """(name, length, coverage, seed[, kind]) -> (AlignmentTable, genome bytes) of one contig (runs in a forked worker)."""
+    name, length, coverage, seed = job[:4]
+    if len(job) > 4 and job[4] == "ont":     # ONT ultra-long stand-in: log-normal lengths (median 50 kb), 5 % small events
+        cfg = synth.SimConfig(contigs=[(name, length)], coverage=coverage, seed=seed, read_len_mean=50_000, lognormal=True,
+                              lognormal_sigma=0.7, err_rate=0.05)
+    else:
+        cfg = synth.SimConfig(contigs=[(name, length)], coverage=coverage, seed=seed)
+    table, genome, _svs = synth.simulate(cfg)
     return table, genome[name]
 
 
 def build_workload(args, rank, world, cores):
     """-> (samples: list of (table, fasta) per contig of this rank, windows of this rank, description dict)."""
-    if args.workload == "cfg2":
-        jobs = [("chr21", args.contig_len, args.coverage, 1 + rank)]
+    if args.workload in ("cfg2", "ont"):
+        jobs = [("chr21", args.contig_len, args.coverage, 1 + rank) + (("ont",) if args.workload == "ont" else ())]
         strong = False
         total_windows = None
     else:
@@ -134,7 +139,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="windows to time (cfg2: per rank, default 200; wg: whole job, default all)")
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", choices=("cfg2", "wg"), default="cfg2")
+    ap.add_argument("--workload", choices=("cfg2", "wg", "ont"), default="cfg2",
+                    help="cfg2: chr21-sized HiFi sample per rank (weak scaling, the default); wg: 24 GRCh38-length contigs sharded over the "
+                         "ranks (strong scaling); ont: chr21-sized ONT ultra-long stand-in per rank (BASELINE configs[3] stress: ~5,000 CIGAR ops per read)")
     ap.add_argument("--batch", type=int, default=64, help="candidate images per CNN batch (BASELINE configs[1])")
     ap.add_argument("--contig-len", type=int, default=CHR21)
     ap.add_argument("--coverage", type=float, default=30.0)
@@ -256,6 +263,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": ("cfg3 stand-in: synthetic whole-genome HiFi, 24 contigs of GRCh38 length (N(15kb,2kb) reads, %gx), "
                                 "chromosomes LPT-sharded over the ranks" % args.coverage) if strong else
+                               ("cfg4 stand-in on one contig per rank: synthetic ONT ultra-long chr21 (%d bp, log-normal reads, median 50 kb, "
+                                "5 %% small events, %gx)" % (args.contig_len, args.coverage)) if args.workload == "ont" else
                                ("cfg2 stand-in: synthetic HiFi chr21 (%d bp, N(15kb,2kb) reads, %gx)" % (args.contig_len, args.coverage)),
                    "step": "one 10 Mb collection window through scan -> collection -> encode + CNN (batches of %d candidate images, fp32) -> vote" % B,
                    "batch": B, "alignments_rank0": len(table), "cigar_ops_rank0": int(table.cigar.size),

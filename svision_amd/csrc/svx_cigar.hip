@@ -6,19 +6,24 @@
 // batch of alignments whose packed BAM CIGAR words already sit in HBM.
 //
 // HBM-read bound: 4 B per CIGAR op, 16 B per alignment of CSR/start data,
-// 24 B written per long gap (rare).  Four launches, no atomics, output deterministic and
+// 24 B written per long gap (rare).  No atomics on results, output deterministic and
 // sorted by (alignment, op) without a sort:
 //   1. count_kernel  : eight lanes per alignment (eight alignments in flight per wave)
 //                      stream the CIGAR once in 16-byte quads and reduce the per-alignment
 //                      spans, clip runs and the number of long gaps; every workgroup also
-//                      stores its gap and owner totals;
+//                      stores its gap and owner totals.  An alignment of more than 512 words
+//                      (ONT) is only started here and put on a list;
+//   1b. count_long_kernel + retotal_kernel: one wave per listed alignment streams the rest of it
+//                      with eight 16-byte loads in flight per lane and adds its (integer) sums;
+//                      the totals of the count workgroups concerned are recomputed from the counts;
 //   2. scan_kernel   : exclusive prefix of the totals per tile of 256 alignments (one workgroup);
 //   3. offsets_kernel: a workgroup per tile scans its counts into the CSR offsets d_gap_off
 //                      and writes the alignments that own a gap (a few % of HiFi reads, most
 //                      ONT reads) into a work list, in alignment order;
 //   4. emit_kernel   : resident waves walk the work list, one wave per alignment, 256
-//                      CIGAR words per step: wave prefix sums of read/ref advance give
-//                      readPos/refPos at every op, ballot-ranked stores keep op order.
+//                      CIGAR words per step requested two steps ahead: wave prefix sums of
+//                      read/ref advance give readPos/refPos at every op, ballot-ranked stores
+//                      keep op order.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/svx.h"
@@ -53,6 +58,7 @@ constexpr int CGROUP = SVX_CGROUP;                  // lanes per alignment in th
 constexpr int CQUADS = SVX_CQUADS;                  // 16-byte loads in flight per lane
 constexpr int ALN_PER_CBLOCK = BLOCK / CGROUP;      // alignments per workgroup of the count pass
 constexpr int CBLOCKS_PER_TILE = TILE / ALN_PER_CBLOCK;
+constexpr int LONG_Q = 128;                         // quads (512 words) of an alignment the eight-lane count pass handles itself
 
 __device__ inline unsigned cgroup_sum(unsigned v)
 {
@@ -83,7 +89,7 @@ __device__ inline void tally(uint32_t w, int32_t min_sv, unsigned& ref_span, uns
 __global__ __launch_bounds__(BLOCK)
 void count_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict__ cig_off,
                   uint32_t n_aln, int32_t min_sv, uint32_t* __restrict__ gap_off, int32_t* __restrict__ stats,
-                  uint2* __restrict__ block_tot)
+                  uint2* __restrict__ block_tot, uint32_t* __restrict__ long_list, uint32_t* __restrict__ long_count)
 {
     __shared__ uint32_t s_tot[3];                        // gaps, owners, waves done
     if (threadIdx.x < 3) s_tot[threadIdx.x] = 0u;
@@ -95,7 +101,23 @@ void count_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict
     const uint64_t full = cig_off[n_aln] >> 2;           // quads that lie entirely inside the array
     const uint64_t b = live ? cig_off[a] : 0, e = live ? cig_off[a + 1] : 0;
     const long long n = (long long)(e - b);
-    const uint64_t q0 = b >> 2, q1 = min((e + 3) >> 2, full);
+    const uint64_t q0 = b >> 2, q_end = min((e + 3) >> 2, full);
+    // an alignment of more than LONG_Q quads (ONT: 10^3-10^5 ops) leaves everything behind its first LONG_Q quads to
+    // count_long_kernel (a wave of its own, deep load pipeline): for its eight lanes here it would be a chain of
+    // hundreds of memory round trips that the whole launch waits for.  All sums are modular and additive, so the
+    // corrections below (computed from q_end) and the partial sums of the two kernels simply add up.
+    const bool is_long = q_end - q0 > (uint64_t)LONG_Q;
+    const uint64_t q1 = is_long ? q0 + LONG_Q : q_end;
+    {                                                    // one atomic per wave: the (up to eight) group leaders share a reservation
+        const unsigned long long m = __ballot(is_long && sub == 0);
+        if (m) {
+            const int wl = threadIdx.x & (WAVE - 1), first = __ffsll((long long)m) - 1;
+            uint32_t base = 0;
+            if (wl == first) base = atomicAdd(long_count, (uint32_t)__popcll(m));
+            base = __shfl(base, first, WAVE);
+            if (is_long && sub == 0) long_list[base + (uint32_t)__popcll(m & ((1ull << wl) - 1ull))] = a;
+        }
+    }
     // the words at either end for the clip runs, the neighbours' words inside the first / last quad (lanes 0-2
     // look before b and from e on), the alignment's words beyond the last whole quad of the array (at most 3,
     // last alignments only), then the quads
@@ -103,8 +125,8 @@ void count_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict
     const uint32_t w_head = sub < n ? cigar[b + sub] : 0u;
     const uint32_t w_tail = it >= 0 ? cigar[b + it] : 0u;
     const uint64_t fl = (b & ~3ull) + sub, ft = e + sub, tg = max(b, 4 * full) + sub;
-    const uint32_t w_before = (q0 < q1 && sub < 3 && fl < b) ? cigar[fl] : 0u;
-    const uint32_t w_after = (q0 < q1 && sub < 3 && ft < 4 * q1) ? cigar[ft] : 0u;
+    const uint32_t w_before = (q0 < q_end && sub < 3 && fl < b) ? cigar[fl] : 0u;
+    const uint32_t w_after = (q0 < q_end && sub < 3 && ft < 4 * q_end) ? cigar[ft] : 0u;
     const uint32_t w_loose = (sub < 3 && tg < e) ? cigar[tg] : 0u;
     unsigned ref_span = 0, qlen = 0, ngap = 0;
     const uint4* __restrict__ quads = reinterpret_cast<const uint4*>(cigar);
@@ -171,6 +193,62 @@ void count_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict
             s4.x = (int)ref_span; s4.y = (int)lead; s4.z = (int)trail; s4.w = (int)qlen;
             reinterpret_cast<int4*>(stats)[a] = s4;
         }
+    }
+}
+
+// Long alignments (listed by count_kernel, any order): one wave each, everything behind the first LONG_Q quads,
+// LQUADS 16-byte loads in flight per lane (2048 words per step).  Adds its sums to what count_kernel stored
+// (retotal_kernel then refreshes the totals of the count workgroups concerned).
+constexpr int LQUADS = 8;
+
+__global__ __launch_bounds__(BLOCK)
+void count_long_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict__ cig_off, uint32_t n_aln, int32_t min_sv,
+                       uint32_t* __restrict__ gap_off, int32_t* __restrict__ stats,
+                       const uint32_t* __restrict__ long_list, const uint32_t* __restrict__ long_count)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const uint32_t n_long = *long_count, n_waves = gridDim.x * (BLOCK / WAVE);
+    const uint64_t full = cig_off[n_aln] >> 2;
+    const uint4* __restrict__ quads = reinterpret_cast<const uint4*>(cigar);
+    for (uint32_t k = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6); k < n_long; k += n_waves) {
+        const uint32_t a = long_list[k];
+        const uint64_t b = cig_off[a], e = cig_off[a + 1];
+        const uint64_t q0 = (b >> 2) + LONG_Q, q1 = min((e + 3) >> 2, full);
+        unsigned ref_span = 0, qlen = 0, ngap = 0;
+        for (uint64_t q = q0 + lane; q < q1; q += (uint64_t)LQUADS * WAVE) {
+            uint4 w[LQUADS];
+#pragma unroll
+            for (int u = 0; u < LQUADS; ++u) w[u] = quads[min(q + (uint64_t)u * WAVE, q1 - 1)];
+#pragma unroll
+            for (int u = 0; u < LQUADS; ++u) {
+                const bool in = q + (uint64_t)u * WAVE < q1;
+                tally(in ? w[u].x : 0u, min_sv, ref_span, qlen, ngap); tally(in ? w[u].y : 0u, min_sv, ref_span, qlen, ngap);
+                tally(in ? w[u].z : 0u, min_sv, ref_span, qlen, ngap); tally(in ? w[u].w : 0u, min_sv, ref_span, qlen, ngap);
+            }
+        }
+        ref_span = wave_sum_u(ref_span); qlen = wave_sum_u(qlen); ngap = wave_sum_u(ngap);
+        if (lane == 0) {
+            if (stats) { stats[4 * (size_t)a] += (int)ref_span; stats[4 * (size_t)a + 3] += (int)qlen; }
+            if (ngap) gap_off[a] += ngap;
+        }
+    }
+}
+
+// Totals of the count workgroups that hold a long alignment, recomputed from the final per-alignment counts (the
+// count pass stored them before count_long_kernel added its share): one wave per listed alignment rewrites the totals
+// of that alignment's group of ALN_PER_CBLOCK alignments -- idempotent, so several long alignments of one group are harmless.
+__global__ __launch_bounds__(BLOCK)
+void retotal_kernel(const uint32_t* __restrict__ gap_off, uint32_t n_aln, uint2* __restrict__ block_tot,
+                    const uint32_t* __restrict__ long_list, const uint32_t* __restrict__ long_count)
+{
+    static_assert(ALN_PER_CBLOCK <= WAVE, "one lane per alignment of a count workgroup");
+    const int lane = threadIdx.x & (WAVE - 1);
+    const uint32_t n_long = *long_count, n_waves = gridDim.x * (BLOCK / WAVE);
+    for (uint32_t k = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6); k < n_long; k += n_waves) {
+        const uint32_t blk = long_list[k] / ALN_PER_CBLOCK, a = blk * ALN_PER_CBLOCK + lane;
+        const uint32_t c = (lane < ALN_PER_CBLOCK && a < n_aln) ? gap_off[a] : 0u;
+        const unsigned gaps = wave_sum_u(c), owners = (unsigned)__popcll(__ballot(c != 0u));
+        if (lane == 0) block_tot[blk] = make_uint2(gaps, owners);
     }
 }
 
@@ -274,11 +352,16 @@ void emit_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict_
         const uint64_t b = cig_off[a];
         const long long n = (long long)(cig_off[a + 1] - b);
         uint32_t read_pos = 0, ref_pos = (uint32_t)ref_start[a];
-        for (long long j0 = 0; j0 < n; j0 += 4 * WAVE) {
+        // the words of a step are requested two steps ahead (three register sets, statically rotated): the positions
+        // are a serial chain over the steps, so an ultra-long read (ONT: 10^4-10^5 ops, 40-400 steps) would otherwise
+        // pay one memory round trip per step
+        auto load = [&](long long j0, uint32_t (&w)[4]) {
             const long long j = j0 + 4 * lane;
-            uint32_t w[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) w[u] = j + u < n ? cigar[b + j + u] : 6u;      // "0P": advances nothing
+        };
+        auto step = [&](long long j0, const uint32_t (&w)[4]) {
+            const long long j = j0 + 4 * lane;
             uint32_t dr[4], df[4], tr = 0, tf = 0;
             bool hit[4];
 #pragma unroll
@@ -321,6 +404,20 @@ void emit_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict_
             dst += all;
             read_pos += __shfl(ir, WAVE - 1, WAVE);
             ref_pos += __shfl(irf, WAVE - 1, WAVE);
+        };
+        constexpr long long STEP = 4 * WAVE;
+        uint32_t w0[4], w1[4], w2[4];
+        load(0, w0);
+        load(STEP, w1);
+        for (long long j0 = 0; j0 < n; j0 += 3 * STEP) {
+            load(j0 + 2 * STEP, w2);
+            step(j0, w0);
+            if (j0 + STEP >= n) break;
+            load(j0 + 3 * STEP, w0);
+            step(j0 + STEP, w1);
+            if (j0 + 2 * STEP >= n) break;
+            load(j0 + 4 * STEP, w1);
+            step(j0 + 2 * STEP, w2);
         }
     }
 }
@@ -362,7 +459,16 @@ extern "C" int svx_cigar_scan(const uint32_t* d_cigar, const uint64_t* d_cig_off
     uint2* block_tot = static_cast<uint2*>(d_ws);
     uint2* tile_pre = reinterpret_cast<uint2*>(static_cast<char*>(d_ws) + ws_tile_offset(n_aln));
     uint2* work = reinterpret_cast<uint2*>(static_cast<char*>(d_ws) + ws_work_offset(n_aln));
-    hipLaunchKernelGGL(count_kernel, dim3(count_blocks), dim3(BLOCK), 0, st, d_cigar, d_cig_off, n_aln, min_sv, d_gap_off, d_stats, block_tot);
+    // list of the long alignments: built by the count pass in the (not yet used) work area, its counter in the area's last word
+    uint32_t* long_list = reinterpret_cast<uint32_t*>(work);
+    uint32_t* long_count = reinterpret_cast<uint32_t*>(work + n_aln) - 1;
+    if (hipMemsetAsync(long_count, 0, sizeof(uint32_t), st) != hipSuccess) return SVX_ELAUNCH;
+    hipLaunchKernelGGL(count_kernel, dim3(count_blocks), dim3(BLOCK), 0, st, d_cigar, d_cig_off, n_aln, min_sv, d_gap_off, d_stats, block_tot,
+                       long_list, long_count);
+    const uint32_t long_blocks = min(2048u, (n_aln + 3u) / 4u);
+    hipLaunchKernelGGL(count_long_kernel, dim3(long_blocks), dim3(BLOCK), 0, st, d_cigar, d_cig_off, n_aln, min_sv,
+                       d_gap_off, d_stats, long_list, long_count);
+    hipLaunchKernelGGL(retotal_kernel, dim3(long_blocks), dim3(BLOCK), 0, st, d_gap_off, n_aln, block_tot, long_list, long_count);
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(SBLOCK), 0, st, block_tot, count_blocks, tile_pre, tiles);
     hipLaunchKernelGGL(offsets_kernel, dim3(tiles), dim3(BLOCK), 0, st, n_aln, d_gap_off, tile_pre, work);
     // resident waves (8 workgroups per CU at most); small inputs get one wave per 4 alignments

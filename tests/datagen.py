@@ -36,11 +36,14 @@ def random_records(n, seed=0, hostile=True):
 _OPS = np.array([0, 1, 2, 3, 4, 5, 6, 7, 8])
 
 
-def random_cigars(n_aln, seed=0, mean_ops=200, long_gap_rate=0.01, max_ops=None):
+def random_cigars(n_aln, seed=0, mean_ops=200, long_gap_rate=0.01, max_ops=None, lognormal_sigma=None):
     """Packed CIGAR words + CSR offsets + ref_start for n_aln synthetic alignments
     (HiFi-like: =/X/I/D soup, optional S/H clips, occasional long I/D, rare N/P)."""
     rng = np.random.default_rng(seed)
-    n_ops = np.maximum(1, rng.poisson(mean_ops, n_aln)).astype(np.int64)
+    if lognormal_sigma is None:
+        n_ops = np.maximum(1, rng.poisson(mean_ops, n_aln)).astype(np.int64)
+    else:                                                     # ONT-like: op count follows the read length (median mean_ops)
+        n_ops = np.maximum(1, rng.lognormal(np.log(mean_ops), lognormal_sigma, n_aln)).astype(np.int64)
     if max_ops is not None:
         n_ops = np.minimum(n_ops, max_ops)
     n_ops[rng.random(n_aln) < 0.02] = 1

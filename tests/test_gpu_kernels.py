@@ -91,6 +91,33 @@ def test_cigar_scan_full_size(oracle_lib):
     assert again.to_host()[0].tobytes() == gaps.tobytes()                # deterministic
 
 
+def test_cigar_scan_ultra_long_reads(oracle_lib):
+    """ONT-like op counts (log-normal around 4,000, tail beyond 10^5): most alignments exceed the 512 words the eight-lane count
+    pass keeps for itself and are finished by count_long_kernel; mixed with short ones so that count workgroups hold both kinds,
+    gaps on either side of the hand-over, lengths around the threshold (511..516 words, 2047..2049)."""
+    from oracle import cbind
+    cigar, off, ref_start = datagen.random_cigars(6000, seed=77, mean_ops=4000, long_gap_rate=0.002, lognormal_sigma=1.0)
+    n_ops = np.diff(off.astype(np.int64))
+    assert n_ops.max() > 100_000 and (n_ops > 512).sum() > 4000 and (n_ops <= 512).sum() > 100
+    parts = [(cigar, off, ref_start)]
+    for i, n in enumerate((511, 512, 513, 514, 515, 516, 2047, 2048, 2049, 1, 3)):
+        parts.append(datagen.random_cigars(1, seed=900 + i, mean_ops=n + 200, long_gap_rate=0.05, max_ops=n))
+        parts[-1][1][1] = len(parts[-1][0])
+    cig = np.concatenate([p[0] for p in parts])
+    lens = np.concatenate([np.diff(p[1].astype(np.int64)) for p in parts])
+    offs = np.zeros(lens.size + 1, np.uint64)
+    offs[1:] = np.cumsum(lens)
+    rs = np.concatenate([p[2] for p in parts])
+    res = kernels.cigar_scan(_dev(cig.view(np.int32)), _dev(offs.astype(np.int64)), _dev(rs), 50)
+    gaps, gap_off, stats = res.to_host()
+    o_gaps, o_off, o_stats = cbind.cigar_scan(cig, offs, rs, 50)
+    assert np.array_equal(gap_off, o_off)
+    assert np.array_equal(stats, o_stats)
+    assert gaps.tobytes() == o_gaps.tobytes() and int(gap_off[-1]) > 15_000
+    again = kernels.cigar_scan(_dev(cig.view(np.int32)), _dev(offs.astype(np.int64)), _dev(rs), 50)
+    assert again.to_host()[0].tobytes() == gaps.tobytes()                # the long list's order varies, the output does not
+
+
 def test_cigar_scan_ragged_and_empty(oracle_lib):
     from oracle import cbind
     # empty batch
