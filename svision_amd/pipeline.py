@@ -438,6 +438,7 @@ class PooledHotPath(HotPath):
         ready = collections.deque()   # (conn index, WindowResult with records) waiting for the device
         inflight = collections.deque()  # (conn index, WindowResult) enqueued on the device
         scans = collections.deque()     # handles of the window scans enqueued ahead (Sample.rescan_window_async)
+        ahead = min(16, len(self.conns) + 2)    # every helper can turn idle in one burst; a scan takes ~15 ms on the saturated device
         remaining = len(windows)
         import time as _time
         prof = self.owner_profile = {"scan+send": 0.0, "launch": 0.0, "fetch+send": 0.0, "wait": 0.0, "recv": 0.0}     # owner-thread seconds
@@ -451,11 +452,14 @@ class PooledHotPath(HotPath):
                 scan = None
                 if rescan:                                            # device scan of the window's block: the helper collects on ITS result
                     ta = clock()
-                    while len(scans) < 4 and nxt + len(scans) < len(windows):        # enqueued a few windows ahead, read back here
+                    while len(scans) < ahead and nxt + len(scans) < len(windows):    # enqueued several windows ahead, read back here
                         scans.append(self.sample.rescan_window_async(*windows[nxt + len(scans)]))
                     tb = clock(); prof["scan.enqueue"] = prof.get("scan.enqueue", 0.0) + tb - ta
                     hd = scans.popleft()
                     if hd is not None:
+                        prof["scan.n"] = prof.get("scan.n", 0) + 1
+                        prof["scan.ready_on_entry"] = prof.get("scan.ready_on_entry", 0) + (1 if hd[5].query() else 0)
+                        prof["scan.age_s"] = prof.get("scan.age_s", 0.0) + (clock() - hd[7])
                         hd[5].synchronize()
                     tc = clock(); prof["scan.sync"] = prof.get("scan.sync", 0.0) + tc - tb
                     scan = self.sample.last_window_scan if self.sample.finish_rescan(hd) else None

@@ -97,7 +97,8 @@ class Sample:
             host[n + 1 + capd * 6:need].copy_(res.stats.view(-1), non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-        return (lo, hi, cap, capd, host, ev, res)
+        import time
+        return (lo, hi, cap, capd, host, ev, res, time.perf_counter())
 
     def finish_rescan(self, handle):
         """Wait for an enqueued window scan, check it against the resident scan and install it; -> number of rows."""
@@ -105,7 +106,7 @@ class Sample:
         if handle is None:
             self.last_window_scan = None
             return 0
-        lo, hi, cap, capd, host, ev, _res = handle
+        lo, hi, cap, capd, host, ev, _res = handle[:7]
         ev.synchronize()
         n = hi - lo
         h = host.numpy()
