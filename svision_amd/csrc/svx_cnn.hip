@@ -102,6 +102,16 @@ __device__ unsigned long long svx_enc_prof[8];
 #define ENC_MARK(i_) do { } while (0)
 #endif
 
+// ENC_ROWS pooled rows per workgroup (the planes are drawn once for all of them, their touched windows share one queue).
+// ONE is the measured optimum: the kernel is a chain of short latency-bound phases and lives on the number of
+// workgroups a CU holds (four at 34 KB of LDS); three rows per workgroup -- a third of the drawing, fuller passes over the
+// lanes, but two resident workgroups -- take 141 us per 128 images instead of 78 (tools/exp/ab_encode.py).
+#ifndef SVX_ENC_ROWS
+#define SVX_ENC_ROWS 1
+#endif
+constexpr int ENC_ROWS = SVX_ENC_ROWS;
+static_assert(P1 % ENC_ROWS == 0 && ENC_ROWS * WAVE <= ENC_BLOCK, "rows per workgroup: a divisor of 27, one wave each for the masks");
+
 __global__ __launch_bounds__(ENC_BLOCK)
 void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __restrict__ w1, const float* __restrict__ base,
                          float* __restrict__ y, int lrn, int radius, float alpha, float beta, float kk,
@@ -111,14 +121,15 @@ void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __res
     __shared__ unsigned bits[3 * PLANE_WORDS];
     __shared__ unsigned colcnt[IMG];
     __shared__ unsigned colmask[ROW_WORDS];
-    __shared__ unsigned pooled_bits[P1 * C1P];        // [ox][k] pooled activations as float bit patterns (row padded: no bank conflicts)
-    __shared__ unsigned rowany[3][ROW_WORDS];
-    __shared__ int has_empty[P1];         // per conv row of this strip: OR of its 11 image rows x 3 planes
-    __shared__ unsigned short queue[P1 * 9];
+    __shared__ unsigned pooled_bits[ENC_ROWS][P1 * C1P];  // [row][ox][k] pooled activations as float bit patterns (padded: no bank conflicts)
+    __shared__ unsigned rowany[ENC_ROWS][3][ROW_WORDS];
+    __shared__ int has_empty[ENC_ROWS][P1];   // per conv row of a strip: OR of its 11 image rows x 3 planes
+    __shared__ unsigned short queue[ENC_ROWS * P1 * 9];
     __shared__ int n_queue;
 
-    const int img = blockIdx.x / P1;
-    const int oyp = blockIdx.x - img * P1;
+    constexpr int STRIPS = P1 / ENC_ROWS;
+    const int img = blockIdx.x / STRIPS;
+    const int oyp0 = (blockIdx.x - img * STRIPS) * ENC_ROWS;          // first pooled row of this workgroup
 #ifdef SVX_ENC_PROFILE
     unsigned long long t_prev = wall_clock64();
 #endif
@@ -126,57 +137,61 @@ void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __res
     ENC_MARK(0);
 
     const int tid = threadIdx.x;
-    if (tid < 3 * ROW_WORDS) {
-        const int dy = tid / ROW_WORDS, w = tid - dy * ROW_WORDS;
-        const int r0 = 4 * (2 * oyp + dy);
+    if (tid < ENC_ROWS * 3 * ROW_WORDS) {
+        const int rr = tid / (3 * ROW_WORDS), t2 = tid - rr * 3 * ROW_WORDS;
+        const int dy = t2 / ROW_WORDS, w = t2 - dy * ROW_WORDS;
+        const int r0 = 4 * (2 * (oyp0 + rr) + dy);
         unsigned any = 0;
         for (int ky = 0; ky < 11; ++ky)
             any |= bits[(r0 + ky) * ROW_WORDS + w] | bits[2 * PLANE_WORDS + (r0 + ky) * ROW_WORDS + w];   // plane 1 is a subset of plane 0
-        rowany[dy][w] = any;
+        rowany[rr][dy][w] = any;
     }
     __syncthreads();
-    {                                                 // does this pooled pixel see at least one empty window?
+    {                                                 // does this pooled pixel see at least one empty window?  (wave rr: row rr)
+        const int rr = tid >> 6, lane = tid & (WAVE - 1);
         bool any_empty = false, any_set = false;
-        if (tid < P1)
+        if (rr < ENC_ROWS && lane < P1)
             for (int win = 0; win < 9; ++win) {
-                const bool empty = window_mask(rowany[win / 3], 4 * (2 * tid + win % 3)) == 0;
+                const bool empty = window_mask(rowany[rr][win / 3], 4 * (2 * lane + win % 3)) == 0;
                 any_empty |= empty;
                 any_set |= !empty;
             }
-        if (tid < P1) has_empty[tid] = any_empty ? 1 : 0;
+        if (rr < ENC_ROWS && lane < P1) has_empty[rr][lane] = any_empty ? 1 : 0;
         if (tid == 0) n_queue = 0;
         // pooled pixels with a set tap under them: everything else in this row is the constant background vector
-        const unsigned long long t = __ballot(tid < P1 && any_set);
-        if (touched && tid == 0) touched[blockIdx.x] = (uint32_t)t;     // P1 = 27 lanes of the first wave
+        const unsigned long long t = __ballot(rr < ENC_ROWS && lane < P1 && any_set);
+        if (touched && rr < ENC_ROWS && lane == 0) touched[(size_t)img * P1 + oyp0 + rr] = (uint32_t)t;
     }
     __syncthreads();
-    for (int i = tid; i < P1 * C1; i += ENC_BLOCK) {  // empty windows all respond relu(base[k]); relu floor otherwise
-        const int ox = i / C1, k = i - ox * C1;
-        pooled_bits[ox * C1P + k] = has_empty[ox] ? __float_as_uint(fmaxf(base[k], 0.0f)) : 0u;
+    for (int i = tid; i < ENC_ROWS * P1 * C1; i += ENC_BLOCK) {  // empty windows all respond relu(base[k]); relu floor otherwise
+        const int rr = i / (P1 * C1), i2 = i - rr * (P1 * C1);
+        const int ox = i2 / C1, k = i2 - ox * C1;
+        pooled_bits[rr][ox * C1P + k] = has_empty[rr][ox] ? __float_as_uint(fmaxf(base[k], 0.0f)) : 0u;
     }
-    __syncthreads();
-    // ~90 % of the 27 x 9 (pooled pixel, conv window under it) pairs of the row are empty (constant response base[k]);
+    // ~90 % of the 27 x 9 (pooled pixel, conv window under it) pairs of a row are empty (constant response base[k]);
     // the touched ones are compacted into a queue so that every lane below has work: one lane per (touched window,
     // 8-channel group) walks the window's 33 row masks and adds the weight rows of its set taps.  Max-pool = integer
     // atomic max on the (non-negative) float bit patterns: exact and order independent.
-    if (tid < P1 * 9) {
-        const int oxp = tid / 9, win = tid - oxp * 9;
-        if (window_mask(rowany[win / 3], 4 * (2 * oxp + win % 3)) != 0) queue[atomicAdd(&n_queue, 1)] = (unsigned short)tid;
+    for (int e = tid; e < ENC_ROWS * P1 * 9; e += ENC_BLOCK) {
+        const int rr = e / (P1 * 9), pw = e - rr * (P1 * 9);
+        const int oxp = pw / 9, win = pw - oxp * 9;
+        if (window_mask(rowany[rr][win / 3], 4 * (2 * oxp + win % 3)) != 0) queue[atomicAdd(&n_queue, 1)] = (unsigned short)e;
     }
     __syncthreads();
     ENC_MARK(1);
     const int n_items = n_queue * C1_GROUPS;
     for (int item = tid; item < n_items; item += ENC_BLOCK) {
-        const int g = item % C1_GROUPS, pw = queue[item / C1_GROUPS];
+        const int g = item % C1_GROUPS, e = queue[item / C1_GROUPS];
+        const int rr = e / (P1 * 9), pw = e - rr * (P1 * 9);
         const int oxp = pw / 9, win = pw - oxp * 9;
         const int dy = win / 3, dx = win - dy * 3;
-        const int oy = 2 * oyp + dy, ox = 2 * oxp + dx;
+        const int oy = 2 * (oyp0 + rr) + dy, ox = 2 * oxp + dx;
         const float4 b0 = reinterpret_cast<const float4*>(base)[2 * g];
         const float4 b1 = reinterpret_cast<const float4*>(base)[2 * g + 1];
         float acc[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
         {
             // (A two-deep software pipeline of the weight-row loads -- request a tap's rows, add the previous tap's -- was
-            // measured and is not faster: the phase is bound by the 66 dependent LDS mask reads per item and by the four
+            // measured and is not faster: the phase is bound by the 66 dependent LDS mask reads per item and by the
             // workgroups sharing a CU, not by the L2 latency of the rows; tools/exp/enc_prof.py.)
             for (int ky = 0; ky < 11; ++ky) {
                 const int r = 4 * oy + ky;
@@ -198,15 +213,16 @@ void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __res
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            if (acc[j] > 0.0f) atomicMax(&pooled_bits[oxp * C1P + 8 * g + j], __float_as_uint(acc[j]));
+            if (acc[j] > 0.0f) atomicMax(&pooled_bits[rr][oxp * C1P + 8 * g + j], __float_as_uint(acc[j]));
     }
     __syncthreads();
     ENC_MARK(2);
-    const float* pooled = reinterpret_cast<const float*>(pooled_bits);
     // C8 output [image][12 octets][27][27][8]: consecutive lanes -> the 8 channels of an octet, then consecutive ox
     // (one contiguous 864-byte run per octet and row)
-    float* yb = y + ((size_t)img * (C1 / 8) * P1 * P1 + (size_t)oyp * P1) * 8;
-    for (int idx = tid; idx < C1 * P1; idx += ENC_BLOCK) {
+    for (int i = tid; i < ENC_ROWS * C1 * P1; i += ENC_BLOCK) {
+        const int rr = i / (C1 * P1), idx = i - rr * (C1 * P1);
+        const float* pooled = reinterpret_cast<const float*>(pooled_bits[rr]);
+        float* yb = y + ((size_t)img * (C1 / 8) * P1 * P1 + (size_t)(oyp0 + rr) * P1) * 8;
         const int c8 = idx & 7, rest = idx >> 3;
         const int oct = rest / P1, ox = rest - oct * P1;
         const int k = oct * 8 + c8;
@@ -242,7 +258,7 @@ extern "C" int svx_encode_conv1(const int32_t* d_records, uint32_t n, const floa
     if (n == 0) return SVX_OK;
     if (!d_records || !d_w1 || !d_base || !d_y) return SVX_EINVAL;
     if ((reinterpret_cast<uintptr_t>(d_w1) & 15u) || (reinterpret_cast<uintptr_t>(d_base) & 15u)) return SVX_EINVAL;
-    hipLaunchKernelGGL(encode_conv1_kernel, dim3(n * P1), dim3(ENC_BLOCK), 0, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(encode_conv1_kernel, dim3(n * (P1 / ENC_ROWS)), dim3(ENC_BLOCK), 0, static_cast<hipStream_t>(stream),
                        d_records, d_w1, d_base, d_y, lrn, (int)radius, alpha, beta, k, d_touched);
     return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
 }
