@@ -118,9 +118,9 @@ void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __res
                          uint32_t* __restrict__ touched)
 {
     using namespace svx_raster;
-    __shared__ unsigned bits[3 * PLANE_WORDS];
+    __shared__ unsigned bits[2 * PLANE_WORDS];        // plane 0 (all segments) and the reverse-segment plane; plane 1 = plane 0 & colmask
     __shared__ unsigned colcnt[IMG];
-    __shared__ unsigned colmask[ROW_WORDS];
+    __shared__ unsigned colmask[ROW_WORDS + 1];       // (+1: window_mask may look one word past a row)
     __shared__ unsigned pooled_bits[ENC_ROWS][P1 * C1P];  // [row][ox][k] pooled activations as float bit patterns (padded: no bank conflicts)
     __shared__ unsigned rowany[ENC_ROWS][3][ROW_WORDS];
     __shared__ int has_empty[ENC_ROWS][P1];   // per conv row of a strip: OR of its 11 image rows x 3 planes
@@ -133,7 +133,8 @@ void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __res
 #ifdef SVX_ENC_PROFILE
     unsigned long long t_prev = wall_clock64();
 #endif
-    draw_planes<ENC_BLOCK>(records + (size_t)img * 12, bits, colcnt, colmask);
+    if (threadIdx.x == 0) colmask[ROW_WORDS] = 0;
+    draw_planes<ENC_BLOCK, false>(records + (size_t)img * 12, bits, colcnt, colmask);
     ENC_MARK(0);
 
     const int tid = threadIdx.x;
@@ -143,7 +144,7 @@ void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __res
         const int r0 = 4 * (2 * (oyp0 + rr) + dy);
         unsigned any = 0;
         for (int ky = 0; ky < 11; ++ky)
-            any |= bits[(r0 + ky) * ROW_WORDS + w] | bits[2 * PLANE_WORDS + (r0 + ky) * ROW_WORDS + w];   // plane 1 is a subset of plane 0
+            any |= bits[(r0 + ky) * ROW_WORDS + w] | bits[PLANE_WORDS + (r0 + ky) * ROW_WORDS + w];       // plane 1 is a subset of plane 0
         rowany[rr][dy][w] = any;
     }
     __syncthreads();
@@ -193,11 +194,14 @@ void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __res
             // (A two-deep software pipeline of the weight-row loads -- request a tap's rows, add the previous tap's -- was
             // measured and is not faster: the phase is bound by the 66 dependent LDS mask reads per item and by the
             // workgroups sharing a CU, not by the L2 latency of the rows; tools/exp/enc_prof.py.)
+            const unsigned cm = window_mask(colmask, 4 * ox);          // columns with >= 2 hits (row independent): channel 1 = channel 0 & cm
             for (int ky = 0; ky < 11; ++ky) {
                 const int r = 4 * oy + ky;
+                const unsigned m0 = window_mask(bits + r * ROW_WORDS, 4 * ox);
+                const unsigned m2 = window_mask(bits + PLANE_WORDS + r * ROW_WORDS, 4 * ox);
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
-                    unsigned m = window_mask(bits + ch * PLANE_WORDS + r * ROW_WORDS, 4 * ox);
+                    unsigned m = ch == 0 ? m0 : (ch == 1 ? (m0 & cm) : m2);
                     while (m) {
                         const int kx = __ffs(m) - 1;
                         m &= m - 1;

@@ -104,11 +104,14 @@ __device__ inline long long scale_coord(int v, double ratio) { return (long long
 // Draw one record's three bit planes into LDS.  bits: 3 * PLANE_WORDS words (plane 0: all segments,
 // plane 1: columns with >= 2 hits, plane 2: reverse segments), colcnt: IMG words, colmask: ROW_WORDS
 // words.  Must be called by every thread of the block; ends with a barrier.
-template <int BLOCK_T>
+// PLANE1 = false: plane 1 is not materialised (it is plane 0 AND the column mask: a consumer that reads windows of a
+// few columns applies the mask itself) and ``bits`` holds two planes only: [plane 0][plane 2].
+template <int BLOCK_T, bool PLANE1 = true>
 __device__ inline void draw_planes(const int32_t* __restrict__ r, unsigned* bits, unsigned* colcnt, unsigned* colmask)
 {
     const int tid = threadIdx.x;
-    for (int i = tid; i < 3 * PLANE_WORDS; i += BLOCK_T) bits[i] = 0;
+    constexpr int REV = PLANE1 ? 2 * PLANE_WORDS : PLANE_WORDS;       // word offset of the reverse-segment plane
+    for (int i = tid; i < (PLANE1 ? 3 : 2) * PLANE_WORDS; i += BLOCK_T) bits[i] = 0;
     for (int i = tid; i < IMG; i += BLOCK_T) colcnt[i] = 0;
     if (tid < ROW_WORDS) colmask[tid] = 0;
 
@@ -144,15 +147,17 @@ __device__ inline void draw_planes(const int32_t* __restrict__ r, unsigned* bits
             const int w = row * ROW_WORDS + (col >> 5);
             const unsigned old = atomicOr(&bits[w], bit);
             if (!(old & bit)) atomicAdd(&colcnt[col], 1u);
-            if (rev[s]) atomicOr(&bits[2 * PLANE_WORDS + w], bit);
+            if (rev[s]) atomicOr(&bits[REV + w], bit);
         }
     }
     __syncthreads();
     for (int c = tid; c < IMG; c += BLOCK_T)
         if (colcnt[c] >= 2) atomicOr(&colmask[c >> 5], 1u << (c & 31));
     __syncthreads();
-    for (int i = tid; i < PLANE_WORDS; i += BLOCK_T) bits[PLANE_WORDS + i] = bits[i] & colmask[i & (ROW_WORDS - 1)];
-    __syncthreads();
+    if (PLANE1) {
+        for (int i = tid; i < PLANE_WORDS; i += BLOCK_T) bits[PLANE_WORDS + i] = bits[i] & colmask[i & (ROW_WORDS - 1)];
+        __syncthreads();
+    }
 }
 
 }  // namespace svx_raster
