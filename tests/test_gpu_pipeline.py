@@ -301,3 +301,20 @@ def test_cli_graph_mode_on_device(checkpoint, tmp_path):
         assert open(os.path.join(out, "segments", "chrG.segments.all.bed")).read() == "".join(w["tsv"] for w in want["windows"])
         outs[tag] = {n: open(os.path.join(out, n)).read() for n in ("HGg.svision.s3.graph.vcf", "HGg.graph_exactly_match.txt")}
     assert outs["one"] == outs["three"]
+
+
+@pytest.mark.gpu
+def test_cli_batch_size_does_not_change_results(checkpoint, tmp_path):
+    """--batch_size is the padding granule and the launch size (two batches per graph replay), never a result: 16, 32
+    (fc tile 32x32), 64, 128 (the reference default) and an odd 200 give the same VCF."""
+    from svision_amd.io import bam
+    prefix, _params = checkpoint
+    fasta = helpers.load_golden_fasta()
+    fa = str(tmp_path / "genome.fa")
+    bam.write_fasta(fa, {n: fasta._seq[n] for n in fasta.references})
+    texts = {}
+    for bs in (16, 32, 64, 128, 200):
+        opts = cli.parse_arguments(["-o", str(tmp_path / ("o%d" % bs)), "-b", os.path.join(helpers.GOLDEN, "collect_small.bam"), "-m", prefix,
+                                    "-g", fa, "-n", "S", "-s", "3", "--window_size", "60000", "--batch_size", str(bs)])
+        texts[bs] = open(cli.run(opts)).read()
+    assert len(set(texts.values())) == 1 and texts[64].count("\n") > 20
