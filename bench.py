@@ -148,7 +148,7 @@ def main():
     ap.add_argument("--workers", type=int, default=8, help="helper processes per rank for the Python host glue (capped at cores / ranks)")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the per-batch graphs are replayed on")
     ap.add_argument("--inflight", type=int, default=6, help="windows enqueued on the device at once")
-    ap.add_argument("--launch-batches", type=int, default=2, help="batches of --batch images per device launch (graph replay)")
+    ap.add_argument("--launch-batches", type=int, default=4, help="batches of --batch images per device launch (graph replay)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-calibration", action="store_true", help="skip the per-kernel timings outside the timed region")
     args = ap.parse_args()

@@ -110,16 +110,20 @@ class DeviceStage:
     svx_encode_conv1 -> active sets -> conv2..5 -> fc6/7 -> svx_fc8_softmax.
 
     ``batch`` is the reference's batch (the padding granule of BatchGenerator, create_batch.py:54-59); a launch carries
-    ``launch_batches`` of them while that many are left and single batches otherwise.  Every image is independent of its
-    neighbours in every kernel (fixed k order per output element, tests/test_gpu_pipeline.py), so the grouping changes no
-    result; it halves the fc6 / fc7 weight traffic per image (218 MB per launch whatever its size) and the share of
-    partly filled tile rounds of the convolutions."""
+    ``launch_batches`` of them while that many are left, then half as many, ... down to single batches.  Every image is
+    independent of its neighbours in every kernel (fixed k order per output element, tests/test_gpu_pipeline.py), so the
+    grouping changes no result; it divides the fc6 / fc7 weight traffic per image (218 MB per launch whatever its size) and
+    the share of partly filled tile rounds of the convolutions."""
 
-    def __init__(self, net, batch, device, n_streams=2, use_graph=True, launch_batches=2):
+    def __init__(self, net, batch, device, n_streams=2, use_graph=True, launch_batches=4):
         self.net, self.batch, self.device = net, batch, torch.device(device)
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
         self.use_graph = use_graph
-        self.sizes = sorted({batch * max(1, int(launch_batches)), batch}, reverse=True)
+        sizes, k = {batch}, max(1, int(launch_batches))
+        while k > 1:                                          # launch_batches, half of it, ... one batch: a window's tail uses the largest that fits
+            sizes.add(batch * k)
+            k //= 2
+        self.sizes = sorted(sizes, reverse=True)
         self.slots = []                                       # per stream: {images per launch: (records, packed out, graph)}
         for s in self.streams:
             slot = {}
@@ -202,7 +206,7 @@ class HotPath:
     """Single-process form: collect -> device -> vote, with the device work of window k overlapped
     with the host collection of window k+1."""
 
-    def __init__(self, sample, options, net, device="cuda", n_streams=2, use_graph=True, launch_batches=2):
+    def __init__(self, sample, options, net, device="cuda", n_streams=2, use_graph=True, launch_batches=4):
         self.sample, self.options, self.net = sample, options, net
         self.device = torch.device(device)
         self.batch = options.batch_size
@@ -418,7 +422,7 @@ class HelperPool:
 class PooledHotPath(HotPath):
     """Owner process = device feeder; the helpers of a :class:`HelperPool` do the Python glue."""
 
-    def __init__(self, sample, options, net, device="cuda", n_workers=8, n_streams=2, use_graph=True, max_inflight=3, launch_batches=2,
+    def __init__(self, sample, options, net, device="cuda", n_workers=8, n_streams=2, use_graph=True, max_inflight=3, launch_batches=4,
                  want_tsv=False, pool=None):
         super().__init__(sample, options, net, device, n_streams, use_graph, launch_batches)
         self.pool = pool if pool is not None else HelperPool(n_workers, options, sample=sample, want_tsv=want_tsv)

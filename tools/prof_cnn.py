@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run N eager launches of the device stage (for rocprofv3 --kernel-trace --stats); IMAGES = images per launch
-(default 128 = the pipeline's two batches of 64)."""
+(default 256 = the pipeline's four batches of 64)."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +11,7 @@ if os.environ.get("SVX_EXP_LIB"):
 from svision_amd.network.alexnet import AlexNet
 from tests import datagen
 dev = torch.device("cuda:0")
-IMAGES = int(os.environ.get("IMAGES", "128"))
+IMAGES = int(os.environ.get("IMAGES", "256"))
 net = AlexNet(random_weights(0), device=dev)
 if os.environ.get("REAL"):                        # records of real candidate sites (bench-like sample) instead of random segments
     from bench import options_ns
