@@ -53,7 +53,10 @@ constexpr unsigned OOB = 0x80000000u;             // per-lane byte offset no des
 constexpr int N_SHAPES = 5;
 constexpr int SHAPE_NA[N_SHAPES] = {2, 1, 2, 2, 1};
 constexpr int SHAPE_NB[N_SHAPES] = {1, 3, 3, 2, 2};
-constexpr int LIST_SHAPES = 2;            // list mode (pixel count known on the device only) picks among the first two
+#ifndef SVX_LIST_SHAPES
+#define SVX_LIST_SHAPES 2
+#endif
+constexpr int LIST_SHAPES = SVX_LIST_SHAPES;   // list mode (pixel count known on the device only) picks among the first two
 
 struct ConvArgs {
     const float* in; const float* w; const float* bias; float* out;
@@ -285,8 +288,13 @@ void conv_wave_list_kernel(const ConvArgs a, int shape)
     int Mtot = Mall;
     { const long long c = (long long)*a.pixel_count; if (c * 100 < (long long)Mall * SVX_CONV_DENSE_PCT) Mtot = (int)c; }
     if (shape < 0) shape = conv_pick_shape(Mtot, a.Cout / a.groups, a.groups, a.n_simd, LIST_SHAPES);
-    if (shape == 0) conv_wave_tile<KS, SHAPE_NA[0], SHAPE_NB[0]>(a, Mtot, Mall);
-    else            conv_wave_tile<KS, SHAPE_NA[1], SHAPE_NB[1]>(a, Mtot, Mall);
+    if (shape == 0)      conv_wave_tile<KS, SHAPE_NA[0], SHAPE_NB[0]>(a, Mtot, Mall);
+#if SVX_LIST_SHAPES > 2                           // experiments only: every shape in one kernel costs its registers (178) in all of them
+    else if (shape == 2) conv_wave_tile<KS, SHAPE_NA[2], SHAPE_NB[2]>(a, Mtot, Mall);
+    else if (shape == 3) conv_wave_tile<KS, SHAPE_NA[3], SHAPE_NB[3]>(a, Mtot, Mall);
+    else if (shape == 4) conv_wave_tile<KS, SHAPE_NA[4], SHAPE_NB[4]>(a, Mtot, Mall);
+#endif
+    else                 conv_wave_tile<KS, SHAPE_NA[1], SHAPE_NB[1]>(a, Mtot, Mall);
 }
 
 template <int KS>
