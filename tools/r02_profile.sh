@@ -11,7 +11,7 @@ run() { name=$1; shift; rm -rf /tmp/rp_$name; "$@" > $OUT/$name.log 2>&1; }
 # 1. eager device stage on the records of real candidate sites, per-kernel time
 REAL=1 run stage_trace rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_stage_trace -- python $REPO/tools/prof_cnn.py 30
 cp $(find /tmp/rp_stage_trace -name "*kernel_stats.csv" | head -1) $OUT/stage_kernel_stats.csv
-# 2. the bench command itself (graph replays on 3 streams)
+# 2. the bench command itself (graph replays of 256 images on 3 streams)
 run bench_trace rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_bench_trace -- python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-calibration
 cp $(find /tmp/rp_bench_trace -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
 # 3. PMC: matrix-pipe utilisation and wave stall breakdown (SQ, <= 8 counters), clock (GRBM), HBM traffic (TCC; separate passes)
