@@ -85,7 +85,10 @@ def windows_of(name, length):
 def _simulate_contig(job):
     """(name, length, coverage, seed[, kind]) -> (AlignmentTable, genome bytes) of one contig (runs in a forked worker)."""
     name, length, coverage, seed = job[:4]
-    if len(job) > 4 and job[4] == "ont":     # ONT ultra-long stand-in: log-normal lengths (median 50 kb), 5 % small events
+    if len(job) > 4 and job[4] == "contig":  # assembly-vs-reference stand-in: two haplotypes of ~2 Mb contigs, 0.1 % small events
+        cfg = synth.SimConfig(contigs=[(name, length)], coverage=coverage, seed=seed, read_len_mean=2_000_000, read_len_sd=600_000,
+                              err_rate=0.001)
+    elif len(job) > 4 and job[4] == "ont":   # ONT ultra-long stand-in: log-normal lengths (median 50 kb), 5 % small events
         cfg = synth.SimConfig(contigs=[(name, length)], coverage=coverage, seed=seed, read_len_mean=50_000, lognormal=True,
                               lognormal_sigma=0.7, err_rate=0.05)
     else:
@@ -102,14 +105,15 @@ def build_workload(args, rank, world, cores):
         total_windows = None
     else:
         contigs = list(GRCH38)
-        all_windows = sum(len(windows_of(n, l)) for n, l in contigs)
-        if args.steps and args.steps < all_windows:          # a prefix of every chromosome, same proportions
+        all_windows = len(contigs) if args.workload == "contig" else sum(len(windows_of(n, l)) for n, l in contigs)
+        if args.workload != "contig" and args.steps and args.steps < all_windows:          # a prefix of every chromosome, same proportions
             f = args.steps / all_windows
             contigs = [(n, min(l, max(1, round(len(windows_of(n, l)) * f)) * WINDOW)) for n, l in contigs]
         shard = sdist.shard_chromosomes([n for n, _l in contigs], [l for _n, l in contigs], world)[rank]
-        jobs = [(n, l, args.coverage, 100 + i) for i, (n, l) in enumerate(contigs) if n in shard]
+        jobs = [(n, l, 2.0, 100 + i, "contig") if args.workload == "contig" else (n, l, args.coverage, 100 + i)
+                for i, (n, l) in enumerate(contigs) if n in shard]
         strong = True
-        total_windows = sum(len(windows_of(n, l)) for n, l in contigs)
+        total_windows = len(contigs) if args.workload == "contig" else sum(len(windows_of(n, l)) for n, l in contigs)
     if len(jobs) > 1:
         import multiprocessing as mp
         with mp.get_context("fork").Pool(min(len(jobs), max(1, cores // world))) as pool:     # before the first HIP call
@@ -117,7 +121,10 @@ def build_workload(args, rank, world, cores):
     else:
         made = [_simulate_contig(j) for j in jobs]
     parts = [(j[0], j[1], t, g) for j, (t, g) in zip(jobs, made)]
-    windows = [w for name, length, _t, _g in parts for w in windows_of(name, length)]
+    if args.workload == "contig":             # --contig: one task per chromosome (SVision:161-180)
+        windows = [(name, 0, length) for name, length, _t, _g in parts]
+    else:
+        windows = [w for name, length, _t, _g in parts for w in windows_of(name, length)]
     return parts, windows, strong, total_windows
 
 
@@ -139,9 +146,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="windows to time (cfg2: per rank, default 200; wg: whole job, default all)")
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", choices=("cfg2", "wg", "ont"), default="cfg2",
+    ap.add_argument("--workload", choices=("cfg2", "wg", "ont", "contig"), default="cfg2",
                     help="cfg2: chr21-sized HiFi sample per rank (weak scaling, the default); wg: 24 GRCh38-length contigs sharded over the "
-                         "ranks (strong scaling); ont: chr21-sized ONT ultra-long stand-in per rank (BASELINE configs[3] stress: ~5,000 CIGAR ops per read)")
+                         "ranks (strong scaling); ont: chr21-sized ONT ultra-long stand-in per rank (BASELINE configs[3] stress: ~5,000 CIGAR ops per read); "
+                         "contig: --contig mode, two haplotypes of ~2 Mb assembly contigs on the 24 GRCh38-length chromosomes, one task per chromosome")
     ap.add_argument("--batch", type=int, default=64, help="candidate images per CNN batch (BASELINE configs[1])")
     ap.add_argument("--contig-len", type=int, default=CHR21)
     ap.add_argument("--coverage", type=float, default=30.0)
@@ -162,6 +170,8 @@ def main():
     # happens before the first HIP call (forking with a live GPU context makes the driver evict / restore the queues)
     parts, windows, strong, total_windows = build_workload(args, rank, world, cores)
     opts = options_ns(args.batch)
+    if args.workload == "contig":             # SVision:161-180, collect_signatures.py:125
+        opts.contig, opts.min_support = True, 1
     table = bam.concat_tables([t for _n, _l, t, _g in parts]) if len(parts) > 1 else parts[0][2]
     fasta = bam.Fasta(sequences={n: g for n, _l, _t, g in parts})
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
@@ -261,12 +271,16 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": ("cfg3 stand-in: synthetic whole-genome HiFi, 24 contigs of GRCh38 length (N(15kb,2kb) reads, %gx), "
+        "config": {"workload": ("cfg5 stand-in: --contig mode, two haplotypes of N(2 Mb, 0.6 Mb) assembly contigs (0.1 % small events) on 24 "
+                                "chromosomes of GRCh38 length, one task per chromosome, chromosomes LPT-sharded over the ranks")
+                               if args.workload == "contig" else
+                               ("cfg3 stand-in: synthetic whole-genome HiFi, 24 contigs of GRCh38 length (N(15kb,2kb) reads, %gx), "
                                 "chromosomes LPT-sharded over the ranks" % args.coverage) if strong else
                                ("cfg4 stand-in on one contig per rank: synthetic ONT ultra-long chr21 (%d bp, log-normal reads, median 50 kb, "
                                 "5 %% small events, %gx)" % (args.contig_len, args.coverage)) if args.workload == "ont" else
                                ("cfg2 stand-in: synthetic HiFi chr21 (%d bp, N(15kb,2kb) reads, %gx)" % (args.contig_len, args.coverage)),
-                   "step": "one 10 Mb collection window through scan -> collection -> encode + CNN (batches of %d candidate images, fp32) -> vote" % B,
+                   "step": ("one chromosome" if args.workload == "contig" else "one 10 Mb collection window") +
+                           " through scan -> collection -> encode + CNN (batches of %d candidate images, fp32) -> vote" % B,
                    "batch": B, "alignments_rank0": len(table), "cigar_ops_rank0": int(table.cigar.size),
                    "windows_rank0": len(windows), "sites_per_step": tot_sites / max(steps_job * (1 if strong else world), 1),
                    "images_per_site": tot_images / max(tot_sites, 1), "images_per_s": tot_images / dt,
