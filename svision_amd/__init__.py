@@ -6,3 +6,18 @@ The compute kernels live in ``libsvx.so`` (hand-written HIP for gfx950, C ABI in
 CPU fallback: importing the device ops without the built library raises.
 """
 __version__ = "0.1.0"
+
+
+def _check_host_modules():
+    import sys
+    if "svision_amd.build_host" in sys.modules or (sys.argv and sys.argv[0].endswith("build_host.py")):
+        return
+    try:
+        from .build_host import drop_stale
+        drop_stale(log=lambda msg: print(msg, file=sys.stderr))
+    except Exception:                                         # noqa: BLE001 -- never block an import on housekeeping
+        pass
+
+
+_check_host_modules()
+del _check_host_modules

@@ -14,7 +14,44 @@ MODULES = ["collection/analyze_reads.py", "collection/collect_signatures.py", "c
            "segmentplot/classes.py", "network/predict.py"]
 
 
+STAMP = "_host_build.json"               # sha1 of every source the extension modules were compiled from
+
+
+def _sha1(path):
+    import hashlib
+    with open(path, "rb") as f:
+        return hashlib.sha1(f.read()).hexdigest()
+
+
+def drop_stale(log=None):
+    """Remove extension modules whose ``.py`` source changed since they were compiled (``import`` would silently prefer the
+    stale binary).  Called on package import; cheap (eight small files)."""
+    import json
+    here = os.path.dirname(os.path.abspath(__file__))
+    try:
+        with open(os.path.join(here, STAMP)) as f:
+            stamp = json.load(f)
+    except (OSError, ValueError):
+        stamp = {}
+    dropped = []
+    for m in MODULES:
+        src = os.path.join(here, m)
+        d, base = os.path.dirname(src), os.path.basename(m)[:-3]
+        sos = [n for n in os.listdir(d) if n.startswith(base + ".") and n.endswith(".so")]
+        if sos and stamp.get(m) != _sha1(src):
+            for n in sos:
+                try:
+                    os.remove(os.path.join(d, n))
+                    dropped.append(os.path.join(os.path.dirname(m), n))
+                except OSError:
+                    pass
+    if dropped and log is not None:
+        log("svision_amd: removed compiled host modules older than their source (run `python -m svision_amd.build_host`): " + ", ".join(dropped))
+    return dropped
+
+
 def build(quiet=True):
+    import json
     import shutil
     import tempfile
     from setuptools import setup
@@ -30,6 +67,8 @@ def build(quiet=True):
                         compiler_directives={"binding": True, "embedsignature": True})
         setup(name="svision_amd_host", ext_modules=ext,
               script_args=["build_ext", "--inplace", "--build-temp", tmp, "--build-lib", tmp] + (["-q"] if quiet else []))
+        with open(os.path.join(here, STAMP), "w") as f:
+            json.dump({m: _sha1(os.path.join(here, m)) for m in MODULES}, f, indent=0, sort_keys=True)
     finally:
         os.chdir(cwd)
         shutil.rmtree(tmp, ignore_errors=True)
