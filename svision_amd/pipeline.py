@@ -336,6 +336,7 @@ def _worker_main(conn):
     # young-generation passes cost 20 % of a window and a full pass over the alignment table's objects ~70 ms: it runs
     # by hand, rarely.
     import gc
+    import time
     gc.collect()
     gc.freeze()
     gc.disable()
@@ -353,18 +354,20 @@ def _worker_main(conn):
             continue
         if msg[0] == "win":
             _t, wid, chrom, start, end, scan = msg
+            t0 = time.perf_counter()
             if scan is not None:
                 sample.apply_window_scan(*scan)
             lines = _collect_lines(sample, options, chrom, start, end)
-            held[wid] = (chrom, lines, start, end)
             recs = np.asarray([ln.record() for ln in lines], np.int32).reshape(-1, 12)
+            held[wid] = (chrom, lines, start, end, time.perf_counter() - t0)
             conn.send(("rec", wid, recs))
         elif msg[0] == "pred":
             _t, wid, classes, probs = msg
-            chrom, lines, start, end = held.pop(wid)
+            chrom, lines, start, end, t_collect = held.pop(wid)
+            t0 = time.perf_counter()
             vcf, scores, n_sites, head, tail = _vote(sample, options, chrom, lines, classes, probs, start, end)
             tsv = "".join(ln.text() for ln in lines) if _POOL_STATE.get("want_tsv") else None
-            conn.send(("done", wid, vcf, scores, n_sites, len(lines), tsv, head, tail))
+            conn.send(("done", wid, vcf, scores, n_sites, len(lines), tsv, head, tail, (t_collect, time.perf_counter() - t0)))
             n_done += 1
             if n_done % 128 == 0:
                 gc.collect()
@@ -500,7 +503,9 @@ class PooledHotPath(HotPath):
                     res.t_device = None
                     ready.append((ci, res))
                 else:
-                    _t, wid, vcf, scores, n_sites, n_images, tsv, head, tail = msg
+                    _t, wid, vcf, scores, n_sites, n_images, tsv, head, tail, host_s = msg
+                    prof["helper.collect_s"] = prof.get("helper.collect_s", 0.0) + host_s[0]      # host seconds inside the helpers
+                    prof["helper.vote_s"] = prof.get("helper.vote_s", 0.0) + host_s[1]
                     res = WindowResult()
                     res.chrom, res.start, res.end = windows[wid]
                     res.wid, res.tsv = wid, tsv
