@@ -437,7 +437,12 @@ class PooledHotPath(HotPath):
         self.conns, self.procs = [], []
 
     def run_windows(self, windows, rescan=True):
-        """Yields WindowResults (completion order).  Each helper holds one window at a time."""
+        """Yields WindowResults (completion order).  Each helper holds one window at a time.
+
+        ``self.owner_profile`` afterwards: where this (GPU-owning) thread spent its time -- seconds per phase of the
+        loop, the scans found ready on entry, the host seconds the helpers report for collection and vote, and when the
+        first launch / last read-back / last result happened (SVX_TIMING=1 python bench.py prints it)."""
+        import time
         windows = list(windows)
         nxt = 0
         idle = list(range(len(self.conns)))
@@ -447,10 +452,15 @@ class PooledHotPath(HotPath):
         scans = collections.deque()     # handles of the window scans enqueued ahead (Sample.rescan_window_async)
         ahead = min(16, len(self.conns) + 2)    # every helper can turn idle in one burst; a scan takes ~15 ms on the saturated device
         remaining = len(windows)
-        import time as _time
-        prof = self.owner_profile = {"scan+send": 0.0, "launch": 0.0, "fetch+send": 0.0, "wait": 0.0, "recv": 0.0}     # owner-thread seconds
-        clock = _time.perf_counter
+        prof = self.owner_profile = collections.defaultdict(float)
+        clock = time.perf_counter
         t_loop = clock()
+
+        def lap(key, since):
+            now = clock()
+            prof[key] += now - since
+            return now
+
         while remaining:
             t = clock()
             while idle and nxt < len(windows):
@@ -458,37 +468,37 @@ class PooledHotPath(HotPath):
                 chrom, start, end = windows[nxt]
                 scan = None
                 if rescan:                                            # device scan of the window's block: the helper collects on ITS result
-                    ta = clock()
+                    t_s = clock()
                     while len(scans) < ahead and nxt + len(scans) < len(windows):    # enqueued several windows ahead, read back here
                         scans.append(self.sample.rescan_window_async(*windows[nxt + len(scans)]))
-                    tb = clock(); prof["scan.enqueue"] = prof.get("scan.enqueue", 0.0) + tb - ta
-                    hd = scans.popleft()
-                    if hd is not None:
-                        prof["scan.n"] = prof.get("scan.n", 0) + 1
-                        prof["scan.ready_on_entry"] = prof.get("scan.ready_on_entry", 0) + (1 if hd[5].query() else 0)
-                        prof["scan.age_s"] = prof.get("scan.age_s", 0.0) + (clock() - hd[7])
-                        hd[5].synchronize()
-                    tc = clock(); prof["scan.sync"] = prof.get("scan.sync", 0.0) + tc - tb
-                    scan = self.sample.last_window_scan if self.sample.finish_rescan(hd) else None
-                    td = clock(); prof["scan.apply"] = prof.get("scan.apply", 0.0) + td - tc
+                    t_s = lap("scan.enqueue", t_s)
+                    handle = scans.popleft()
+                    if handle is not None:
+                        prof["scan.n"] += 1
+                        prof["scan.ready_on_entry"] += 1 if handle[5].query() else 0
+                        prof["scan.age_s"] += clock() - handle[7]
+                        handle[5].synchronize()
+                    t_s = lap("scan.sync", t_s)
+                    scan = self.sample.last_window_scan if self.sample.finish_rescan(handle) else None
+                    lap("scan.apply", t_s)
                 self.conns[ci].send(("win", nxt, chrom, start, end, scan))
                 busy[ci] = nxt
                 nxt += 1
-            t1 = clock(); prof["scan+send"] += t1 - t
+            t = lap("scan+send", t)
             while ready and len(inflight) < self.max_inflight:
                 ci, res = ready.popleft()
                 prof.setdefault("first_launch_at", clock() - t_loop)
                 inflight.append((ci, self.launch(res)))
-            t2 = clock(); prof["launch"] += t2 - t1
+            t = lap("launch", t)
             while inflight and (inflight[0][1].n_images == 0 or inflight[0][1].done_event.query()):
                 ci, res = inflight.popleft()
                 classes, probs = self.fetch_predictions(res)
                 self.conns[ci].send(("pred", busy[ci], classes, probs))
                 prof["last_fetch_at"] = clock() - t_loop
-            t3 = clock(); prof["fetch+send"] += t3 - t2
+            t = lap("fetch+send", t)
             waiting = [self.conns[ci] for ci in busy]
             got = mpc.wait(waiting, timeout=0.0005 if inflight else 0.05)
-            t4 = clock(); prof["wait"] += t4 - t3
+            lap("wait", t)
             if not got and not inflight and not ready:
                 dead = [ci for ci in busy if not self.procs[ci].is_alive()]
                 if dead:
@@ -504,8 +514,8 @@ class PooledHotPath(HotPath):
                     ready.append((ci, res))
                 else:
                     _t, wid, vcf, scores, n_sites, n_images, tsv, head, tail, host_s = msg
-                    prof["helper.collect_s"] = prof.get("helper.collect_s", 0.0) + host_s[0]      # host seconds inside the helpers
-                    prof["helper.vote_s"] = prof.get("helper.vote_s", 0.0) + host_s[1]
+                    prof["helper.collect_s"] += host_s[0]             # host seconds inside the helpers
+                    prof["helper.vote_s"] += host_s[1]
                     res = WindowResult()
                     res.chrom, res.start, res.end = windows[wid]
                     res.wid, res.tsv = wid, tsv
