@@ -344,15 +344,19 @@ def kernel_calibration(hot, sample, net, dev, B, window, reps=20):
                                   "us": timed(lambda: kernels.encode_conv1(rec, net.conv1_hwio, net.conv1_base, touched=True)) * 1e6,
                                   "note": "rasterise + sparse conv1 + relu + pool + LRN; replaces %.1f MB of image traffic and %.1f GFLOP "
                                           "of dense conv1 per launch" % (IMG_BYTES * B / 1e6, 210_830_400 * B / 1e9)}
-    l2, l3, l4, l5, counts = kernels.alexnet_active_sets(touched)
+    l2, l3, l4, l5, counts, rows2 = kernels.alexnet_active_sets(touched, rows=True)
     out["active_counts + active_lists"] = {"bound": "latency", "launch": "%d images" % B, "us": timed(lambda: kernels.alexnet_active_sets(touched)) * 1e6}
     cnt = counts.cpu().numpy().astype(np.float64)
     x = x1
     for li, (name, lst, bias, relu, groups) in enumerate((("conv2", l2, None, False, 2), ("conv3", l3, net.conv3_b, True, 1),
                                                           ("conv4", l4, net.conv4_b, True, 2), ("conv5", l5, None, False, 2))):
         w = getattr(net, name + "_w")
-        fn = lambda x=x, w=w, lst=lst, li=li, bias=bias, relu=relu, groups=groups, name=name: kernels.conv2d_same(       # noqa: E731
-            x, w, bias, groups=groups, relu=relu, pixels=lst, pixel_count=counts[li:li + 1], background=bg[name])
+        if name == "conv2":                  # as in the stage: active pixels only, the pool reads the background for the others
+            out2 = torch.empty((B, 32, 27, 27, 8), dtype=torch.float32, device=dev)
+            fn = lambda x=x, w=w, lst=lst: kernels.conv2d_same(x, w, None, groups=2, pixels=lst, pixel_count=counts[0:1], out=out2)   # noqa: E731
+        else:
+            fn = lambda x=x, w=w, lst=lst, li=li, bias=bias, relu=relu, groups=groups, name=name: kernels.conv2d_same(       # noqa: E731
+                x, w, bias, groups=groups, relu=relu, pixels=lst, pixel_count=counts[li:li + 1], background=bg[name])
         t = timed(fn)
         npix = B * LAYER_PIX[name]
         computed = npix if cnt[li] * 100 >= npix * 97 else cnt[li]
@@ -366,11 +370,12 @@ def kernel_calibration(hot, sample, net, dev, B, window, reps=20):
                                                                       "peak": F32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": LAYER_FLOP[name] * B / tdense / F32_MFMA_PEAK}
         if name in ("conv2", "conv5"):
             b2 = getattr(net, name + "_b")
-            t = timed(lambda y=y, b2=b2, name=name: kernels.bias_relu_pool_lrn(y, b2, lrn=name == "conv2"))
+            extra = dict(active_rows=rows2, background=bg["conv2"]) if name == "conv2" else {}
+            t = timed(lambda y=y, b2=b2, name=name, extra=extra: kernels.bias_relu_pool_lrn(y, b2, lrn=name == "conv2", **extra))
             out["bias_relu_pool_lrn_kernel %s" % name] = {"bound": "hbm", "us": t * 1e6, "achieved": (y.numel() * 4 + y.numel()) / t / 1e9,
                                                           "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": (y.numel() * 5) / t / HBM_PEAK,
                                                           "note": "launch-latency regime (%.1f MB)" % (y.numel() * 5 / 1e6)}
-            x = kernels.bias_relu_pool_lrn(y, b2, lrn=name == "conv2")
+            x = kernels.bias_relu_pool_lrn(y, b2, lrn=name == "conv2", **extra)
         else:
             x = y
     h = x.reshape(B, 9216)

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SVX_VERSION 200            /* 0.2.0: C8 activation layout, packed conv weights, distance / hash kernels */
+#define SVX_VERSION 210            /* 0.2.1: + active-row masks out of svx_alexnet_active_sets, into svx_bias_relu_pool_lrn */
 
 #define SVX_OK            0
 #define SVX_EINVAL       (-1)      /* bad argument (null pointer, bad layout...) */
@@ -126,10 +126,12 @@ int svx_encode_conv1(const int32_t* d_records, uint32_t n, const float* d_w1, co
  *   d_counts [4]: out, number of active entries in the four lists;  d_ws: scratch, 16 * n bytes, 16-B aligned
  *   d_totals: NULL, or uint64 [5] running sums the launch ADDS to (never cleared here): [0..4) the output pixels
  *             svx_conv2d_same computes for conv2..conv5 given these lists (all of them once a list is
- *             SVX_CONV_DENSE_PCT full), [4] images -- the executed work of a run, for measurement */
+ *             SVX_CONV_DENSE_PCT full), [4] images -- the executed work of a run, for measurement
+ *   d_active2: NULL, or out [n][27]: bit x of word [i][y] = conv2 output pixel (y, x) of image i is in the active set
+ *             (what svx_bias_relu_pool_lrn needs to read the others from the background tensor) */
 int svx_alexnet_active_sets(const uint32_t* d_touched, uint32_t n, int32_t* d_list2, int32_t* d_list3,
                             int32_t* d_list4, int32_t* d_list5, uint32_t* d_counts, uint32_t* d_ws,
-                            uint64_t* d_totals, void* stream);
+                            uint64_t* d_totals, uint32_t* d_active2, void* stream);
 
 /* Fused conv epilogue: bias add + ReLU + 3x3/2 VALID max-pool (+ TF local response
  * normalisation across channels when lrn != 0), C8 float32 in and out.
@@ -138,10 +140,15 @@ int svx_alexnet_active_sets(const uint32_t* d_touched, uint32_t n, int32_t* d_li
  * as composed at alexnet.py:29-31, :34-36, :45-46.
  *   d_x   C8 [n][channels/8][height][width][8]  raw convolution output (no bias); channels % 8 == 0
  *   d_y   C8 [n][channels/8][(height-3)/2+1][(width-3)/2+1][8]          (d_x, d_bias, d_y 16-byte aligned)
- *   LRN:  y = p / (k + alpha * sum_{|j-c| <= radius} p_j^2)^beta   (alpha NOT divided by the window) */
+ *   LRN:  y = p / (k + alpha * sum_{|j-c| <= radius} p_j^2)^beta   (alpha NOT divided by the window)
+ *   d_active_rows + d_background: both NULL, or [n][height] row masks (bit x = pixel (y, x) of d_x was computed; width <= 32)
+ *         and the C8 [channels/8][height][width][8] raw response of the producing convolution to an empty image: pixels
+ *         whose bit is clear are NOT read from d_x (the active-set convolution need not have written them) but from the
+ *         background -- their exact value.  The producer saves the copy of its inactive pixels (61 % of conv2's output),
+ *         this kernel the HBM reads of them. */
 int svx_bias_relu_pool_lrn(const float* d_x, const float* d_bias, float* d_y, uint32_t n, uint32_t channels,
                            uint32_t height, uint32_t width, int lrn, uint32_t radius, float alpha, float beta,
-                           float k, void* stream);
+                           float k, const uint32_t* d_active_rows, const float* d_background, void* stream);
 
 /* Fully connected layer with bias (+ ReLU) on the fp32 matrix cores: out[m][n] = act(bias[n] + sum_k x[m][k] * W[n][k]).
  * Replaces tf.nn.xw_plus_b + relu of fc6 / fc7 (reference src/network/alexnet.py:49-55 via :141-155).

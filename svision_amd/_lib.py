@@ -31,13 +31,13 @@ SYMBOLS = {
     "svx_rasterize": (ctypes.c_int, [_vp, _u32, _vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float), _vp]),
     "svx_encode_conv1": (ctypes.c_int, [_vp, _u32, _vp, _vp, _vp, ctypes.c_int, _u32, ctypes.c_float, ctypes.c_float,
                                         ctypes.c_float, _vp, _vp]),
-    "svx_alexnet_active_sets": (ctypes.c_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "svx_alexnet_active_sets": (ctypes.c_int, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "svx_conv2d_same": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _u32, _u32, ctypes.c_int, _vp, _vp, _vp, _vp]),
     "svx_fc_ws_bytes": (_sz, [_u32, _u32, _u32]),
     "svx_fc_bias_act": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, ctypes.c_int, _vp]),
     "svx_fc8_softmax": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _vp]),
     "svx_bias_relu_pool_lrn": (ctypes.c_int, [_vp, _vp, _vp, _u32, _u32, _u32, _u32, ctypes.c_int, _u32,
-                                              ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),
+                                              ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp]),
     "svx_span_position_distance": (ctypes.c_int, [_vp, _vp, _vp, _u32, _vp, _u64, ctypes.c_double, _vp, _vp]),
     "svx_hash_seeds": (ctypes.c_int, [_vp, _vp, _u32, _vp, _vp, _vp, _u32, _u32, _u32, _vp]),
     "svx_bam_open": (_vp, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
@@ -57,7 +57,7 @@ class SvxError(RuntimeError):
 _lib = None
 
 
-ABI_VERSION = 200                     # SVX_VERSION of include/svx.h this binding was written against
+ABI_VERSION = 210                     # SVX_VERSION of include/svx.h this binding was written against
 
 
 def load():

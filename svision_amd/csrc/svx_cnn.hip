@@ -32,22 +32,39 @@ __device__ inline float4 max4(float4 a, float4 b) { return make_float4(fmaxf(a.x
 // the kernel issued four times the loads and ran at a third of the HBM rate).
 __global__ __launch_bounds__(BLOCK)
 void bias_relu_pool_lrn_kernel(const float* __restrict__ x, const float* __restrict__ bias, float* __restrict__ y,
-                               int C, int H, int W, int OH, int OW, int lrn, int radius, float alpha, float beta, float k)
+                               int C, int H, int W, int OH, int OW, int lrn, int radius, float alpha, float beta, float k,
+                               const uint32_t* __restrict__ active_rows, const float* __restrict__ background)
 {
     extern __shared__ __attribute__((aligned(16))) float pooled[];    // [OW][C + 1]
     const int b = blockIdx.x / OH;
     const int oy = blockIdx.x - b * OH;
     const int CP = C + 1, HW = H * W;
     const float* xb = x + ((size_t)b * (C / 8) * HW + (size_t)(2 * oy) * W) * 8;
+    // active_rows (with background): bit x of word [image][row] = that input pixel was computed by the active-set convolution;
+    // the others were NOT written and are read from the background tensor (their exact value) instead -- the producer saves
+    // the copy, this kernel most of its HBM reads (the background of a layer is L2 resident)
+    const float* gb = background ? background + (size_t)(2 * oy) * W * 8 : xb;
+    uint32_t rows[3] = {~0u, ~0u, ~0u};
+    if (active_rows) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) rows[dy] = active_rows[(size_t)b * H + 2 * oy + dy];
+    }
     const int n = (C / 4) * OW;
     for (int idx = threadIdx.x; idx < n; idx += BLOCK) {
         const int h = idx & 1, rest = idx >> 1;
         const int oct = rest / OW, ox = rest - oct * OW;
-        const float4* p = reinterpret_cast<const float4*>(xb + ((size_t)oct * HW + 2 * ox) * 8 + 4 * h);   // pixel = 2 float4
-        float4 m = p[0];
-        m = max4(m, p[2]); m = max4(m, p[4]);
-        m = max4(m, p[2 * W]); m = max4(m, p[2 * W + 2]); m = max4(m, p[2 * W + 4]);
-        m = max4(m, p[4 * W]); m = max4(m, p[4 * W + 2]); m = max4(m, p[4 * W + 4]);
+        const size_t at = ((size_t)oct * HW + 2 * ox) * 8 + 4 * h;
+        const float4* p = reinterpret_cast<const float4*>(xb + at);   // pixel = 2 float4
+        const float4* g = reinterpret_cast<const float4*>(gb + at);
+        float4 m;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int off = 2 * (dy * W + dx);
+                const float4 v = ((rows[dy] >> (2 * ox + dx)) & 1u) ? p[off] : g[off];
+                m = (dy | dx) ? max4(m, v) : v;
+            }
         const int c = oct * 8 + 4 * h;
         const float4 bv = *reinterpret_cast<const float4*>(bias + c);
         float* q = pooled + ox * CP + c;
@@ -335,7 +352,8 @@ void active_counts_kernel(const uint32_t* __restrict__ touched, uint32_t* __rest
 __global__ __launch_bounds__(BLOCK)
 void active_lists_kernel(const uint32_t* __restrict__ touched, const uint32_t* __restrict__ per_image, uint32_t n,
                          int32_t* __restrict__ list2, int32_t* __restrict__ list3, int32_t* __restrict__ list4,
-                         int32_t* __restrict__ list5, uint32_t* __restrict__ counts, unsigned long long* __restrict__ totals)
+                         int32_t* __restrict__ list5, uint32_t* __restrict__ counts, unsigned long long* __restrict__ totals,
+                         uint32_t* __restrict__ active2)
 {
     __shared__ uint32_t masks[MASK_ROWS], tmp[A1], rowoff[MASK_ROWS];
     __shared__ uint32_t s_part[8][BLOCK / WAVE];
@@ -377,6 +395,7 @@ void active_lists_kernel(const uint32_t* __restrict__ touched, const uint32_t* _
         }
     }
     __syncthreads();
+    if (active2 && t < A1) active2[(size_t)img * A1 + t] = masks[t];          // conv2's active pixels as row masks (for its consumer)
     for (int p = t; p < A1 * A1; p += BLOCK) {
         const int y = p / A1, x = p - y * A1;
         const uint32_t m = masks[y], below = (1u << x) - 1u;
@@ -396,7 +415,7 @@ void active_lists_kernel(const uint32_t* __restrict__ touched, const uint32_t* _
 
 extern "C" int svx_alexnet_active_sets(const uint32_t* d_touched, uint32_t n, int32_t* d_list2, int32_t* d_list3,
                                        int32_t* d_list4, int32_t* d_list5, uint32_t* d_counts, uint32_t* d_ws,
-                                       uint64_t* d_totals, void* stream)
+                                       uint64_t* d_totals, uint32_t* d_active2, void* stream)
 {
     if (!d_counts) return SVX_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -404,7 +423,7 @@ extern "C" int svx_alexnet_active_sets(const uint32_t* d_touched, uint32_t n, in
     if (!d_touched || !d_list2 || !d_list3 || !d_list4 || !d_list5 || !d_ws || (reinterpret_cast<uintptr_t>(d_ws) & 15u)) return SVX_EINVAL;
     hipLaunchKernelGGL(active_counts_kernel, dim3(n), dim3(64), 0, st, d_touched, d_ws);
     hipLaunchKernelGGL(active_lists_kernel, dim3(n), dim3(BLOCK), 0, st, d_touched, d_ws, n, d_list2, d_list3, d_list4, d_list5, d_counts,
-                       reinterpret_cast<unsigned long long*>(d_totals));
+                       reinterpret_cast<unsigned long long*>(d_totals), d_active2);
     return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
 }
 
@@ -456,15 +475,17 @@ extern "C" int svx_fc8_softmax(const float* d_x, const float* d_w, const float* 
 
 extern "C" int svx_bias_relu_pool_lrn(const float* d_x, const float* d_bias, float* d_y, uint32_t n, uint32_t channels,
                                       uint32_t height, uint32_t width, int lrn, uint32_t radius, float alpha, float beta,
-                                      float k, void* stream)
+                                      float k, const uint32_t* d_active_rows, const float* d_background, void* stream)
 {
     if (n == 0) return SVX_OK;
     if (!d_x || !d_bias || !d_y || channels == 0 || channels % 8 || height < 3 || width < 3) return SVX_EINVAL;
     if ((reinterpret_cast<uintptr_t>(d_x) | reinterpret_cast<uintptr_t>(d_bias) | reinterpret_cast<uintptr_t>(d_y)) & 15u) return SVX_EINVAL;
+    if ((d_active_rows == nullptr) != (d_background == nullptr) || (reinterpret_cast<uintptr_t>(d_background) & 15u) || (d_active_rows && width > 32)) return SVX_EINVAL;
     const int OH = (int)(height - 3) / 2 + 1, OW = (int)(width - 3) / 2 + 1;
     const size_t lds = (size_t)(channels + 1) * OW * sizeof(float);
     if (lds > 64 * 1024) return SVX_EINVAL;
     hipLaunchKernelGGL(bias_relu_pool_lrn_kernel, dim3(n * OH), dim3(BLOCK), lds, static_cast<hipStream_t>(stream),
-                       d_x, d_bias, d_y, (int)channels, (int)height, (int)width, OH, OW, lrn, (int)radius, alpha, beta, k);
+                       d_x, d_bias, d_y, (int)channels, (int)height, (int)width, OH, OW, lrn, (int)radius, alpha, beta, k,
+                       d_active_rows, d_background);
     return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
 }

@@ -102,6 +102,10 @@ void conv_wave_tile(const ConvArgs& a, int Mtot, int Mall)
     const int wg_c = (total_c + WAVES - 1) / WAVES;
     const int oct_units = (a.Cout / 8 + FILL_OCT - 1) / FILL_OCT;
     const int fill_units = (a.pixels && a.background) ? ((Mall - Mtot + FILL_PIX - 1) / FILL_PIX) * oct_units : 0;
+    // (Background units spread evenly BETWEEN the compute workgroups instead of behind them were measured: slower.  Memory-
+    // bound workgroups do not ride along with matrix-bound ones even inside one launch -- on conv2 at 256 images the copy of
+    // the 61 % inactive pixels costs 80 us on top of 335, 2.5x its stand-alone time -- which is why the layer with the most
+    // inactive pixels, conv2, no longer copies at all: its consumer reads the background itself, svx_bias_relu_pool_lrn.)
     // XCD-aware order (workgroup b runs on XCD b % 8, each XCD has its own 4 MB L2): every XCD gets an equal contiguous
     // run of the compute workgroups -- the activation slice of a pixel tile is fetched into one L2 and re-used by all its
     // channel tiles, whose waves sit in the same workgroup (one L1) -- and, behind it, of the background units

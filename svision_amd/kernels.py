@@ -120,9 +120,10 @@ def cigar_scan(cigar, cig_off, ref_start, min_sv, gaps_cap=None):
     return res
 
 
-def bias_relu_pool_lrn(x, bias, lrn=True, radius=2, alpha=2e-05, beta=0.75, k=1.0):
+def bias_relu_pool_lrn(x, bias, lrn=True, radius=2, alpha=2e-05, beta=0.75, k=1.0, active_rows=None, background=None):
     """x: float32 C8 [n,C/8,H,W,8] raw conv output -> relu(x+bias) -> max-pool 3x3/2 -> (LRN) as one kernel, C8 out.
-    See include/svx.h svx_bias_relu_pool_lrn."""
+    ``active_rows`` (int32 [n,H] row masks) + ``background`` (C8 [C/8,H,W,8]): pixels whose bit is clear are read from the
+    background instead of ``x`` (an active-set convolution that did not write them).  See include/svx.h svx_bias_relu_pool_lrn."""
     lib = _lib.load()
     _require_cuda(x, "x")
     _require_cuda(bias, "bias")
@@ -130,8 +131,18 @@ def bias_relu_pool_lrn(x, bias, lrn=True, radius=2, alpha=2e-05, beta=0.75, k=1.
         raise _lib.SvxError("x must be float32 C8 [n,C/8,H,W,8] and bias float32 [C]")
     n, o, h, w, _e = x.shape
     y = torch.empty((n, o, (h - 3) // 2 + 1, (w - 3) // 2 + 1, 8), dtype=torch.float32, device=x.device)
+    if (active_rows is None) != (background is None):
+        raise _lib.SvxError("active_rows and background go together")
+    if active_rows is not None:
+        _require_cuda(active_rows, "active_rows")
+        _require_cuda(background, "background")
+        if active_rows.dtype != torch.int32 or tuple(active_rows.shape) != (n, h) or background.dtype != torch.float32 \
+                or tuple(background.shape)[-4:] != (o, h, w, 8) or background.numel() != o * h * w * 8 \
+                or not background.is_contiguous() or not active_rows.is_contiguous():
+            raise _lib.SvxError("active_rows must be int32 [n,H] and background float32 C8 [C/8,H,W,8]")
     rc = lib.svx_bias_relu_pool_lrn(x.data_ptr(), bias.data_ptr(), y.data_ptr(), n, o * 8, h, w, 1 if lrn else 0, radius,
-                                    alpha, beta, k, _stream_ptr(x.device))
+                                    alpha, beta, k, active_rows.data_ptr() if active_rows is not None else None,
+                                    background.data_ptr() if background is not None else None, _stream_ptr(x.device))
     _lib.check(rc, "svx_bias_relu_pool_lrn")
     return y
 
@@ -156,7 +167,7 @@ def encode_conv1(records, w1_hwio, base, lrn=True, radius=2, alpha=2e-05, beta=0
     return (y, mask) if touched else y
 
 
-def alexnet_active_sets(touched, totals=None):
+def alexnet_active_sets(touched, totals=None, rows=False):
     """touched int32 [n,27] (encode_conv1) -> (list2 [n*729], list3, list4, list5 [n*169], counts [4]) int32 device
     tensors: the output pixels of conv2..conv5 that can differ from the response to an empty image.
     ``totals``: optional int64 device tensor [5] the launch adds its executed pixel counts (conv2..conv5) and image count to.
@@ -171,10 +182,14 @@ def alexnet_active_sets(touched, totals=None):
     lists = [torch.empty(n * hw, dtype=torch.int32, device=dev) for hw in (729, 169, 169, 169)]
     counts = torch.empty(4, dtype=torch.int32, device=dev)
     ws = torch.empty(max(n, 1) * 4, dtype=torch.int32, device=dev)
+    active2 = torch.empty((n, 27), dtype=torch.int32, device=dev) if rows else None
     rc = lib.svx_alexnet_active_sets(touched.data_ptr(), n, lists[0].data_ptr(), lists[1].data_ptr(), lists[2].data_ptr(),
                                      lists[3].data_ptr(), counts.data_ptr(), ws.data_ptr(),
-                                     totals.data_ptr() if totals is not None else None, _stream_ptr(dev))
+                                     totals.data_ptr() if totals is not None else None,
+                                     active2.data_ptr() if rows else None, _stream_ptr(dev))
     _lib.check(rc, "svx_alexnet_active_sets")
+    if rows:                                                  # + int32 [n,27] row masks of conv2's active pixels
+        return lists[0], lists[1], lists[2], lists[3], counts, active2
     return lists[0], lists[1], lists[2], lists[3], counts
 
 

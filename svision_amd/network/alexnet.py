@@ -107,14 +107,17 @@ class AlexNet(torch.nn.Module):
             return kernels.bias_relu_pool_lrn(x, self.conv5_b, lrn=False)
         bg = self.background()
         x, touched = kernels.encode_conv1(records, self.conv1_hwio, self.conv1_base, touched=True)
-        l2, l3, l4, l5, counts = kernels.alexnet_active_sets(touched, totals=self.executed)
+        l2, l3, l4, l5, counts, rows2 = kernels.alexnet_active_sets(touched, totals=self.executed, rows=True)
 
         def conv(name, x, pixels, k, bias, relu, groups):
             # active pixels computed, the others copied from the background by the workgroups behind the compute tiles
             return kernels.conv2d_same(x, getattr(self, name + "_w"), bias, groups=groups, relu=relu, pixels=pixels,
                                        pixel_count=counts[k:k + 1], background=bg[name])
-        x = conv("conv2", x, l2, 0, None, False, 2)
-        x = kernels.bias_relu_pool_lrn(x, self.conv2_b, lrn=True)
+        # conv2 writes its active pixels only (61 % of its output would be copies of the background, and that copy is
+        # not hidden behind the matrix work): the pool reads the background for the others itself
+        x = kernels.conv2d_same(x, self.conv2_w, None, groups=2, pixels=l2, pixel_count=counts[0:1],
+                                out=torch.empty((records.shape[0], 32, 27, 27, 8), dtype=torch.float32, device=records.device))
+        x = kernels.bias_relu_pool_lrn(x, self.conv2_b, lrn=True, active_rows=rows2, background=bg["conv2"])
         x = conv("conv3", x, l3, 1, self.conv3_b, True, 1)
         x = conv("conv4", x, l4, 2, self.conv4_b, True, 2)
         x = conv("conv5", x, l5, 3, None, False, 2)

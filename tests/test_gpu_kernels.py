@@ -434,3 +434,25 @@ def test_fc_bias_act_matches_fp64_reference(m, n, k):
     ref = torch.zeros(m, n, device=DEV)
     ref[m - 1] = 2.0 * w[:, k - 3]
     assert torch.equal(hot, ref)
+
+
+@pytest.mark.parametrize("c,hw,lrn", [(256, 27, True), (256, 13, False), (96, 27, True)])
+def test_pool_reads_inactive_pixels_from_the_background(c, hw, lrn):
+    """svx_bias_relu_pool_lrn with row masks: a pixel whose bit is clear is taken from the background tensor and never read
+    from the input (NaN there must not leak) -- bit-identical to the plain kernel on the merged tensor."""
+    torch.manual_seed(c + hw)
+    n = 5
+    x = torch.randn(n, c // 8, hw, hw, 8, device=DEV)
+    bg = torch.randn(c // 8, hw, hw, 8, device=DEV)
+    bias = torch.randn(c, device=DEV)
+    active = torch.rand(n, hw, hw, device=DEV) < 0.4
+    active[0] = True                                          # one image fully active, one fully inactive
+    active[1] = False
+    rows = (active.to(torch.int64) << torch.arange(hw, device=DEV)).sum(2).to(torch.int32).contiguous()
+    merged = torch.where(active[:, None, :, :, None], x, bg[None])
+    want = kernels.bias_relu_pool_lrn(merged, bias, lrn=lrn)
+    holes = torch.where(active[:, None, :, :, None], x, torch.full_like(x, float("nan")))
+    got = kernels.bias_relu_pool_lrn(holes, bias, lrn=lrn, active_rows=rows, background=bg)
+    assert torch.equal(got, want) and not torch.isnan(got).any()
+    with pytest.raises(Exception):
+        kernels.bias_relu_pool_lrn(holes, bias, lrn=lrn, active_rows=rows)
