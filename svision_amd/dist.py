@@ -45,7 +45,10 @@ def init_from_env(timeout_hours=24.0):
         if torch.cuda.is_available():
             torch.cuda.set_device(local_device_index())
         import datetime
-        dist.init_process_group(backend, timeout=datetime.timedelta(hours=timeout_hours))
+        kw = {}
+        if backend == "nccl":                  # bind the communicator to this rank's GPU (otherwise guessed from the global rank)
+            kw["device_id"] = torch.device("cuda", local_device_index())
+        dist.init_process_group(backend, timeout=datetime.timedelta(hours=timeout_hours), **kw)
     return world()
 
 
