@@ -102,7 +102,12 @@ void bias_relu_pool_lrn_kernel(const float* __restrict__ x, const float* __restr
 // positions under it, extracts the 11-bit window masks from the bit planes and accumulates the
 // weight rows of the set taps (checkpoint layout HWIO = [tap][96 channels], 32 B per lane,
 // L2 resident).  ReLU, max-pool and the cross-channel LRN follow from LDS.
-constexpr int C1 = 96, C1_GROUPS = 12, P1 = 27, ENC_BLOCK = 384, C1P = C1 + 1;   // conv1 output is 55x55, pooled 27x27
+// threads per encode workgroup: 256 measured best (93 us per 256 images; 128: 137, 192: 106, 320: 108, 384: 110, 512: 110) --
+// six workgroups per CU instead of five, the phases of a workgroup are too short to need more lanes
+#ifndef SVX_ENC_BLOCK
+#define SVX_ENC_BLOCK 256
+#endif
+constexpr int C1 = 96, C1_GROUPS = 12, P1 = 27, ENC_BLOCK = SVX_ENC_BLOCK, C1P = C1 + 1;   // conv1 output is 55x55, pooled 27x27
 
 __device__ inline unsigned window_mask(const unsigned* row_words, int c0)
 {
