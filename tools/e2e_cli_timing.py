@@ -30,3 +30,5 @@ for nt in threads:                                   # a fresh process per run: 
     print("-t %d: %s (process wall %.2f s)" % (nt, " | ".join(l for l in r.stdout.strip().splitlines() if "window " not in l and "owner: " not in l and "  helper " not in l) or r.stderr[-500:], time.time() - t), flush=True)
     for line in open([os.path.join(out, f) for f in os.listdir(out) if f.endswith(".log")][0]):
         if "Cost time" in line: print("   ", line.rstrip())
+vcfs = {nt: open(os.path.join(d, "out%d" % nt, "S.svision.s5.vcf")).read() for nt in threads}
+print("VCFs of -t %s identical: %s (%d records)" % (",".join(map(str, threads)), len(set(vcfs.values())) == 1, sum(1 for l in vcfs[threads[0]].splitlines() if not l.startswith("#"))))
