@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -124,6 +125,13 @@ struct RawBuf {
     void clear() { n = 0; }
 };
 
+// SVX_TIMING=1: seconds spent reading, inflating, chaining records (serial) and scattering fields (parallel), on stderr
+struct BamClock {
+    double read = 0, inflate = 0, chain = 0, scatter = 0;
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+};
+BamClock g_clock;
+
 template <class F>
 void parallel_for(size_t n, int threads, F fn)
 {
@@ -165,7 +173,9 @@ public:
         const uint64_t want = capped_ ? 0 : std::min<uint64_t>(chunk, end_ - pos_);
         cbuf_.resize(have + want);
         if (have) memcpy(cbuf_.data(), carry_.data(), have);
+        const double t_read = BamClock::now();
         const size_t got = want ? fread(cbuf_.data() + have, 1, want, f_) : 0;
+        g_clock.read += BamClock::now() - t_read;
         if (got < want) eof_ = true;
         cbuf_.resize(have + got);
         const uint64_t base = pos_ - have;                 // file offset of cbuf_[0]
@@ -202,6 +212,7 @@ public:
             if (end_ == ~0ull) { err_ = "truncated BGZF file"; return false; }
             // a byte range cut in the middle of its last block: callers ask for one block more than they need
         }
+        const double t_inf = BamClock::now();
         out.resize(total);
         std::atomic<bool> ok{true};
         parallel_for(src.size(), threads_, [&](size_t lo, size_t hi) {
@@ -219,6 +230,7 @@ public:
                 if (rc != Z_STREAM_END || zs.avail_out != 0) { ok = false; return; }
             }
         });
+        g_clock.inflate += BamClock::now() - t_inf;
         if (!ok) { err_ = "BGZF inflate failed"; return false; }
         carry_.assign(cbuf_.begin() + p, cbuf_.end());
         if (eof_ && !capped) carry_.clear();
@@ -267,6 +279,7 @@ long long parse_records(const RawBuf& buf, uint64_t from, uint64_t limit, int th
 {
     struct Rec { uint64_t at; const uint8_t* cig; uint32_t n_cig; };
     std::vector<Rec> recs;
+    const double t_chain = BamClock::now();
     uint64_t p = from, words = 0, seq_bytes = 0;
     while (p + 4 <= limit) {
         const uint64_t bs = rd32(&buf[p]);
@@ -315,7 +328,10 @@ long long parse_records(const RawBuf& buf, uint64_t from, uint64_t limit, int th
             if (keep_seq) { b->seq_off[n0 + i] = s; s += (rd32(&buf[recs[i].at + 4 + 16]) + 1ull) / 2; }
         }
     }
-    parallel_for(n, threads, [&](size_t lo, size_t hi) {
+    const double t_scatter = BamClock::now();
+    g_clock.chain += t_scatter - t_chain;
+    // (a thread per ~4096 records: spawning 64 threads for a chunk of 30 k short records cost more than the copies)
+    parallel_for(n, std::max(1, std::min<int>(threads, (int)(n / 4096))), [&](size_t lo, size_t hi) {
         for (size_t i = lo; i < hi; ++i) {
             const uint8_t* rec = &buf[recs[i].at + 4];
             const size_t k = n0 + i;
@@ -327,6 +343,7 @@ long long parse_records(const RawBuf& buf, uint64_t from, uint64_t limit, int th
             if (keep_seq) memcpy(&b->seq[b->seq_off[k]], rec + 32 + rec[8] + 4ull * rd16(rec + 12), ((uint32_t)b->l_seq[k] + 1ull) / 2);
         }
     });
+    g_clock.scatter += BamClock::now() - t_scatter;
     return (long long)p;
 }
 
@@ -401,6 +418,10 @@ void* bam_open_impl(const char* path, int threads, int flags, bool ranged, uint6
         if (!reached) return fail("BAM index does not match the file");
     }
     fclose(f);
+    if (getenv("SVX_TIMING"))
+        fprintf(stderr, "svx_bam_open (%d threads): read %.3f s, inflate %.3f s, chain records %.3f s, scatter fields %.3f s\n", threads,
+                g_clock.read, g_clock.inflate, g_clock.chain, g_clock.scatter);
+    g_clock = BamClock();
     return b.release();
 }
 
