@@ -53,6 +53,9 @@ constexpr unsigned OOB = 0x80000000u;             // per-lane byte offset no des
 constexpr int N_SHAPES = 5;
 constexpr int SHAPE_NA[N_SHAPES] = {2, 1, 2, 2, 1};
 constexpr int SHAPE_NB[N_SHAPES] = {1, 3, 3, 2, 2};
+#ifndef SVX_CONV_XCD_2D
+#define SVX_CONV_XCD_2D 1
+#endif
 #ifndef SVX_LIST_SHAPES
 #define SVX_LIST_SHAPES 2
 #endif
@@ -69,6 +72,18 @@ struct ConvArgs {
 __host__ __device__ inline int conv_wave_tiles(int M, int cout_g, int groups, int shape)
 {
     return ((M + 32 * SHAPE_NB[shape] - 1) / (32 * SHAPE_NB[shape])) * groups * (cout_g / (32 * SHAPE_NA[shape]));
+}
+
+// compute workgroups of a launch (a multiple of 8: the same number on every XCD)
+inline int conv_compute_wgs(int M, int cout_g, int groups, int shape)
+{
+#if SVX_CONV_XCD_2D
+    const int m_tiles = (M + 32 * SHAPE_NB[shape] - 1) / (32 * SHAPE_NB[shape]);
+    const int ny = groups * (cout_g / (32 * SHAPE_NA[shape])), halves = (ny & 1) ? 1 : 2;
+    return 8 * ((((m_tiles * halves + 7) / 8) * (ny / halves) + WAVES - 1) / WAVES);
+#else
+    return 8 * (((conv_wave_tiles(M, cout_g, groups, shape) + WAVES - 1) / WAVES + 7) / 8);
+#endif
 }
 
 // The busiest SIMD runs ceil(tiles / SIMDs) waves of NA * NB accumulators each: pick the shape that minimises that.
@@ -98,8 +113,21 @@ void conv_wave_tile(const ConvArgs& a, int Mtot, int Mall)
     const int CinG = a.Cin / a.groups, CoutG = a.Cout / a.groups;
     const int n_tiles = CoutG / (32 * NA), ny = a.groups * n_tiles;
     const int m_tiles = (Mtot + 32 * NB - 1) / (32 * NB);
+#if SVX_CONV_XCD_2D
+    // XCD-aware order (workgroup b runs on XCD b % 8, each XCD has its own 4 MB L2): the 8 XCDs are 4 pixel ranges x 2
+    // channel halves.  An XCD then needs HALF the layer's weights (0.6-1.75 MB: they stay in its L2 however many rounds of
+    // workgroups the launch takes) and, in the grouped layers -- a channel half is a group there -- only that group's half
+    // of the input channels: every activation byte is fetched by one XCD, in conv3 (one group) by two.  With 8 pixel ranges
+    // x all channel tiles every XCD streamed all the weights and later rounds of workgroups found them evicted
+    // (PMC FETCH_SIZE of conv3..5 at 256 images: 5x their operands).
+    const int halves = (ny & 1) ? 1 : 2;                                // (an odd number of channel tiles: 8 pixel ranges x all of them)
+    const int n_half = ny / halves;                                     // channel tiles of this XCD
+    const int mp = (m_tiles * halves + 7) / 8;                          // pixel tiles per pixel range
+    const int per_c = (mp * n_half + WAVES - 1) / WAVES;                // compute workgroups per XCD
+#else
     const int total_c = m_tiles * ny;                                   // wave tiles, channel tile fastest
     const int wg_c = (total_c + WAVES - 1) / WAVES;
+#endif
     const int oct_units = (a.Cout / 8 + FILL_OCT - 1) / FILL_OCT;
     const int fill_units = (a.pixels && a.background) ? ((Mall - Mtot + FILL_PIX - 1) / FILL_PIX) * oct_units : 0;
     // (Background units spread evenly BETWEEN the compute workgroups instead of behind them were measured: slower.  Memory-
@@ -109,7 +137,11 @@ void conv_wave_tile(const ConvArgs& a, int Mtot, int Mall)
     // XCD-aware order (workgroup b runs on XCD b % 8, each XCD has its own 4 MB L2): every XCD gets an equal contiguous
     // run of the compute workgroups -- the activation slice of a pixel tile is fetched into one L2 and re-used by all its
     // channel tiles, whose waves sit in the same workgroup (one L1) -- and, behind it, of the background units
+#if SVX_CONV_XCD_2D
+    const int per_f = (fill_units + 7) / 8;
+#else
     const int per_c = (wg_c + 7) / 8, per_f = (fill_units + 7) / 8;
+#endif
     const int local = blockIdx.x >> 3, xcd = blockIdx.x & 7;
     const int tid = threadIdx.x;
     if (local >= per_c) {
@@ -131,11 +163,19 @@ void conv_wave_tile(const ConvArgs& a, int Mtot, int Mall)
         }
         return;
     }
+#if SVX_CONV_XCD_2D
+    const int wl = local * WAVES + (tid >> 6);                          // wave tile of this XCD, channel tile fastest
+    if (wl >= mp * n_half) return;
+    const int mt = (xcd / halves) * mp + wl / n_half;
+    if (mt >= m_tiles) return;
+    const int yy_ = (xcd % halves) * n_half + wl % n_half;
+#else
     const int wg = xcd * per_c + local;
     const int wt = wg * WAVES + (tid >> 6);
     if (wg >= wg_c || wt >= total_c) return;
     const int mt = wt / ny;
     const int yy_ = wt - mt * ny;
+#endif
     const int g = yy_ / n_tiles;
     const int n0 = (yy_ - g * n_tiles) * 32 * NA;
     const int m0 = mt * 32 * NB;
@@ -349,14 +389,13 @@ extern "C" int svx_conv2d_same(const float* d_in, const float* d_w_packed, const
     if (const char* e = getenv("SVX_CONV_SHAPE")) if (atoi(e) >= 0 && atoi(e) < (d_pixels ? LIST_SHAPES : N_SHAPES)) shape = atoi(e);
 #endif
     if (d_pixels) {
-        int most = 0;
-        for (int s = 0; s < LIST_SHAPES; ++s) { const int t = conv_wave_tiles(mall, (int)cout_g, (int)groups, s); if (t > most) most = t; }
-        int wgs = 8 * (((most + WAVES - 1) / WAVES + 7) / 8);
+        int wgs = 0;
+        for (int s = 0; s < LIST_SHAPES; ++s) { const int t = conv_compute_wgs(mall, (int)cout_g, (int)groups, s); if (t > wgs) wgs = t; }
         if (d_background) wgs += 8 * ((((mall + FILL_PIX - 1) / FILL_PIX) * (int)((cout / 8 + FILL_OCT - 1) / FILL_OCT) + 7) / 8 + 1);
         if (ksize == 3) hipLaunchKernelGGL(conv_wave_list_kernel<3>, dim3((unsigned)wgs), dim3(THREADS), 0, st, a, shape);
         else            hipLaunchKernelGGL(conv_wave_list_kernel<5>, dim3((unsigned)wgs), dim3(THREADS), 0, st, a, shape);
     } else {
-        const int wgs = 8 * (((conv_wave_tiles(mall, (int)cout_g, (int)groups, shape) + WAVES - 1) / WAVES + 7) / 8);
+        const int wgs = conv_compute_wgs(mall, (int)cout_g, (int)groups, shape);
         if (ksize == 3) launch_conv<3>(shape, wgs, st, a);
         else            launch_conv<5>(shape, wgs, st, a);
     }
