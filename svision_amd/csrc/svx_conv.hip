@@ -30,7 +30,8 @@
 //   * Operands are fetched two octets (8 k-pairs, >= 1000 cycles of MFMA work) ahead into a ring of three register
 //     sets, statically indexed by unrolling three octets; the loads of an octet are spread between the MFMAs of
 //     another (a wave issues in order: a cluster of loads longer than one MFMA's 64 cycles would idle the pipe).
-//   * k order per output element is fixed -- (ky, kx, octet, j, half) -- in every shape and mode: the active-set path
+//   * k order per output element is fixed -- (octet, ky, kx, j, half) in the 3x3 layers, (ky, kx, octet, j, half) in the
+//     5x5 one -- in every shape and mode: the active-set path
 //     stays bit-identical to the dense path.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -53,6 +54,9 @@ constexpr unsigned OOB = 0x80000000u;             // per-lane byte offset no des
 constexpr int N_SHAPES = 5;
 constexpr int SHAPE_NA[N_SHAPES] = {2, 1, 2, 2, 1};
 constexpr int SHAPE_NB[N_SHAPES] = {1, 3, 3, 2, 2};
+#ifndef SVX_CONV_TAP_INNER
+#define SVX_CONV_TAP_INNER 1
+#endif
 #ifndef SVX_CONV_XCD_2D
 #define SVX_CONV_XCD_2D 1
 #endif
@@ -236,13 +240,29 @@ void conv_wave_tile(const ConvArgs& a, int Mtot, int Mall)
         if (q < NA) ra[slot][q] = buf_load4(rs_w, voff_a[q], soff_a);
         else        rb[slot][q - NA] = buf_load4(rs_x, voff_b[q - NA], soff_b);
     };
-    auto advance = [&]() {                                // the load iterator moves to the next octet (past the end: the
-        soff_a += step_a;                                 // offsets leave the descriptors and the loads return zeros)
-        soff_b += step_b;
-        if (++lq == octs) {
-            lq = 0; soff_b = 0;
+    // 3x3 layers -- k order (octet, ky, kx): all taps of an octet before the next octet.  The 9 (25) taps of a pixel tile read the same
+    // few KB of its neighbourhood in that octet -- L1 hits -- where the order (ky, kx, octet) streamed the whole 32-octet
+    // slice once per tap and had it re-fetched through L2 and, at the launch sizes of the pipeline, through the fabric
+    // (PMC FETCH_SIZE 3-5x the operands).  The weights are walked with a stride (tap-major packing kept: the pack is
+    // part of the ABI); the per-lane tap offsets are recomputed every stage (a dozen VALU instructions next to 8+ MFMAs).
+    // 5x5 layer (conv2, 6 octets per tap) -- k order (ky, kx, octet): its slice per tap is small enough to stay cached, and
+    // with 25 taps per octet the per-stage tap arithmetic made the dense launch 11 % slower for no change in traffic.
+    constexpr bool TAP_INNER = SVX_CONV_TAP_INNER && KS == 3;
+    const unsigned step_tap = (unsigned)octs * step_a;
+    auto advance = [&]() {                                // past the end the prefetches read valid memory or zeros: never used
+        if (TAP_INNER) {
+            soff_a += step_tap;
             if (++lkx == KS) { lkx = 0; ++lky; }
+            if (lky == KS) { lky = 0; ++lq; soff_a = (unsigned)lq * step_a; soff_b += step_b; }
             set_tap();
+        } else {
+            soff_a += step_a;
+            soff_b += step_b;
+            if (++lq == octs) {
+                lq = 0; soff_b = 0;
+                if (++lkx == KS) { lkx = 0; ++lky; }
+                set_tap();
+            }
         }
     };
     // One stage: the 4 * NA * NB MFMAs of the octet in ring slot `cs` with the L loads of a later octet (into slot `ls`)
