@@ -244,7 +244,9 @@ void conv_wave_tile(const ConvArgs& a, int Mtot, int Mall)
     // few KB of its neighbourhood in that octet -- L1 hits -- where the order (ky, kx, octet) streamed the whole 32-octet
     // slice once per tap and had it re-fetched through L2 and, at the launch sizes of the pipeline, through the fabric
     // (PMC FETCH_SIZE 3-5x the operands).  The weights are walked with a stride (tap-major packing kept: the pack is
-    // part of the ABI); the per-lane tap offsets are recomputed every stage (a dozen VALU instructions next to 8+ MFMAs).
+    // part of the ABI); the per-lane tap offsets are recomputed every stage (a dozen VALU instructions next to 8+ MFMAs:
+    // free where several waves share a SIMD -- the pipeline's launches -- and 6-19 % of a 64-image dense launch whose waves
+    // sit alone on theirs; per-tile validity bits + a uniform tap offset instead were measured: 5 % slower in list mode).
     // 5x5 layer (conv2, 6 octets per tap) -- k order (ky, kx, octet): its slice per tap is small enough to stay cached, and
     // with 25 taps per octet the per-stage tap arithmetic made the dense launch 11 % slower for no change in traffic.
     constexpr bool TAP_INNER = SVX_CONV_TAP_INNER && KS == 3;

@@ -3,7 +3,9 @@
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from svision_amd import kernels
+from svision_amd import kernels, _lib
+if os.environ.get("SVX_EXP_LIB"):
+    _lib.LIB_PATH = os.environ["SVX_EXP_LIB"]
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 for name, cin, cout, g, hw, k in (("conv2",96,256,2,27,5),("conv3",256,384,1,13,3),("conv4",384,384,2,13,3),("conv5",384,256,2,13,3)):
