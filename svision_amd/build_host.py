@@ -23,11 +23,11 @@ def _sha1(path):
         return hashlib.sha1(f.read()).hexdigest()
 
 
-def drop_stale(log=None):
+def drop_stale(log=None, here=None):
     """Remove extension modules whose ``.py`` source changed since they were compiled (``import`` would silently prefer the
-    stale binary).  Called on package import; cheap (eight small files)."""
+    stale binary).  Called on package import; cheap (eight small files).  ``here``: package directory (tests)."""
     import json
-    here = os.path.dirname(os.path.abspath(__file__))
+    here = here or os.path.dirname(os.path.abspath(__file__))
     try:
         with open(os.path.join(here, STAMP)) as f:
             stamp = json.load(f)
