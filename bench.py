@@ -185,6 +185,7 @@ def main():
     net = AlexNet(random_weights(0), device=dev)
     net.executed = torch.zeros(5, dtype=torch.int64, device=dev)     # executed conv pixels per layer + images, summed on the device
     hot = PooledHotPath(sample, opts, net, device=dev, n_streams=args.streams, max_inflight=args.inflight, launch_batches=args.launch_batches, pool=pool)
+    hot.record_timing = True                  # HIP events around every launch, on the launch's stream (roofline.achieved)
 
     import torch.distributed as tdist
     grouped = tdist.is_available() and tdist.is_initialized()

@@ -12,11 +12,9 @@ def _check_host_modules():
     import sys
     if "svision_amd.build_host" in sys.modules or (sys.argv and sys.argv[0].endswith("build_host.py")):
         return
-    try:
-        from .build_host import drop_stale
-        drop_stale(log=lambda msg: print(msg, file=sys.stderr))
-    except Exception:                                         # noqa: BLE001 -- never block an import on housekeeping
-        pass
+    # read-only: a compiled host module older than its .py source is bypassed (meta-path finder), never deleted here
+    from .build_host import guard_imports
+    guard_imports(log=lambda msg: print(msg, file=sys.stderr))
 
 
 _check_host_modules()

@@ -54,6 +54,10 @@ class SvxError(RuntimeError):
     pass
 
 
+class SvxMissing(SvxError):
+    """libsvx.so has not been built (as opposed to: built, but wrong)."""
+
+
 _lib = None
 
 
@@ -65,7 +69,7 @@ def load():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
-            raise SvxError(
+            raise SvxMissing(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C svision_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
         lib = ctypes.CDLL(LIB_PATH)

@@ -23,9 +23,9 @@ def _sha1(path):
         return hashlib.sha1(f.read()).hexdigest()
 
 
-def drop_stale(log=None, here=None):
-    """Remove extension modules whose ``.py`` source changed since they were compiled (``import`` would silently prefer the
-    stale binary).  Called on package import; cheap (eight small files).  ``here``: package directory (tests)."""
+def stale_modules(here=None):
+    """-> [(module path relative to the package, [its extension files])] for every compiled host module whose ``.py``
+    source is not the one it was compiled from.  Read-only (eight small files are hashed)."""
     import json
     here = here or os.path.dirname(os.path.abspath(__file__))
     try:
@@ -33,18 +33,65 @@ def drop_stale(log=None, here=None):
             stamp = json.load(f)
     except (OSError, ValueError):
         stamp = {}
-    dropped = []
+    stale = []
     for m in MODULES:
         src = os.path.join(here, m)
         d, base = os.path.dirname(src), os.path.basename(m)[:-3]
-        sos = [n for n in os.listdir(d) if n.startswith(base + ".") and n.endswith(".so")]
+        try:
+            sos = [n for n in os.listdir(d) if n.startswith(base + ".") and n.endswith(".so")]
+        except OSError:
+            continue
         if sos and stamp.get(m) != _sha1(src):
-            for n in sos:
-                try:
-                    os.remove(os.path.join(d, n))
-                    dropped.append(os.path.join(os.path.dirname(m), n))
-                except OSError:
-                    pass
+            stale.append((m, sos))
+    return stale
+
+
+class _SourceFirst:
+    """Meta-path finder: the listed modules are imported from their ``.py`` source although an extension module of the
+    same name sits next to it.  What ``import svision_amd`` installs when it finds stale binaries: nothing on disk is
+    touched (no race between ranks, works on a read-only install), and the stale code cannot run."""
+
+    def __init__(self, sources):
+        self.sources = dict(sources)                          # {fully qualified module name: path of its .py}
+
+    def find_spec(self, fullname, path=None, target=None):
+        py = self.sources.get(fullname)
+        if py is None:
+            return None
+        import importlib.util
+        return importlib.util.spec_from_file_location(fullname, py)
+
+
+def guard_imports(package="svision_amd", here=None, log=None):
+    """Called on package import: stale extension modules are bypassed (their sources run interpreted) and reported."""
+    here = here or os.path.dirname(os.path.abspath(__file__))
+    stale = stale_modules(here)
+    if not stale:
+        return []
+    names = {package + "." + m[:-3].replace("/", "."): os.path.join(here, m) for m, _sos in stale}
+    sys.meta_path.insert(0, _SourceFirst(names))
+    if log is not None:
+        log("svision_amd: compiled host modules older than their source are ignored, the .py files run interpreted "
+            "(rebuild with `python -m svision_amd.build_host`): " + ", ".join(m for m, _s in stale))
+    return sorted(names)
+
+
+def drop_stale(log=None, here=None):
+    """Remove extension modules whose ``.py`` source changed since they were compiled.  Build-time housekeeping
+    (``build()`` below, ``clean``); importing the package never deletes anything (see :func:`guard_imports`)."""
+    here = here or os.path.dirname(os.path.abspath(__file__))
+    dropped = []
+    for m, sos in stale_modules(here):
+        d = os.path.dirname(os.path.join(here, m))
+        for n in sos:
+            try:
+                os.remove(os.path.join(d, n))
+                dropped.append(os.path.join(os.path.dirname(m), n))
+            except FileNotFoundError:
+                pass
+            except OSError as exc:
+                if log is not None:
+                    log("svision_amd: cannot remove stale %s: %s" % (os.path.join(d, n), exc))
     if dropped and log is not None:
         log("svision_amd: removed compiled host modules older than their source (run `python -m svision_amd.build_host`): " + ", ".join(dropped))
     return dropped
@@ -60,6 +107,7 @@ def build(quiet=True):
     root = os.path.dirname(here)
     cwd = os.getcwd()
     os.chdir(root)
+    drop_stale(log=lambda msg: print(msg, file=sys.stderr))
     tmp = tempfile.mkdtemp(prefix="svx_host_build_")
     os.environ["CFLAGS"] = (os.environ.get("CFLAGS", "") + " -g0 -O2").strip()           # no debug info: 8 x 0.1 MB instead of 8 x 1 MB
     try:

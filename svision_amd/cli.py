@@ -257,6 +257,25 @@ def run(options, sample=None, classifier=None):
             for chrom, text in bodies.items():
                 with open(os.path.join(pred_dir, "%s.predict.s%s.vcf" % (chrom, options.min_support)), "w") as f:
                     f.write(text)
+        if options.graph:
+            # the per-read graphs of a reported cluster are written by the rank that collected it (graphs/{chrom}-{start}-{end}/
+            # {read}.gfa); step 3 below runs on rank 0, and the out_path need not be a filesystem the ranks share: the
+            # graph texts travel with the VCF bodies
+            mine_set, texts = set(mine), {}
+            for name in sorted(os.listdir(graph_dir)):
+                d = os.path.join(graph_dir, name)
+                if os.path.isdir(d) and name.rsplit("-", 2)[0] in mine_set:
+                    for fn in sorted(os.listdir(d)):
+                        with open(os.path.join(d, fn)) as f:
+                            texts[name + "/" + fn] = f.read()
+            texts = sdist.gather_texts(texts, dst=0)
+            if rank == 0:
+                for rel, text in texts.items():
+                    path = os.path.join(graph_dir, rel)
+                    if not os.path.exists(path):
+                        os.makedirs(os.path.dirname(path), exist_ok=True)
+                        with open(path, "w") as f:
+                            f.write(text)
     if rank == 0:
         options.source_version = REFERENCE_VERSION
         merge_split_vcfs(pred_dir, merged_path, max_score, min_score, chroms, options, fasta=fasta)

@@ -19,18 +19,21 @@ extern "C" const char* svx_strerror(int code)
 // the 228 MB of AlexNet weights.
 extern "C" uint32_t svx_crc32c(const void* data, size_t n)
 {
-    static uint32_t tbl[8][256];
-    static bool ready = false;
-    if (!ready) {
-        for (uint32_t i = 0; i < 256; ++i) {
-            uint32_t c = i;
-            for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
-            tbl[0][i] = c;
+    struct Tables {
+        uint32_t t[8][256];
+        Tables()
+        {
+            for (uint32_t i = 0; i < 256; ++i) {
+                uint32_t c = i;
+                for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+                t[0][i] = c;
+            }
+            for (uint32_t i = 0; i < 256; ++i)
+                for (int k = 1; k < 8; ++k) t[k][i] = (t[k - 1][i] >> 8) ^ t[0][t[k - 1][i] & 0xFF];
         }
-        for (uint32_t i = 0; i < 256; ++i)
-            for (int t = 1; t < 8; ++t) tbl[t][i] = (tbl[t - 1][i] >> 8) ^ tbl[0][tbl[t - 1][i] & 0xFF];
-        ready = true;
-    }
+    };
+    static const Tables tables;                   // function-local static: initialised once, thread-safe (C++11)
+    const uint32_t (*tbl)[256] = tables.t;
     const unsigned char* p = static_cast<const unsigned char*>(data);
     uint32_t c = 0xFFFFFFFFu;
     while (n >= 8) {

@@ -157,7 +157,7 @@ class SiteVoter:
 
     @staticmethod
     def _span(region):
-        f = region.split("+")
+        f = region.rsplit("+", 3)                                 # chrom+start+end+coverage; the contig name may hold a '+'
         return int(f[1]), int(f[2])
 
     def finish(self):

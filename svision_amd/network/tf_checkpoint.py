@@ -110,10 +110,12 @@ def _mask_crc(c):
 
 def _crc32c_fast(buf):
     """crc32c through libsvx.so (slicing-by-8) when it is built, the Python loop otherwise (index blocks are tiny)."""
+    from .. import _lib
     try:
-        from .. import _lib
         lib = _lib.load()
-    except Exception:                                         # noqa: BLE001 -- library not built: CPU-only tooling
+    except (OSError, _lib.SvxMissing) as exc:                 # library not built (CPU-only tooling); an ABI mismatch still raises
+        import logging
+        logging.warning("libsvx.so not loadable (%s): crc32c of %d bytes in the Python byte loop", exc, len(buf))
         return _crc32c(bytes(buf))
     a = np.ascontiguousarray(np.frombuffer(buf, np.uint8))
     return int(lib.svx_crc32c(a.ctypes.data, a.size))
@@ -121,11 +123,11 @@ def _crc32c_fast(buf):
 
 # ---------------------------------------------------------------- SSTable
 def _read_block(data, off, size):
+    if len(data) < off + size + 5:                            # block + type byte + masked crc32c
+        raise ValueError("truncated SSTable block")
     if data[off + size] != 0:
         raise ValueError("compressed SSTable blocks are not supported (type %d)" % data[off + size])
     blk = data[off:off + size]
-    if len(data) < off + size + 5:
-        raise ValueError("truncated SSTable block")
     stored = struct.unpack_from("<I", data, off + size + 1)[0]
     if stored != _mask_crc(_crc32c(data[off:off + size + 1])):
         raise ValueError("corrupt checkpoint index: block checksum mismatch at offset %d" % off)

@@ -212,6 +212,7 @@ class HotPath:
         self.batch = options.batch_size
         self.stage = DeviceStage(net, self.batch, self.device, n_streams, use_graph, launch_batches)
         self.batch_events = []           # (start, end) event pair of every batch, on the batch's stream
+        self.record_timing = bool(os.environ.get("SVX_TIMING"))      # bench.py switches it on; a plain run records no timing events
         self.device_images = 0           # images (padding included) launched since reset_timing()
         self._t_ref = None
 
@@ -252,11 +253,11 @@ class HotPath:
         recs = np.concatenate([res.records, np.tile(np.asarray(_PAD_REC, np.int32), (pad, 1))]) if pad else res.records
         d_rec = torch.from_numpy(np.ascontiguousarray(recs)).to(self.device, non_blocking=True)
         out = torch.empty((n + pad, 6), dtype=torch.float32, device=self.device)
-        up = torch.cuda.Event(enable_timing=True)
+        up = torch.cuda.Event(enable_timing=self.record_timing)
         up.record()                                                   # behind the upload of the records
-        if getattr(self, "_t_ref", None) is None:
+        if self.record_timing and getattr(self, "_t_ref", None) is None:
             self._t_ref = up                                          # time origin of batch_events
-        done = self.stage.run(d_rec, out, after=up, timing=self.batch_events)
+        done = self.stage.run(d_rec, out, after=up, timing=self.batch_events if self.record_timing else None)
         if getattr(self, "_d2h", None) is None:
             self._d2h = torch.cuda.Stream(device=self.device)
         host = self._pinned(n + pad)

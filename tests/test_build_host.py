@@ -41,3 +41,34 @@ def test_without_a_stamp_every_extension_module_goes(tmp_path):
     _layout(str(tmp_path), True)
     os.remove(os.path.join(tmp_path, build_host.STAMP))
     assert len(build_host.drop_stale(here=str(tmp_path))) == len(build_host.MODULES)
+
+
+def test_import_guard_runs_the_source_of_a_stale_module_and_touches_nothing(tmp_path):
+    """`import svision_amd` with a stale extension module on disk: the .py runs, the file stays (no deletion at import)."""
+    import importlib
+    import sys
+    pkg = tmp_path / "fakepkg"
+    _layout(str(pkg), True)
+    for d in {os.path.dirname(m) for m in build_host.MODULES}:
+        open(os.path.join(pkg, d, "__init__.py"), "w").close()
+    open(pkg / "__init__.py", "w").close()
+    changed = build_host.MODULES[0]
+    with open(os.path.join(pkg, changed), "a") as f:
+        f.write("y = 2\n")
+    def binaries():
+        return sorted(n for n in os.listdir(os.path.join(pkg, os.path.dirname(changed))) if n.endswith(".so"))
+    before = binaries()
+    messages = []
+    sys.path.insert(0, str(tmp_path))
+    n_finders = len(sys.meta_path)
+    try:
+        names = build_host.guard_imports(package="fakepkg", here=str(pkg), log=messages.append)
+        assert names == ["fakepkg." + changed[:-3].replace("/", ".")] and messages
+        mod = importlib.import_module(names[0])               # the fake .so is not a loadable ELF: only the source can import
+        assert mod.y == 2 and mod.__file__.endswith(".py")
+        assert binaries() == before and len(before) >= 1
+    finally:
+        sys.path.remove(str(tmp_path))
+        del sys.meta_path[:len(sys.meta_path) - n_finders]
+        for k in [k for k in sys.modules if k.startswith("fakepkg")]:
+            del sys.modules[k]

@@ -1,0 +1,265 @@
+"""BAM + FASTA + ``-m`` checkpoint -> merged VCF, end to end, against the REFERENCE'S OWN DRIVER run with real CNN
+arithmetic (tests/golden/make_e2e_fixture.py: /root/reference/SVision executed unmodified, its TensorFlow session =
+oracle/alexnet_ref.py on the weights of tests/e2e_weights.py).
+
+CPU: the product's driver with the session's stored outputs replayed reproduces every file byte for byte (tasking,
+collection, ``cat``, vote, VCF body, scores, merge) -- the host side of "VCF identical to the CPU reference".
+GPU: the whole command line on the device (svx_cigar_scan -> collection -> svx_encode_conv1 -> MFMA AlexNet -> vote) from
+the files on disk.  fp32 sums in a different order than the session's differ in the last bits (<= 1e-3 on softmax is the
+north_star tolerance; measured ~1e-6), and the reference rounds every softmax to 2 decimals before it averages them
+(predict.py:251, output.py:473-474): an image whose softmax lies within that distance of an x.xx5 boundary can flip by
+0.01.  So the test demands: CHROM, POS, ID, REF, ALT, FILTER, INFO (END, SVLEN, SVTYPE, SUPPORT, BKPS, READS), GT:DR:DV
+byte-identical; QUAL identical wherever no image of the record's site flipped, and bounded as DESIGN.md section 3a states
+where one did; and it prints how many flipped."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from svision_amd import cli
+from svision_amd.io import bam
+from svision_amd.sample import Sample
+from tests import e2e_weights, helpers
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASES = ("collect", "boundary", "ont", "contig")
+
+
+@pytest.fixture(scope="module")
+def expected():
+    return e2e_weights.load_fixture()
+
+
+class Replay:
+    """classifier(images) -> the stored (argmax, softmax) of the next batch, chromosome by chromosome in task order."""
+    needs_images = False
+
+    def __init__(self, case, preds=None):
+        self.queue = []
+        b = case["batch_size"]
+        for c in case["chrom_order"]:
+            if preds is None:
+                cls = np.asarray(case["chroms"][c]["classes"], np.int64)
+                pr = np.asarray(case["chroms"][c]["probs"], np.uint32).view(np.float32).reshape(-1, 5)
+            else:
+                cls, pr = preds[c]
+            for i in range(0, len(cls), b):
+                self.queue.append((cls[i:i + b], pr[i:i + b]))
+
+    def __call__(self, _images):
+        cls, pr = self.queue.pop(0)
+        return None, cls, pr
+
+
+def _argv(expected, case, out, bam_path="/virtual/sample.bam", model="/virtual/model.ckpt", genome="/virtual/genome.fa", extra=()):
+    return ["-o", out, "-b", bam_path, "-m", model, "-g", genome, "-n", expected["sample"], "--debug"] + case["args"] + list(extra)
+
+
+def _compare_files(case, out, what=("tsv", "vcf", "score")):
+    s = case["min_support"]
+    for chrom in case["chrom_order"]:
+        c = case["chroms"][chrom]
+        if "tsv" in what:
+            assert open(os.path.join(out, "segments", chrom + ".segments.all.bed")).read() == c["tsv"], chrom
+        if "vcf" in what:
+            assert open(os.path.join(out, "predict_results", "%s.predict.s%d.vcf" % (chrom, s))).read() == c["vcf"], chrom
+        if "score" in what:
+            assert open(os.path.join(out, "predict_results", "%s.predict.s%d.score.txt" % (chrom, s))).read() == c["score"], chrom
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_driver_with_the_sessions_outputs_replayed_reproduces_the_reference_run(expected, name, tmp_path, oracle_lib):
+    case = expected["cases"][name]
+    table = bam.read_bam(os.path.join(helpers.GOLDEN, case["data"] + ".bam"))
+    sample = Sample.with_scan(table, helpers.load_golden_fasta(case["data"] + ".fa.gz"), 50, helpers.oracle_scan(table, 50))
+    out = str(tmp_path / "out")
+    merged = cli.run(cli.parse_arguments(_argv(expected, case, out)), sample=sample, classifier=Replay(case))
+    assert os.path.basename(merged) == "%s.svision.s%d.vcf" % (expected["sample"], case["min_support"])
+    assert open(merged).read() == case["merged_vcf"]
+    _compare_files(case, out)
+
+
+def test_fixture_weights_rebuild_and_the_oracle_reproduces_a_stored_batch(expected):
+    """The weights come back from the seed (crc checked) and the oracle CNN on the oracle images of the first stored
+    lines returns the stored softmax bits: the fixture's CNN leg is reproducible outside the generator."""
+    from oracle import alexnet_ref, encode_ref
+    from svision_amd.network.create_batch import parse_data_fields
+    params = e2e_weights.fixture_params(expected)
+    c = expected["cases"]["boundary"]["chroms"][expected["cases"]["boundary"]["chrom_order"][0]]
+    lines = c["tsv"].splitlines()[:8]
+    rec = np.asarray([parse_data_fields(l.split("\t")[1:13]) for l in lines], np.int32)
+    _lo, cls, prob = alexnet_ref.predict(params, encode_ref.encode_records(rec))
+    want = np.asarray(c["probs"], np.uint32).view(np.float32).reshape(-1, 5)[:8]
+    assert np.array_equal(cls, np.asarray(c["classes"][:8]))
+    # BLAS blocks a [8 x K] product differently from the generator's [64 x K]: same values to the last few ulps
+    assert np.abs(prob - want).max() < 2e-6
+
+
+# ------------------------------------------------------------------------------------------------------------------ GPU
+def _rounded(prob, cls):
+    return np.round(prob[np.arange(len(cls)), cls], 2)
+
+
+def _site_of_line(tsv):
+    return [l.split("\t")[0] for l in tsv.splitlines()]
+
+
+def _split_qual(text):
+    """VCF text -> ([line without the QUAL column], [QUAL strings]) for the body lines; header lines pass whole."""
+    rest, qual = [], []
+    for l in text.splitlines():
+        if l.startswith("#"):
+            rest.append(l)
+            continue
+        f = l.split("\t")
+        qual.append(f[5])
+        rest.append("\t".join(f[:5] + f[6:]))
+    return rest, qual
+
+
+@pytest.fixture(scope="module")
+def device_model(expected, tmp_path_factory):
+    from svision_amd.network import tf_checkpoint as ck
+    params = e2e_weights.fixture_params(expected)
+    prefix = str(tmp_path_factory.mktemp("e2e_ckpt") / "svision-cnn-model.ckpt")
+    ck.write_checkpoint(prefix, params)
+    return prefix
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_full_command_line_on_the_device_reproduces_the_reference_vcf(expected, device_model, name, tmp_path):
+    import torch
+    from svision_amd.network.create_batch import BatchGenerator
+    from svision_amd.network.predict import load_classifier
+    case = expected["cases"][name]
+    fasta = helpers.load_golden_fasta(case["data"] + ".fa.gz")
+    fa = str(tmp_path / "genome.fa")
+    bam.write_fasta(fa, {n: fasta._seq[n] for n in fasta.references})
+    bam_path = os.path.join(helpers.GOLDEN, case["data"] + ".bam")
+
+    # 1. the device CNN on every stored line vs the session's stored outputs
+    classify = load_classifier(device_model, device="cuda:0")
+    b = case["batch_size"]
+    dev_preds, flipped_sites, n_img, n_flip, n_cls, max_d = {}, set(), 0, 0, 0, 0.0
+    for chrom in case["chrom_order"]:
+        c = case["chroms"][chrom]
+        bed = tmp_path / (chrom + ".bed")
+        bed.write_text(c["tsv"])
+        gen = BatchGenerator(str(bed), nb_classes=5, batch_size=b, device="cuda:0")
+        cls, prob = [], []
+        for _ in range(gen.data_size // b):
+            records, _labels = gen.next_records(b)
+            _lo, k, p = classify(records)
+            cls.append(k)
+            prob.append(p)
+        cls, prob = np.concatenate(cls), np.concatenate(prob).astype(np.float32)
+        dev_preds[chrom] = (cls, prob)
+        want_cls = np.asarray(c["classes"], np.int64)
+        want = np.asarray(c["probs"], np.uint32).view(np.float32).reshape(-1, 5)
+        n = c["tsv"].count("\n")                                   # the padding images behind it carry no vote
+        sites = _site_of_line(c["tsv"])
+        max_d = max(max_d, float(np.abs(prob[:n] - want[:n]).max()))
+        n_img += n
+        cls_diff = cls[:n] != want_cls[:n]
+        flip = (_rounded(prob[:n], cls[:n]) != _rounded(want[:n], want_cls[:n])) | cls_diff
+        n_cls += int(cls_diff.sum())
+        n_flip += int(flip.sum())
+        flipped_sites |= {sites[i] for i in np.nonzero(flip)[0]}
+    print("\n[e2e %s] images %d  max |softmax - session| %.2e  images whose round(softmax, 2) differs %d  argmax differs %d  sites touched %d"
+          % (name, n_img, max_d, n_flip, n_cls, len(flipped_sites)))
+    assert max_d < 1e-3                                            # north_star tolerance
+    assert n_cls == 0                                              # a changed class would be a changed SVTYPE: not tolerated here
+    # a flip needs a softmax within max_d of an x.xx5 boundary: expected count 2 * max_d / 0.01 per image
+    assert n_flip <= 3 + 4 * n_img * max_d / 0.01
+
+    # 2. the command line from the files, one process (-t 1, streamed windows) and with helper processes (-t 3, pooled)
+    outs = {}
+    for t in (1, 3):
+        out = str(tmp_path / ("out_t%d" % t))
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "SVision")] + _argv(expected, case, out, bam_path, device_model, fa, ["-t", str(t)]),
+                           capture_output=True, text=True, timeout=900, env=dict(os.environ, PYTHONPATH=ROOT))
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[t] = open(os.path.join(out, "%s.svision.s%d.vcf" % (expected["sample"], case["min_support"]))).read()
+        _compare_files(case, out, what=("tsv",))                   # Step 1 does not depend on the CNN: identical, always
+    assert outs[1] == outs[3]
+
+    # 3. against the reference run
+    got_rest, got_q = _split_qual(outs[1])
+    want_rest, want_q = _split_qual(case["merged_vcf"])
+    assert got_rest == want_rest                                   # everything but QUAL: byte-identical
+    if not flipped_sites:
+        assert outs[1] == case["merged_vcf"]
+        _compare_files(case, str(tmp_path / "out_t1"), what=("vcf", "score"))
+        return
+    # QUAL of the records: the body score of a site with a flipped image moves by at most 1.0 (one step of
+    # round(mean, 2) * 100), the others not at all; the merged QUAL is that score rescaled by the job's score range
+    s = case["min_support"]
+    body_got, body_want = [], []
+    for chrom in case["chrom_order"]:
+        with open(os.path.join(str(tmp_path / "out_t1"), "predict_results", "%s.predict.s%d.vcf" % (chrom, s))) as f:
+            body_got += f.read().splitlines()
+        body_want += case["chroms"][chrom]["vcf"].splitlines()
+    assert len(body_got) == len(body_want)
+    touched = 0
+    for g, w in zip(body_got, body_want):
+        gf, wf = g.split("\t"), w.split("\t")
+        region_hit = any(site.split("+")[0] == wf[0] and site.split("+")[1] == wf[1] and ("END=%s;" % site.split("+")[2]) in wf[7] for site in flipped_sites)
+        if region_hit:
+            touched += 1
+            assert abs(float(gf[5]) - float(wf[5])) <= 1.0 + 1e-9
+        else:
+            assert gf[5] == wf[5]
+    scores = [float(l.split("\t")[5]) for l in body_want if float(l.split("\t")[5]) != 0]
+    span = max(scores) - min(scores)
+    bound = int(np.ceil(400.0 / span)) + 1 if span > 0 else 100
+    worst = max(abs(int(a) - int(b)) for a, b in zip(got_q, want_q))
+    print("[e2e %s] records on a touched site %d of %d, max |QUAL - reference| in the merged VCF %d (bound %d)" % (name, touched, len(body_want), worst, bound))
+    assert worst <= bound
+
+
+@pytest.mark.gpu
+def test_chr21_scale_count_of_rounding_flips_device_vs_cpu_fp32():
+    """How often does the 2-decimal rounding of predict.py:251 differ between the device CNN and a CPU fp32 CNN?  Counted
+    over the candidate images of a synthetic chr21-sized HiFi sample's first window (plain PyTorch fp32 on the host as
+    the second opinion: another legal fp32 summation order, like TensorFlow's own).  The bound is the one DESIGN.md
+    section 3a states: flips <= 3 + 4 * images * max|d softmax| / 0.01, classes equal wherever the top-2 margin exceeds 2e-3."""
+    import torch
+    from oracle import alexnet_ref, cbind
+    from oracle.alexnet_torch import TorchAlexNet
+    from svision_amd import synth
+    from svision_amd.collection.output_clusters import collect_pair_lines
+    from svision_amd.collection.run_collection import detect_window
+    from svision_amd.network.alexnet import AlexNet
+    expected = e2e_weights.load_fixture()
+    params = e2e_weights.fixture_params(expected)
+    table, genome, _svs = synth.simulate(synth.SimConfig(contigs=[("chr21", 12_000_000)], coverage=30.0, seed=3))
+    sample = Sample.from_table(table, bam.Fasta(sequences=genome), 50, device="cuda:0")
+    opts = helpers.default_options(min_support=5, batch_size=64, bam_path="<resident>")
+    _sigs, clusters = detect_window(opts, sample, "chr21", 0, 10_000_000)
+    lines = collect_pair_lines(clusters, opts)
+    rec = np.asarray([ln.record() for ln in lines], np.int32).reshape(-1, 12)
+    assert len(rec) > 1000
+    net = AlexNet(params, device="cuda:0")
+    checker = TorchAlexNet(params, device="cpu")
+    n_flip = n_cls = 0
+    max_d = 0.0
+    for lo in range(0, len(rec), 256):
+        r = rec[lo:lo + 256]
+        packed = net.predict_records_packed(torch.from_numpy(r).cuda()).cpu().numpy()
+        prob, cls = packed[:, :5], packed[:, 5].astype(np.int64)
+        img = cbind.rasterize(r, "NCHW")
+        _l, wcls, wprob = checker.predict(torch.from_numpy(img))
+        wcls, wprob = wcls.numpy(), wprob.numpy()
+        max_d = max(max_d, float(np.abs(prob - wprob).max()))
+        top = np.sort(wprob, axis=1)
+        sure = top[:, -1] - top[:, -2] > 2e-3
+        assert np.array_equal(cls[sure], wcls[sure])
+        n_cls += int((cls != wcls).sum())
+        n_flip += int((_rounded(prob, cls) != _rounded(wprob, wcls)).sum())
+    print("\n[e2e chr21-scale] images %d  max |softmax device - CPU fp32| %.2e  round(softmax, 2) differs on %d  argmax differs on %d"
+          % (len(rec), max_d, n_flip, n_cls))
+    assert max_d < 1e-3
+    assert n_flip <= 3 + 4 * len(rec) * max_d / 0.01
