@@ -3,11 +3,14 @@
 
 Workloads (synthetic: the reference ships no BAM; svision_amd/synth.py, fixed seeds):
 
-  cfg2 (default)  BASELINE.json configs[1] stand-in: a chr21-sized contig (46,709,983 bp), HiFi reads
-                  N(15 kb, 2 kb) at 30x with planted SVs.  N > 1: every rank owns its own such shard (weak scaling).
-  wg              BASELINE.json configs[2] stand-in: 24 contigs with the GRCh38 primary lengths (3.1 Gb), same read
-                  model, chromosomes LPT-sharded over the ranks exactly as the command line does it
-                  (svision_amd.dist.shard_chromosomes, cli.load_rank_table); strong scaling: the job is the genome.
+  wg (default)    BASELINE.json configs[2] stand-in, the config the metric is quoted on: 24 contigs with the GRCh38
+                  primary lengths (3.1 Gb, 322 collection windows), HiFi reads N(15 kb, 2 kb) at 30x with planted SVs,
+                  chromosomes LPT-sharded over the ranks exactly as the command line does it
+                  (svision_amd.dist.shard_chromosomes, cli.load_rank_table).  Strong scaling: the job is the genome,
+                  whatever N.  `--steps K` makes the job exactly K windows: every chromosome keeps a prefix, the
+                  windows apportioned to the chromosomes by length (K < 24: the K longest chromosomes, one window each).
+  cfg2            BASELINE.json configs[1] stand-in: a chr21-sized contig (46,709,983 bp), same read model.  N > 1:
+                  every rank owns its own such shard (weak scaling).
 
 The alignments are decoded to packed arrays and resident in HBM before the timed region.  A *step* is one collection
 window of the reference driver (10 Mb, SVision:88) through the whole hot path:
@@ -17,7 +20,8 @@ window of the reference driver (10 Mb, SVision:88) through the whole hot path:
   device  similarity-image encoding + AlexNet fp32, batches of 64 candidate images
   host    per-site vote -> VCF body lines + scores
 
-value = candidate sites (distinct regions of the segment TSV) per second, whole job.  No data-path collective; one
+value = candidate sites (distinct region keys of the chromosomes' segment TSVs: a site spanning a window boundary counts
+once) per second, whole job.  No data-path collective; one
 score-range all_reduce + one record gather at the end, inside the timed region.  Prints ONE JSON line on rank 0.
 `--gpus N` without a launcher environment starts the N ranks itself (torch.distributed.run, one per GPU, RCCL).
 """
@@ -82,6 +86,32 @@ def windows_of(name, length):
     return [(name, pos, min(length, pos + WINDOW)) for pos in range(0, length, WINDOW)]
 
 
+def job_contigs(steps):
+    """The contigs of a `wg` job of exactly `steps` windows (None / >= 322: the whole genome): a prefix of every
+    chromosome, windows apportioned by length (largest remainder, at least one each); fewer steps than chromosomes: the
+    `steps` longest chromosomes, one window each.  Header order is kept."""
+    full = [(n, l, len(windows_of(n, l))) for n, l in GRCH38]
+    total = sum(w for _n, _l, w in full)
+    if not steps or steps >= total:
+        return list(GRCH38)
+    if steps < len(full):
+        keep = {n for n, _l, _w in sorted(full, key=lambda t: -t[1])[:steps]}
+        return [(n, min(l, WINDOW)) for n, l, _w in full if n in keep]
+    quota = [w * steps / total for _n, _l, w in full]
+    k = [max(1, int(q)) for q in quota]
+    order = sorted(range(len(full)), key=lambda i: -(quota[i] - int(quota[i])))
+    i = 0
+    while sum(k) < steps:                                     # largest remainders first
+        j = order[i % len(order)]
+        if k[j] < full[j][2]:
+            k[j] += 1
+        i += 1
+    while sum(k) > steps:                                     # the one-window minimum overshot: take from the longest
+        j = max(range(len(k)), key=lambda t: k[t])
+        k[j] -= 1
+    return [(n, min(l, kk * WINDOW)) for (n, l, _w), kk in zip(full, k)]
+
+
 def _simulate_contig(job):
     """(name, length, coverage, seed[, kind]) -> (AlignmentTable, genome bytes) of one contig (runs in a forked worker)."""
     name, length, coverage, seed = job[:4]
@@ -104,12 +134,11 @@ def build_workload(args, rank, world, cores):
         strong = False
         total_windows = None
     else:
-        contigs = list(GRCH38)
-        all_windows = len(contigs) if args.workload == "contig" else sum(len(windows_of(n, l)) for n, l in contigs)
-        if args.workload != "contig" and args.steps and args.steps < all_windows:          # a prefix of every chromosome, same proportions
-            f = args.steps / all_windows
-            contigs = [(n, min(l, max(1, round(len(windows_of(n, l)) * f)) * WINDOW)) for n, l in contigs]
-        shard = sdist.shard_chromosomes([n for n, _l in contigs], [l for _n, l in contigs], world)[rank]
+        contigs = list(GRCH38) if args.workload == "contig" else job_contigs(args.steps)
+        shards = sdist.shard_chromosomes([n for n, _l in contigs], [l for _n, l in contigs], world)
+        shard = shards[rank]
+        length_of = dict(contigs)
+        args.rank_mb = [sum(length_of[c] for c in sh) / 1e6 for sh in shards]               # the LPT loads, for the report
         jobs = [(n, l, 2.0, 100 + i, "contig") if args.workload == "contig" else (n, l, args.coverage, 100 + i)
                 for i, (n, l) in enumerate(contigs) if n in shard]
         strong = True
@@ -144,11 +173,11 @@ def spawn_ranks(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="windows to time (cfg2: per rank, default 200; wg: whole job, default all)")
+    ap.add_argument("--steps", type=int, default=None, help="windows to time (wg: whole job, default all 322; cfg2 / ont: per rank, default 200)")
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", choices=("cfg2", "wg", "ont", "contig"), default="cfg2",
-                    help="cfg2: chr21-sized HiFi sample per rank (weak scaling, the default); wg: 24 GRCh38-length contigs sharded over the "
-                         "ranks (strong scaling); ont: chr21-sized ONT ultra-long stand-in per rank (BASELINE configs[3] stress: ~5,000 CIGAR ops per read); "
+    ap.add_argument("--workload", choices=("cfg2", "wg", "ont", "contig"), default="wg",
+                    help="wg: 24 GRCh38-length contigs sharded over the ranks (strong scaling, the default: the config the metric is quoted on); "
+                         "cfg2: chr21-sized HiFi sample per rank (weak scaling); ont: chr21-sized ONT ultra-long stand-in per rank (BASELINE configs[3] stress: ~5,000 CIGAR ops per read); "
                          "contig: --contig mode, two haplotypes of ~2 Mb assembly contigs on the 24 GRCh38-length chromosomes, one task per chromosome")
     ap.add_argument("--batch", type=int, default=64, help="candidate images per CNN batch (BASELINE configs[1])")
     ap.add_argument("--contig-len", type=int, default=CHR21)
@@ -195,7 +224,7 @@ def main():
             tdist.barrier()
         torch.cuda.synchronize()
 
-    from svision_amd.pipeline import stitch_windows
+    from svision_amd.pipeline import distinct_sites, stitch_windows
 
     def run(seq):
         """seq: windows in task order (a chromosome's windows contiguous).  Windows complete in any order; a run of
@@ -205,13 +234,14 @@ def main():
         hot.reset_timing()
         done = {}
         for res in hot.run_windows(seq):
-            sites += res.n_sites; images += res.n_images
+            images += res.n_images
             done[res.wid] = res
         lo = 0
         while lo < len(seq):                                           # maximal runs of ascending windows of one chromosome
             hi = lo + 1
             while hi < len(seq) and seq[hi][0] == seq[hi - 1][0] and seq[hi][1] == seq[hi - 1][2]:
                 hi += 1
+            sites += distinct_sites([done[w] for w in range(lo, hi)])  # a site spanning a window boundary counts once
             for vcf_text, score_text in stitch_windows([done[w] for w in range(lo, hi)], opts, sample).values():
                 records += vcf_text.count("\n")
                 scores += [float(s) for s in score_text.split()]
@@ -285,6 +315,9 @@ def main():
                    "batch": B, "alignments_rank0": len(table), "cigar_ops_rank0": int(table.cigar.size),
                    "windows_rank0": len(windows), "sites_per_step": tot_sites / max(steps_job * (1 if strong else world), 1),
                    "images_per_site": tot_images / max(tot_sites, 1), "images_per_s": tot_images / dt,
+                   "rccl_world": world if grouped else 0, "dist_backend": (tdist.get_backend() if grouped else None),
+                   "rank_mb": [round(v, 1) for v in getattr(args, "rank_mb", [])] or None,
+                   "imbalance": (max(args.rank_mb) / (sum(args.rank_mb) / len(args.rank_mb)) if getattr(args, "rank_mb", None) else None),
                    "host_workers_per_rank": workers, "host_cores": cores, "streams": args.streams, "batches_per_launch": args.launch_batches,
                    "parallelism": "one process per GPU, chromosomes per rank, no data-path collective "
                                   "(score-range all_reduce + record gather once)"},

@@ -247,7 +247,8 @@ def run(options, sample=None, classifier=None):
         print("Empty output in the score file!!! Program exit")
         raise SystemExit(0)
     merged_path = os.path.join(options.out_path, "%s.svision.s%s.vcf" % (options.sample, options.min_support))
-    if ws > 1:
+    grouped = sdist.world_initialized()      # ws > 1, or one rank with SVX_FORCE_DIST=1 (the RCCL path on a one-GPU box)
+    if grouped:
         bodies = {}
         for chrom in mine:
             with open(os.path.join(pred_dir, "%s.predict.s%s.vcf" % (chrom, options.min_support))) as f:
@@ -291,8 +292,11 @@ def run(options, sample=None, classifier=None):
             logging.info("[Graph creation finished] Generate graphs")
         logging.info("[All steps finished] Total Cost time: %ss", (datetime.datetime.now() - t0).seconds)
     _tick("exchange + merge")
-    if ws > 1:
+    if grouped:
         import torch.distributed as tdist
+        if _tick.on:
+            print("exchange backend %s, world %d" % (tdist.get_backend(), tdist.get_world_size()), flush=True)
+        logging.info("cross-rank exchange over %s, world size %d", tdist.get_backend(), tdist.get_world_size())
         tdist.barrier()
     if not options.debug and rank == 0:
         shutil.rmtree(seg_dir, ignore_errors=True)

@@ -22,6 +22,10 @@ def world():
     return 0, 1
 
 
+def world_initialized():
+    return dist.is_available() and dist.is_initialized()
+
+
 def env_rank():
     """(rank, world size) from the launcher's environment, without bringing the process group up."""
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))

@@ -36,7 +36,7 @@ _PAD_REC = parse_data_fields(PAD_DATA.split("_"))
 
 class WindowResult:
     __slots__ = ("chrom", "start", "end", "lines", "n_images", "packed", "vcf", "scores", "n_sites", "n_records",
-                 "records", "done_event", "t_device", "wid", "tsv", "head", "tail")
+                 "records", "done_event", "t_device", "wid", "tsv", "head", "tail", "edges")
 
 
 def _collect_lines(sample, options, chrom, start, end):
@@ -83,6 +83,24 @@ def _vote(sample, options, chrom, lines, classes, probs, start=None, end=None):
         # candidate sites = distinct region keys of the segment TSV, whatever the CNN says
         n_sites = len({ln.region for ln in lines})
     return vcf.getvalue(), score.getvalue(), n_sites, head, tail
+
+
+def _edge_regions(lines):
+    """(region of the window's first TSV line, of its last one) -- what :func:`distinct_sites` compares across a boundary."""
+    return (lines[0].region, lines[-1].region) if lines else (None, None)
+
+
+def distinct_sites(results):
+    """Candidate sites of WindowResults in task order = distinct region keys of the chromosomes' concatenated TSVs
+    (SURVEY 8(d)): a cluster that ends window k and opens window k+1 of a chromosome is in both windows' counts and is
+    one site."""
+    total, prev = 0, None
+    for res in results:
+        total += res.n_sites
+        if prev is not None and prev.chrom == res.chrom and prev.edges[1] is not None and prev.edges[1] == res.edges[0]:
+            total -= 1
+        prev = res
+    return total
 
 
 def stitch_windows(results, options, sample):
@@ -304,6 +322,7 @@ class HotPath:
         classes, probs = self.fetch_predictions(res)
         res.vcf, res.scores, res.n_sites, res.head, res.tail = _vote(self.sample, self.options, res.chrom, res.lines, classes, probs, res.start, res.end)
         res.n_records = res.vcf.count("\n")
+        res.edges = _edge_regions(res.lines)
         return res
 
     def run_windows(self, windows):
@@ -368,7 +387,7 @@ def _worker_main(conn):
             t0 = time.perf_counter()
             vcf, scores, n_sites, head, tail = _vote(sample, options, chrom, lines, classes, probs, start, end)
             tsv = "".join(ln.text() for ln in lines) if _POOL_STATE.get("want_tsv") else None
-            conn.send(("done", wid, vcf, scores, n_sites, len(lines), tsv, head, tail, (t_collect, time.perf_counter() - t0)))
+            conn.send(("done", wid, vcf, scores, n_sites, len(lines), tsv, head, tail, (t_collect, time.perf_counter() - t0), _edge_regions(lines)))
             n_done += 1
             if n_done % 128 == 0:
                 gc.collect()
@@ -514,14 +533,14 @@ class PooledHotPath(HotPath):
                     res.t_device = None
                     ready.append((ci, res))
                 else:
-                    _t, wid, vcf, scores, n_sites, n_images, tsv, head, tail, host_s = msg
+                    _t, wid, vcf, scores, n_sites, n_images, tsv, head, tail, host_s, edges = msg
                     prof["helper.collect_s"] += host_s[0]             # host seconds inside the helpers
                     prof["helper.vote_s"] += host_s[1]
                     res = WindowResult()
                     res.chrom, res.start, res.end = windows[wid]
                     res.wid, res.tsv = wid, tsv
                     res.vcf, res.scores, res.n_sites, res.n_images = vcf, scores, n_sites, n_images
-                    res.head, res.tail = head, tail
+                    res.head, res.tail, res.edges = head, tail, edges
                     res.n_records = vcf.count("\n")
                     del busy[ci]
                     idle.append(ci)
