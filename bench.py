@@ -113,48 +113,80 @@ def job_contigs(steps):
 
 
 def _simulate_contig(job):
-    """(name, length, coverage, seed[, kind]) -> (AlignmentTable, genome bytes) of one contig (runs in a forked worker)."""
-    name, length, coverage, seed = job[:4]
-    if len(job) > 4 and job[4] == "contig":  # assembly-vs-reference stand-in: two haplotypes of ~2 Mb contigs, 0.1 % small events
+    """job: dict(name, length, coverage, seed, kind, e2e=(tid in the rank's file, prefix length) or None) ->
+    (AlignmentTable, genome bytes, BGZF segment of the prefix or None) of one contig (runs in a forked worker)."""
+    name, length, coverage, seed, kind = job["name"], job["length"], job["coverage"], job["seed"], job.get("kind")
+    if kind == "contig":                     # assembly-vs-reference stand-in: two haplotypes of ~2 Mb contigs, 0.1 % small events
         cfg = synth.SimConfig(contigs=[(name, length)], coverage=coverage, seed=seed, read_len_mean=2_000_000, read_len_sd=600_000,
                               err_rate=0.001)
-    elif len(job) > 4 and job[4] == "ont":   # ONT ultra-long stand-in: log-normal lengths (median 50 kb), 5 % small events
+    elif kind == "ont":                      # ONT ultra-long stand-in: log-normal lengths (median 50 kb), 5 % small events
         cfg = synth.SimConfig(contigs=[(name, length)], coverage=coverage, seed=seed, read_len_mean=50_000, lognormal=True,
                               lognormal_sigma=0.7, err_rate=0.05)
     else:
         cfg = synth.SimConfig(contigs=[(name, length)], coverage=coverage, seed=seed)
     table, genome, _svs = synth.simulate(cfg)
-    return table, genome[name]
+    segment = None
+    if job.get("e2e") is not None:           # the records of the e2e leg's prefix as one compressed BGZF segment (realistic SEQ / QUAL)
+        tid, prefix = job["e2e"]
+        part = table if prefix >= length else table.subset(np.flatnonzero(table.pos < prefix))
+        part.tid[:] = tid
+        segment = bam.encode_reference_segment(part, seq="random", seed=seed)
+        if part is table:
+            table.tid[:] = 0
+    return table, genome[name], segment
 
 
 def build_workload(args, rank, world, cores):
-    """-> (samples: list of (table, fasta) per contig of this rank, windows of this rank, description dict)."""
+    """-> (parts: (name, length, table, genome bytes) per contig of this rank, windows of this rank, strong?, windows of the
+    whole job, e2e = dict(path of this rank's BAM, windows, bytes) or None)."""
+    e2e_prefix = {}
     if args.workload in ("cfg2", "ont"):
-        jobs = [("chr21", args.contig_len, args.coverage, 1 + rank) + (("ont",) if args.workload == "ont" else ())]
+        jobs = [dict(name="chr21", length=args.contig_len, coverage=args.coverage, seed=1 + rank, kind="ont" if args.workload == "ont" else None)]
         strong = False
         total_windows = None
+        if args.e2e_windows:
+            e2e_prefix = {"chr21": min(args.contig_len, args.e2e_windows * WINDOW)}
     else:
         contigs = list(GRCH38) if args.workload == "contig" else job_contigs(args.steps)
         shards = sdist.shard_chromosomes([n for n, _l in contigs], [l for _n, l in contigs], world)
         shard = shards[rank]
         length_of = dict(contigs)
         args.rank_mb = [sum(length_of[c] for c in sh) / 1e6 for sh in shards]               # the LPT loads, for the report
-        jobs = [(n, l, 2.0, 100 + i, "contig") if args.workload == "contig" else (n, l, args.coverage, 100 + i)
-                for i, (n, l) in enumerate(contigs) if n in shard]
+        jobs = [dict(name=n, length=l, coverage=2.0 if args.workload == "contig" else args.coverage, seed=100 + i,
+                     kind="contig" if args.workload == "contig" else None) for i, (n, l) in enumerate(contigs) if n in shard]
         strong = True
         total_windows = len(contigs) if args.workload == "contig" else sum(len(windows_of(n, l)) for n, l in contigs)
+        if args.e2e_windows and args.workload == "wg":
+            # the file-inclusive leg runs on a bounded job: the same chromosomes, every one cut to its share of --e2e-windows
+            small = dict(job_contigs(args.e2e_windows)) if total_windows > args.e2e_windows else length_of
+            e2e_prefix = {n: min(small[n], length_of[n]) for n in shard if n in small}
+    k = 0
+    for j in jobs:
+        if j["name"] in e2e_prefix:
+            j["e2e"] = (k, e2e_prefix[j["name"]])
+            k += 1
     if len(jobs) > 1:
         import multiprocessing as mp
         with mp.get_context("fork").Pool(min(len(jobs), max(1, cores // world))) as pool:     # before the first HIP call
             made = pool.map(_simulate_contig, jobs, chunksize=1)
     else:
         made = [_simulate_contig(j) for j in jobs]
-    parts = [(j[0], j[1], t, g) for j, (t, g) in zip(jobs, made)]
+    parts = [(j["name"], j["length"], t, g) for j, (t, g, _seg) in zip(jobs, made)]
     if args.workload == "contig":             # --contig: one task per chromosome (SVision:161-180)
         windows = [(name, 0, length) for name, length, _t, _g in parts]
     else:
         windows = [w for name, length, _t, _g in parts for w in windows_of(name, length)]
-    return parts, windows, strong, total_windows
+    e2e = None
+    if e2e_prefix:
+        import tempfile
+        names = [j["name"] for j in jobs if "e2e" in j]
+        d = tempfile.mkdtemp(prefix="svx_bench_bam_", dir=args.bam_dir)
+        path = os.path.join(d, "rank%d.bam" % rank)
+        segs = [seg for _t, _g, seg in made if seg is not None]
+        bam.write_bam_segments(path, names, [dict((j["name"], j["length"]) for j in jobs)[n] for n in names], segs, index=True)
+        e2e = {"path": path, "dir": d, "references": names, "windows": [w for n in names for w in windows_of(n, e2e_prefix[n])],
+               "bytes": os.path.getsize(path), "inflated": sum(s["inflated"] for s in segs)}
+    return parts, windows, strong, total_windows, e2e
 
 
 def spawn_ranks(args):
@@ -186,6 +218,11 @@ def main():
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the per-batch graphs are replayed on")
     ap.add_argument("--inflight", type=int, default=6, help="windows enqueued on the device at once")
     ap.add_argument("--launch-batches", type=int, default=4, help="batches of --batch images per device launch (graph replay)")
+    ap.add_argument("--e2e-windows", type=int, default=20,
+                    help="windows of the file-inclusive leg (`e2e` block): the job cut to that many windows is written as a BAM (+ .bai, "
+                         "random bases, binned qualities) to local disk during set-up and run from the file -- BGZF inflate on host threads, "
+                         "upload, device scan, pipeline -- in a timed region of its own; 0 = skip")
+    ap.add_argument("--bam-dir", default=None, help="where the synthetic BAM of the e2e leg is written (default: the temp directory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-calibration", action="store_true", help="skip the per-kernel timings outside the timed region")
     args = ap.parse_args()
@@ -197,7 +234,7 @@ def main():
     workers = max(1, min(args.workers, cores // world))
     # ---- untimed set-up.  Order matters: everything that forks (simulation pool, CPU-baseline pool, host helpers)
     # happens before the first HIP call (forking with a live GPU context makes the driver evict / restore the queues)
-    parts, windows, strong, total_windows = build_workload(args, rank, world, cores)
+    parts, windows, strong, total_windows, e2e = build_workload(args, rank, world, cores)
     opts = options_ns(args.batch)
     if args.workload == "contig":             # SVision:161-180, collect_signatures.py:125
         opts.contig, opts.min_support = True, 1
@@ -226,14 +263,15 @@ def main():
 
     from svision_amd.pipeline import distinct_sites, stitch_windows
 
-    def run(seq):
+    def run(seq, rescan=True):
         """seq: windows in task order (a chromosome's windows contiguous).  Windows complete in any order; a run of
         consecutive windows of one chromosome is one per-chromosome vote (sites spanning a window boundary are written once)."""
         sites = images = records = 0
         scores = []
         hot.reset_timing()
         done = {}
-        for res in hot.run_windows(seq):
+        sample = lambda chrom: hot.feed.get(chrom, block=True)[1]     # noqa: E731  (the resident Sample, or the chromosome's own)
+        for res in hot.run_windows(seq, rescan=rescan):
             images += res.n_images
             done[res.wid] = res
         lo = 0
@@ -272,6 +310,7 @@ def main():
 
     dev_ms = hot.device_busy_ms()            # time with at least one batch in flight (HIP events on the batches' streams)
     dev_images = hot.device_images
+    e2e_block = run_from_file(args, e2e, hot, run, fasta, opts, dev, sync_all, cores, world, workers, grouped) if e2e is not None else None
     executed = net.executed.cpu().numpy().astype(np.float64)         # [conv2, conv3, conv4, conv5 pixels, images]
     totals = torch.tensor([sites, images, dt, dev_ms, dev_images] + executed.tolist(), dtype=torch.float64, device=dev)
     if grouped:
@@ -340,6 +379,10 @@ def main():
                                      "the same stage are summarised in profiles/r02_pmc_traffic.md",
                      "ms_per_batch": ms_batch, "batches": sum_dev_images / B, "device_busy_frac": dev_s / dt},
     }
+    if e2e_block is not None:
+        e2e_block["resident_sites_per_s"] = line["value"]
+        e2e_block["ratio_to_resident"] = e2e_block["value"] / max(line["value"], 1e-9)
+        line["e2e"] = e2e_block
     if rank == 0 and not args.no_calibration:
         line["roofline_kernels"] = kernel_calibration(hot, sample, net, dev, B * max(1, args.launch_batches), windows[0])
     hot.close()
@@ -349,6 +392,52 @@ def main():
         print(json.dumps(line))
     if grouped:
         tdist.destroy_process_group()
+
+
+def run_from_file(args, e2e, hot, run, fasta, opts, dev, sync_all, cores, world, workers, grouped):
+    """The file-inclusive leg (wall of Step 1 + Step 2 with the BAM on local disk): a timed region of its
+    own that starts with nothing but the file -- svx_bam_stream_* reads and inflates it on host threads chromosome by
+    chromosome, every chromosome is uploaded and scanned on the device when it arrives and handed to the helpers through
+    shared memory, the windows flow through the same pipeline -- and ends after the cross-rank exchange."""
+    import shutil
+    import torch.distributed as tdist
+    from svision_amd.ingest import ChromosomeFeed, StaticFeed
+    refs = e2e["references"]
+    lens = [fasta.get_reference_length(n) for n in refs]
+    threads = max(1, min(64, cores // world - workers - 2))
+    resident = hot.feed
+    sync_all()
+    t0 = time.perf_counter()
+    feed = ChromosomeFeed(e2e["path"], fasta, opts, refs, refs, lens, device=dev, index=e2e["path"] + ".bai", threads=threads)
+    hot.feed = feed
+    try:
+        sites, images, records, scores = run(e2e["windows"], rescan=False)
+        sdist.exchange_score_range(scores)
+        sdist.gather_texts({"rank%d" % sdist.world()[0]: "%d records" % records})
+        sync_all()
+        dt = time.perf_counter() - t0
+    finally:
+        for chrom in refs:
+            hot.release(chrom)
+        feed.close()
+        hot.feed = resident
+        shutil.rmtree(e2e["dir"], ignore_errors=True)
+    dev_ms = hot.device_busy_ms()
+    tot = torch.tensor([sites, images, len(e2e["windows"]), e2e["bytes"], e2e["inflated"], dev_ms], dtype=torch.float64, device=dev)
+    if grouped:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tdist.all_reduce(tot, op=tdist.ReduceOp.SUM)
+        tdist.all_reduce(tmax, op=tdist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    tot = tot.cpu().numpy()
+    st = feed.stats
+    return {"value": float(tot[0]) / dt, "unit": "sites/s", "seconds": dt, "windows": int(tot[2]), "sites": int(tot[0]), "images": int(tot[1]),
+            "bam_bytes": int(tot[3]), "inflated_bytes": int(tot[4]), "compressed_GB_per_s": float(tot[3]) / dt / 1e9,
+            "inflated_GB_per_s": float(tot[4]) / dt / 1e9, "inflate_threads_per_rank": threads, "device_busy_frac": float(tot[5]) * 1e-3 / world / dt,
+            "rank0_feed": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in st.items()},
+            "owner_profile_rank0": {k: round(v, 4) for k, v in getattr(hot, "owner_profile", {}).items()},
+            "note": "timed from opening the BAM (random bases, 7-bin qualities: ~0.4 compressed bytes per base, like a HiFi BAM) to the end of "
+                    "the cross-rank exchange; the BAM sits in the page cache of the box (written during set-up), not on a cold disk"}
 
 
 def kernel_calibration(hot, sample, net, dev, B, window, reps=20):
@@ -474,9 +563,10 @@ def _cpu_worker(conn, table, fasta, opts):
             return
         chrom, start, end, part, parts, max_images = msg
         t0 = time.perf_counter()
-        if sample is None:                                    # C oracle scan of the rank's alignments (once per process)
-            scan = cbind.cigar_scan(table.cigar, table.cig_off.astype(np.uint64), table.pos, opts.min_sv_size)
-            sample = Sample.with_scan(table, fasta, opts.min_sv_size, scan)
+        if sample is None:                                    # C oracle scan of the window's chromosome (once per process)
+            sub = table.subset(np.flatnonzero(table.tid == table.get_tid(chrom)))
+            scan = cbind.cigar_scan(sub.cigar, sub.cig_off.astype(np.uint64), sub.pos, opts.min_sv_size)
+            sample = Sample.with_scan(sub, fasta, opts.min_sv_size, scan)
             net = TorchAlexNet(random_weights(0), device="cpu")
         _sigs, clusters = detect_window(opts, sample, chrom, start, end)
         lines = collect_pair_lines(clusters, opts)
@@ -535,8 +625,8 @@ class CpuBaselinePool:
             p.join(timeout=5)
         sites, images = sum(g[0] for g in got), sum(g[1] for g in got)
         return {"value": sites / wall, "unit": "sites/s", "cores": P, "kind": "port",
-                "sample": "pool of %d single-thread processes (the reference's -t P, SVision:261,311), each: C oracle scan of the sample "
-                          "(once), host collection of one 10 Mb window, then C oracle rasteriser + PyTorch-CPU fp32 AlexNet (batch 128, "
+                "sample": "pool of %d single-thread processes (the reference's -t P, SVision:261,311), each: C oracle scan of its window's "
+                          "chromosome, host collection of one 10 Mb window, then C oracle rasteriser + PyTorch-CPU fp32 AlexNet (batch 128, "
                           "1 thread) + vote on its 1/%d share of that window's sites, capped at %d images: %d sites, %d images in %.1f s "
                           "wall (slowest process %.1f s)" % (P, per_win, images_per_proc, sites, images, wall, max(g[2] for g in got))}
 

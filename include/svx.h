@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SVX_VERSION 210            /* 0.2.1: + active-row masks out of svx_alexnet_active_sets, into svx_bias_relu_pool_lrn */
+#define SVX_VERSION 300            /* 0.2.1: + active-row masks out of svx_alexnet_active_sets, into svx_bias_relu_pool_lrn */
 
 #define SVX_OK            0
 #define SVX_EINVAL       (-1)      /* bad argument (null pointer, bad layout...) */
@@ -257,6 +257,20 @@ void           svx_bam_export(void* handle, int threads, int32_t* tid, int32_t* 
                               char* header, char* ref_names, int32_t* ref_lens, int64_t* seq_off);
 const uint8_t* svx_bam_seq(void* handle);
 void           svx_bam_close(void* handle);
+
+/* Streaming ingestion, one reference sequence at a time (replaces the reference's window-by-window
+ * AlignmentFile.fetch(chrom, start, end), run_collection.py:23-26, by one pass over the file that hands chromosome k
+ * to the caller while chromosome k+1 is being read and inflated on the handle's own threads):
+ *   svx_bam_stream_open  -> opaque stream or NULL (svx_bam_error()); voffs = n_ranges pairs of BGZF virtual offsets
+ *                           from the .bai (a rank's chromosomes, ascending), n_ranges = 0: every record of the file;
+ *                           threads <= 0: the CPUs of the process (max 64); flags as svx_bam_open
+ *   svx_bam_stream_next  -> the next reference's records as a handle for svx_bam_sizes / svx_bam_export /
+ *                           svx_bam_seq / svx_bam_close (QNAME ids count from 0 in every part), or NULL with
+ *                           *status = 0 at the end, -1 on error; blocks while that part is being decoded
+ *   svx_bam_stream_close -> stops the threads, frees what was not handed out */
+void*          svx_bam_stream_open(const char* path, int threads, int flags, const uint64_t* voffs, int n_ranges);
+void*          svx_bam_stream_next(void* stream, int* status);
+void           svx_bam_stream_close(void* stream);
 
 #ifdef __cplusplus
 }

@@ -161,21 +161,37 @@ def run(options, sample=None, classifier=None):
     logging.info("INPUT BAM: %s", os.path.abspath(options.bam_path))
 
     pool = None
+    feed = None
     _tick = _Ticker()
     if sample is None:
-        table = load_rank_table(options, rank, ws)
-        _tick("decode BAM")
-        if table.sort_order != "coordinate":
+        # file-driven run: header now, the records chromosome by chromosome while the pipeline runs (ingest.ChromosomeFeed)
+        from .io.bam import find_index, read_bam_header
+        head = read_bam_header(options.bam_path)
+        if head.sort_order != "coordinate":
             logging.error("This is not a coordinate sorted BAM file")
             raise SystemExit(1)
         fasta = Fasta(options.genome)
-        if options.contig:
-            options.min_support = 1
-        if options.thread_num > 1 and classifier is None:
-            # -t N: fork the host helpers before the first HIP call (pipeline.HelperPool); they get the scan below
+        references, lengths = head.references, head.lengths
+    else:
+        fasta = sample.fasta
+        references, lengths = sample.table.references, sample.table.lengths
+        _sample.register(options.bam_path, sample)
+    if options.contig:
+        options.min_support = 1
+    tasks = build_tasks(options, references, lengths, fasta.references)
+    if len(tasks) == 0:
+        logging.error("No mapped reads in the BAM, please check your reference input!")
+        raise SystemExit(1)
+    chroms = list(tasks.keys())
+    length_of = dict(zip(references, lengths))
+    mine = sdist.shard_chromosomes(chroms, [length_of.get(c, 1) for c in chroms], ws)[rank]
+    if classifier is None:
+        if options.thread_num > 1 and sample is None:
+            # -t N: fork the host helpers before the first HIP call (pipeline.HelperPool); they map every chromosome
+            # from shared memory when the feed announces it
             from .pipeline import HelperPool
-            pool = HelperPool(options.thread_num, options, table=table, fasta=fasta, want_tsv=True)
-        _tick("open FASTA, fork helpers")
+            pool = HelperPool(options.thread_num, options, fasta=fasta, want_tsv=True)
+        _tick("header, FASTA index, fork helpers")
         # one process per GPU: every device tensor of this rank (scan buffers, weights, graphs) lives on its own GPU.
         # The process group comes up now (after the fork, before the first long phase), not when the first rank is done:
         # a late rendezvous would time out whenever the shards finish far apart.
@@ -183,22 +199,16 @@ def run(options, sample=None, classifier=None):
         if torch.cuda.is_available():
             torch.cuda.set_device(sdist.local_device_index())
         sdist.init_from_env()
-        sample = _sample.Sample.from_table(table, fasta, options.min_sv_size)
-        if pool is not None:
-            pool.attach_scan(sample)
-        _tick("upload + device scan")
-    elif options.contig:
-        options.min_support = 1
-    _sample.register(options.bam_path, sample)
-    table, fasta = sample.table, sample.fasta
-
-    tasks = build_tasks(options, table.references, table.lengths, fasta.references)
-    if len(tasks) == 0:
-        logging.error("No mapped reads in the BAM, please check your reference input!")
-        raise SystemExit(1)
-    chroms = list(tasks.keys())
-    length_of = dict(zip(table.references, table.lengths))
-    mine = sdist.shard_chromosomes(chroms, [length_of.get(c, 1) for c in chroms], ws)[rank]
+        from .ingest import ChromosomeFeed, StaticFeed
+        if sample is None:
+            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            local_ws = int(os.environ.get("LOCAL_WORLD_SIZE", ws))
+            threads = max(1, min(64, cores // max(local_ws, 1) - max(options.thread_num, 1) - 2))     # decode threads of this rank
+            feed = ChromosomeFeed(options.bam_path, fasta, options, [c for c in mine if c in references], references, lengths,
+                                  device=torch.device("cuda", torch.cuda.current_device()), index=find_index(options.bam_path), threads=threads)
+            logging.info("rank %d/%d: %s streamed from %s with %d decode threads", rank, ws, ",".join(mine) or "-", options.bam_path, threads)
+        else:
+            feed = StaticFeed(sample)
 
     seg_dir = os.path.join(work_dir, "segments")
     pred_dir = os.path.join(work_dir, "predict_results")
@@ -208,10 +218,15 @@ def run(options, sample=None, classifier=None):
     if classifier is None:
         # device path: Step 1 and Step 2 streamed window by window (collection of window k+1 on the host while the
         # device classifies window k), one vote stream per chromosome in window order = the order of all.bed
-        if options.thread_num > 1:
-            _run_pooled(options, sample, tasks, mine, seg_dir, pred_dir, pool)
-        else:
-            _run_streaming(options, sample, tasks, mine, seg_dir, pred_dir)
+        try:
+            if options.thread_num > 1:
+                _run_pooled(options, feed, tasks, mine, seg_dir, pred_dir, pool)
+            else:
+                _run_streaming(options, feed, tasks, mine, seg_dir, pred_dir)
+        finally:
+            feed.close()
+        if _tick.on and hasattr(feed, "stats"):
+            print("ingest: %s" % {k: (round(v, 3) if isinstance(v, float) else v) for k, v in feed.stats.items()}, flush=True)
         t1 = t2 = datetime.datetime.now()
         logging.info("[Coding + prediction finished]: streamed, Cost time: %s", (t2 - t0).seconds)
     else:
@@ -306,27 +321,28 @@ def run(options, sample=None, classifier=None):
     return merged_path if rank == 0 else None
 
 
-def _run_streaming(options, sample, tasks, chroms, seg_dir, pred_dir):
+def _run_streaming(options, feed, tasks, chroms, seg_dir, pred_dir):
     """Steps 1 + 2 without the TSV round trip: same functions, same order of lines, same vote semantics as
     Predict.run over ``{chrom}.segments.all.bed`` (predict.py:206-300); the segment files are still written."""
     import sys
     import traceback
-    import numpy as np
     from .network.predict import Predict, SiteVoter, load_network
     from .pipeline import HotPath
     import time as _time
     _t0 = _time.time()
     net = load_network(options.model_path)
-    hot = HotPath(sample, options, net, n_streams=3)
+    hot = HotPath(None, options, net, n_streams=3)
     _t1 = _time.time()
     for chrom in chroms:
+        _key, sample = feed.get(chrom, block=True)                # waits for the chromosome's records (decoded ahead)
+        hot.sample = sample
         prefix = os.path.join(pred_dir, "%s.predict.s%s" % (chrom, options.min_support))
         with open(prefix + ".score.txt", "w") as score_out, open(prefix + ".vcf", "w") as vcf_out, \
                 open(os.path.join(seg_dir, chrom + ".segments.all.bed"), "w") as all_bed:
             voter = SiteVoter(Predict(chrom, None), vcf_out, score_out, options, sample)
             logging.info("Predicting " + chrom)
 
-            def feed(res):
+            def feed_votes(res):
                 classes, probs = hot.fetch_predictions(res)
                 voter.feed_batch([ln.label() for ln in res.lines], classes, probs)
 
@@ -343,54 +359,69 @@ def _run_streaming(options, sample, tasks, chroms, seg_dir, pred_dir):
                     f.write(text)
                 all_bed.write(text)
                 if prev is not None:
-                    feed(prev)
+                    feed_votes(prev)
                 prev = hot.launch(cur)
             if prev is not None:
-                feed(prev)
+                feed_votes(prev)
             voter.finish()
+        feed.release(chrom)
     if os.environ.get("SVX_TIMING"):
         print("network + graphs %.3f, windows %.3f" % (_t1 - _t0, _time.time() - _t1), flush=True)
 
 
-def _run_pooled(options, sample, tasks, chroms, seg_dir, pred_dir, pool=None):
+def _run_pooled(options, feed, tasks, chroms, seg_dir, pred_dir, pool=None):
     """``-t N`` (the reference's process-pool size, SVision:261,311): N forked helper processes run the collection and
     the vote of whole windows while this process feeds the device (pipeline.PooledHotPath); windows complete in any
-    order and are written out in task order, so the files are those of the one-process path."""
+    order; a chromosome is stitched and written (in task order inside it) as soon as its last window is done, so the
+    files are those of the one-process path and only the chromosomes in flight are resident."""
     from .network.predict import load_network
-    from .pipeline import PooledHotPath
+    from .pipeline import PooledHotPath, stitch_windows
     net = load_network(options.model_path)
     windows = [(chrom, start, end) for chrom in chroms for start, end in tasks[chrom]]
-    part_of = [part for chrom in chroms for part in range(len(tasks[chrom]))]
+    first = {}
+    for wid, (chrom, _s, _e) in enumerate(windows):
+        first.setdefault(chrom, wid)
+    left = {chrom: len(tasks[chrom]) for chrom in chroms}
     import time as _time
     _t0 = _time.time()
-    hot = PooledHotPath(sample, options, net, n_workers=options.thread_num, n_streams=3, max_inflight=6, want_tsv=True, pool=pool)
+    static = getattr(feed, "sample", None)
+    hot = PooledHotPath(static, options, net, n_workers=options.thread_num, n_streams=3, max_inflight=6, want_tsv=True, pool=pool, feed=feed)
     _t1 = _time.time()
     done = {}
+
+    def write_chromosome(chrom):
+        wids = range(first[chrom], first[chrom] + len(tasks[chrom]))
+        _key, sample = feed.get(chrom, block=True)
+        texts = stitch_windows([done[w] for w in wids], options, sample)      # per-chromosome vote: edge sites written once
+        vcf_text, score_text = texts.get(chrom, ("", ""))
+        prefix = os.path.join(pred_dir, "%s.predict.s%s" % (chrom, options.min_support))
+        logging.info("Predicting " + chrom)
+        with open(prefix + ".score.txt", "w") as score_out, open(prefix + ".vcf", "w") as vcf_out, \
+                open(os.path.join(seg_dir, chrom + ".segments.all.bed"), "w") as all_bed:
+            for part, w in enumerate(wids):
+                with open(os.path.join(seg_dir, "%s.segments.%d.bed" % (chrom, part)), "w") as f:
+                    f.write(done[w].tsv)
+                all_bed.write(done[w].tsv)
+                del done[w]
+            vcf_out.write(vcf_text)
+            score_out.write(score_text)
+        hot.release(chrom)
+
     try:
         for res in hot.run_windows(windows, rescan=False):
             done[res.wid] = res
+            left[res.chrom] -= 1
+            if left[res.chrom] == 0:
+                write_chromosome(res.chrom)
     finally:
         _t2 = _time.time()
         hot.close()
+    for chrom in chroms:                                          # chromosomes without a window (cannot happen) or never reached
+        if left[chrom] and not os.path.exists(os.path.join(pred_dir, "%s.predict.s%s.vcf" % (chrom, options.min_support))):
+            raise RuntimeError("chromosome %s was not completed" % chrom)
     if os.environ.get("SVX_TIMING"):
-        print("pool up %.3f, windows %.3f, close %.3f" % (_t1 - _t0, _t2 - _t1, _time.time() - _t2), flush=True)
-    from .pipeline import stitch_windows
-    texts = stitch_windows([done[w] for w in range(len(windows))], options, sample)   # per-chromosome vote: edge sites written once
-    wid = 0
-    for chrom in chroms:
-        prefix = os.path.join(pred_dir, "%s.predict.s%s" % (chrom, options.min_support))
-        logging.info("Predicting " + chrom)
-        vcf_text, score_text = texts.get(chrom, ("", ""))
-        with open(prefix + ".score.txt", "w") as score_out, open(prefix + ".vcf", "w") as vcf_out, \
-                open(os.path.join(seg_dir, chrom + ".segments.all.bed"), "w") as all_bed:
-            for _ in tasks[chrom]:
-                res = done[wid]
-                with open(os.path.join(seg_dir, "%s.segments.%d.bed" % (chrom, part_of[wid])), "w") as f:
-                    f.write(res.tsv)
-                all_bed.write(res.tsv)
-                wid += 1
-            vcf_out.write(vcf_text)
-            score_out.write(score_text)
+        print("pool up %.3f, windows %.3f, close %.3f, owner %s" % (_t1 - _t0, _t2 - _t1, _time.time() - _t2,
+              {k: round(v, 3) for k, v in getattr(hot, "owner_profile", {}).items()}), flush=True)
 
 
 def _scores_of(pred_dir, chroms, options):

@@ -9,17 +9,22 @@
 // read, so the resident size is that of the packed arrays that go to the GPU unchanged (svx_cigar_scan
 // input), not that of the file.  SAMv1 section 4 layouts, including CIGARs with more than 65535 operations
 // (CG:B,I tag).  With two virtual offsets from the .bai index only that byte range is read.
+#include <dlfcn.h>
 #include <sched.h>
 #include <zlib.h>
 
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <string_view>
 #include <thread>
@@ -132,18 +137,125 @@ struct BamClock {
 };
 BamClock g_clock;
 
-template <class F>
-void parallel_for(size_t n, int threads, F fn)
-{
-    if (threads <= 1 || n < 2) { fn(0, n); return; }
-    std::vector<std::thread> pool;
-    const size_t chunk = (n + threads - 1) / threads;
-    for (int t = 0; t < threads; ++t) {
-        const size_t lo = std::min(n, t * chunk), hi = std::min(n, lo + chunk);
-        if (lo < hi) pool.emplace_back([=] { fn(lo, hi); });
+// Raw-deflate decoder of one BGZF block.  libdeflate (whole-buffer decoder, 2-3x zlib's rate on BGZF blocks) when
+// libdeflate.so.0 is on the machine -- bound with dlopen: the image ships the library without its header -- else zlib.
+struct Deflate {
+    using alloc_fn = void* (*)();
+    using free_fn = void (*)(void*);
+    using run_fn = int (*)(void*, const void*, size_t, void*, size_t, size_t*);
+    alloc_fn alloc = nullptr;
+    free_fn release = nullptr;
+    run_fn run = nullptr;
+    Deflate()
+    {
+        if (getenv("SVX_BAM_ZLIB")) return;                  // A/B switch: force zlib
+        void* h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        alloc = (alloc_fn)dlsym(h, "libdeflate_alloc_decompressor");
+        release = (free_fn)dlsym(h, "libdeflate_free_decompressor");
+        run = (run_fn)dlsym(h, "libdeflate_deflate_decompress");
+        if (!alloc || !release || !run) alloc = nullptr;
     }
-    for (auto& th : pool) th.join();
-}
+    bool fast() const { return alloc != nullptr; }
+};
+const Deflate& deflate_lib() { static const Deflate d; return d; }
+
+// one per worker thread and call
+struct BlockInflater {
+    void* ld = nullptr;
+    BlockInflater() { if (deflate_lib().fast()) ld = deflate_lib().alloc(); }
+    ~BlockInflater() { if (ld) deflate_lib().release(ld); }
+    bool operator()(const uint8_t* in, size_t n_in, uint8_t* out, size_t n_out)
+    {
+        if (n_out == 0) return true;
+        if (ld) {
+            size_t got = 0;
+            return deflate_lib().run(ld, in, n_in, out, n_out, &got) == 0 && got == n_out;
+        }
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, -15) != Z_OK) return false;
+        zs.next_in = const_cast<Bytef*>(in);
+        zs.avail_in = (uInt)n_in;
+        zs.next_out = out;
+        zs.avail_out = (uInt)n_out;
+        const int rc = inflate(&zs, Z_FINISH);
+        inflateEnd(&zs);
+        return rc == Z_STREAM_END && zs.avail_out == 0;
+    }
+};
+
+// Persistent worker threads: run(n, grain, fn) hands out [lo, hi) slices of `grain` items from an atomic counter to
+// the workers and the caller and returns when all are done.  (Round 2 spawned up to 64 std::threads per chunk.)
+class Pool {
+public:
+    explicit Pool(int threads)
+    {
+        for (int t = 1; t < threads; ++t) workers_.emplace_back([this] { loop(); });
+    }
+    ~Pool()
+    {
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; ++gen_; }
+        cv_.notify_all();
+        for (auto& th : workers_) th.join();
+    }
+    int size() const { return (int)workers_.size() + 1; }
+    void run(size_t n, size_t grain, const std::function<void(size_t, size_t)>& fn)
+    {
+        if (n == 0) return;
+        grain = std::max<size_t>(1, grain);
+        if (workers_.empty() || n <= grain) { fn(0, n); return; }
+        {
+            std::lock_guard<std::mutex> g(m_);
+            fn_ = &fn; n_ = n; grain_ = grain; next_ = 0; active_ = 0; ++gen_;
+        }
+        cv_.notify_all();
+        drain();
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [this] { return active_ == 0 && next_ >= n_; });
+        fn_ = nullptr;
+    }
+
+private:
+    void drain()
+    {
+        for (;;) {
+            const size_t lo = next_.fetch_add(grain_);
+            if (lo >= n_) return;
+            (*fn_)(lo, std::min(n_, lo + grain_));
+        }
+    }
+    void loop()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+                if (!fn_) continue;
+                ++active_;
+            }
+            drain();
+            {
+                std::lock_guard<std::mutex> g(m_);
+                --active_;
+            }
+            done_.notify_one();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(size_t, size_t)>* fn_ = nullptr;
+    size_t n_ = 0, grain_ = 1;
+    std::atomic<size_t> next_{0};
+    int active_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
 
 // Sequential reader of the whole BGZF blocks of file[pos, end): next() appends the inflated bytes of the next
 // chunk of blocks to `out`.
@@ -152,13 +264,13 @@ public:
     size_t chunk;                                        // compressed bytes read per step
     static constexpr uint64_t MAX_INFLATED = 96ull << 20; // inflated bytes per step (keeps the stream buffer cache sized)
 
-    BgzfStream(FILE* f, uint64_t pos, uint64_t end, int threads, size_t first_chunk)
-        : chunk(first_chunk), f_(f), pos_(pos), end_(end), threads_(threads)
+    BgzfStream(FILE* f, uint64_t pos, uint64_t end, Pool* pool, size_t first_chunk)
+        : chunk(first_chunk), f_(f), pos_(pos), end_(end), pool_(pool)
     {
         fseeko(f_, (off_t)pos, SEEK_SET);
     }
     // compressed file offset of the first block of the last chunk, and of every block in it with its position in `out`
-    struct Block { uint64_t coff, dst; uint32_t isize; };
+    struct Block { uint64_t coff, dst; uint32_t isize, csize; };   // file offset, position in `out`, inflated / whole-block bytes
     const std::vector<Block>& blocks() const { return blocks_; }
     bool done() const { return eof_ && carry_.empty(); }
     const std::string& error() const { return err_; }
@@ -201,7 +313,7 @@ public:
             if (end < data + 8) { err_ = "corrupt BGZF block"; return false; }
             const uint32_t isize = rd32(&cbuf_[end - 4]);
             src.push_back({data, end - 8 - data});
-            blocks_.push_back({base + p, total, isize});
+            blocks_.push_back({base + p, total, isize, (uint32_t)(end - p)});
             total += isize;
             p = end;
             if (total - out.size() >= MAX_INFLATED) break;  // highly compressible input: the rest waits in the carry
@@ -215,20 +327,10 @@ public:
         const double t_inf = BamClock::now();
         out.resize(total);
         std::atomic<bool> ok{true};
-        parallel_for(src.size(), threads_, [&](size_t lo, size_t hi) {
-            z_stream zs;
-            for (size_t i = lo; i < hi && ok; ++i) {
-                if (blocks_[i].isize == 0) continue;
-                memset(&zs, 0, sizeof zs);
-                if (inflateInit2(&zs, -15) != Z_OK) { ok = false; return; }
-                zs.next_in = const_cast<Bytef*>(&cbuf_[src[i].data]);
-                zs.avail_in = (uInt)src[i].csize;
-                zs.next_out = out.data() + blocks_[i].dst;
-                zs.avail_out = blocks_[i].isize;
-                const int rc = inflate(&zs, Z_FINISH);
-                inflateEnd(&zs);
-                if (rc != Z_STREAM_END || zs.avail_out != 0) { ok = false; return; }
-            }
+        pool_->run(src.size(), 8, [&](size_t lo, size_t hi) {          // slices of 8 blocks (~0.5 MB inflated) from a shared counter
+            BlockInflater inflate_block;
+            for (size_t i = lo; i < hi && ok; ++i)
+                if (!inflate_block(&cbuf_[src[i].data], src[i].csize, out.data() + blocks_[i].dst, blocks_[i].isize)) { ok = false; return; }
         });
         g_clock.inflate += BamClock::now() - t_inf;
         if (!ok) { err_ = "BGZF inflate failed"; return false; }
@@ -240,7 +342,7 @@ public:
 private:
     FILE* f_;
     uint64_t pos_, end_;
-    int threads_;
+    Pool* pool_;
     bool eof_ = false, capped_ = false;
     std::vector<uint8_t> cbuf_, carry_;
     std::vector<Block> blocks_;
@@ -275,7 +377,11 @@ long long parse_header(const RawBuf& buf, Bam* b)
 
 // Appends the whole records of buf[from, limit) to the arrays; returns the offset of the first byte not consumed
 // (a partial record at the end stays for the next chunk), or -1 on a malformed record.
-long long parse_records(const RawBuf& buf, uint64_t from, uint64_t limit, int threads, bool keep_seq, Bam* b)
+//
+// split: a part holds the records of ONE reference (svx_bam_stream_*): the walk stops in front of the first record
+// whose reference differs from the part's, and *tid_changed says so.
+long long parse_records(const RawBuf& buf, uint64_t from, uint64_t limit, Pool* pool, bool keep_seq, Bam* b, bool split = false,
+                        bool* tid_changed = nullptr)
 {
     struct Rec { uint64_t at; const uint8_t* cig; uint32_t n_cig; };
     std::vector<Rec> recs;
@@ -286,6 +392,13 @@ long long parse_records(const RawBuf& buf, uint64_t from, uint64_t limit, int th
         if (p + 4 + bs > limit) break;
         if (bs < 32) return -1;
         const uint8_t* rec = &buf[p + 4];
+        if (split) {
+            const int32_t rtid = (int32_t)rd32(rec);
+            if (!b->tid.empty() || !recs.empty()) {
+                const int32_t cur = b->tid.empty() ? (int32_t)rd32(&buf[recs[0].at + 4]) : b->tid[0];
+                if (rtid != cur) { *tid_changed = true; break; }
+            }
+        }
         const uint32_t l_name = rec[8], l_seq = rd32(rec + 16);
         uint32_t n_cig = rd16(rec + 12);
         if (32ull + l_name + 4ull * n_cig + (l_seq + 1ull) / 2 + l_seq > bs) return -1;
@@ -330,8 +443,7 @@ long long parse_records(const RawBuf& buf, uint64_t from, uint64_t limit, int th
     }
     const double t_scatter = BamClock::now();
     g_clock.chain += t_scatter - t_chain;
-    // (a thread per ~4096 records: spawning 64 threads for a chunk of 30 k short records cost more than the copies)
-    parallel_for(n, std::max(1, std::min<int>(threads, (int)(n / 4096))), [&](size_t lo, size_t hi) {
+    pool->run(n, 2048, [&](size_t lo, size_t hi) {
         for (size_t i = lo; i < hi; ++i) {
             const uint8_t* rec = &buf[recs[i].at + 4];
             const size_t k = n0 + i;
@@ -348,18 +460,17 @@ long long parse_records(const RawBuf& buf, uint64_t from, uint64_t limit, int th
 }
 
 thread_local std::string g_bam_error;
+int default_threads();
 
 void* bam_open_impl(const char* path, int threads, int flags, bool ranged, uint64_t voff_beg, uint64_t voff_end)
 {
     g_bam_error.clear();
-    if (threads <= 0) {                                   // the CPUs this process may run on (not the machine's), at most 64
-        cpu_set_t set;
-        const int avail = sched_getaffinity(0, sizeof set, &set) == 0 ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
-        threads = std::max(1, std::min(64, avail));
-    }
+    if (threads <= 0) threads = default_threads();        // the CPUs this process may run on (not the machine's), at most 64
     const bool keep_seq = flags & SVX_BAM_KEEP_SEQ;
     FILE* f = fopen(path, "rb");
     if (!f) { g_bam_error = std::string("cannot open ") + path; return nullptr; }
+    Pool workers(threads);
+    Pool* pool = &workers;
     std::unique_ptr<Bam> b(new Bam());
     RawBuf buf;
     auto fail = [&](const std::string& why) -> void* { g_bam_error = why; fclose(f); return nullptr; };
@@ -368,7 +479,7 @@ void* bam_open_impl(const char* path, int threads, int flags, bool ranged, uint6
     // SVX_BAM_CHUNK (bytes) shrinks the read size so that tests cross chunk boundaries on small files
     const char* env = getenv("SVX_BAM_CHUNK");
     const size_t steady = env && atol(env) > 0 ? (size_t)atol(env) : (16u << 20);   // inflated chunk stays cache-warm for the parse
-    BgzfStream head(f, 0, ~0ull, threads, std::min<size_t>(steady, 256u << 10));
+    BgzfStream head(f, 0, ~0ull, pool, std::min<size_t>(steady, 256u << 10));
     long long hdr = 0;
     while (hdr == 0) {
         if (head.done()) return fail(buf.empty() ? "empty file" : "truncated BAM header");
@@ -382,7 +493,7 @@ void* bam_open_impl(const char* path, int threads, int flags, bool ranged, uint6
     if (!ranged) {
         uint64_t cur = (uint64_t)hdr;
         for (;;) {
-            const long long used = parse_records(buf, cur, buf.size(), threads, keep_seq, b.get());
+            const long long used = parse_records(buf, cur, buf.size(), pool, keep_seq, b.get());
             if (used < 0) return fail("malformed BAM record");
             buf.drop_front((size_t)used);                       // keeps a partial record for the next chunk
             cur = 0;
@@ -393,7 +504,7 @@ void* bam_open_impl(const char* path, int threads, int flags, bool ranged, uint6
     } else if (voff_end > voff_beg) {
         // the compressed range [coffset(voff_beg), end of the block at coffset(voff_end)): one spare block is read
         const uint64_t c0 = voff_beg >> 16, c1 = voff_end >> 16;
-        BgzfStream body(f, c0, c1 + 65536 + 26, threads, steady);
+        BgzfStream body(f, c0, c1 + 65536 + 26, pool, steady);
         buf.clear();
         uint64_t cur = voff_beg & 0xffff, limit = ~0ull;      // limit: position in buf of (c1, voff_end & 0xffff)
         bool reached = false;
@@ -409,7 +520,7 @@ void* bam_open_impl(const char* path, int threads, int flags, bool ranged, uint6
                 if (reached) return fail("BAM index does not match the file");
                 continue;
             }
-            const long long used = parse_records(buf, cur, stop, threads, keep_seq, b.get());
+            const long long used = parse_records(buf, cur, stop, pool, keep_seq, b.get());
             if (used < 0) return fail("malformed BAM record");
             if (reached) { if ((uint64_t)used != stop) return fail("BAM index does not match the file"); break; }
             buf.drop_front((size_t)used);
@@ -419,10 +530,238 @@ void* bam_open_impl(const char* path, int threads, int flags, bool ranged, uint6
     }
     fclose(f);
     if (getenv("SVX_TIMING"))
-        fprintf(stderr, "svx_bam_open (%d threads): read %.3f s, inflate %.3f s, chain records %.3f s, scatter fields %.3f s\n", threads,
-                g_clock.read, g_clock.inflate, g_clock.chain, g_clock.scatter);
+        fprintf(stderr, "svx_bam_open (%d threads, %s): read %.3f s, inflate %.3f s, chain records %.3f s, scatter fields %.3f s\n", threads,
+                deflate_lib().fast() ? "libdeflate" : "zlib", g_clock.read, g_clock.inflate, g_clock.chain, g_clock.scatter);
     g_clock = BamClock();
     return b.release();
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Streaming ingestion, one reference at a time (svx_bam_stream_*): the consumer gets the records of chromosome k as
+// soon as they are decoded, while chromosome k+1 is being read and inflated.  Two threads behind the handle:
+//
+//   feeder   reads the next chunk of whole BGZF blocks and inflates it on the worker pool into one of a few chunk
+//            buffers (data starts HEAD bytes into the buffer);
+//   parser   walks the records of the chunk in hand (the partial record a chunk ends with is copied in front of the
+//            next chunk's data, into the HEAD room), splits at every change of reference and queues finished parts.
+//
+// The reference fetches window by window through the index (run_collection.py:23-26); here a rank's byte ranges (its
+// chromosomes, from the .bai) or the whole file are streamed once, in file order.
+struct Stream {
+    static constexpr size_t HEAD = 8u << 20;                 // room in front of a chunk for the previous chunk's partial record
+    struct Chunk {
+        RawBuf buf;
+        size_t begin = HEAD;                                  // first byte to parse
+        size_t limit = 0;                                     // one past the last byte to parse (range mode: the end virtual offset)
+        bool range_end = false;                               // nothing of this range follows
+        bool fresh = true;                                    // first chunk of a range: no carry from the chunk before
+    };
+    std::string path;
+    FILE* f = nullptr;
+    int flags = 0;
+    std::unique_ptr<Pool> inflate_pool, scatter_pool;
+    std::vector<std::pair<uint64_t, uint64_t>> ranges;       // virtual offsets; empty: everything behind the header
+    Bam proto;                                               // header text + reference dictionary, copied into every part
+    uint64_t body_voff = 0;                                  // virtual offset of the first record (whole-file mode)
+
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<std::unique_ptr<Chunk>> filled, spare;        // feeder -> parser, parser -> feeder
+    std::deque<std::unique_ptr<Bam>> ready;                  // parser -> consumer
+    size_t max_ready = 2;
+    bool feeder_done = false, parser_done = false, cancel = false;
+    std::string error;
+    std::thread feeder, parser;
+    double t_read = 0, t_inflate = 0, t_chain = 0, t_wait_chunk = 0, t_wait_ready = 0;
+    uint64_t bytes_in = 0, bytes_out = 0;
+
+    ~Stream()
+    {
+        { std::lock_guard<std::mutex> g(m); cancel = true; }
+        cv.notify_all();
+        if (feeder.joinable()) feeder.join();
+        if (parser.joinable()) parser.join();
+        if (f) fclose(f);
+    }
+
+    void fail(const std::string& why)
+    {
+        std::lock_guard<std::mutex> g(m);
+        if (error.empty()) error = why;
+        cancel = true;
+        cv.notify_all();
+    }
+
+    // ---- feeder ------------------------------------------------------------------------------------------------
+    void feed()
+    {
+        const char* env = getenv("SVX_BAM_CHUNK");
+        const size_t steady = env && atol(env) > 0 ? (size_t)atol(env) : (16u << 20);
+        std::vector<std::pair<uint64_t, uint64_t>> todo = ranges;
+        if (todo.empty()) todo.push_back({body_voff, ~0ull});
+        for (const auto& r : todo) {
+            const bool open_end = r.second == ~0ull;
+            if (!open_end && r.second <= r.first) continue;
+            const uint64_t c0 = r.first >> 16, c1 = open_end ? ~0ull : r.second >> 16;
+            BgzfStream body(f, c0, open_end ? ~0ull : c1 + 65536 + 26, inflate_pool.get(), steady);
+            bool first = true, reached = false;
+            std::unique_ptr<Chunk> ch;
+            while (!reached) {
+                if (!ch) {
+                    std::unique_lock<std::mutex> g(m);
+                    cv.wait(g, [&] { return cancel || !spare.empty(); });
+                    if (cancel) return;
+                    ch = std::move(spare.front());
+                    spare.pop_front();
+                }
+                ch->buf.resize(HEAD);                           // BgzfStream::next appends behind the HEAD room
+                const double t0 = BamClock::now();
+                const double read0 = g_clock.read;
+                if (!body.next(ch->buf)) { fail(body.error()); return; }
+                if (body.blocks().empty() && !body.done()) continue;     // a read shorter than one block: nothing to hand over yet
+                const double dt = BamClock::now() - t0, dread = g_clock.read - read0;
+                t_read += dread;
+                t_inflate += dt - dread;
+                ch->fresh = first;
+                ch->begin = HEAD + (first ? (size_t)(r.first & 0xffff) : 0);
+                ch->limit = ch->buf.size();
+                for (const auto& blk : body.blocks()) {
+                    bytes_out += blk.isize;
+                    bytes_in += blk.csize;
+                    if (open_end || reached) continue;
+                    if (blk.coff == c1) { ch->limit = blk.dst + (size_t)(r.second & 0xffff); reached = true; }
+                    else if (blk.coff > c1) { ch->limit = blk.dst; reached = true; }
+                }
+                if (body.done()) {
+                    if (!open_end && !reached) { fail("BAM index does not match the file"); return; }
+                    reached = true;
+                }
+                if (first && ch->begin > ch->limit) { fail("BAM index does not match the file"); return; }
+                first = false;
+                ch->range_end = reached;
+                {
+                    std::lock_guard<std::mutex> g(m);
+                    filled.push_back(std::move(ch));
+                }
+                ch.reset();
+                cv.notify_all();
+            }
+            if (ch) {                                           // taken but not used
+                std::lock_guard<std::mutex> g(m);
+                spare.push_back(std::move(ch));
+            }
+        }
+        {
+            std::lock_guard<std::mutex> g(m);
+            feeder_done = true;
+        }
+        cv.notify_all();
+    }
+
+    // ---- parser ------------------------------------------------------------------------------------------------
+    std::unique_ptr<Bam> new_part() const
+    {
+        std::unique_ptr<Bam> b(new Bam());
+        b->header_text = proto.header_text;
+        b->ref_names = proto.ref_names;
+        b->ref_lens = proto.ref_lens;
+        return b;
+    }
+
+    bool publish(std::unique_ptr<Bam>& part)                  // false: cancelled
+    {
+        if (part->tid.empty()) return true;
+        std::unique_lock<std::mutex> g(m);
+        const double t0 = BamClock::now();
+        cv.wait(g, [&] { return cancel || ready.size() < max_ready; });
+        t_wait_ready += BamClock::now() - t0;
+        if (cancel) return false;
+        ready.push_back(std::move(part));
+        g.unlock();
+        cv.notify_all();
+        part = new_part();
+        return true;
+    }
+
+    void parse()
+    {
+        const bool keep_seq = flags & SVX_BAM_KEEP_SEQ;
+        std::unique_ptr<Bam> part = new_part();
+        std::vector<uint8_t> carry;                           // partial record left by the previous chunk of the range
+        for (;;) {
+            std::unique_ptr<Chunk> ch;
+            {
+                std::unique_lock<std::mutex> g(m);
+                const double t0 = BamClock::now();
+                cv.wait(g, [&] { return cancel || !filled.empty() || feeder_done; });
+                t_wait_chunk += BamClock::now() - t0;
+                if (cancel) return;
+                if (filled.empty()) break;                    // feeder_done and nothing left
+                ch = std::move(filled.front());
+                filled.pop_front();
+            }
+            if (ch->fresh) {
+                if (!carry.empty()) { fail("truncated BAM record"); return; }
+            } else if (!carry.empty()) {
+                if (carry.size() > ch->begin) {               // a record longer than the HEAD room: make room (rare: > 8 MB)
+                    RawBuf bigger;
+                    bigger.resize(carry.size() + (ch->buf.size() - ch->begin));
+                    memcpy(bigger.data() + carry.size(), ch->buf.data() + ch->begin, ch->buf.size() - ch->begin);
+                    const size_t shift = carry.size() - ch->begin;
+                    ch->limit += shift;
+                    ch->begin = carry.size();
+                    ch->buf = std::move(bigger);
+                }
+                memcpy(ch->buf.data() + ch->begin - carry.size(), carry.data(), carry.size());
+                ch->begin -= carry.size();
+                carry.clear();
+            }
+            const double t0 = BamClock::now();
+            uint64_t cur = ch->begin;
+            const uint64_t stop = std::min<uint64_t>(ch->limit, ch->buf.size());
+            for (;;) {
+                bool changed = false;
+                const long long used = parse_records(ch->buf, cur, stop, scatter_pool.get(), keep_seq, part.get(), true, &changed);
+                if (used < 0) { fail("malformed BAM record"); return; }
+                cur = (uint64_t)used;
+                if (!changed) break;
+                t_chain += BamClock::now() - t0;
+                if (!publish(part)) return;
+            }
+            t_chain += BamClock::now() - t0;
+            if (cur < stop) {
+                if (ch->range_end) { fail(ch->limit < ch->buf.size() ? "BAM index does not match the file" : "truncated BAM record"); return; }
+                carry.assign(ch->buf.data() + cur, ch->buf.data() + stop);
+            }
+            const bool range_end = ch->range_end;
+            {
+                std::lock_guard<std::mutex> g(m);
+                spare.push_back(std::move(ch));
+            }
+            cv.notify_all();
+            if (range_end && !publish(part)) return;          // ranges are whole references: never merged across a gap
+        }
+        if (!carry.empty()) { fail("truncated BAM record"); return; }
+        if (!publish(part)) return;
+        {
+            std::lock_guard<std::mutex> g(m);
+            parser_done = true;
+        }
+        cv.notify_all();
+        if (getenv("SVX_TIMING"))
+            fprintf(stderr, "svx_bam_stream (%d inflate threads, %s): %.1f MB in, %.1f MB inflated; feeder read %.3f s, inflate %.3f s; "
+                            "parser walk+scatter %.3f s, waited for chunks %.3f s, for the consumer %.3f s\n",
+                    inflate_pool->size(), deflate_lib().fast() ? "libdeflate" : "zlib", bytes_in / 1e6, bytes_out / 1e6, t_read, t_inflate,
+                    t_chain, t_wait_chunk, t_wait_ready);
+    }
+};
+
+int default_threads()
+{
+    cpu_set_t set;
+    const int avail = sched_getaffinity(0, sizeof set, &set) == 0 ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
+    return std::max(1, std::min(64, avail));
 }
 
 }  // namespace
@@ -480,6 +819,71 @@ void svx_bam_export(void* h, int threads, int32_t* tid, int32_t* pos, uint16_t* 
 }
 
 const uint8_t* svx_bam_seq(void* h) { return static_cast<const Bam*>(h)->seq.data(); }
+
+// ---- streaming: one part per reference, decoded ahead of the consumer ------------------------------------------
+void* svx_bam_stream_open(const char* path, int threads, int flags, const uint64_t* voffs, int n_ranges)
+{
+    g_bam_error.clear();
+    if (threads <= 0) threads = default_threads();
+    std::unique_ptr<Stream> s(new Stream());
+    s->path = path;
+    s->flags = flags;
+    s->f = fopen(path, "rb");
+    if (!s->f) { g_bam_error = std::string("cannot open ") + path; return nullptr; }
+    for (int i = 0; i < n_ranges; ++i) s->ranges.push_back({voffs[2 * i], voffs[2 * i + 1]});
+    // the parser's field scatter is a few memcpy per record: a handful of threads; everything else inflates
+    const int scatter = std::max(1, std::min(8, threads / 8));
+    s->inflate_pool.reset(new Pool(std::max(1, threads - scatter)));
+    s->scatter_pool.reset(new Pool(scatter));
+    {   // header: synchronously, from the start of the file; remembers where the records begin
+        RawBuf buf;
+        BgzfStream head(s->f, 0, ~0ull, s->inflate_pool.get(), 256u << 10);
+        long long hdr = 0;
+        std::vector<BgzfStream::Block> seen;
+        while (hdr == 0) {
+            if (head.done()) { g_bam_error = buf.empty() ? "empty file" : "truncated BAM header"; return nullptr; }
+            if (!head.next(buf)) { g_bam_error = head.error(); return nullptr; }
+            for (const auto& b : head.blocks()) seen.push_back(b);
+            hdr = parse_header(buf, &s->proto);
+            head.chunk = std::min<size_t>(head.chunk * 4, 16u << 20);
+        }
+        if (hdr < 0) { g_bam_error = "not a BAM file"; return nullptr; }
+        // virtual offset of byte `hdr` of the inflated stream: inside a block that was read, or the start of the block
+        // behind the last one (a header that fills its blocks exactly, as htslib writes it)
+        uint64_t voff = ~0ull;
+        for (const auto& b : seen)
+            if ((uint64_t)hdr < b.dst + b.isize) { voff = (b.coff << 16) | ((uint64_t)hdr - b.dst); break; }
+        if (voff == ~0ull) voff = (seen.back().coff + seen.back().csize) << 16;
+        s->body_voff = voff;
+    }
+    for (int i = 0; i < 3; ++i) s->spare.emplace_back(new Stream::Chunk());
+    Stream* raw = s.get();
+    s->feeder = std::thread([raw] { raw->feed(); });
+    s->parser = std::thread([raw] { raw->parse(); });
+    return s.release();
+}
+
+// Next reference's records: a handle for svx_bam_sizes / svx_bam_export / svx_bam_seq / svx_bam_close, or NULL with
+// *status = 0 at the end of the stream, -1 on an error (svx_bam_error()).  Blocks while the part is being decoded.
+void* svx_bam_stream_next(void* stream, int* status)
+{
+    Stream* s = static_cast<Stream*>(stream);
+    std::unique_lock<std::mutex> g(s->m);
+    s->cv.wait(g, [&] { return !s->ready.empty() || s->parser_done || !s->error.empty(); });
+    if (!s->ready.empty()) {
+        std::unique_ptr<Bam> part = std::move(s->ready.front());
+        s->ready.pop_front();
+        g.unlock();
+        s->cv.notify_all();
+        *status = 1;
+        return part.release();
+    }
+    if (!s->error.empty()) { g_bam_error = s->error; *status = -1; return nullptr; }
+    *status = 0;
+    return nullptr;
+}
+
+void svx_bam_stream_close(void* stream) { delete static_cast<Stream*>(stream); }
 
 void svx_bam_close(void* h) { delete static_cast<Bam*>(h); }
 

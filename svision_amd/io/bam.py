@@ -275,12 +275,47 @@ def read_bai(path):
     return out
 
 
+def _table_from_handle(lib, h, with_seq, threads=0, alloc=None):
+    """A decoded handle (svx_bam_open / svx_bam_stream_next) -> AlignmentTable; the handle is closed.
+    ``alloc(name, dtype, n)``: where the big arrays are created (a shared-memory file for the host helpers)."""
+    import ctypes
+    if alloc is None:
+        def alloc(_name, dtype, n):
+            return np.empty(n, dtype)
+    try:
+        sizes = np.zeros(8, np.uint64)
+        lib.svx_bam_sizes(h, sizes.ctypes.data)
+        n, nc, nref, _nn, nb, hb, rb, rawb = (int(v) for v in sizes)
+        tid, pos, l_seq, name_id = (alloc(k, np.int32, n) for k in ("tid", "pos", "l_seq", "name_id"))
+        flag, mapq = alloc("flag", np.uint16, n), alloc("mapq", np.uint8, n)
+        cig_off, cigar = alloc("cig_off", np.int64, n + 1), alloc("cigar", np.uint32, nc)
+        names, header, ref_names = alloc("names", np.uint8, nb), np.empty(hb, np.uint8), np.empty(rb, np.uint8)
+        ref_lens = np.empty(nref, np.int32)
+        seq_off = alloc("seq_off", np.int64, n) if with_seq else None
+        lib.svx_bam_export(h, int(threads), tid.ctypes.data, pos.ctypes.data, flag.ctypes.data, mapq.ctypes.data,
+                           l_seq.ctypes.data, name_id.ctypes.data, cig_off.ctypes.data, cigar.ctypes.data, names.ctypes.data,
+                           header.ctypes.data, ref_names.ctypes.data, ref_lens.ctypes.data,
+                           seq_off.ctypes.data if with_seq else None)
+        seq_packed = None
+        if with_seq:
+            seq_packed = alloc("seq_packed", np.uint8, rawb)
+            if rawb:
+                ctypes.memmove(seq_packed.ctypes.data, lib.svx_bam_seq(h), rawb)
+    finally:
+        lib.svx_bam_close(h)
+    name_list = names.tobytes().decode().split("\n")[:-1] if nb else []
+    refs = ref_names.tobytes().decode().split("\n")[:-1] if rb else []
+    table = AlignmentTable(refs, [int(v) for v in ref_lens], tid, pos, flag, mapq, l_seq, name_id, name_list, cigar, cig_off,
+                           header.tobytes().decode(), seq_packed, seq_off)
+    table._names_blob = names                                  # the '\n'-joined QNAMEs as they were exported (shared with the helpers)
+    return table
+
+
 def read_bam(path, with_seq=False, threads=0, tids=None, index=None):
     """Decode a BAM file into an :class:`AlignmentTable` with the native multi-threaded decoder of libsvx.so
     (svx_bam_*); ``with_seq``: keep the 4-bit read bases (needed by --hash only).  ``tids`` (with a ``.bai`` next to
     the file or given as ``index``): decode only the byte range holding those references' records -- one rank's
     chromosome shard -- instead of the whole file."""
-    import ctypes
     from .. import _lib
     lib = _lib.load()
     flags = 1 if with_seq else 0                          # SVX_BAM_KEEP_SEQ
@@ -298,32 +333,84 @@ def read_bam(path, with_seq=False, threads=0, tids=None, index=None):
     if not h:
         msg = lib.svx_bam_error().decode()
         raise ValueError("%s: %s" % (path, msg))
-    try:
-        sizes = np.zeros(8, np.uint64)
-        lib.svx_bam_sizes(h, sizes.ctypes.data)
-        n, nc, nref, _nn, nb, hb, rb, rawb = (int(v) for v in sizes)
-        tid, pos, l_seq, name_id = (np.empty(n, np.int32) for _ in range(4))
-        flag, mapq = np.empty(n, np.uint16), np.empty(n, np.uint8)
-        cig_off, cigar = np.empty(n + 1, np.int64), np.empty(nc, np.uint32)
-        names, header, ref_names = np.empty(nb, np.uint8), np.empty(hb, np.uint8), np.empty(rb, np.uint8)
-        ref_lens = np.empty(nref, np.int32)
-        seq_off = np.empty(n, np.int64) if with_seq else None
-        lib.svx_bam_export(h, int(threads), tid.ctypes.data, pos.ctypes.data, flag.ctypes.data, mapq.ctypes.data,
-                           l_seq.ctypes.data, name_id.ctypes.data, cig_off.ctypes.data, cigar.ctypes.data, names.ctypes.data,
-                           header.ctypes.data, ref_names.ctypes.data, ref_lens.ctypes.data,
-                           seq_off.ctypes.data if with_seq else None)
-        seq_packed = None
-        if with_seq:
-            seq_packed = ctypes.string_at(lib.svx_bam_seq(h), rawb) if rawb else b""
-    finally:
-        lib.svx_bam_close(h)
-    name_list = names.tobytes().decode().split("\n")[:-1] if nb else []
-    refs = ref_names.tobytes().decode().split("\n")[:-1] if rb else []
-    table = AlignmentTable(refs, [int(v) for v in ref_lens], tid, pos, flag, mapq, l_seq, name_id, name_list, cigar, cig_off,
-                           header.tobytes().decode(), seq_packed, seq_off)
+    table = _table_from_handle(lib, h, with_seq, threads)
+    if table.seq_packed is not None:
+        table.seq_packed = table.seq_packed.tobytes()
     if keep_tids is not None and len(table) and not set(np.unique(table.tid).tolist()) <= keep_tids:
         table = table.subset(np.flatnonzero(np.isin(table.tid, list(keep_tids))))     # references between two requested ones
     return table
+
+
+def read_bam_header(path):
+    """Header text + reference dictionary only (an AlignmentTable without records); no index needed."""
+    from .. import _lib
+    lib = _lib.load()
+    h = lib.svx_bam_open_range(path.encode(), 1, 0, 0, 0)
+    if not h:
+        raise ValueError("%s: %s" % (path, lib.svx_bam_error().decode()))
+    return _table_from_handle(lib, h, False)
+
+
+def find_index(path):
+    """The .bai next to a BAM (``x.bam.bai`` or ``x.bai``), or None."""
+    return next((c for c in (path + ".bai", os.path.splitext(path)[0] + ".bai") if os.path.exists(c)), None)
+
+
+class BamStream:
+    """Iterator over a BAM file's reference sequences: yields one :class:`AlignmentTable` per reference that has
+    records (file order; all tables carry the whole reference dictionary and the file's ``tid`` numbering; QNAME ids
+    count from 0 in every table), each as soon as it is decoded, while the native reader's own threads read and inflate
+    the next ones (svx_bam_stream_*).  ``tids`` + a ``.bai``: only those references' byte ranges are read (a rank's
+    chromosomes); ``tids`` without an index: the whole file is streamed and the other references are skipped.
+
+    What the reference does window by window through pysam's ``fetch`` (run_collection.py:23-26)."""
+
+    def __init__(self, path, with_seq=False, threads=0, tids=None, index=None, alloc=None):
+        from .. import _lib
+        self.lib = _lib.load()
+        self.path, self.with_seq, self.alloc = path, with_seq, alloc
+        self.keep = None if tids is None else set(int(t) for t in tids)
+        voffs = np.zeros(0, np.uint64)
+        if tids is not None and index is None:
+            index = find_index(path)
+        if tids is not None and index is not None:
+            spans = read_bai(index)
+            have = sorted(spans[t] for t in self.keep if t < len(spans) and spans[t] is not None)
+            voffs = np.asarray([v for span in have for v in span], np.uint64)
+            if not have:                                       # nothing of this rank's in the file: an empty range
+                voffs = np.zeros(2, np.uint64)
+        self.h = self.lib.svx_bam_stream_open(path.encode(), int(threads), 1 if with_seq else 0,
+                                              voffs.ctypes.data if voffs.size else None, int(voffs.size // 2))
+        if not self.h:
+            raise ValueError("%s: %s" % (path, self.lib.svx_bam_error().decode()))
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        import ctypes
+        while True:
+            if self.h is None:
+                raise StopIteration
+            status = ctypes.c_int(0)
+            part = self.lib.svx_bam_stream_next(self.h, ctypes.byref(status))
+            if not part:
+                err = self.lib.svx_bam_error().decode() if status.value < 0 else None
+                self.close()
+                if err is not None:
+                    raise ValueError("%s: %s" % (self.path, err))
+                raise StopIteration
+            table = _table_from_handle(self.lib, part, self.with_seq, alloc=self.alloc)
+            if len(table) and (self.keep is None or int(table.tid[0]) in self.keep):
+                return table
+
+    def close(self):
+        if self.h is not None:
+            self.lib.svx_bam_stream_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
 
 
 def read_bam_python(path, with_seq=False):
@@ -466,6 +553,198 @@ def _write_bai(path, table, block_coff, part_sizes):
         u += size
     out = [b"BAI\x01", struct.pack("<i", len(table.references))]
     for t in range(len(table.references)):
+        out.append(struct.pack("<i", len(bins[t])))
+        for b, chunks in sorted(bins[t].items()):
+            out.append(struct.pack("<Ii", b, len(chunks)) + b"".join(struct.pack("<QQ", c0, c1) for c0, c1 in chunks))
+        n_intv = (max(linear[t]) + 1) if linear[t] else 0
+        out.append(struct.pack("<i", n_intv))
+        last = 0
+        for w in range(n_intv):
+            last = linear[t].get(w, last)
+            out.append(struct.pack("<Q", last))
+    with open(path, "wb") as f:
+        f.write(b"".join(out))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Fast writer for large synthetic samples (bench.py --from-bam): NumPy-assembled record stream, realistic SEQ / QUAL
+# entropy, libdeflate (ctypes) per BGZF block, one independently compressed segment per reference so that the
+# references can be encoded in parallel processes and concatenated (BGZF members are independent).
+_SPAN_OPS = np.array([1, 0, 1, 1, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0], np.int64)
+
+
+def reference_spans(table):
+    """Reference bases covered by every record (>= 1), from the CIGAR words."""
+    n = len(table)
+    if n == 0:
+        return np.zeros(0, np.int64)
+    contrib = (table.cigar >> 4).astype(np.int64) * _SPAN_OPS[table.cigar & 15]
+    csum = np.concatenate([[0], np.cumsum(contrib)])
+    return np.maximum(1, csum[table.cig_off[1:]] - csum[table.cig_off[:-1]])
+
+
+def encode_record_stream(table, seq="random", seed=0):
+    """The uncompressed BAM record stream of ``table`` -> (uint8 array, int64 offsets [n+1] of the records in it).
+    ``seq``: 'random' = uniformly random bases (2 bits of entropy per base, like real reads) and HiFi-like binned
+    qualities (7 values, skewed); 'N' = N bases and 0xFF qualities (what :func:`write_bam` writes).  CIGARs of more than
+    65535 operations are not supported here."""
+    n = len(table)
+    n_cig = (table.cig_off[1:] - table.cig_off[:-1]).astype(np.int64)
+    if n and int(n_cig.max()) > 65535:
+        raise ValueError("encode_record_stream: CG-tag CIGARs are written by write_bam only")
+    names = [table.names[i].encode() + b"\x00" for i in table.name_id]
+    l_name = np.fromiter((len(b) for b in names), np.int64, n)
+    l_seq = table.l_seq.astype(np.int64)
+    sq = (l_seq + 1) // 2
+    size = 32 + l_name + 4 * n_cig + sq + l_seq
+    off = np.zeros(n + 1, np.int64)
+    off[1:] = np.cumsum(size + 4)
+    buf = np.empty(int(off[-1]), np.uint8)
+    span = reference_spans(table)
+    pos = table.pos.astype(np.int64)
+    fixed = np.zeros(n, np.dtype([("block_size", "<i4"), ("tid", "<i4"), ("pos", "<i4"), ("l_name", "u1"), ("mapq", "u1"), ("bin", "<u2"),
+                                  ("n_cig", "<u2"), ("flag", "<u2"), ("l_seq", "<i4"), ("next_tid", "<i4"), ("next_pos", "<i4"), ("tlen", "<i4")]))
+    fixed["block_size"], fixed["tid"], fixed["pos"], fixed["l_name"], fixed["mapq"] = size, table.tid, table.pos, l_name, table.mapq
+    fixed["bin"] = _reg2bin_vec(pos, pos + span)
+    fixed["n_cig"], fixed["flag"], fixed["l_seq"], fixed["next_tid"], fixed["next_pos"] = n_cig, table.flag, table.l_seq, -1, -1
+    buf[(off[:-1, None] + np.arange(36)).ravel()] = fixed.view(np.uint8).ravel()
+
+    def scatter(starts, lengths, payload):
+        tot = int(lengths.sum())
+        if tot:
+            first = np.zeros(len(lengths), np.int64)
+            first[1:] = np.cumsum(lengths)[:-1]
+            buf[np.repeat(starts - first, lengths) + np.arange(tot)] = payload
+    scatter(off[:-1] + 36, l_name, np.frombuffer(b"".join(names), np.uint8))
+    scatter(off[:-1] + 36 + l_name, 4 * n_cig, table.cigar.astype("<u4").view(np.uint8))
+    at = off[:-1] + 36 + l_name + 4 * n_cig
+    if seq == "N":
+        for i in range(n):
+            buf[at[i]:at[i] + sq[i] + l_seq[i]] = 0xFF
+    else:
+        rng = np.random.default_rng(seed)
+        codes = np.array([1, 2, 4, 8], np.uint8)
+        pair = ((codes[:, None] << 4) | codes[None, :]).ravel()
+        # qualities: 7 bins with probabilities ~ .70 .10 .07 .05 .04 .03 .01 (a 256-entry table indexed by random bytes)
+        qlut = np.repeat(np.array([93, 40, 35, 30, 25, 20, 10], np.uint8), [179, 26, 18, 13, 10, 8, 2])
+        # a pool of random bases / qualities a few hundred deflate windows (32 KB) long; every record copies a slice from
+        # its own pseudo-random offset: for the compressor that is random data (drawing 1.4 G fresh values per
+        # chromosome-sized sample would take minutes in NumPy and compress to the same size)
+        longest = int(l_seq.max()) if n else 0
+        pool_n = max(16 << 20, 4 * longest)
+        raw = rng.bit_generator.random_raw((2 * pool_n + 7) // 8).view(np.uint8)
+        seq_pool = pair[raw[:pool_n] & 15]
+        qual_pool = qlut[raw[pool_n:2 * pool_n]]
+        for i in range(n):                                     # two large slice copies per record
+            a, k, q = int(at[i]), int(sq[i]), int(l_seq[i])
+            o = (i * 2654435761) % (pool_n - longest)
+            buf[a:a + k] = seq_pool[o:o + k]
+            buf[a + k:a + k + q] = qual_pool[o:o + q]
+    return buf, off
+
+
+def _reg2bin_vec(beg, end):
+    end = end - 1
+    out = np.zeros(beg.shape, np.int64)
+    done = np.zeros(beg.shape, bool)
+    for shift, base in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        hit = ~done & ((beg >> shift) == (end >> shift))
+        out[hit] = base + (beg[hit] >> shift)
+        done |= hit
+    return out
+
+
+class _Deflater:
+    """Raw deflate of one block: libdeflate through ctypes when the library is on the machine, zlib otherwise."""
+
+    def __init__(self, level=1):
+        import ctypes
+        self.level, self.ld, self.c = level, None, None
+        try:
+            ld = ctypes.CDLL("libdeflate.so.0")
+            ld.libdeflate_alloc_compressor.restype = ctypes.c_void_p
+            ld.libdeflate_alloc_compressor.argtypes = [ctypes.c_int]
+            ld.libdeflate_deflate_compress.restype = ctypes.c_size_t
+            ld.libdeflate_deflate_compress.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+            self.ld, self.c = ld, ld.libdeflate_alloc_compressor(level)
+            self.out = np.empty(_MAX_BLOCK + 1024, np.uint8)
+        except OSError:
+            pass
+
+    def __call__(self, chunk):
+        """chunk: contiguous uint8 array -> compressed bytes."""
+        if self.c:
+            k = self.ld.libdeflate_deflate_compress(self.c, chunk.ctypes.data, chunk.size, self.out.ctypes.data, self.out.size)
+            if k:
+                return self.out[:k].tobytes()
+        co = zlib.compressobj(self.level, zlib.DEFLATED, -15)
+        return co.compress(chunk.tobytes()) + co.flush()
+
+
+def bgzf_segment(stream, level=1):
+    """uint8 array -> (BGZF blocks without the EOF marker as bytes, file offset of every block relative to the segment
+    [n_blocks + 1]); blocks are cut every _MAX_BLOCK bytes."""
+    deflate = _Deflater(level)
+    out, coff, at = [], [], 0
+    for i in range(0, int(stream.size), _MAX_BLOCK):
+        chunk = stream[i:i + _MAX_BLOCK]
+        cdata = deflate(chunk)
+        blk = (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(cdata) + 25) + cdata
+               + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, chunk.size))
+        coff.append(at)
+        at += len(blk)
+        out.append(blk)
+    coff.append(at)
+    return b"".join(out), np.asarray(coff, np.int64)
+
+
+def encode_reference_segment(table, seq="random", seed=0, level=1):
+    """One reference's records as an independently compressed BGZF segment plus what the index needs:
+    -> dict(data=bytes, coff=block offsets, rec_off=record offsets in the uncompressed segment, pos, span, tid)."""
+    stream, rec_off = encode_record_stream(table, seq, seed)
+    data, coff = bgzf_segment(stream, level)
+    return {"data": data, "coff": coff, "rec_off": rec_off, "pos": table.pos.astype(np.int64), "span": reference_spans(table),
+            "tid": int(table.tid[0]) if len(table) else -1, "inflated": int(stream.size)}
+
+
+def write_bam_segments(path, references, lengths, segments, index=True):
+    """Header + the segments of :func:`encode_reference_segment` (ascending tid) + EOF marker -> ``path`` (+ ``.bai``)."""
+    text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (r, l) for r, l in zip(references, lengths))
+    head = [b"BAM\x01", struct.pack("<i", len(text)), text.encode(), struct.pack("<i", len(references))]
+    for r, l in zip(references, lengths):
+        head.append(struct.pack("<i", len(r) + 1) + r.encode() + b"\x00" + struct.pack("<i", l))
+    head_bytes = bgzf_compress(b"".join(head), 1)[:-len(_BGZF_EOF)]
+    bins = [dict() for _ in references]
+    linear = [dict() for _ in references]
+    with open(path, "wb") as f:
+        f.write(head_bytes)
+        base = len(head_bytes)
+        for seg in segments:
+            f.write(seg["data"])
+            if index and seg["tid"] >= 0:
+                t, coff, ro = seg["tid"], seg["coff"] + base, seg["rec_off"]
+                blk = ro // _MAX_BLOCK
+                v = (coff[np.minimum(blk, len(coff) - 1)] << 16) | np.where(blk < len(coff) - 1, ro - blk * _MAX_BLOCK, 0)
+                beg, end = seg["pos"], seg["pos"] + seg["span"]
+                rb = _reg2bin_vec(beg, end)
+                for i in range(len(beg)):
+                    chunks = bins[t].setdefault(int(rb[i]), [])
+                    v0, v1 = int(v[i]), int(v[i + 1])
+                    if chunks and chunks[-1][1] == v0:
+                        chunks[-1][1] = v1
+                    else:
+                        chunks.append([v0, v1])
+                    for w in range(int(beg[i]) >> 14, ((int(end[i]) - 1) >> 14) + 1):
+                        linear[t].setdefault(w, v0)
+            base += len(seg["data"])
+        f.write(_BGZF_EOF)
+    if index:
+        _dump_bai(path + ".bai", bins, linear)
+
+
+def _dump_bai(path, bins, linear):
+    out = [b"BAI\x01", struct.pack("<i", len(bins))]
+    for t in range(len(bins)):
         out.append(struct.pack("<i", len(bins[t])))
         for b, chunks in sorted(bins[t].items()):
             out.append(struct.pack("<Ii", b, len(chunks)) + b"".join(struct.pack("<QQ", c0, c1) for c0, c1 in chunks))

@@ -105,7 +105,8 @@ def distinct_sites(results):
 
 def stitch_windows(results, options, sample):
     """WindowResults of any number of chromosomes in task order -> {chrom: (VCF body text, score text)}: the
-    per-chromosome vote over the windows' held-back edge sites and their interior texts."""
+    per-chromosome vote over the windows' held-back edge sites and their interior texts.  ``sample``: the Sample, or a
+    callable chromosome -> Sample (file-driven runs hold one Sample per chromosome in flight, svision_amd/ingest.py)."""
     from .network.predict import ChromosomeVote
     out, cur, bufs = {}, None, None
     for res in results:
@@ -114,7 +115,7 @@ def stitch_windows(results, options, sample):
                 cur.finish()
             bufs = (io.StringIO(), io.StringIO())
             out[res.chrom] = bufs
-            cur = ChromosomeVote(res.chrom, bufs[0], bufs[1], options, sample)
+            cur = ChromosomeVote(res.chrom, bufs[0], bufs[1], options, sample(res.chrom) if callable(sample) else sample)
         elif out[res.chrom] is not bufs:
             raise ValueError("windows of %s are not contiguous in task order" % res.chrom)
         cur.add(res.head, res.vcf, res.scores, res.tail)
@@ -343,9 +344,11 @@ _POOL_STATE = {}
 
 def _worker_main(conn):
     """Helper process: never touches the GPU.  Protocol on the duplex pipe:
-       owner -> ("win", wid, chrom, start, end, scan of the window's rows or None)   helper -> ("rec", wid, records int32[n,12])
-       owner -> ("pred", wid, classes, probs)      helper -> ("done", wid, vcf, scores, n_sites, n_images, tsv, head, tail)
+       owner -> ("win", wid, key, chrom, start, end, scan of the window's rows or None)   helper -> ("rec", wid, records int32[n,12])
+       owner -> ("pred", wid, classes, probs)      helper -> ("done", wid, vcf, scores, n_sites, n_images, tsv, head, tail, ...)
        owner -> ("scan", min_sv, gaps.npy, gap_off.npy, stats.npy)   (HelperPool.attach_scan: helpers forked before the scan)
+       owner -> ("chrom", key, meta) / ("drop", key)   a chromosome of a file-driven run arrives in / leaves shared memory
+                                                        (ingest.ChromosomeFeed); key None = the Sample of the fork / "scan"
        owner -> ("stop",)"""
     sample, options = _POOL_STATE["sample"], _POOL_STATE["options"]
     from .segmentplot import run_hash_lineplot
@@ -362,30 +365,40 @@ def _worker_main(conn):
     gc.disable()
     held = {}
     n_done = 0
+    samples = {None: sample}
     while True:
         msg = conn.recv()
         if msg[0] == "stop":
             return
+        if msg[0] == "chrom":
+            if msg[1] not in samples:
+                from .ingest import load_shared_sample
+                samples[msg[1]] = load_shared_sample(msg[2], sample.fasta if sample is not None else _POOL_STATE.get("fasta"))
+            continue
+        if msg[0] == "drop":
+            samples.pop(msg[1], None)
+            continue
         if msg[0] == "scan":                                  # forked before the device scan existed: build the Sample now
             from .sample import Sample
             _t, min_sv, gaps, gap_off, stats = msg
             gaps, gap_off, stats = (np.load(p, mmap_mode="c") for p in (gaps, gap_off, stats))     # copy-on-write: windows' rescans land here
-            sample = Sample.with_scan(_POOL_STATE["table"], _POOL_STATE["fasta"], min_sv, (gaps, gap_off, stats))
+            sample = samples[None] = Sample.with_scan(_POOL_STATE["table"], _POOL_STATE["fasta"], min_sv, (gaps, gap_off, stats))
             continue
         if msg[0] == "win":
-            _t, wid, chrom, start, end, scan = msg
+            _t, wid, key, chrom, start, end, scan = msg
             t0 = time.perf_counter()
+            smp = samples[key]
             if scan is not None:
-                sample.apply_window_scan(*scan)
-            lines = _collect_lines(sample, options, chrom, start, end)
+                smp.apply_window_scan(*scan)
+            lines = _collect_lines(smp, options, chrom, start, end)
             recs = np.asarray([ln.record() for ln in lines], np.int32).reshape(-1, 12)
-            held[wid] = (chrom, lines, start, end, time.perf_counter() - t0)
+            held[wid] = (chrom, lines, start, end, time.perf_counter() - t0, smp)
             conn.send(("rec", wid, recs))
         elif msg[0] == "pred":
             _t, wid, classes, probs = msg
-            chrom, lines, start, end, t_collect = held.pop(wid)
+            chrom, lines, start, end, t_collect, smp = held.pop(wid)
             t0 = time.perf_counter()
-            vcf, scores, n_sites, head, tail = _vote(sample, options, chrom, lines, classes, probs, start, end)
+            vcf, scores, n_sites, head, tail = _vote(smp, options, chrom, lines, classes, probs, start, end)
             tsv = "".join(ln.text() for ln in lines) if _POOL_STATE.get("want_tsv") else None
             conn.send(("done", wid, vcf, scores, n_sites, len(lines), tsv, head, tail, (t_collect, time.perf_counter() - t0), _edge_regions(lines)))
             n_done += 1
@@ -446,11 +459,24 @@ class PooledHotPath(HotPath):
     """Owner process = device feeder; the helpers of a :class:`HelperPool` do the Python glue."""
 
     def __init__(self, sample, options, net, device="cuda", n_workers=8, n_streams=2, use_graph=True, max_inflight=3, launch_batches=4,
-                 want_tsv=False, pool=None):
+                 want_tsv=False, pool=None, feed=None):
         super().__init__(sample, options, net, device, n_streams, use_graph, launch_batches)
         self.pool = pool if pool is not None else HelperPool(n_workers, options, sample=sample, want_tsv=want_tsv)
         self.conns, self.procs = self.pool.conns, self.pool.procs
         self.max_inflight = max_inflight
+        from .ingest import StaticFeed
+        self.feed = feed if feed is not None else StaticFeed(sample)   # where a chromosome's Sample comes from
+
+    def release(self, chrom):
+        """A chromosome of a file-driven run is finished (voted, stitched): the helpers unmap it, the feed frees it."""
+        try:
+            key = self.feed.key_of(chrom)
+        except KeyError:
+            return
+        if key is not None:
+            for c in self.conns:
+                c.send(("drop", key))
+        self.feed.release(chrom)
 
     def close(self):
         self.pool.close()
@@ -484,8 +510,15 @@ class PooledHotPath(HotPath):
         while remaining:
             t = clock()
             while idle and nxt < len(windows):
-                ci = idle.pop()
                 chrom, start, end = windows[nxt]
+                key, smp = self.feed.get(chrom, block=False)          # file-driven runs: is the chromosome decoded + scanned yet?
+                for k, _c, meta in self.feed.take_fresh():            # tell the helpers where it lies in shared memory
+                    for c in self.conns:
+                        c.send(("chrom", k, meta))
+                if smp is None:
+                    prof["feed.not_ready"] += 1
+                    break
+                ci = idle.pop()
                 scan = None
                 if rescan:                                            # device scan of the window's block: the helper collects on ITS result
                     t_s = clock()
@@ -501,7 +534,7 @@ class PooledHotPath(HotPath):
                     t_s = lap("scan.sync", t_s)
                     scan = self.sample.last_window_scan if self.sample.finish_rescan(handle) else None
                     lap("scan.apply", t_s)
-                self.conns[ci].send(("win", nxt, chrom, start, end, scan))
+                self.conns[ci].send(("win", nxt, key, chrom, start, end, scan))
                 busy[ci] = nxt
                 nxt += 1
             t = lap("scan+send", t)
@@ -517,7 +550,11 @@ class PooledHotPath(HotPath):
                 prof["last_fetch_at"] = clock() - t_loop
             t = lap("fetch+send", t)
             waiting = [self.conns[ci] for ci in busy]
-            got = mpc.wait(waiting, timeout=0.0005 if inflight else 0.05)
+            if not waiting and not inflight and not ready and nxt < len(windows):
+                self.feed.poll(block=True)                            # nothing to do but wait for the next chromosome
+                lap("feed.wait", t)
+                continue
+            got = mpc.wait(waiting, timeout=0.0005 if inflight else (0.002 if nxt < len(windows) and idle else 0.05))
             lap("wait", t)
             if not got and not inflight and not ready:
                 dead = [ci for ci in busy if not self.procs[ci].is_alive()]

@@ -292,3 +292,117 @@ def test_fasta_gzip_and_bgzip(tmp_path):
         for name in a.references:
             assert b.get_reference_length(name) == a.get_reference_length(name)
             assert b.fetch(name, 1234, 2345) == a.fetch(name, 1234, 2345)
+
+
+def _stream_parts(path, **kw):
+    return list(bam.BamStream(path, **kw))
+
+
+@pytest.mark.parametrize("chunk", [None, "900", "30000"])
+def test_bam_stream_yields_one_table_per_reference(tmp_path, chunk):
+    """svx_bam_stream_*: the parts, reference by reference, are the rows of the whole-file decode (QNAME ids restart per
+    part); with / without an index, a subset of the references, tiny chunks (every record and block straddles reads),
+    read bases kept."""
+    import pickle
+    import subprocess
+    import sys
+    cfg = synth.SimConfig(contigs=[("c1", 260_000), ("c2", 10_000), ("c3", 150_000), ("c4", 90_000)], coverage=6, read_len_mean=5000,
+                          read_len_sd=800, sv_spacing=9000, sv_min_gap=5000, sv_max=1000, seed=33)
+    table, _g, _ = synth.simulate(cfg, with_genome=False, with_seq=True)
+    table = table.subset(np.flatnonzero(table.tid != 1))          # a reference without records in the middle
+    path = str(tmp_path / "st.bam")
+    bam.write_bam(path, table, index=True)
+    whole = bam.read_bam_python(path, with_seq=True)
+    if chunk is not None:                                          # the chunk size is read once per process
+        code = ("import sys, pickle; sys.path.insert(0, %r); from svision_amd.io import bam; "
+                "pickle.dump([[(t.tid, t.pos, t.flag, t.mapq, t.l_seq, t.name_id, t.names, t.cigar, t.cig_off, t.references) "
+                "for t in bam.BamStream(%r, **kw)] for kw in ({}, {'tids': [3, 0]})], sys.stdout.buffer)" % (ROOT, path))
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SVX_BAM_CHUNK=chunk), capture_output=True, timeout=120)
+        assert out.returncode == 0, out.stderr.decode()
+        runs = pickle.loads(out.stdout)
+        for parts, tids in zip(runs, ([0, 2, 3], [0, 3])):
+            assert [int(p[0][0]) for p in parts] == tids
+            for p in parts:
+                ref = whole.subset(np.flatnonzero(whole.tid == int(p[0][0])))
+                for k, name in enumerate(("tid", "pos", "flag", "mapq", "l_seq", "name_id")):
+                    assert np.array_equal(p[k], getattr(ref, name)), name
+                assert p[6] == ref.names and np.array_equal(p[7], ref.cigar) and np.array_equal(p[8], ref.cig_off) and p[9] == ref.references
+        return
+    for kw, tids in (({}, [0, 2, 3]), ({"tids": [2]}, [2]), ({"tids": [3, 0]}, [0, 3]), ({"tids": [1]}, []), ({"with_seq": True, "threads": 3}, [0, 2, 3])):
+        parts = _stream_parts(path, **kw)
+        assert [int(p.tid[0]) for p in parts] == tids
+        for p in parts:
+            ref = whole.subset(np.flatnonzero(whole.tid == int(p.tid[0])))
+            _same(p, ref)
+            if kw.get("with_seq"):
+                rows = np.flatnonzero(whole.tid == int(p.tid[0]))
+                assert [p.query_sequence(i) for i in range(0, len(p), 11)] == [whole.query_sequence(int(rows[i])) for i in range(0, len(p), 11)]
+    os.remove(path + ".bai")                                       # no index: the whole file is streamed, unwanted references skipped
+    parts = _stream_parts(path, tids=[2])
+    assert len(parts) == 1 and int(parts[0].tid[0]) == 2
+    _same(parts[0], whole.subset(np.flatnonzero(whole.tid == 2)))
+
+
+def test_bam_stream_reports_damage_and_can_be_abandoned(tmp_path):
+    cfg = synth.SimConfig(contigs=[("c1", 150_000), ("c2", 100_000)], coverage=5, read_len_mean=4000, read_len_sd=500, seed=5)
+    table, _g, _ = synth.simulate(cfg, with_genome=False)
+    good = str(tmp_path / "good.bam")
+    bam.write_bam(good, table, index=True)
+    raw = open(good, "rb").read()
+    cut = str(tmp_path / "cut.bam")
+    with open(cut, "wb") as f:
+        f.write(raw[:len(raw) * 2 // 3])
+    with pytest.raises(ValueError):
+        _stream_parts(cut)
+    with pytest.raises(ValueError):
+        bam.BamStream(str(tmp_path / "nope.bam"))
+    junk = str(tmp_path / "junk.bam")
+    with open(junk, "wb") as f:
+        f.write(b"not a bam" * 50)
+    with pytest.raises(ValueError):
+        bam.BamStream(junk)
+    s = bam.BamStream(good)                                        # closed with parts still queued and threads running
+    first = next(s)
+    assert int(first.tid[0]) == 0
+    s.close()
+    # unmapped records without a position (tid -1) come last, as their own part
+    t2 = bam.read_bam(good)
+    t2.tid[-3:] = -1
+    t2.pos[-3:] = -1
+    t2.flag[-3:] |= 4
+    um = str(tmp_path / "um.bam")
+    bam.write_bam(um, t2)
+    assert [int(p.tid[0]) for p in _stream_parts(um)] == [0, 1, -1]
+
+
+def test_segment_writer_round_trip_and_index(tmp_path):
+    """bench.py's fast writer (NumPy record stream, random SEQ / binned QUAL, one BGZF segment per reference): the file
+    decodes to the tables it was made from, by the Python decoder, the native one, the stream, and through the index."""
+    cfg = synth.SimConfig(contigs=[("c1", 200_000), ("c2", 90_000), ("c3", 120_000)], coverage=6, read_len_mean=5000, read_len_sd=800,
+                          sv_spacing=9000, sv_min_gap=5000, sv_max=1000, seed=17)
+    table, _g, _ = synth.simulate(cfg, with_genome=False)
+    parts = [table.subset(np.flatnonzero(table.tid == t)) for t in (0, 1, 2)]
+    segs = [bam.encode_reference_segment(p, seq="random", seed=3 + i) for i, p in enumerate(parts)]
+    path = str(tmp_path / "seg.bam")
+    bam.write_bam_segments(path, table.references, table.lengths, segs)
+    for back in (bam.read_bam_python(path), bam.read_bam(path, threads=3)):
+        for f in ("tid", "pos", "flag", "mapq", "l_seq", "cigar", "cig_off"):
+            assert np.array_equal(getattr(back, f), getattr(table, f)), f
+        assert [back.names[i] for i in back.name_id] == [table.names[i] for i in table.name_id]
+    with_seq = bam.read_bam(path, with_seq=True)
+    s = with_seq.query_sequence(5)
+    assert len(s) == int(table.l_seq[5]) and set(s) <= set("ACGT") and len(set(s)) == 4
+    for tids in ([1], [2, 0]):
+        got = list(bam.BamStream(path, tids=tids))
+        assert [int(t.tid[0]) for t in got] == sorted(tids)
+        for t in got:
+            _same(t, bam.read_bam(path, tids=[int(t.tid[0])]))
+            want = parts[int(t.tid[0])]
+            assert np.array_equal(t.cigar, want.cigar) and np.array_equal(t.pos, want.pos)
+    size = os.path.getsize(path)
+    bases = int(table.l_seq.sum())
+    assert 0.3 < size / bases < 0.8                                # realistic: ~0.5 compressed bytes per base, not the 0.02 of N / 0xFF
+    plain = str(tmp_path / "plain.bam")
+    bam.write_bam(plain, table, index=True)                         # both writers index the same record set
+    a, b = bam.read_bai(path + ".bai"), bam.read_bai(plain + ".bai")
+    assert [x is None for x in a] == [x is None for x in b]
