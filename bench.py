@@ -222,6 +222,7 @@ def main():
                     help="windows of the file-inclusive leg (`e2e` block): the job cut to that many windows is written as a BAM (+ .bai, "
                          "random bases, binned qualities) to local disk during set-up and run from the file -- BGZF inflate on host threads, "
                          "upload, device scan, pipeline -- in a timed region of its own; 0 = skip")
+    ap.add_argument("--decode-threads", type=int, default=0, help="inflate threads of the e2e leg per rank (default: cores / ranks - helpers - 2, at most 128)")
     ap.add_argument("--bam-dir", default=None, help="where the synthetic BAM of the e2e leg is written (default: the temp directory)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-calibration", action="store_true", help="skip the per-kernel timings outside the timed region")
@@ -404,7 +405,7 @@ def run_from_file(args, e2e, hot, run, fasta, opts, dev, sync_all, cores, world,
     from svision_amd.ingest import ChromosomeFeed, StaticFeed
     refs = e2e["references"]
     lens = [fasta.get_reference_length(n) for n in refs]
-    threads = max(1, min(64, cores // world - workers - 2))
+    threads = args.decode_threads or max(1, min(128, cores // world - workers - 2))
     resident = hot.feed
     sync_all()
     t0 = time.perf_counter()

@@ -237,7 +237,7 @@ int svx_hash_seeds(const uint8_t* d_bases, const SvxHashJob* d_jobs, uint32_t n_
  * src/collection/run_collection.py:23-26, field reads at src/collection/collect_signatures.py:128-155):
  * the file is streamed in chunks of BGZF blocks (block-parallel inflate) and the records' fields are appended to
  * packed arrays; SEQ is kept only on request, QUAL and tags never (resident size = the arrays, not the file).
- *   svx_bam_open    -> opaque handle or NULL (svx_bam_error() tells why); threads <= 0: all cores (max 64);
+ *   svx_bam_open    -> opaque handle or NULL (svx_bam_error() tells why); threads <= 0: all cores (max 128);
  *                      flags: SVX_BAM_KEEP_SEQ keeps the 4-bit read bases (the --hash re-aligner needs them)
  *   svx_bam_sizes   -> sizes[8] = n_records, n_cigar_words, n_refs, n_names, names_bytes, header_bytes,
  *                      ref_names_bytes, seq_bytes
@@ -263,7 +263,7 @@ void           svx_bam_close(void* handle);
  * to the caller while chromosome k+1 is being read and inflated on the handle's own threads):
  *   svx_bam_stream_open  -> opaque stream or NULL (svx_bam_error()); voffs = n_ranges pairs of BGZF virtual offsets
  *                           from the .bai (a rank's chromosomes, ascending), n_ranges = 0: every record of the file;
- *                           threads <= 0: the CPUs of the process (max 64); flags as svx_bam_open
+ *                           threads <= 0: the CPUs of the process (max 128); flags as svx_bam_open
  *   svx_bam_stream_next  -> the next reference's records as a handle for svx_bam_sizes / svx_bam_export /
  *                           svx_bam_seq / svx_bam_close (QNAME ids count from 0 in every part), or NULL with
  *                           *status = 0 at the end, -1 on error; blocks while that part is being decoded

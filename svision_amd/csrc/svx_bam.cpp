@@ -10,7 +10,11 @@
 // input), not that of the file.  SAMv1 section 4 layouts, including CIGARs with more than 65535 operations
 // (CG:B,I tag).  With two virtual offsets from the .bai index only that byte range is read.
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -257,22 +261,59 @@ private:
     bool stop_ = false;
 };
 
+// The file, memory mapped read-only: blocks are inflated straight out of the page cache (no read buffer, no copy);
+// on a cold file the kernel's read-ahead, nudged one chunk ahead with MADV_WILLNEED, overlaps the I/O with the inflate.
+struct MappedFile {
+    int fd = -1;
+    const uint8_t* p = nullptr;
+    uint64_t n = 0;
+    std::string error;
+    bool open(const char* path)
+    {
+        fd = ::open(path, O_RDONLY);
+        if (fd < 0) { error = std::string("cannot open ") + path; return false; }
+        struct stat st;
+        if (fstat(fd, &st) != 0) { error = std::string("cannot stat ") + path; return false; }
+        n = (uint64_t)st.st_size;
+        if (n == 0) return true;
+        void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) { error = std::string("cannot map ") + path; return false; }
+        p = static_cast<const uint8_t*>(m);
+        madvise(m, n, MADV_SEQUENTIAL);
+        return true;
+    }
+    void will_need(uint64_t from, uint64_t bytes) const
+    {
+        if (!p || from >= n) return;
+        const uint64_t a = from & ~4095ull;
+        madvise(const_cast<uint8_t*>(p) + a, std::min(n - a, bytes + 4096), MADV_WILLNEED);
+    }
+    ~MappedFile()
+    {
+        if (p) munmap(const_cast<uint8_t*>(p), n);
+        if (fd >= 0) ::close(fd);
+    }
+};
+
 // Sequential reader of the whole BGZF blocks of file[pos, end): next() appends the inflated bytes of the next
 // chunk of blocks to `out`.
 class BgzfStream {
 public:
-    size_t chunk;                                        // compressed bytes read per step
+    size_t chunk;                                        // compressed bytes per step (at least one block)
     static constexpr uint64_t MAX_INFLATED = 96ull << 20; // inflated bytes per step (keeps the stream buffer cache sized)
 
-    BgzfStream(FILE* f, uint64_t pos, uint64_t end, Pool* pool, size_t first_chunk)
-        : chunk(first_chunk), f_(f), pos_(pos), end_(end), pool_(pool)
+    // end == ~0ull: to the end of the file, which must then end with a whole block; otherwise a byte range that may be
+    // cut inside its last block (callers ask for one block more than they need)
+    BgzfStream(const MappedFile* mf, uint64_t pos, uint64_t end, Pool* pool, size_t first_chunk)
+        : chunk(first_chunk), mf_(mf), pos_(std::min<uint64_t>(pos, mf->n)), end_(std::min<uint64_t>(end, mf->n)), strict_(end == ~0ull),
+          pool_(pool)
     {
-        fseeko(f_, (off_t)pos, SEEK_SET);
+        if (pos_ >= end_) eof_ = true;
     }
-    // compressed file offset of the first block of the last chunk, and of every block in it with its position in `out`
+    // compressed file offset of every block of the last chunk with its position in `out`
     struct Block { uint64_t coff, dst; uint32_t isize, csize; };   // file offset, position in `out`, inflated / whole-block bytes
     const std::vector<Block>& blocks() const { return blocks_; }
-    bool done() const { return eof_ && carry_.empty(); }
+    bool done() const { return eof_; }
     const std::string& error() const { return err_; }
 
     // false on error (error() says why); appends nothing when done()
@@ -280,71 +321,63 @@ public:
     {
         blocks_.clear();
         if (done()) return true;
-        const size_t have = carry_.size();
-        // (no new read while the carry still holds whole blocks the inflated-size cap left over: highly compressible input)
-        const uint64_t want = capped_ ? 0 : std::min<uint64_t>(chunk, end_ - pos_);
-        cbuf_.resize(have + want);
-        if (have) memcpy(cbuf_.data(), carry_.data(), have);
-        const double t_read = BamClock::now();
-        const size_t got = want ? fread(cbuf_.data() + have, 1, want, f_) : 0;
-        g_clock.read += BamClock::now() - t_read;
-        if (got < want) eof_ = true;
-        cbuf_.resize(have + got);
-        const uint64_t base = pos_ - have;                 // file offset of cbuf_[0]
-        pos_ += got;
-        if (pos_ >= end_) eof_ = true;
+        const uint8_t* base = mf_->p;
         struct Src { uint64_t data, csize; };
         std::vector<Src> src;
-        uint64_t p = 0, total = out.size();
-        while (p + 18 <= cbuf_.size()) {
-            if (!(cbuf_[p] == 0x1f && cbuf_[p + 1] == 0x8b && cbuf_[p + 2] == 8 && (cbuf_[p + 3] & 4))) { err_ = "not a BGZF block"; return false; }
-            const uint32_t xlen = rd16(&cbuf_[p + 10]);
-            if (p + 12 + xlen > cbuf_.size()) break;
+        uint64_t p = pos_, total = out.size();
+        const uint64_t first_total = total;
+        while (p < end_) {
+            if (p + 18 > end_) break;                                  // not even a block header left
+            if (!(base[p] == 0x1f && base[p + 1] == 0x8b && base[p + 2] == 8 && (base[p + 3] & 4))) { err_ = "not a BGZF block"; return false; }
+            const uint32_t xlen = rd16(&base[p + 10]);
+            if (p + 12 + xlen > end_) break;
             uint32_t bsize = 0;
             bool found = false;
             for (uint64_t q = p + 12; q + 4 <= p + 12 + xlen;) {
-                const uint32_t slen = rd16(&cbuf_[q + 2]);
-                if (cbuf_[q] == 'B' && cbuf_[q + 1] == 'C') { bsize = rd16(&cbuf_[q + 4]); found = true; }
+                const uint32_t slen = rd16(&base[q + 2]);
+                if (base[q] == 'B' && base[q + 1] == 'C') { bsize = rd16(&base[q + 4]); found = true; }
                 q += 4 + slen;
             }
             if (!found) { err_ = "corrupt BGZF block"; return false; }
-            if (p + bsize + 1 > cbuf_.size()) break;       // partial block: wait for the next read
+            if (p + bsize + 1 > end_) break;                            // the range (or the file) ends inside this block
             const uint64_t data = p + 12 + xlen, end = p + bsize + 1;
             if (end < data + 8) { err_ = "corrupt BGZF block"; return false; }
-            const uint32_t isize = rd32(&cbuf_[end - 4]);
+            const uint32_t isize = rd32(&base[end - 4]);
             src.push_back({data, end - 8 - data});
-            blocks_.push_back({base + p, total, isize, (uint32_t)(end - p)});
+            blocks_.push_back({p, total, isize, (uint32_t)(end - p)});
             total += isize;
             p = end;
-            if (total - out.size() >= MAX_INFLATED) break;  // highly compressible input: the rest waits in the carry
+            if (p - pos_ >= chunk || total - first_total >= MAX_INFLATED) break;
         }
-        const bool capped = total - out.size() >= MAX_INFLATED && p != cbuf_.size();
-        capped_ = capped;
-        if (eof_ && p != cbuf_.size() && !capped) {
-            if (end_ == ~0ull) { err_ = "truncated BGZF file"; return false; }
-            // a byte range cut in the middle of its last block: callers ask for one block more than they need
+        if (blocks_.empty()) {                                          // nothing whole is left
+            if (strict_ && p < end_) { err_ = "truncated BGZF file"; return false; }
+            eof_ = true;
+            return true;
         }
+        pos_ = p;
+        if (pos_ >= end_) eof_ = true;
+        else if (strict_ == false && pos_ + 18 > end_) eof_ = true;
+        mf_->will_need(pos_, 2 * (uint64_t)chunk);
         const double t_inf = BamClock::now();
         out.resize(total);
         std::atomic<bool> ok{true};
-        pool_->run(src.size(), 8, [&](size_t lo, size_t hi) {          // slices of 8 blocks (~0.5 MB inflated) from a shared counter
+        // slices from a shared counter, about eight per thread: the blocks of a chunk inflate at different speeds
+        pool_->run(src.size(), std::max<size_t>(1, src.size() / (8 * (size_t)pool_->size())), [&](size_t lo, size_t hi) {
             BlockInflater inflate_block;
             for (size_t i = lo; i < hi && ok; ++i)
-                if (!inflate_block(&cbuf_[src[i].data], src[i].csize, out.data() + blocks_[i].dst, blocks_[i].isize)) { ok = false; return; }
+                if (!inflate_block(&base[src[i].data], src[i].csize, out.data() + blocks_[i].dst, blocks_[i].isize)) { ok = false; return; }
         });
         g_clock.inflate += BamClock::now() - t_inf;
         if (!ok) { err_ = "BGZF inflate failed"; return false; }
-        carry_.assign(cbuf_.begin() + p, cbuf_.end());
-        if (eof_ && !capped) carry_.clear();
         return true;
     }
 
 private:
-    FILE* f_;
+    const MappedFile* mf_;
     uint64_t pos_, end_;
+    bool strict_;
     Pool* pool_;
-    bool eof_ = false, capped_ = false;
-    std::vector<uint8_t> cbuf_, carry_;
+    bool eof_ = false;
     std::vector<Block> blocks_;
     std::string err_;
 };
@@ -467,13 +500,15 @@ void* bam_open_impl(const char* path, int threads, int flags, bool ranged, uint6
     g_bam_error.clear();
     if (threads <= 0) threads = default_threads();        // the CPUs this process may run on (not the machine's), at most 64
     const bool keep_seq = flags & SVX_BAM_KEEP_SEQ;
-    FILE* f = fopen(path, "rb");
-    if (!f) { g_bam_error = std::string("cannot open ") + path; return nullptr; }
+    MappedFile file;
+    const MappedFile* f = &file;
+    if (!file.open(path)) { g_bam_error = file.error; return nullptr; }
+    if (file.n == 0) { g_bam_error = "empty file"; return nullptr; }
     Pool workers(threads);
     Pool* pool = &workers;
     std::unique_ptr<Bam> b(new Bam());
     RawBuf buf;
-    auto fail = [&](const std::string& why) -> void* { g_bam_error = why; fclose(f); return nullptr; };
+    auto fail = [&](const std::string& why) -> void* { g_bam_error = why; return nullptr; };
 
     // header: from the start of the file, chunk by chunk until the reference dictionary is complete
     // SVX_BAM_CHUNK (bytes) shrinks the read size so that tests cross chunk boundaries on small files
@@ -528,7 +563,6 @@ void* bam_open_impl(const char* path, int threads, int flags, bool ranged, uint6
         }
         if (!reached) return fail("BAM index does not match the file");
     }
-    fclose(f);
     if (getenv("SVX_TIMING"))
         fprintf(stderr, "svx_bam_open (%d threads, %s): read %.3f s, inflate %.3f s, chain records %.3f s, scatter fields %.3f s\n", threads,
                 deflate_lib().fast() ? "libdeflate" : "zlib", g_clock.read, g_clock.inflate, g_clock.chain, g_clock.scatter);
@@ -558,7 +592,7 @@ struct Stream {
         bool fresh = true;                                    // first chunk of a range: no carry from the chunk before
     };
     std::string path;
-    FILE* f = nullptr;
+    MappedFile file;
     int flags = 0;
     std::unique_ptr<Pool> inflate_pool, scatter_pool;
     std::vector<std::pair<uint64_t, uint64_t>> ranges;       // virtual offsets; empty: everything behind the header
@@ -582,7 +616,6 @@ struct Stream {
         cv.notify_all();
         if (feeder.joinable()) feeder.join();
         if (parser.joinable()) parser.join();
-        if (f) fclose(f);
     }
 
     void fail(const std::string& why)
@@ -597,14 +630,14 @@ struct Stream {
     void feed()
     {
         const char* env = getenv("SVX_BAM_CHUNK");
-        const size_t steady = env && atol(env) > 0 ? (size_t)atol(env) : (16u << 20);
+        const size_t steady = env && atol(env) > 0 ? (size_t)atol(env) : (48u << 20);      // ~100 MB inflated per step
         std::vector<std::pair<uint64_t, uint64_t>> todo = ranges;
         if (todo.empty()) todo.push_back({body_voff, ~0ull});
         for (const auto& r : todo) {
             const bool open_end = r.second == ~0ull;
             if (!open_end && r.second <= r.first) continue;
             const uint64_t c0 = r.first >> 16, c1 = open_end ? ~0ull : r.second >> 16;
-            BgzfStream body(f, c0, open_end ? ~0ull : c1 + 65536 + 26, inflate_pool.get(), steady);
+            BgzfStream body(&file, c0, open_end ? ~0ull : c1 + 65536 + 26, inflate_pool.get(), steady);
             bool first = true, reached = false;
             std::unique_ptr<Chunk> ch;
             while (!reached) {
@@ -761,7 +794,7 @@ int default_threads()
 {
     cpu_set_t set;
     const int avail = sched_getaffinity(0, sizeof set, &set) == 0 ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
-    return std::max(1, std::min(64, avail));
+    return std::max(1, std::min(128, avail));
 }
 
 }  // namespace
@@ -828,8 +861,8 @@ void* svx_bam_stream_open(const char* path, int threads, int flags, const uint64
     std::unique_ptr<Stream> s(new Stream());
     s->path = path;
     s->flags = flags;
-    s->f = fopen(path, "rb");
-    if (!s->f) { g_bam_error = std::string("cannot open ") + path; return nullptr; }
+    if (!s->file.open(path)) { g_bam_error = s->file.error; return nullptr; }
+    if (s->file.n == 0) { g_bam_error = "empty file"; return nullptr; }
     for (int i = 0; i < n_ranges; ++i) s->ranges.push_back({voffs[2 * i], voffs[2 * i + 1]});
     // the parser's field scatter is a few memcpy per record: a handful of threads; everything else inflates
     const int scatter = std::max(1, std::min(8, threads / 8));
@@ -837,7 +870,7 @@ void* svx_bam_stream_open(const char* path, int threads, int flags, const uint64
     s->scatter_pool.reset(new Pool(scatter));
     {   // header: synchronously, from the start of the file; remembers where the records begin
         RawBuf buf;
-        BgzfStream head(s->f, 0, ~0ull, s->inflate_pool.get(), 256u << 10);
+        BgzfStream head(&s->file, 0, ~0ull, s->inflate_pool.get(), 256u << 10);
         long long hdr = 0;
         std::vector<BgzfStream::Block> seen;
         while (hdr == 0) {

@@ -157,7 +157,9 @@ class DeviceStage:
                 s.synchronize()
                 if use_graph:
                     graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph, stream=s):
+                    # thread_local: the feeder thread of a file-driven run (ingest.ChromosomeFeed) uploads and synchronises on
+                    # its own stream while this thread captures; in the default global mode any such call invalidates the capture
+                    with torch.cuda.graph(graph, stream=s, capture_error_mode="thread_local"):
                         self._body(rec, out)
                 slot[size] = (rec, out, graph)
             self.slots.append(slot)
