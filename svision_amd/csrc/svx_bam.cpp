@@ -261,123 +261,130 @@ private:
     bool stop_ = false;
 };
 
-// The file, memory mapped read-only: blocks are inflated straight out of the page cache (no read buffer, no copy);
-// on a cold file the kernel's read-ahead, nudged one chunk ahead with MADV_WILLNEED, overlaps the I/O with the inflate.
-struct MappedFile {
-    int fd = -1;
-    const uint8_t* p = nullptr;
-    uint64_t n = 0;
-    std::string error;
-    bool open(const char* path)
-    {
-        fd = ::open(path, O_RDONLY);
-        if (fd < 0) { error = std::string("cannot open ") + path; return false; }
-        struct stat st;
-        if (fstat(fd, &st) != 0) { error = std::string("cannot stat ") + path; return false; }
-        n = (uint64_t)st.st_size;
-        if (n == 0) return true;
-        void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
-        if (m == MAP_FAILED) { error = std::string("cannot map ") + path; return false; }
-        p = static_cast<const uint8_t*>(m);
-        madvise(m, n, MADV_SEQUENTIAL);
-        return true;
-    }
-    void will_need(uint64_t from, uint64_t bytes) const
-    {
-        if (!p || from >= n) return;
-        const uint64_t a = from & ~4095ull;
-        madvise(const_cast<uint8_t*>(p) + a, std::min(n - a, bytes + 4096), MADV_WILLNEED);
-    }
-    ~MappedFile()
-    {
-        if (p) munmap(const_cast<uint8_t*>(p), n);
-        if (fd >= 0) ::close(fd);
-    }
+// A run of whole BGZF blocks, still compressed (what the reader thread hands to the inflating one).
+struct CChunk {
+    struct Blk { uint64_t coff; uint32_t data, csize, isize, bsize; };   // file offset; payload offset / size in `bytes`; inflated size; block size
+    std::vector<uint8_t> bytes;
+    std::vector<Blk> blk;
+    uint64_t inflated = 0;
 };
 
-// Sequential reader of the whole BGZF blocks of file[pos, end): next() appends the inflated bytes of the next
-// chunk of blocks to `out`.
-class BgzfStream {
+// Sequential reader of file[pos, end): read() fills a CChunk with the next whole blocks (about `want` compressed bytes,
+// at most MAX_INFLATED inflated ones); a block cut by a read stays in the carry.  One fread per chunk: the page cache
+// (or the disk) is copied once, by one thread, while other threads inflate the chunk before.
+class BgzfReader {
 public:
-    size_t chunk;                                        // compressed bytes per step (at least one block)
-    static constexpr uint64_t MAX_INFLATED = 96ull << 20; // inflated bytes per step (keeps the stream buffer cache sized)
-
+    static constexpr uint64_t MAX_INFLATED = 96ull << 20;
     // end == ~0ull: to the end of the file, which must then end with a whole block; otherwise a byte range that may be
     // cut inside its last block (callers ask for one block more than they need)
-    BgzfStream(const MappedFile* mf, uint64_t pos, uint64_t end, Pool* pool, size_t first_chunk)
-        : chunk(first_chunk), mf_(mf), pos_(std::min<uint64_t>(pos, mf->n)), end_(std::min<uint64_t>(end, mf->n)), strict_(end == ~0ull),
-          pool_(pool)
-    {
-        if (pos_ >= end_) eof_ = true;
-    }
-    // compressed file offset of every block of the last chunk with its position in `out`
-    struct Block { uint64_t coff, dst; uint32_t isize, csize; };   // file offset, position in `out`, inflated / whole-block bytes
-    const std::vector<Block>& blocks() const { return blocks_; }
-    bool done() const { return eof_; }
+    BgzfReader(FILE* f, uint64_t pos, uint64_t end) : f_(f), pos_(pos), end_(end), strict_(end == ~0ull) { fseeko(f_, (off_t)pos, SEEK_SET); }
+    bool done() const { return eof_ && carry_.empty(); }
     const std::string& error() const { return err_; }
+    double seconds = 0;                                     // spent in fread
 
-    // false on error (error() says why); appends nothing when done()
-    bool next(RawBuf& out)
+    bool read(CChunk& c, size_t want)                       // false on error; c.blk empty: nothing (more) to read
     {
-        blocks_.clear();
+        c.blk.clear();
+        c.inflated = 0;
         if (done()) return true;
-        const uint8_t* base = mf_->p;
-        struct Src { uint64_t data, csize; };
-        std::vector<Src> src;
-        uint64_t p = pos_, total = out.size();
-        const uint64_t first_total = total;
-        while (p < end_) {
-            if (p + 18 > end_) break;                                  // not even a block header left
-            if (!(base[p] == 0x1f && base[p + 1] == 0x8b && base[p + 2] == 8 && (base[p + 3] & 4))) { err_ = "not a BGZF block"; return false; }
-            const uint32_t xlen = rd16(&base[p + 10]);
-            if (p + 12 + xlen > end_) break;
+        const size_t have = carry_.size();
+        const uint64_t ask = capped_ ? 0 : std::min<uint64_t>(want, end_ - pos_);   // no new read while the carry holds whole blocks
+        c.bytes.resize(have + ask);
+        if (have) memcpy(c.bytes.data(), carry_.data(), have);
+        const double t0 = BamClock::now();
+        const size_t got = ask ? fread(c.bytes.data() + have, 1, ask, f_) : 0;
+        seconds += BamClock::now() - t0;
+        if (got < ask) eof_ = true;
+        c.bytes.resize(have + got);
+        const uint64_t base = pos_ - have;                  // file offset of bytes[0]
+        pos_ += got;
+        if (pos_ >= end_) eof_ = true;
+        const std::vector<uint8_t>& b = c.bytes;
+        uint64_t p = 0;
+        while (p + 18 <= b.size()) {
+            if (!(b[p] == 0x1f && b[p + 1] == 0x8b && b[p + 2] == 8 && (b[p + 3] & 4))) { err_ = "not a BGZF block"; return false; }
+            const uint32_t xlen = rd16(&b[p + 10]);
+            if (p + 12 + xlen > b.size()) break;
             uint32_t bsize = 0;
             bool found = false;
             for (uint64_t q = p + 12; q + 4 <= p + 12 + xlen;) {
-                const uint32_t slen = rd16(&base[q + 2]);
-                if (base[q] == 'B' && base[q + 1] == 'C') { bsize = rd16(&base[q + 4]); found = true; }
+                const uint32_t slen = rd16(&b[q + 2]);
+                if (b[q] == 'B' && b[q + 1] == 'C') { bsize = rd16(&b[q + 4]); found = true; }
                 q += 4 + slen;
             }
             if (!found) { err_ = "corrupt BGZF block"; return false; }
-            if (p + bsize + 1 > end_) break;                            // the range (or the file) ends inside this block
+            if (p + bsize + 1 > b.size()) break;            // partial block: wait for the next read
             const uint64_t data = p + 12 + xlen, end = p + bsize + 1;
             if (end < data + 8) { err_ = "corrupt BGZF block"; return false; }
-            const uint32_t isize = rd32(&base[end - 4]);
-            src.push_back({data, end - 8 - data});
-            blocks_.push_back({p, total, isize, (uint32_t)(end - p)});
-            total += isize;
+            const uint32_t isize = rd32(&b[end - 4]);
+            c.blk.push_back({base + p, (uint32_t)data, (uint32_t)(end - 8 - data), isize, (uint32_t)(end - p)});
+            c.inflated += isize;
             p = end;
-            if (p - pos_ >= chunk || total - first_total >= MAX_INFLATED) break;
+            if (c.inflated >= MAX_INFLATED) break;           // highly compressible input: the rest waits in the carry
         }
-        if (blocks_.empty()) {                                          // nothing whole is left
-            if (strict_ && p < end_) { err_ = "truncated BGZF file"; return false; }
-            eof_ = true;
-            return true;
-        }
-        pos_ = p;
-        if (pos_ >= end_) eof_ = true;
-        else if (strict_ == false && pos_ + 18 > end_) eof_ = true;
-        mf_->will_need(pos_, 2 * (uint64_t)chunk);
-        const double t_inf = BamClock::now();
-        out.resize(total);
-        std::atomic<bool> ok{true};
-        // slices from a shared counter, about eight per thread: the blocks of a chunk inflate at different speeds
-        pool_->run(src.size(), std::max<size_t>(1, src.size() / (8 * (size_t)pool_->size())), [&](size_t lo, size_t hi) {
-            BlockInflater inflate_block;
-            for (size_t i = lo; i < hi && ok; ++i)
-                if (!inflate_block(&base[src[i].data], src[i].csize, out.data() + blocks_[i].dst, blocks_[i].isize)) { ok = false; return; }
-        });
-        g_clock.inflate += BamClock::now() - t_inf;
+        capped_ = c.inflated >= MAX_INFLATED && p != b.size();
+        if (eof_ && p != b.size() && !capped_ && strict_) { err_ = "truncated BGZF file"; return false; }
+        // (a byte range cut in the middle of its last block: callers ask for one block more than they need)
+        carry_.assign(b.begin() + p, b.end());
+        if (eof_ && !capped_) carry_.clear();
+        return true;
+    }
+
+private:
+    FILE* f_;
+    uint64_t pos_, end_;
+    bool strict_, eof_ = false, capped_ = false;
+    std::vector<uint8_t> carry_;
+    std::string err_;
+};
+
+// position of a block's inflated bytes in an output buffer
+struct OutBlock { uint64_t coff, dst; uint32_t isize, csize; };
+
+// Inflates the blocks of `c` behind out.size(), block-parallel on `pool`; `blocks` receives where each one went.
+bool inflate_chunk(const CChunk& c, RawBuf& out, Pool* pool, std::vector<OutBlock>* blocks)
+{
+    blocks->clear();
+    uint64_t total = out.size();
+    for (const auto& k : c.blk) { blocks->push_back({k.coff, total, k.isize, k.bsize}); total += k.isize; }
+    out.resize(total);
+    std::atomic<bool> ok{true};
+    const std::vector<OutBlock>& ob = *blocks;
+    // slices from a shared counter, about eight per thread: the blocks of a chunk inflate at different speeds
+    pool->run(c.blk.size(), std::max<size_t>(1, c.blk.size() / (8 * (size_t)pool->size())), [&](size_t lo, size_t hi) {
+        thread_local BlockInflater inflate_block;
+        for (size_t i = lo; i < hi && ok; ++i)
+            if (!inflate_block(&c.bytes[c.blk[i].data], c.blk[i].csize, out.data() + ob[i].dst, ob[i].isize)) { ok = false; return; }
+    });
+    return ok;
+}
+
+// The two steps in one call, for the callers that decode synchronously (header, svx_bam_open*).
+class BgzfStream {
+public:
+    size_t chunk;                                        // compressed bytes read per step
+    using Block = OutBlock;
+    BgzfStream(FILE* f, uint64_t pos, uint64_t end, Pool* pool, size_t first_chunk) : chunk(first_chunk), reader_(f, pos, end), pool_(pool) {}
+    const std::vector<Block>& blocks() const { return blocks_; }
+    bool done() const { return reader_.done(); }
+    const std::string& error() const { return err_; }
+    bool next(RawBuf& out)                               // false on error; appends nothing when done()
+    {
+        blocks_.clear();
+        if (done()) return true;
+        if (!reader_.read(cc_, chunk)) { err_ = reader_.error(); return false; }
+        g_clock.read = reader_.seconds;
+        const double t0 = BamClock::now();
+        const bool ok = inflate_chunk(cc_, out, pool_, &blocks_);
+        g_clock.inflate += BamClock::now() - t0;
         if (!ok) { err_ = "BGZF inflate failed"; return false; }
         return true;
     }
 
 private:
-    const MappedFile* mf_;
-    uint64_t pos_, end_;
-    bool strict_;
+    BgzfReader reader_;
     Pool* pool_;
-    bool eof_ = false;
+    CChunk cc_;
     std::vector<Block> blocks_;
     std::string err_;
 };
@@ -424,6 +431,10 @@ long long parse_records(const RawBuf& buf, uint64_t from, uint64_t limit, Pool* 
         const uint64_t bs = rd32(&buf[p]);
         if (p + 4 + bs > limit) break;
         if (bs < 32) return -1;
+        if (p + 4 + bs + 128 <= limit) {                       // the next record's header: ~20 KB ahead in freshly inflated memory
+            __builtin_prefetch(&buf[p + 4 + bs]);
+            __builtin_prefetch(&buf[p + 4 + bs + 64]);
+        }
         const uint8_t* rec = &buf[p + 4];
         if (split) {
             const int32_t rtid = (int32_t)rd32(rec);
@@ -500,10 +511,9 @@ void* bam_open_impl(const char* path, int threads, int flags, bool ranged, uint6
     g_bam_error.clear();
     if (threads <= 0) threads = default_threads();        // the CPUs this process may run on (not the machine's), at most 64
     const bool keep_seq = flags & SVX_BAM_KEEP_SEQ;
-    MappedFile file;
-    const MappedFile* f = &file;
-    if (!file.open(path)) { g_bam_error = file.error; return nullptr; }
-    if (file.n == 0) { g_bam_error = "empty file"; return nullptr; }
+    FILE* f = fopen(path, "rb");
+    if (!f) { g_bam_error = std::string("cannot open ") + path; return nullptr; }
+    struct Closer { FILE* f; ~Closer() { fclose(f); } } closer{f};
     Pool workers(threads);
     Pool* pool = &workers;
     std::unique_ptr<Bam> b(new Bam());
@@ -592,7 +602,7 @@ struct Stream {
         bool fresh = true;                                    // first chunk of a range: no carry from the chunk before
     };
     std::string path;
-    MappedFile file;
+    FILE* f = nullptr;
     int flags = 0;
     std::unique_ptr<Pool> inflate_pool, scatter_pool;
     std::vector<std::pair<uint64_t, uint64_t>> ranges;       // virtual offsets; empty: everything behind the header
@@ -614,8 +624,10 @@ struct Stream {
     {
         { std::lock_guard<std::mutex> g(m); cancel = true; }
         cv.notify_all();
+        if (reader.joinable()) reader.join();
         if (feeder.joinable()) feeder.join();
         if (parser.joinable()) parser.join();
+        if (f) fclose(f);
     }
 
     void fail(const std::string& why)
@@ -626,64 +638,119 @@ struct Stream {
         cv.notify_all();
     }
 
-    // ---- feeder ------------------------------------------------------------------------------------------------
-    void feed()
+    // ---- reader: compressed chunks, one fread each, a few ahead of the inflate ------------------------------------
+    struct CItem {
+        CChunk c;
+        int range = 0;                                        // index into the range list
+        bool first = false, last = false;                     // first / last chunk of its range
+    };
+    std::deque<std::unique_ptr<CItem>> cfilled, cspare;       // reader -> feeder, feeder -> reader
+    bool reader_done = false;
+    std::thread reader;
+    std::vector<std::pair<uint64_t, uint64_t>> todo;
+
+    void read_ahead()
     {
         const char* env = getenv("SVX_BAM_CHUNK");
-        const size_t steady = env && atol(env) > 0 ? (size_t)atol(env) : (48u << 20);      // ~100 MB inflated per step
-        std::vector<std::pair<uint64_t, uint64_t>> todo = ranges;
-        if (todo.empty()) todo.push_back({body_voff, ~0ull});
-        for (const auto& r : todo) {
+        const size_t steady = env && atol(env) > 0 ? (size_t)atol(env) : (40u << 20);      // ~96 MB inflated per step
+        for (size_t ri = 0; ri < todo.size(); ++ri) {
+            const auto& r = todo[ri];
             const bool open_end = r.second == ~0ull;
             if (!open_end && r.second <= r.first) continue;
             const uint64_t c0 = r.first >> 16, c1 = open_end ? ~0ull : r.second >> 16;
-            BgzfStream body(&file, c0, open_end ? ~0ull : c1 + 65536 + 26, inflate_pool.get(), steady);
-            bool first = true, reached = false;
-            std::unique_ptr<Chunk> ch;
-            while (!reached) {
-                if (!ch) {
+            BgzfReader body(f, c0, open_end ? ~0ull : c1 + 65536 + 26);
+            bool first = true;
+            for (;;) {
+                std::unique_ptr<CItem> it;
+                {
+                    std::unique_lock<std::mutex> g(m);
+                    cv.wait(g, [&] { return cancel || !cspare.empty(); });
+                    if (cancel) return;
+                    it = std::move(cspare.front());
+                    cspare.pop_front();
+                }
+                do {                                            // (a read shorter than one block hands over nothing: read on)
+                    if (!body.read(it->c, steady)) { fail(body.error()); return; }
+                } while (it->c.blk.empty() && !body.done());
+                it->range = (int)ri;
+                it->first = first;
+                it->last = body.done();
+                first = false;
+                const bool last = it->last;
+                {
+                    std::lock_guard<std::mutex> g(m);
+                    cfilled.push_back(std::move(it));
+                }
+                cv.notify_all();
+                if (last) break;
+            }
+            t_read += body.seconds;
+        }
+        {
+            std::lock_guard<std::mutex> g(m);
+            reader_done = true;
+        }
+        cv.notify_all();
+    }
+
+    // ---- feeder: inflates the chunks the reader has ready -------------------------------------------------------------
+    void feed()
+    {
+        std::vector<OutBlock> blocks;
+        bool reached = false;                                   // the current range's end offset has been seen: skip its tail
+        for (;;) {
+            std::unique_ptr<CItem> it;
+            {
+                std::unique_lock<std::mutex> g(m);
+                cv.wait(g, [&] { return cancel || !cfilled.empty() || reader_done; });
+                if (cancel) return;
+                if (cfilled.empty()) break;
+                it = std::move(cfilled.front());
+                cfilled.pop_front();
+            }
+            const auto& r = todo[it->range];
+            const bool open_end = r.second == ~0ull;
+            const uint64_t c1 = open_end ? ~0ull : r.second >> 16;
+            if (it->first) reached = false;
+            if (!reached) {
+                std::unique_ptr<Chunk> ch;
+                {
                     std::unique_lock<std::mutex> g(m);
                     cv.wait(g, [&] { return cancel || !spare.empty(); });
                     if (cancel) return;
                     ch = std::move(spare.front());
                     spare.pop_front();
                 }
-                ch->buf.resize(HEAD);                           // BgzfStream::next appends behind the HEAD room
+                ch->buf.resize(HEAD);                           // the inflated bytes go behind the HEAD room
                 const double t0 = BamClock::now();
-                const double read0 = g_clock.read;
-                if (!body.next(ch->buf)) { fail(body.error()); return; }
-                if (body.blocks().empty() && !body.done()) continue;     // a read shorter than one block: nothing to hand over yet
-                const double dt = BamClock::now() - t0, dread = g_clock.read - read0;
-                t_read += dread;
-                t_inflate += dt - dread;
-                ch->fresh = first;
-                ch->begin = HEAD + (first ? (size_t)(r.first & 0xffff) : 0);
+                if (!inflate_chunk(it->c, ch->buf, inflate_pool.get(), &blocks)) { fail("BGZF inflate failed"); return; }
+                t_inflate += BamClock::now() - t0;
+                ch->fresh = it->first;
+                ch->begin = HEAD + (it->first ? (size_t)(r.first & 0xffff) : 0);
                 ch->limit = ch->buf.size();
-                for (const auto& blk : body.blocks()) {
+                for (const auto& blk : blocks) {
                     bytes_out += blk.isize;
                     bytes_in += blk.csize;
                     if (open_end || reached) continue;
                     if (blk.coff == c1) { ch->limit = blk.dst + (size_t)(r.second & 0xffff); reached = true; }
                     else if (blk.coff > c1) { ch->limit = blk.dst; reached = true; }
                 }
-                if (body.done()) {
+                if (it->last) {
                     if (!open_end && !reached) { fail("BAM index does not match the file"); return; }
                     reached = true;
                 }
-                if (first && ch->begin > ch->limit) { fail("BAM index does not match the file"); return; }
-                first = false;
+                if (it->first && ch->begin > ch->limit) { fail("BAM index does not match the file"); return; }
                 ch->range_end = reached;
                 {
                     std::lock_guard<std::mutex> g(m);
                     filled.push_back(std::move(ch));
                 }
-                ch.reset();
-                cv.notify_all();
             }
-            if (ch) {                                           // taken but not used
+            {
                 std::lock_guard<std::mutex> g(m);
-                spare.push_back(std::move(ch));
+                cspare.push_back(std::move(it));
             }
+            cv.notify_all();
         }
         {
             std::lock_guard<std::mutex> g(m);
@@ -699,6 +766,7 @@ struct Stream {
         b->header_text = proto.header_text;
         b->ref_names = proto.ref_names;
         b->ref_lens = proto.ref_lens;
+        b->seen.reserve(1u << 18);                            // a chromosome holds 10^5..10^6 reads: no rehash while the part grows
         return b;
     }
 
@@ -861,8 +929,8 @@ void* svx_bam_stream_open(const char* path, int threads, int flags, const uint64
     std::unique_ptr<Stream> s(new Stream());
     s->path = path;
     s->flags = flags;
-    if (!s->file.open(path)) { g_bam_error = s->file.error; return nullptr; }
-    if (s->file.n == 0) { g_bam_error = "empty file"; return nullptr; }
+    s->f = fopen(path, "rb");
+    if (!s->f) { g_bam_error = std::string("cannot open ") + path; return nullptr; }
     for (int i = 0; i < n_ranges; ++i) s->ranges.push_back({voffs[2 * i], voffs[2 * i + 1]});
     // the parser's field scatter is a few memcpy per record: a handful of threads; everything else inflates
     const int scatter = std::max(1, std::min(8, threads / 8));
@@ -870,7 +938,7 @@ void* svx_bam_stream_open(const char* path, int threads, int flags, const uint64
     s->scatter_pool.reset(new Pool(scatter));
     {   // header: synchronously, from the start of the file; remembers where the records begin
         RawBuf buf;
-        BgzfStream head(&s->file, 0, ~0ull, s->inflate_pool.get(), 256u << 10);
+        BgzfStream head(s->f, 0, ~0ull, s->inflate_pool.get(), 256u << 10);
         long long hdr = 0;
         std::vector<BgzfStream::Block> seen;
         while (hdr == 0) {
@@ -890,7 +958,11 @@ void* svx_bam_stream_open(const char* path, int threads, int flags, const uint64
         s->body_voff = voff;
     }
     for (int i = 0; i < 3; ++i) s->spare.emplace_back(new Stream::Chunk());
+    for (int i = 0; i < 3; ++i) s->cspare.emplace_back(new Stream::CItem());
+    s->todo = s->ranges;
+    if (s->todo.empty()) s->todo.push_back({s->body_voff, ~0ull});
     Stream* raw = s.get();
+    s->reader = std::thread([raw] { raw->read_ahead(); });
     s->feeder = std::thread([raw] { raw->feed(); });
     s->parser = std::thread([raw] { raw->parse(); });
     return s.release();

@@ -191,7 +191,7 @@ def test_two_ranks_from_an_indexed_bam_equal_one_rank(checkpoint, tmp_path, thre
     two = os.path.join(str(tmp_path / "two"), os.path.basename(one))
     assert open(two).read() == open(one).read()
     logs = [f for f in os.listdir(str(tmp_path / "two")) if f.endswith(".log")]
-    assert any("decoded through" in open(os.path.join(str(tmp_path / "two"), f)).read() for f in logs)
+    assert any("streamed from" in open(os.path.join(str(tmp_path / "two"), f)).read() for f in logs)
 
 
 def test_cli_with_helper_processes_equals_one_process(checkpoint, tmp_path):
