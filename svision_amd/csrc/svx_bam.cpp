@@ -264,7 +264,7 @@ private:
 // A run of whole BGZF blocks, still compressed (what the reader thread hands to the inflating one).
 struct CChunk {
     struct Blk { uint64_t coff; uint32_t data, csize, isize, bsize; };   // file offset; payload offset / size in `bytes`; inflated size; block size
-    std::vector<uint8_t> bytes;
+    RawBuf bytes;                                            // (no zero fill: fread overwrites it)
     std::vector<Blk> blk;
     uint64_t inflated = 0;
 };
@@ -299,7 +299,7 @@ public:
         const uint64_t base = pos_ - have;                  // file offset of bytes[0]
         pos_ += got;
         if (pos_ >= end_) eof_ = true;
-        const std::vector<uint8_t>& b = c.bytes;
+        const RawBuf& b = c.bytes;
         uint64_t p = 0;
         while (p + 18 <= b.size()) {
             if (!(b[p] == 0x1f && b[p + 1] == 0x8b && b[p + 2] == 8 && (b[p + 3] & 4))) { err_ = "not a BGZF block"; return false; }
@@ -325,7 +325,7 @@ public:
         capped_ = c.inflated >= MAX_INFLATED && p != b.size();
         if (eof_ && p != b.size() && !capped_ && strict_) { err_ = "truncated BGZF file"; return false; }
         // (a byte range cut in the middle of its last block: callers ask for one block more than they need)
-        carry_.assign(b.begin() + p, b.end());
+        carry_.assign(b.data() + p, b.data() + b.size());
         if (eof_ && !capped_) carry_.clear();
         return true;
     }
