@@ -231,7 +231,8 @@ def main():
         sys.exit(spawn_ranks(args))
 
     rank, world = sdist.env_rank()
-    cores = os.cpu_count() or 1
+    from svision_amd.ingest import decode_threads, effective_cpus
+    cores, visible_cpus = effective_cpus()        # the cgroup's CPU-time quota, not the CPUs the container merely sees
     workers = max(1, min(args.workers, cores // world))
     # ---- untimed set-up.  Order matters: everything that forks (simulation pool, CPU-baseline pool, host helpers)
     # happens before the first HIP call (forking with a live GPU context makes the driver evict / restore the queues)
@@ -242,7 +243,7 @@ def main():
     table = bam.concat_tables([t for _n, _l, t, _g in parts]) if len(parts) > 1 else parts[0][2]
     fasta = bam.Fasta(sequences={n: g for n, _l, _t, g in parts})
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
-    cpu_pool = CpuBaselinePool(cores, table, fasta, opts) if want_cpu else None
+    cpu_pool = CpuBaselinePool(cores, table, fasta, opts, visible_cpus) if want_cpu else None
     pool = HelperPool(workers, opts, table=table, fasta=fasta)
     torch.cuda.set_device(sdist.local_device_index())
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -358,7 +359,7 @@ def main():
                    "rccl_world": world if grouped else 0, "dist_backend": (tdist.get_backend() if grouped else None),
                    "rank_mb": [round(v, 1) for v in getattr(args, "rank_mb", [])] or None,
                    "imbalance": (max(args.rank_mb) / (sum(args.rank_mb) / len(args.rank_mb)) if getattr(args, "rank_mb", None) else None),
-                   "host_workers_per_rank": workers, "host_cores": cores, "streams": args.streams, "batches_per_launch": args.launch_batches,
+                   "host_workers_per_rank": workers, "host_cores": cores, "host_cpus_visible": visible_cpus, "streams": args.streams, "batches_per_launch": args.launch_batches,
                    "parallelism": "one process per GPU, chromosomes per rank, no data-path collective "
                                   "(score-range all_reduce + record gather once)"},
         "roofline": {"kernel": "device stage per batch of %d images (a graph replay carries --launch-batches of them): encode_conv1_kernel (rasterise + sparse conv1) + "
@@ -405,7 +406,8 @@ def run_from_file(args, e2e, hot, run, fasta, opts, dev, sync_all, cores, world,
     from svision_amd.ingest import ChromosomeFeed, StaticFeed
     refs = e2e["references"]
     lens = [fasta.get_reference_length(n) for n in refs]
-    threads = args.decode_threads or max(1, min(128, cores // world - workers - 2))
+    from svision_amd.ingest import decode_threads
+    threads = args.decode_threads or decode_threads(world, workers)
     resident = hot.feed
     sync_all()
     t0 = time.perf_counter()
@@ -546,8 +548,9 @@ def kernel_calibration(hot, sample, net, dev, B, window, reps=20):
 
 
 # --------------------------------------------------------------------------------------------------------------------
-# CPU baseline: the oracle port of the same step on this box's host cores, as a pool of P = os.cpu_count() single-thread
-# processes (the reference's `-t P`, SVision:261,311), on a bounded sample of the same workload.
+# CPU baseline: the oracle port of the same step on this box's host cores, as a pool of P single-thread processes, P = the
+# CPUs the process may really use (affinity mask capped by the cgroup's CPU-time quota: svision_amd.ingest.effective_cpus) --
+# the reference's `-t P` (SVision:261,311) -- on a bounded sample of the same workload.
 def _cpu_worker(conn, table, fasta, opts):
     import io
     from oracle import cbind
@@ -597,8 +600,9 @@ def _cpu_worker(conn, table, fasta, opts):
 class CpuBaselinePool:
     """P forked single-thread processes (forked before the first HIP call; idle until run())."""
 
-    def __init__(self, procs, table, fasta, opts):
+    def __init__(self, procs, table, fasta, opts, visible=None):
         import multiprocessing as mp
+        self.visible = visible or procs
         ctx = mp.get_context("fork")
         self.conns, self.procs = [], []
         for _ in range(procs):
@@ -609,10 +613,12 @@ class CpuBaselinePool:
             self.conns.append(a)
             self.procs.append(p)
 
-    def run(self, windows, images_per_proc=192):
+    def run(self, windows, images_per_proc=None):
         """Every process takes 1/P of the sites of one window (round-robin over the windows) and at most `images_per_proc`
         of their images: about 10-30 s of wall time; value = sites classified by the pool / wall time."""
         P = len(self.conns)
+        if images_per_proc is None:                           # ~25 s of wall: a 1-thread process classifies 15-25 images per second
+            images_per_proc = 192 if P >= 64 else 384
         per_win = max(1, P // max(len(windows), 1))
         t0 = time.perf_counter()
         for i, c in enumerate(self.conns):
@@ -625,7 +631,7 @@ class CpuBaselinePool:
         for p in self.procs:
             p.join(timeout=5)
         sites, images = sum(g[0] for g in got), sum(g[1] for g in got)
-        return {"value": sites / wall, "unit": "sites/s", "cores": P, "kind": "port",
+        return {"value": sites / wall, "unit": "sites/s", "cores": P, "kind": "port", "cpus_visible": self.visible,
                 "sample": "pool of %d single-thread processes (the reference's -t P, SVision:261,311), each: C oracle scan of its window's "
                           "chromosome, host collection of one 10 Mb window, then C oracle rasteriser + PyTorch-CPU fp32 AlexNet (batch 128, "
                           "1 thread) + vote on its 1/%d share of that window's sites, capped at %d images: %d sites, %d images in %.1f s "

@@ -201,9 +201,8 @@ def run(options, sample=None, classifier=None):
         sdist.init_from_env()
         from .ingest import ChromosomeFeed, StaticFeed
         if sample is None:
-            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            local_ws = int(os.environ.get("LOCAL_WORLD_SIZE", ws))
-            threads = max(1, min(128, cores // max(local_ws, 1) - max(options.thread_num, 1) - 2))     # decode threads of this rank
+            from .ingest import decode_threads
+            threads = decode_threads(int(os.environ.get("LOCAL_WORLD_SIZE", ws)), options.thread_num)      # inflate threads of this rank
             feed = ChromosomeFeed(options.bam_path, fasta, options, [c for c in mine if c in references], references, lengths,
                                   device=torch.device("cuda", torch.cuda.current_device()), index=find_index(options.bam_path), threads=threads)
             logging.info("rank %d/%d: %s streamed from %s with %d decode threads", rank, ws, ",".join(mine) or "-", options.bam_path, threads)

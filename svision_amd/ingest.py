@@ -26,6 +26,36 @@ from .io.bam import AlignmentTable, BamStream
 from .sample import Sample
 
 
+def effective_cpus():
+    """CPUs this process can actually use: its affinity mask, capped by the cgroup's CPU-time quota (a container that
+    sees 256 CPUs may be allowed the time of 16: more runnable threads than that get the whole group throttled for the
+    rest of every scheduling period, the GPU-feeding thread included).  -> (usable CPUs, visible CPUs)."""
+    visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:              # cgroup v2: "<quota> <period>" or "max <period>"
+            q, period = f.read().split()[:2]
+            if q != "max":
+                quota = int(q) / int(period)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, period = int(f.read()), int(g.read())
+                if q > 0:
+                    quota = q / period
+        except (OSError, ValueError):
+            pass
+    usable = visible if quota is None else max(1, min(visible, int(quota)))
+    return usable, visible
+
+
+def decode_threads(ranks_on_node=1, helpers=1):
+    """Inflate threads of one rank: what the node's usable CPUs leave next to the helpers (about half busy each) and
+    the GPU-feeding thread, at most 128."""
+    usable, _visible = effective_cpus()
+    return max(2, min(128, usable // max(ranks_on_node, 1) - (helpers + 1) // 2 - 1))
+
+
 def empty_sample(references, lengths, fasta, min_sv, header_text=""):
     """A chromosome without records: its windows still exist as tasks (SVision:172-201) and yield nothing."""
     from . import kernels
