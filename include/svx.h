@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SVX_VERSION 300            /* 0.2.1: + active-row masks out of svx_alexnet_active_sets, into svx_bias_relu_pool_lrn */
+#define SVX_VERSION 310            /* 0.2.1: + active-row masks out of svx_alexnet_active_sets, into svx_bias_relu_pool_lrn */
 
 #define SVX_OK            0
 #define SVX_EINVAL       (-1)      /* bad argument (null pointer, bad layout...) */
@@ -257,6 +257,16 @@ void           svx_bam_export(void* handle, int threads, int32_t* tid, int32_t* 
                               char* header, char* ref_names, int32_t* ref_lens, int64_t* seq_off);
 const uint8_t* svx_bam_seq(void* handle);
 void           svx_bam_close(void* handle);
+
+/* BGZF inflate on the device (svx_inflate.hip): every block of a launch decoded by one lane, all blocks in parallel.
+ * Replaces the host-side DEFLATE decoding of htslib / pysam behind run_collection.py:23-26 where host cores are the
+ * scarce resource.  d_comp: the compressed bytes as they sit in the file (4-byte aligned, readable up to the next
+ * multiple of 4 behind the last payload); d_src_off / d_src_len [n]: byte offset in d_comp and size of every block's
+ * DEFLATE payload (behind the block header, in front of CRC32 + ISIZE); d_dst_off [n + 1]: running sum of the ISIZE
+ * fields = where every block's bytes go in d_out; d_status [n]: 0 = the block inflated to exactly ISIZE bytes,
+ * anything else = corrupt (the caller falls back to the host decoder). */
+int            svx_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len,
+                                const uint64_t* d_dst_off, uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, void* stream);
 
 /* Streaming ingestion, one reference sequence at a time (replaces the reference's window-by-window
  * AlignmentFile.fetch(chrom, start, end), run_collection.py:23-26, by one pass over the file that hands chromosome k

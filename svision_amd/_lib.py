@@ -47,6 +47,7 @@ SYMBOLS = {
     "svx_bam_export": (None, [_vp, ctypes.c_int] + [_vp] * 13),
     "svx_bam_seq": (_vp, [_vp]),
     "svx_bam_close": (None, [_vp]),
+    "svx_bgzf_inflate": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
     "svx_bam_stream_open": (_vp, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int]),
     "svx_bam_stream_next": (_vp, [_vp, _vp]),
     "svx_bam_stream_close": (None, [_vp]),
@@ -64,7 +65,7 @@ class SvxMissing(SvxError):
 _lib = None
 
 
-ABI_VERSION = 300                     # SVX_VERSION of include/svx.h this binding was written against
+ABI_VERSION = 310                     # SVX_VERSION of include/svx.h this binding was written against
 
 
 def load():

@@ -1,0 +1,263 @@
+// svx_inflate.hip -- BGZF inflate on gfx950 (MI355X): one LANE per BGZF block.
+//
+// Ingestion is bound by DEFLATE decoding: a HiFi BAM inflates to ~22 KB per read (bases + qualities
+// the hot path never looks at, interleaved with the CIGARs it needs), a host core decodes ~0.6 GB/s of it
+// (libdeflate), and the GPU boxes this was built on give a container the CPU time of 16 cores: ~10 GB/s, four times
+// less than the device pipeline consumes.  BGZF makes the problem embarrassingly parallel -- every block (<= 64 KB
+// inflated) is an independent raw-DEFLATE stream (SAMv1 4.1) and a chromosome has 10^4..10^5 of them -- so the blocks
+// are decoded on the device, one lane each, from the compressed bytes uploaded as they sit in the file:
+//
+//   * a lane owns its block from the first bit to the last byte: no cross-lane dependency, no barrier, no atomics;
+//   * Huffman decoding is canonical (RFC 1951 3.2.2): the per-length code counts of the block in hand live in
+//     REGISTERS (fifteen 9-bit counts packed into five dwords per alphabet), the walk over the lengths is unrolled,
+//     and only the final symbol lookup goes to the lane's private slice of LDS (288 + 32 symbols x 2 B: 640 B per lane,
+//     one wave per workgroup, three workgroups per CU);
+//   * input: a 64-bit bit buffer per lane refilled with aligned dword loads; output: literals are gathered into an
+//     aligned dword before they are stored, matches are copied byte by byte from the lane's own earlier output
+//     (its stores are visible to its later loads).
+//
+// Integer exact by construction: the result is the byte stream zlib / libdeflate produce (tests/test_gpu_inflate.py).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/svx.h"
+
+namespace {
+
+constexpr int LANES = 64;                 // one wave per workgroup: the LDS slice of a lane is indexed by its lane id
+constexpr int LIT_SYMS = 288, DIST_SYMS = 32, LANE_SYMS = LIT_SYMS + DIST_SYMS;
+
+__constant__ uint16_t LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__constant__ uint8_t LEN_EXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__constant__ uint16_t DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__constant__ uint8_t DIST_EXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__constant__ uint8_t CLEN_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+// per-length code counts of one alphabet, lengths 1..15, 10 bits each (a count is at most 288): three per dword
+struct Counts {
+    uint32_t w[5];
+    __device__ __forceinline__ void clear() { for (int i = 0; i < 5; ++i) w[i] = 0; }
+    __device__ __forceinline__ uint32_t get(int len) const { const int k = len - 1; return (w[k / 3] >> (10 * (k % 3))) & 1023u; }
+    __device__ __forceinline__ void add(int len) { const int k = len - 1; w[k / 3] += 1u << (10 * (k % 3)); }
+};
+
+struct BitReader {
+    const uint32_t* words;                // aligned dwords of the compressed buffer
+    uint64_t next;                        // index of the next dword to fetch
+    uint64_t end;                         // one past the last dword that may be fetched
+    uint64_t buf;                         // unread bits, LSB first
+    int cnt;                              // valid bits in buf
+    bool overrun;
+    __device__ __forceinline__ void init(const uint8_t* base, uint64_t byte_off, uint64_t byte_len)
+    {
+        words = reinterpret_cast<const uint32_t*>(base);
+        next = byte_off >> 2;
+        end = (byte_off + byte_len + 3) >> 2;
+        buf = 0; cnt = 0; overrun = false;
+        refill();
+        const int skip = (int)(byte_off & 3) * 8;             // bytes in front of the stream inside its first dword
+        buf >>= skip;
+        cnt -= skip;
+    }
+    __device__ __forceinline__ void refill()
+    {
+        if (cnt <= 32) {
+            uint32_t v = 0;
+            if (next < end) v = words[next];
+            ++next;                                            // (past the end zeros are shifted in; need() notices)
+            buf |= (uint64_t)v << cnt;
+            cnt += 32;
+        }
+    }
+    __device__ __forceinline__ uint32_t bits(int n)           // n <= 16
+    {
+        refill();
+        const uint32_t v = (uint32_t)buf & ((1u << n) - 1u);
+        buf >>= n;
+        cnt -= n;
+        return v;
+    }
+    __device__ __forceinline__ bool exhausted() const         // more bits consumed than the stream holds
+    {
+        return (int64_t)next * 32 - cnt > (int64_t)end * 32;
+    }
+};
+
+// canonical Huffman decode of one symbol: walks the code lengths 1..15 with the counts in registers, then one LDS read
+__device__ __forceinline__ int decode_symbol(BitReader& br, const Counts& c, const uint16_t* syms)
+{
+    br.refill();
+    uint32_t bitsrc = (uint32_t)br.buf;
+    int code = 0, first = 0, index = 0;
+#pragma unroll
+    for (int len = 1; len <= 15; ++len) {
+        code |= (int)(bitsrc & 1u);
+        bitsrc >>= 1;
+        const int count = (int)c.get(len);
+        if (code - count < first) {
+            br.buf >>= len;
+            br.cnt -= len;
+            return syms[index + (code - first)];
+        }
+        index += count;
+        first += count;
+        first <<= 1;
+        code <<= 1;
+    }
+    return -1;                                                  // not a code of this alphabet
+}
+
+// code lengths -> counts (registers) + symbols sorted by (length, symbol) in the lane's LDS slice (RFC 1951 3.2.2)
+__device__ __forceinline__ bool build(const uint8_t* lens, int n, Counts& c, uint16_t* syms)
+{
+    c.clear();
+    for (int s = 0; s < n; ++s) if (lens[s]) c.add(lens[s]);
+    int left = 1;                                               // over-subscription check
+    uint16_t offs[16];
+    offs[1] = 0;
+    for (int len = 1; len <= 15; ++len) {
+        left <<= 1;
+        left -= (int)c.get(len);
+        if (left < 0) return false;
+        if (len < 15) offs[len + 1] = (uint16_t)(offs[len] + c.get(len));
+    }
+    for (int s = 0; s < n; ++s) if (lens[s]) syms[offs[lens[s]]++] = (uint16_t)s;
+    return true;                                                // (incomplete codes are legal for a single distance code)
+}
+
+struct Writer {
+    uint8_t* base;                        // the whole inflated buffer
+    uint64_t lo, pos, hi;                 // the block's byte range [lo, hi) and the next byte to write
+    uint32_t acc;                         // pending bytes of the aligned dword that ends at pos (nacc of them)
+    int nacc;
+    __device__ __forceinline__ void flush()
+    {
+        for (int i = 0; i < nacc; ++i) base[pos - nacc + i] = (uint8_t)(acc >> (8 * i));
+        nacc = 0; acc = 0;
+    }
+    __device__ __forceinline__ void literal(uint32_t b)
+    {
+        if (nacc == 0 && (pos & 3)) { base[pos++] = (uint8_t)b; return; }     // not on a dword boundary yet
+        acc |= b << (8 * nacc);
+        ++nacc; ++pos;
+        if (nacc == 4) { *reinterpret_cast<uint32_t*>(base + pos - 4) = acc; nacc = 0; acc = 0; }
+    }
+    __device__ __forceinline__ void copy(uint32_t dist, uint32_t len)        // caller checked the bounds
+    {
+        flush();
+        for (uint32_t i = 0; i < len; ++i, ++pos) base[pos] = base[pos - dist];
+    }
+};
+
+// status per block: 0 ok, else the reason
+enum { INF_OK = 0, INF_BAD_TYPE = 1, INF_BAD_STORED = 2, INF_BAD_TABLE = 3, INF_BAD_CODE = 4, INF_OUT_OVERRUN = 5, INF_IN_OVERRUN = 6, INF_SHORT = 7, INF_BAD_DIST = 8 };
+
+__global__ __launch_bounds__(LANES)
+void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const uint64_t* __restrict__ src_off, const uint32_t* __restrict__ src_len,
+                         const uint64_t* __restrict__ dst_off, uint32_t n_blocks, uint8_t* __restrict__ out, uint32_t* __restrict__ status)
+{
+    __shared__ uint16_t lds_syms[LANES * LANE_SYMS];
+    const uint32_t b = blockIdx.x * LANES + threadIdx.x;
+    if (b >= n_blocks) return;
+    uint16_t* lit_syms = lds_syms + threadIdx.x * LANE_SYMS;
+    uint16_t* dist_syms = lit_syms + LIT_SYMS;
+    BitReader br;
+    br.init(comp, src_off[b], src_len[b]);
+    Writer w{out, dst_off[b], dst_off[b], dst_off[b + 1], 0u, 0};
+    int err = INF_OK;
+    Counts lc, dc;
+    uint8_t lens[LIT_SYMS + DIST_SYMS];
+    bool last = w.hi == w.lo;                                   // an empty block (the EOF marker): nothing to decode
+    while (!last && err == INF_OK) {
+        last = br.bits(1) != 0;
+        const uint32_t type = br.bits(2);
+        if (type == 0) {                                        // stored: to the byte boundary, LEN, ~LEN, bytes
+            br.bits(br.cnt & 7);
+            const uint32_t len = br.bits(16), nlen = br.bits(16);
+            if ((len ^ nlen) != 0xffffu) { err = INF_BAD_STORED; break; }
+            if (w.pos + len > w.hi) { err = INF_OUT_OVERRUN; break; }
+            for (uint32_t i = 0; i < len; ++i) w.literal(br.bits(8));
+        } else if (type == 1 || type == 2) {
+            if (type == 1) {                                    // fixed code (RFC 1951 3.2.6)
+                for (int s = 0; s < 144; ++s) lens[s] = 8;
+                for (int s = 144; s < 256; ++s) lens[s] = 9;
+                for (int s = 256; s < 280; ++s) lens[s] = 7;
+                for (int s = 280; s < 288; ++s) lens[s] = 8;
+                for (int s = 0; s < 30; ++s) lens[LIT_SYMS + s] = 5;
+                build(lens, 288, lc, lit_syms);
+                build(lens + LIT_SYMS, 30, dc, dist_syms);
+            } else {                                            // dynamic code (3.2.7)
+                const int nlen = (int)br.bits(5) + 257, ndist = (int)br.bits(5) + 1, ncode = (int)br.bits(4) + 4;
+                if (nlen > 286 || ndist > 30) { err = INF_BAD_TABLE; break; }
+                uint8_t cl[19];
+                for (int i = 0; i < 19; ++i) cl[i] = 0;
+                for (int i = 0; i < ncode; ++i) cl[CLEN_ORDER[i]] = (uint8_t)br.bits(3);
+                Counts cc;
+                if (!build(cl, 19, cc, lit_syms)) { err = INF_BAD_TABLE; break; }      // (the code-length code borrows the slice)
+                int i = 0;
+                while (i < nlen + ndist) {
+                    const int sym = decode_symbol(br, cc, lit_syms);
+                    if (sym < 0) { err = INF_BAD_TABLE; break; }
+                    if (sym < 16) { lens[i < nlen ? i : LIT_SYMS + (i - nlen)] = (uint8_t)sym; ++i; continue; }
+                    int prev = 0, rep;
+                    if (sym == 16) {
+                        if (i == 0) { err = INF_BAD_TABLE; break; }
+                        const int j = i - 1;
+                        prev = lens[j < nlen ? j : LIT_SYMS + (j - nlen)];
+                        rep = 3 + (int)br.bits(2);
+                    } else if (sym == 17) rep = 3 + (int)br.bits(3);
+                    else rep = 11 + (int)br.bits(7);
+                    if (i + rep > nlen + ndist) { err = INF_BAD_TABLE; break; }
+                    for (; rep > 0; --rep, ++i) lens[i < nlen ? i : LIT_SYMS + (i - nlen)] = (uint8_t)prev;
+                }
+                if (err != INF_OK) break;
+                if (lens[256] == 0) { err = INF_BAD_TABLE; break; }
+                if (!build(lens, nlen, lc, lit_syms) || !build(lens + LIT_SYMS, ndist, dc, dist_syms)) { err = INF_BAD_TABLE; break; }
+            }
+            for (;;) {                                          // the symbols of the block
+                const int sym = decode_symbol(br, lc, lit_syms);
+                if (sym < 256) {
+                    if (sym < 0) { err = INF_BAD_CODE; break; }
+                    if (w.pos >= w.hi) { err = INF_OUT_OVERRUN; break; }
+                    w.literal((uint32_t)sym);
+                    continue;
+                }
+                if (sym == 256) break;
+                const int li = sym - 257;
+                if (li >= 29) { err = INF_BAD_CODE; break; }
+                const uint32_t len = LEN_BASE[li] + br.bits(LEN_EXTRA[li]);
+                const int ds = decode_symbol(br, dc, dist_syms);
+                if (ds < 0 || ds >= 30) { err = INF_BAD_CODE; break; }
+                const uint32_t dist = DIST_BASE[ds] + br.bits(DIST_EXTRA[ds]);
+                if (dist > w.pos - w.lo) { err = INF_BAD_DIST; break; }
+                if (w.pos + len > w.hi) { err = INF_OUT_OVERRUN; break; }
+                w.copy(dist, len);
+            }
+            if (br.exhausted()) err = INF_IN_OVERRUN;
+        } else {
+            err = INF_BAD_TYPE;
+        }
+    }
+    w.flush();
+    if (err == INF_OK && w.pos != w.hi) err = INF_SHORT;
+    status[b] = (uint32_t)err;
+}
+
+}  // namespace
+
+// BGZF blocks -> their inflated bytes, all blocks of a launch in parallel (one lane per block).
+//   d_comp      compressed bytes as they sit in the file (any run of whole blocks), 4-byte aligned, readable up to the
+//               next multiple of 4 behind the last payload byte
+//   d_src_off   [n] byte offset in d_comp of every block's DEFLATE payload (behind the 18-byte header)
+//   d_src_len   [n] payload bytes (BSIZE - xlen - 19)
+//   d_dst_off   [n + 1] byte offset in d_out of every block's inflated bytes: the running sum of the ISIZE fields
+//   d_status    [n] 0 = block decoded to exactly its ISIZE bytes; anything else: corrupt block (the host falls back)
+extern "C" int svx_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len, const uint64_t* d_dst_off,
+                                uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, void* stream)
+{
+    if (n_blocks == 0) return SVX_OK;
+    if (!d_comp || !d_src_off || !d_src_len || !d_dst_off || !d_out || !d_status) return SVX_EINVAL;
+    if (reinterpret_cast<uintptr_t>(d_comp) & 3u) return SVX_EINVAL;
+    hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((n_blocks + LANES - 1) / LANES), dim3(LANES), 0, static_cast<hipStream_t>(stream),
+                       d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, d_out, d_status);
+    return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
+}

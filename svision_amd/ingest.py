@@ -50,10 +50,11 @@ def effective_cpus():
 
 
 def decode_threads(ranks_on_node=1, helpers=1):
-    """Inflate threads of one rank: what the node's usable CPUs leave next to the helpers (about half busy each) and
-    the GPU-feeding thread, at most 128."""
+    """Inflate threads of one rank: the node's usable CPUs divided by its ranks, at most 128.  (The helpers wait for the
+    decoder whenever it is the limit, so nothing is subtracted for them: measured on a 16-CPU quota, 24 threads 1.12 s,
+    16 threads 1.18 s, 11 threads 1.63 s for the same 9.3 GB of inflated data.)"""
     usable, _visible = effective_cpus()
-    return max(2, min(128, usable // max(ranks_on_node, 1) - (helpers + 1) // 2 - 1))
+    return max(2, min(128, usable // max(ranks_on_node, 1)))
 
 
 def empty_sample(references, lengths, fasta, min_sv, header_text=""):

@@ -354,3 +354,55 @@ def hash_seeds(jobs, k, window, device):
         na, nb, cap, ho = int(counts[2 * j]), int(counts[2 * j + 1]), int(desc[j]["hit_cap"]), int(desc[j]["hit_off"])
         out.append(None if na > cap or nb > cap else (hits[ho:ho + na], hits[ho + cap:ho + cap + nb]))
     return out
+
+
+def bgzf_block_table(raw):
+    """BGZF bytes (host, uint8 array: a run of whole blocks) -> (src_off uint64 [n], src_len uint32 [n], isize uint32 [n],
+    block_off uint64 [n]): where every block's DEFLATE payload lies, its inflated size, and the block's own offset."""
+    raw = np.ascontiguousarray(raw, np.uint8)
+    src_off, src_len, isize, block_off = [], [], [], []
+    p, n = 0, raw.size
+    while p + 18 <= n:
+        if not (raw[p] == 0x1f and raw[p + 1] == 0x8b and raw[p + 2] == 8 and raw[p + 3] & 4):
+            raise _lib.SvxError("not a BGZF block at offset %d" % p)
+        xlen = int(raw[p + 10]) | int(raw[p + 11]) << 8
+        q, bsize = p + 12, None
+        while q + 4 <= p + 12 + xlen:
+            slen = int(raw[q + 2]) | int(raw[q + 3]) << 8
+            if raw[q] == 66 and raw[q + 1] == 67:
+                bsize = int(raw[q + 4]) | int(raw[q + 5]) << 8
+            q += 4 + slen
+        if bsize is None or p + bsize + 1 > n:
+            break
+        end = p + bsize + 1
+        block_off.append(p)
+        src_off.append(p + 12 + xlen)
+        src_len.append(end - 8 - (p + 12 + xlen))
+        isize.append(int.from_bytes(raw[end - 4:end].tobytes(), "little"))
+        p = end
+    return (np.asarray(src_off, np.uint64), np.asarray(src_len, np.uint32), np.asarray(isize, np.uint32), np.asarray(block_off, np.uint64))
+
+
+def bgzf_inflate(d_comp, src_off, src_len, isize):
+    """d_comp: uint8 device tensor holding the compressed bytes (padded to a multiple of 4); src_off / src_len / isize: host
+    arrays of :func:`bgzf_block_table` (or the native reader's).  -> (uint8 device tensor with the inflated stream,
+    int32 device tensor [n] status: 0 = ok).  See include/svx.h svx_bgzf_inflate."""
+    lib = _lib.load()
+    _require_cuda(d_comp, "d_comp")
+    if d_comp.dtype != torch.uint8:
+        raise _lib.SvxError("d_comp must be a uint8 tensor")
+    n = int(len(src_off))
+    dev = d_comp.device
+    dst = np.zeros(n + 1, np.uint64)
+    dst[1:] = np.cumsum(np.asarray(isize, np.uint64))
+    total = int(dst[-1])
+    d_out = torch.empty(max(total, 4), dtype=torch.uint8, device=dev)
+    d_status = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
+    if n:
+        d_src = torch.from_numpy(np.ascontiguousarray(src_off, np.uint64).view(np.int64)).to(dev)
+        d_len = torch.from_numpy(np.ascontiguousarray(src_len, np.uint32).view(np.int32)).to(dev)
+        d_dst = torch.from_numpy(dst.view(np.int64)).to(dev)
+        rc = lib.svx_bgzf_inflate(d_comp.data_ptr(), d_src.data_ptr(), d_len.data_ptr(), d_dst.data_ptr(), n, d_out.data_ptr(),
+                                  d_status.data_ptr(), _stream_ptr(dev))
+        _lib.check(rc, "svx_bgzf_inflate")
+    return d_out[:total], d_status[:n]
