@@ -9,11 +9,12 @@
 //
 //   * a lane owns its block from the first bit to the last byte: no cross-lane dependency, no barrier, no atomics;
 //   * Huffman decoding is canonical (RFC 1951 3.2.2): the per-length code counts of the block in hand live in
-//     REGISTERS (fifteen 9-bit counts packed into five dwords per alphabet), the walk over the lengths is unrolled,
-//     and only the final symbol lookup goes to the lane's private slice of LDS (288 + 32 symbols x 2 B: 640 B per lane,
-//     one wave per workgroup, three workgroups per CU);
-//   * input: a 64-bit bit buffer per lane refilled with aligned dword loads; output: literals are gathered into an
-//     aligned dword before they are stored, matches are copied byte by byte from the lane's own earlier output
+//     REGISTERS (fifteen 10-bit counts packed into five dwords per alphabet), the walk over the lengths is unrolled,
+//     and only the final symbol lookup goes to the lane's private slice of LDS (356 B per lane: one wave per
+//     workgroup, seven workgroups per CU);
+//   * input: a 64-bit bit buffer per lane fed from 16-byte loads issued a whole vector ahead of their use (every lane
+//     streams its own block: a load is a round trip to L2 or HBM, not an L1 hit); output: literals are gathered into
+//     an aligned dword before they are stored, matches are copied byte by byte from the lane's own earlier output
 //     (its stores are visible to its later loads).
 //
 // Integer exact by construction: the result is the byte stream zlib / libdeflate produce (tests/test_gpu_inflate.py).
@@ -24,7 +25,7 @@
 namespace {
 
 constexpr int LANES = 64;                 // one wave per workgroup: the LDS slice of a lane is indexed by its lane id
-constexpr int LIT_SYMS = 288, DIST_SYMS = 32, LANE_SYMS = LIT_SYMS + DIST_SYMS;
+constexpr int LIT_SYMS = 288, DIST_SYMS = 32, LANE_DWORDS = 9 + (LIT_SYMS + DIST_SYMS) / 4;     // 89 dwords = 356 B of LDS per lane
 
 __constant__ uint16_t LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
 __constant__ uint8_t LEN_EXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -41,49 +42,76 @@ struct Counts {
 };
 
 struct BitReader {
-    const uint32_t* words;                // aligned dwords of the compressed buffer
-    uint64_t next;                        // index of the next dword to fetch
-    uint64_t end;                         // one past the last dword that may be fetched
+    const uint4* vecs;                    // the compressed buffer as aligned 16-byte vectors
+    uint64_t vnext, vend;                 // next vector to fetch, one past the last one that may be fetched
+    uint4 cur, nxt;                       // vector being consumed; the one behind it, fetched a whole vector ahead
+    int curw;                             // next dword of `cur`
     uint64_t buf;                         // unread bits, LSB first
     int cnt;                              // valid bits in buf
-    bool overrun;
+    int64_t fed, limit;                   // bits handed out so far / bits the stream holds
+    __device__ __forceinline__ uint4 fetch()
+    {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (vnext < vend) v = vecs[vnext];                     // (past the end zeros are shifted in; exhausted() notices)
+        ++vnext;
+        return v;
+    }
     __device__ __forceinline__ void init(const uint8_t* base, uint64_t byte_off, uint64_t byte_len)
     {
-        words = reinterpret_cast<const uint32_t*>(base);
-        next = byte_off >> 2;
-        end = (byte_off + byte_len + 3) >> 2;
-        buf = 0; cnt = 0; overrun = false;
+        vecs = reinterpret_cast<const uint4*>(base);
+        vnext = byte_off >> 4;
+        vend = (byte_off + byte_len + 15) >> 4;
+        cur = fetch();
+        nxt = fetch();
+        curw = (int)(byte_off & 15) >> 2;
+        buf = 0; cnt = 0;
         refill();
         const int skip = (int)(byte_off & 3) * 8;             // bytes in front of the stream inside its first dword
         buf >>= skip;
         cnt -= skip;
+        fed = 0;
+        limit = (int64_t)byte_len * 8;
     }
     __device__ __forceinline__ void refill()
     {
         if (cnt <= 32) {
-            uint32_t v = 0;
-            if (next < end) v = words[next];
-            ++next;                                            // (past the end zeros are shifted in; need() notices)
+            const uint32_t v = curw == 0 ? cur.x : curw == 1 ? cur.y : curw == 2 ? cur.z : cur.w;
+            if (++curw == 4) { cur = nxt; nxt = fetch(); curw = 0; }      // the new vector is needed four refills from now
             buf |= (uint64_t)v << cnt;
             cnt += 32;
         }
     }
+    __device__ __forceinline__ void drop(int n) { buf >>= n; cnt -= n; fed += n; }
     __device__ __forceinline__ uint32_t bits(int n)           // n <= 16
     {
         refill();
         const uint32_t v = (uint32_t)buf & ((1u << n) - 1u);
-        buf >>= n;
-        cnt -= n;
+        drop(n);
         return v;
     }
-    __device__ __forceinline__ bool exhausted() const         // more bits consumed than the stream holds
-    {
-        return (int64_t)next * 32 - cnt > (int64_t)end * 32;
-    }
+    __device__ __forceinline__ bool exhausted() const { return fed > limit; }   // more bits consumed than the stream holds
+};
+
+// A lane's symbol tables in LDS, sorted by (code length, symbol): the literal / length alphabet as the low bytes of its
+// symbols plus one bit per entry for the ninth (symbols 256..287), the distance alphabet as bytes -- 356 bytes per lane
+// instead of 640 with 16-bit entries: seven one-wave workgroups per CU instead of four.
+struct LitSyms {
+    uint8_t* lo;                          // [288]
+    uint32_t* hi;                         // [9] bit i = entry i is >= 256
+    __device__ __forceinline__ int get(int i) const { return (int)lo[i] | (int)((hi[i >> 5] >> (i & 31)) & 1u) << 8; }
+    __device__ __forceinline__ void clear() { for (int k = 0; k < 9; ++k) hi[k] = 0; }
+    __device__ __forceinline__ void put(int i, int sym) { lo[i] = (uint8_t)sym; if (sym & 256) hi[i >> 5] |= 1u << (i & 31); }
+};
+struct ByteSyms {
+    uint8_t* lo;
+    __device__ __forceinline__ int get(int i) const { return (int)lo[i]; }
+    __device__ __forceinline__ void clear() {}
+    __device__ __forceinline__ void put(int i, int sym) { lo[i] = (uint8_t)sym; }
 };
 
 // canonical Huffman decode of one symbol: walks the code lengths 1..15 with the counts in registers, then one LDS read
-__device__ __forceinline__ int decode_symbol(BitReader& br, const Counts& c, const uint16_t* syms)
+template <class Syms>
+__device__ __forceinline__ int decode_symbol(BitReader& br, const Counts& c, const Syms& syms)
 {
     br.refill();
     uint32_t bitsrc = (uint32_t)br.buf;
@@ -94,9 +122,8 @@ __device__ __forceinline__ int decode_symbol(BitReader& br, const Counts& c, con
         bitsrc >>= 1;
         const int count = (int)c.get(len);
         if (code - count < first) {
-            br.buf >>= len;
-            br.cnt -= len;
-            return syms[index + (code - first)];
+            br.drop(len);
+            return syms.get(index + (code - first));
         }
         index += count;
         first += count;
@@ -107,9 +134,11 @@ __device__ __forceinline__ int decode_symbol(BitReader& br, const Counts& c, con
 }
 
 // code lengths -> counts (registers) + symbols sorted by (length, symbol) in the lane's LDS slice (RFC 1951 3.2.2)
-__device__ __forceinline__ bool build(const uint8_t* lens, int n, Counts& c, uint16_t* syms)
+template <class Syms>
+__device__ __forceinline__ bool build(const uint8_t* lens, int n, Counts& c, Syms& syms)
 {
     c.clear();
+    syms.clear();
     for (int s = 0; s < n; ++s) if (lens[s]) c.add(lens[s]);
     int left = 1;                                               // over-subscription check
     uint16_t offs[16];
@@ -120,7 +149,7 @@ __device__ __forceinline__ bool build(const uint8_t* lens, int n, Counts& c, uin
         if (left < 0) return false;
         if (len < 15) offs[len + 1] = (uint16_t)(offs[len] + c.get(len));
     }
-    for (int s = 0; s < n; ++s) if (lens[s]) syms[offs[lens[s]]++] = (uint16_t)s;
+    for (int s = 0; s < n; ++s) if (lens[s]) syms.put(offs[lens[s]]++, s);
     return true;                                                // (incomplete codes are legal for a single distance code)
 }
 
@@ -155,11 +184,12 @@ __global__ __launch_bounds__(LANES)
 void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const uint64_t* __restrict__ src_off, const uint32_t* __restrict__ src_len,
                          const uint64_t* __restrict__ dst_off, uint32_t n_blocks, uint8_t* __restrict__ out, uint32_t* __restrict__ status)
 {
-    __shared__ uint16_t lds_syms[LANES * LANE_SYMS];
+    __shared__ uint32_t lds[LANES * LANE_DWORDS];
     const uint32_t b = blockIdx.x * LANES + threadIdx.x;
     if (b >= n_blocks) return;
-    uint16_t* lit_syms = lds_syms + threadIdx.x * LANE_SYMS;
-    uint16_t* dist_syms = lit_syms + LIT_SYMS;
+    uint32_t* mine = lds + threadIdx.x * LANE_DWORDS;         // [9 mask dwords][288 literal bytes][32 distance bytes]
+    LitSyms lit_syms{reinterpret_cast<uint8_t*>(mine + 9), mine};
+    ByteSyms dist_syms{reinterpret_cast<uint8_t*>(mine + 9) + LIT_SYMS};
     BitReader br;
     br.init(comp, src_off[b], src_len[b]);
     Writer w{out, dst_off[b], dst_off[b], dst_off[b + 1], 0u, 0};
@@ -192,10 +222,10 @@ void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const uint64_t* __res
                 for (int i = 0; i < 19; ++i) cl[i] = 0;
                 for (int i = 0; i < ncode; ++i) cl[CLEN_ORDER[i]] = (uint8_t)br.bits(3);
                 Counts cc;
-                if (!build(cl, 19, cc, lit_syms)) { err = INF_BAD_TABLE; break; }      // (the code-length code borrows the slice)
+                if (!build(cl, 19, cc, dist_syms)) { err = INF_BAD_TABLE; break; }     // (the code-length code borrows the distance slice)
                 int i = 0;
                 while (i < nlen + ndist) {
-                    const int sym = decode_symbol(br, cc, lit_syms);
+                    const int sym = decode_symbol(br, cc, dist_syms);
                     if (sym < 0) { err = INF_BAD_TABLE; break; }
                     if (sym < 16) { lens[i < nlen ? i : LIT_SYMS + (i - nlen)] = (uint8_t)sym; ++i; continue; }
                     int prev = 0, rep;
@@ -245,8 +275,8 @@ void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const uint64_t* __res
 }  // namespace
 
 // BGZF blocks -> their inflated bytes, all blocks of a launch in parallel (one lane per block).
-//   d_comp      compressed bytes as they sit in the file (any run of whole blocks), 4-byte aligned, readable up to the
-//               next multiple of 4 behind the last payload byte
+//   d_comp      compressed bytes as they sit in the file (any run of whole blocks), 16-byte aligned, readable up to the
+//               next multiple of 16 behind the last payload byte
 //   d_src_off   [n] byte offset in d_comp of every block's DEFLATE payload (behind the 18-byte header)
 //   d_src_len   [n] payload bytes (BSIZE - xlen - 19)
 //   d_dst_off   [n + 1] byte offset in d_out of every block's inflated bytes: the running sum of the ISIZE fields
@@ -256,7 +286,7 @@ extern "C" int svx_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_src_off
 {
     if (n_blocks == 0) return SVX_OK;
     if (!d_comp || !d_src_off || !d_src_len || !d_dst_off || !d_out || !d_status) return SVX_EINVAL;
-    if (reinterpret_cast<uintptr_t>(d_comp) & 3u) return SVX_EINVAL;
+    if (reinterpret_cast<uintptr_t>(d_comp) & 15u) return SVX_EINVAL;
     hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((n_blocks + LANES - 1) / LANES), dim3(LANES), 0, static_cast<hipStream_t>(stream),
                        d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, d_out, d_status);
     return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;

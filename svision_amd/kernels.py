@@ -384,7 +384,7 @@ def bgzf_block_table(raw):
 
 
 def bgzf_inflate(d_comp, src_off, src_len, isize):
-    """d_comp: uint8 device tensor holding the compressed bytes (padded to a multiple of 4); src_off / src_len / isize: host
+    """d_comp: uint8 device tensor holding the compressed bytes (16-byte aligned, padded to a multiple of 16); src_off / src_len / isize: host
     arrays of :func:`bgzf_block_table` (or the native reader's).  -> (uint8 device tensor with the inflated stream,
     int32 device tensor [n] status: 0 = ok).  See include/svx.h svx_bgzf_inflate."""
     lib = _lib.load()

@@ -26,7 +26,7 @@ def _block(payload, level=6, strategy=zlib.Z_DEFAULT_STRATEGY):
 def _inflate_on_device(raw):
     raw = np.frombuffer(raw, np.uint8)
     src_off, src_len, isize, _blk = kernels.bgzf_block_table(raw)
-    padded = np.zeros((raw.size + 7) // 4 * 4, np.uint8)
+    padded = np.zeros((raw.size + 31) // 16 * 16, np.uint8)
     padded[:raw.size] = raw
     out, status = kernels.bgzf_inflate(torch.from_numpy(padded).cuda(), src_off, src_len, isize)
     return out.cpu().numpy().tobytes(), status.cpu().numpy()

@@ -11,7 +11,7 @@ if not os.path.exists(path):
     bam.write_bam_segments(path, table.references, table.lengths, segs)
 raw = np.fromfile(path, np.uint8)
 t = time.time(); src_off, src_len, isize, _b = kernels.bgzf_block_table(raw); print("block table (python) %.2f s, %d blocks" % (time.time() - t, len(isize)))
-padded = np.zeros((raw.size + 7) // 4 * 4, np.uint8); padded[:raw.size] = raw
+padded = np.zeros((raw.size + 31) // 16 * 16, np.uint8); padded[:raw.size] = raw
 pin = torch.from_numpy(padded).pin_memory()
 torch.cuda.synchronize(); t = time.time(); d = pin.cuda(non_blocking=True); torch.cuda.synchronize(); print("H2D %.1f MB in %.1f ms" % (raw.size / 1e6, (time.time() - t) * 1e3))
 for rep in range(3):
@@ -19,4 +19,12 @@ for rep in range(3):
     out, status = kernels.bgzf_inflate(d, src_off, src_len, isize)
     torch.cuda.synchronize(); dt = time.time() - t
     print("inflate %.1f MB -> %.1f MB in %.1f ms = %.1f GB/s inflated; bad blocks %d" % (raw.size / 1e6, out.numel() / 1e6, dt * 1e3, out.numel() / dt / 1e9, int(status.ne(0).sum())))
+# the same blocks four times over: does the rate follow the number of lanes?
+k = 4
+src4 = np.concatenate([src_off] * k); len4 = np.concatenate([src_len] * k); isz4 = np.concatenate([isize] * k)
+for rep in range(2):
+    torch.cuda.synchronize(); t = time.time()
+    out, status = kernels.bgzf_inflate(d, src4, len4, isz4)
+    torch.cuda.synchronize(); dt = time.time() - t
+    print("x%d: %d blocks -> %.1f MB in %.1f ms = %.1f GB/s inflated; bad blocks %d" % (k, len(isz4), out.numel() / 1e6, dt * 1e3, out.numel() / dt / 1e9, int(status.ne(0).sum())))
 want = bam.bgzf_decompress(raw.tobytes()[:50_000_000 if raw.size > 50_000_000 else raw.size]) if False else None
