@@ -33,12 +33,21 @@ __constant__ uint16_t DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 
 __constant__ uint8_t DIST_EXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __constant__ uint8_t CLEN_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
-// per-length code counts of one alphabet, lengths 1..15, 10 bits each (a count is at most 288): three per dword
+// per-length code counts of one alphabet, lengths 1..15, 10 bits each (a count is at most 288): three per dword.
+// Five named dwords, never an array: one dynamically indexed access anywhere in the kernel would move the whole thing
+// to scratch memory, and the symbol loop reads all fifteen counts for every symbol (first version: 6 scratch loads and
+// 6 scratch stores per decoded symbol, SQ_INSTS_VMEM_RD / _WR).
 struct Counts {
-    uint32_t w[5];
-    __device__ __forceinline__ void clear() { for (int i = 0; i < 5; ++i) w[i] = 0; }
-    __device__ __forceinline__ uint32_t get(int len) const { const int k = len - 1; return (w[k / 3] >> (10 * (k % 3))) & 1023u; }
-    __device__ __forceinline__ void add(int len) { const int k = len - 1; w[k / 3] += 1u << (10 * (k % 3)); }
+    uint32_t w0, w1, w2, w3, w4;
+    __device__ __forceinline__ void clear() { w0 = w1 = w2 = w3 = w4 = 0; }
+    __device__ __forceinline__ uint32_t word(int q) const { return q == 0 ? w0 : q == 1 ? w1 : q == 2 ? w2 : q == 3 ? w3 : w4; }
+    __device__ __forceinline__ uint32_t get(int len) const { const int k = len - 1, q = k / 3; return (word(q) >> (10 * (k - 3 * q))) & 1023u; }
+    __device__ __forceinline__ void add(int len, uint32_t by = 1)
+    {
+        const int k = len - 1, q = k / 3;
+        const uint32_t inc = by << (10 * (k - 3 * q));
+        w0 += q == 0 ? inc : 0u; w1 += q == 1 ? inc : 0u; w2 += q == 2 ? inc : 0u; w3 += q == 3 ? inc : 0u; w4 += q == 4 ? inc : 0u;
+    }
 };
 
 struct BitReader {
@@ -141,15 +150,21 @@ __device__ __forceinline__ bool build(const uint8_t* lens, int n, Counts& c, Sym
     syms.clear();
     for (int s = 0; s < n; ++s) if (lens[s]) c.add(lens[s]);
     int left = 1;                                               // over-subscription check
-    uint16_t offs[16];
-    offs[1] = 0;
+    Counts offs;                                                // first table slot of every length (same packing)
+    offs.clear();
+    uint32_t run = 0;
+#pragma unroll
     for (int len = 1; len <= 15; ++len) {
         left <<= 1;
         left -= (int)c.get(len);
-        if (left < 0) return false;
-        if (len < 15) offs[len + 1] = (uint16_t)(offs[len] + c.get(len));
+        offs.add(len, run);
+        run += c.get(len);
     }
-    for (int s = 0; s < n; ++s) if (lens[s]) syms.put(offs[lens[s]]++, s);
+    if (left < 0) return false;
+    for (int s = 0; s < n; ++s) {
+        const int len = lens[s];
+        if (len) { syms.put((int)offs.get(len), s); offs.add(len); }
+    }
     return true;                                                // (incomplete codes are legal for a single distance code)
 }
 
