@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SVX_VERSION 310            /* 0.2.1: + active-row masks out of svx_alexnet_active_sets, into svx_bias_relu_pool_lrn */
+#define SVX_VERSION 320            /* 0.2.1: + active-row masks out of svx_alexnet_active_sets, into svx_bias_relu_pool_lrn */
 
 #define SVX_OK            0
 #define SVX_EINVAL       (-1)      /* bad argument (null pointer, bad layout...) */
@@ -267,6 +267,27 @@ void           svx_bam_close(void* handle);
  * anything else = corrupt (the caller falls back to the host decoder). */
 int            svx_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len,
                                 const uint64_t* d_dst_off, uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, void* stream);
+
+/* BAM records in an inflated stream on the device -> packed arrays (svx_bamdev.hip).  d_starts [n_starts + 1]: byte
+ * offsets in d_raw of known record starts (from the .bai linear index), ascending, the last entry = end of the part.
+ *   svx_bam_walk_count    d_counts [n_starts][4] = records, CIGAR words, QNAME bytes (one separator per record) between
+ *                         start i and start i + 1, and a status: 0 ok, 1 the walk misses the next start, 2 malformed
+ *                         record, 3 CG-tag CIGAR (the caller decodes that part on the host)
+ *   svx_bam_walk_extract  d_base [n_starts][3] = exclusive prefix sums of the first three counts; fills tid / pos / flag /
+ *                         mapq / l_seq [records], cig_off / name_off [records] (offsets of each record's words / name),
+ *                         cigar [words], names [bytes] ('\n' behind every name) */
+int            svx_bam_walk_count(const uint8_t* d_raw, const uint64_t* d_starts, uint32_t n_starts, uint64_t* d_counts, void* stream);
+int            svx_bam_walk_extract(const uint8_t* d_raw, const uint64_t* d_starts, uint32_t n_starts, const uint64_t* d_base,
+                                    int32_t* d_tid, int32_t* d_pos, uint16_t* d_flag, uint8_t* d_mapq, int32_t* d_l_seq,
+                                    int64_t* d_cig_off, uint32_t* d_cigar, int64_t* d_name_off, uint8_t* d_names, void* stream);
+/* host helpers of the device-side ingestion: parallel positional read into caller memory; the whole BGZF blocks of a
+ * buffer (payload offset / size, ISIZE, file offset; -> their number or -1, *used = bytes they cover); QNAME ids by
+ * first occurrence (-> number of distinct names, written '\n'-separated to uniq) */
+int            svx_read_range(const char* path, uint64_t off, uint64_t n, uint8_t* dst, int threads);
+int64_t        svx_bgzf_index(const uint8_t* bytes, uint64_t n, uint64_t base_coff, uint64_t cap, uint64_t* src_off,
+                              uint32_t* src_len, uint32_t* isize, uint64_t* coff, uint64_t* used);
+int64_t        svx_name_ids(const uint8_t* names, const int64_t* name_off, uint64_t n, int32_t* name_id, uint8_t* uniq,
+                            uint64_t* uniq_bytes);
 
 /* Streaming ingestion, one reference sequence at a time (replaces the reference's window-by-window
  * AlignmentFile.fetch(chrom, start, end), run_collection.py:23-26, by one pass over the file that hands chromosome k

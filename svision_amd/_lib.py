@@ -48,6 +48,11 @@ SYMBOLS = {
     "svx_bam_seq": (_vp, [_vp]),
     "svx_bam_close": (None, [_vp]),
     "svx_bgzf_inflate": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
+    "svx_bam_walk_count": (ctypes.c_int, [_vp, _vp, _u32, _vp, _vp]),
+    "svx_bam_walk_extract": (ctypes.c_int, [_vp, _vp, _u32, _vp] + [_vp] * 9 + [_vp]),
+    "svx_read_range": (ctypes.c_int, [ctypes.c_char_p, _u64, _u64, _vp, ctypes.c_int]),
+    "svx_bgzf_index": (ctypes.c_int64, [_vp, _u64, _u64, _u64, _vp, _vp, _vp, _vp, _vp]),
+    "svx_name_ids": (ctypes.c_int64, [_vp, _vp, _u64, _vp, _vp, _vp]),
     "svx_bam_stream_open": (_vp, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int]),
     "svx_bam_stream_next": (_vp, [_vp, _vp]),
     "svx_bam_stream_close": (None, [_vp]),
@@ -65,7 +70,7 @@ class SvxMissing(SvxError):
 _lib = None
 
 
-ABI_VERSION = 310                     # SVX_VERSION of include/svx.h this binding was written against
+ABI_VERSION = 320                     # SVX_VERSION of include/svx.h this binding was written against
 
 
 def load():

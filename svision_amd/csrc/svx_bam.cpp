@@ -990,6 +990,92 @@ void* svx_bam_stream_next(void* stream, int* status)
 
 void svx_bam_stream_close(void* stream) { delete static_cast<Stream*>(stream); }
 
+// ---- host helpers of the device-side ingestion (svx_inflate.hip, svx_bamdev.hip) ------------------------------------
+// file[off, off + n) -> dst (pinned memory of the caller), `threads` positional reads at once: one thread copies the page
+// cache at ~10 GB/s, the upload runs at ~55
+int svx_read_range(const char* path, uint64_t off, uint64_t n, uint8_t* dst, int threads)
+{
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) { g_bam_error = std::string("cannot open ") + path; return SVX_EINVAL; }
+    threads = std::max(1, std::min(threads, 32));
+    std::atomic<bool> ok{true};
+    const uint64_t piece = ((n + threads - 1) / threads + 4095) & ~4095ull;
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; ++t) {
+        const uint64_t lo = std::min<uint64_t>(n, t * piece), hi = std::min<uint64_t>(n, lo + piece);
+        if (lo >= hi) break;
+        pool.emplace_back([=, &ok] {
+            uint64_t done = lo;
+            while (done < hi) {
+                const ssize_t got = pread(fd, dst + done, hi - done, (off_t)(off + done));
+                if (got <= 0) { ok = false; return; }
+                done += (uint64_t)got;
+            }
+        });
+    }
+    for (auto& th : pool) th.join();
+    ::close(fd);
+    if (!ok) { g_bam_error = "short read"; return SVX_EINVAL; }
+    return SVX_OK;
+}
+
+// Whole BGZF blocks at the start of bytes[0, n): for each its payload offset / size in `bytes`, its inflated size and
+// its own offset (+ base_coff = its file offset).  -> number of blocks (at most cap), or -1 (not BGZF).  *used = bytes
+// covered by them (a block cut by the end of the buffer is not counted).
+int64_t svx_bgzf_index(const uint8_t* b, uint64_t n, uint64_t base_coff, uint64_t cap, uint64_t* src_off, uint32_t* src_len,
+                       uint32_t* isize, uint64_t* coff, uint64_t* used)
+{
+    uint64_t p = 0, k = 0;
+    while (p + 18 <= n && k < cap) {
+        if (!(b[p] == 0x1f && b[p + 1] == 0x8b && b[p + 2] == 8 && (b[p + 3] & 4))) return -1;
+        const uint32_t xlen = rd16(&b[p + 10]);
+        if (p + 12 + xlen > n) break;
+        uint32_t bsize = 0;
+        bool found = false;
+        for (uint64_t q = p + 12; q + 4 <= p + 12 + xlen;) {
+            const uint32_t slen = rd16(&b[q + 2]);
+            if (b[q] == 'B' && b[q + 1] == 'C') { bsize = rd16(&b[q + 4]); found = true; }
+            q += 4 + slen;
+        }
+        if (!found) return -1;
+        if (p + bsize + 1 > n) break;
+        const uint64_t data = p + 12 + xlen, end = p + bsize + 1;
+        if (end < data + 8) return -1;
+        src_off[k] = data;
+        src_len[k] = (uint32_t)(end - 8 - data);
+        isize[k] = rd32(&b[end - 4]);
+        coff[k] = base_coff + p;
+        ++k;
+        p = end;
+    }
+    *used = p;
+    return (int64_t)k;
+}
+
+// QNAME ids by first occurrence (what the host decoder computes while it chains the records): names = the records'
+// names, '\n'-separated, name_off [n + 1] their offsets.  name_id [n]; uniq receives the distinct names in id order,
+// '\n'-separated (*uniq_bytes of them).  -> number of distinct names.
+int64_t svx_name_ids(const uint8_t* names, const int64_t* name_off, uint64_t n, int32_t* name_id, uint8_t* uniq, uint64_t* uniq_bytes)
+{
+    std::unordered_map<std::string_view, int32_t> seen;
+    seen.reserve(n);
+    uint64_t w = 0;
+    int32_t next = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const std::string_view nm(reinterpret_cast<const char*>(names + name_off[i]), (size_t)(name_off[i + 1] - name_off[i] - 1));
+        auto it = seen.find(nm);
+        if (it == seen.end()) {
+            it = seen.emplace(nm, next++).first;
+            memcpy(uniq + w, nm.data(), nm.size());
+            uniq[w + nm.size()] = '\n';
+            w += nm.size() + 1;
+        }
+        name_id[i] = it->second;
+    }
+    *uniq_bytes = w;
+    return next;
+}
+
 void svx_bam_close(void* h) { delete static_cast<Bam*>(h); }
 
 }  // extern "C"

@@ -1,0 +1,124 @@
+// svx_bamdev.hip -- BAM records -> packed structure of arrays, on the device (gfx950).
+//
+// Second half of the device-side ingestion (first half: svx_inflate.hip).  The inflated record stream of a chromosome
+// sits in HBM; what the hot path needs from it is ~3 % of its bytes: the fixed fields, the QNAME and the CIGAR words of
+// every record (SAMv1 4.2) -- the packed arrays svx_cigar_scan consumes, which therefore never cross the PCIe bus.
+//
+// Records are chained by their block_size fields, a serial walk.  The .bai linear index breaks the chain: it stores the
+// virtual offset of the first record overlapping every 16 kb of the reference (SAMv1 5.1.3), i.e. thousands of known
+// record starts per chromosome.  One lane walks from one such start to the next (a few dozen records):
+//
+//   pass 1  svx_bam_walk_count   per start: records, CIGAR words, QNAME bytes; the walk must END exactly on the next start
+//   (host: exclusive prefix sums -> where every lane writes)
+//   pass 2  svx_bam_walk_extract per start: tid / pos / flag / mapq / l_seq, CIGAR words, QNAMEs ('\n'-separated)
+//
+// Integer exact: the arrays equal the host decoder's (svx_bam.cpp) element for element (tests/test_gpu_inflate.py).
+// Records with a CG:B,I long CIGAR (> 65535 operations) set a flag and the caller takes the host decoder for that part.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/svx.h"
+
+namespace {
+
+constexpr int BLOCK = 64;
+
+__device__ __forceinline__ uint32_t ld32(const uint8_t* p)    // unaligned little-endian load
+{
+    return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24;
+}
+
+// counts per start: [0] records, [1] CIGAR words, [2] QNAME bytes (incl. one separator per record), [3] status
+// status: 0 ok, 1 walk does not end on the next start (index does not match the data), 2 malformed record, 3 long CIGAR
+__global__ __launch_bounds__(BLOCK)
+void bam_walk_count_kernel(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ starts, uint32_t n_starts,
+                           uint64_t* __restrict__ counts)
+{
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n_starts) return;
+    uint64_t p = starts[i];
+    const uint64_t end = starts[i + 1];
+    uint64_t n = 0, words = 0, name_bytes = 0, status = 0;
+    while (p < end) {
+        if (p + 36 > end) { status = 2; break; }
+        const uint32_t bs = ld32(raw + p);
+        const uint8_t* rec = raw + p + 4;
+        const uint32_t l_name = rec[8], n_cig = (uint32_t)rec[12] | (uint32_t)rec[13] << 8, l_seq = ld32(rec + 16);
+        if (bs < 32 || p + 4 + bs > end || 32ull + l_name + 4ull * n_cig + (l_seq + 1ull) / 2 + l_seq > bs) { status = 2; break; }
+        if (n_cig == 2) {                                       // "<l_seq>S<span>N": the real CIGAR is in the CG tag
+            const uint32_t w0 = ld32(rec + 32 + l_name), w1 = ld32(rec + 36 + l_name);
+            if ((w0 & 15) == 4 && (w0 >> 4) == l_seq && (w1 & 15) == 3) { status = 3; break; }
+        }
+        ++n;
+        words += n_cig;
+        name_bytes += l_name ? l_name : 1;                      // l_name counts the NUL: the bytes + one separator
+        p += 4 + bs;
+    }
+    if (status == 0 && p != end) status = 1;
+    counts[4ull * i + 0] = n;
+    counts[4ull * i + 1] = words;
+    counts[4ull * i + 2] = name_bytes;
+    counts[4ull * i + 3] = status;
+}
+
+// base per start (exclusive prefix sums of the counts): [0] first record, [1] first CIGAR word, [2] first QNAME byte
+__global__ __launch_bounds__(BLOCK)
+void bam_walk_extract_kernel(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ starts, uint32_t n_starts,
+                             const uint64_t* __restrict__ base, int32_t* __restrict__ tid, int32_t* __restrict__ pos,
+                             uint16_t* __restrict__ flag, uint8_t* __restrict__ mapq, int32_t* __restrict__ l_seq_out,
+                             int64_t* __restrict__ cig_off, uint32_t* __restrict__ cigar, int64_t* __restrict__ name_off,
+                             uint8_t* __restrict__ names)
+{
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n_starts) return;
+    uint64_t p = starts[i];
+    const uint64_t end = starts[i + 1];
+    uint64_t k = base[3ull * i + 0], w = base[3ull * i + 1], nb = base[3ull * i + 2];
+    while (p < end) {
+        const uint32_t bs = ld32(raw + p);
+        const uint8_t* rec = raw + p + 4;
+        const uint32_t l_name = rec[8], n_cig = (uint32_t)rec[12] | (uint32_t)rec[13] << 8;
+        tid[k] = (int32_t)ld32(rec);
+        pos[k] = (int32_t)ld32(rec + 4);
+        mapq[k] = rec[9];
+        flag[k] = (uint16_t)((uint32_t)rec[14] | (uint32_t)rec[15] << 8);
+        l_seq_out[k] = (int32_t)ld32(rec + 16);
+        cig_off[k] = (int64_t)w;
+        name_off[k] = (int64_t)nb;
+        const uint8_t* nm = rec + 32;
+        const uint32_t nn = l_name ? l_name - 1 : 0;
+        for (uint32_t j = 0; j < nn; ++j) names[nb + j] = nm[j];
+        names[nb + nn] = '\n';
+        nb += nn + 1;
+        const uint8_t* cg = rec + 32 + l_name;
+        for (uint32_t j = 0; j < n_cig; ++j) cigar[w + j] = ld32(cg + 4 * j);
+        w += n_cig;
+        ++k;
+        p += 4 + bs;
+    }
+}
+
+}  // namespace
+
+// pass 1: d_starts [n_starts + 1] byte offsets into d_raw (the last entry = end of the part); d_counts [n_starts][4]
+extern "C" int svx_bam_walk_count(const uint8_t* d_raw, const uint64_t* d_starts, uint32_t n_starts, uint64_t* d_counts, void* stream)
+{
+    if (n_starts == 0) return SVX_OK;
+    if (!d_raw || !d_starts || !d_counts) return SVX_EINVAL;
+    hipLaunchKernelGGL(bam_walk_count_kernel, dim3((n_starts + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, static_cast<hipStream_t>(stream),
+                       d_raw, d_starts, n_starts, d_counts);
+    return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
+}
+
+// pass 2: d_base [n_starts][3] = exclusive prefix sums of the first three counts; the output arrays are sized by their
+// totals (d_cig_off / d_name_off get one entry per record; the caller appends the totals)
+extern "C" int svx_bam_walk_extract(const uint8_t* d_raw, const uint64_t* d_starts, uint32_t n_starts, const uint64_t* d_base,
+                                    int32_t* d_tid, int32_t* d_pos, uint16_t* d_flag, uint8_t* d_mapq, int32_t* d_l_seq,
+                                    int64_t* d_cig_off, uint32_t* d_cigar, int64_t* d_name_off, uint8_t* d_names, void* stream)
+{
+    if (n_starts == 0) return SVX_OK;
+    if (!d_raw || !d_starts || !d_base || !d_tid || !d_pos || !d_flag || !d_mapq || !d_l_seq || !d_cig_off || !d_cigar || !d_name_off || !d_names)
+        return SVX_EINVAL;
+    hipLaunchKernelGGL(bam_walk_extract_kernel, dim3((n_starts + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, static_cast<hipStream_t>(stream),
+                       d_raw, d_starts, n_starts, d_base, d_tid, d_pos, d_flag, d_mapq, d_l_seq, d_cig_off, d_cigar, d_name_off, d_names);
+    return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
+}

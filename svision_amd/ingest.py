@@ -94,8 +94,13 @@ class ChromosomeFeed:
     BAM header's dictionary.  ``stats`` afterwards: seconds the feeder thread spent waiting for the decoder, uploading +
     scanning, and blocked on a full hand-over queue; bytes of packed CIGAR uploaded."""
 
-    def __init__(self, bam_path, fasta, options, chroms, references, lengths, device="cuda", index=None, threads=0, depth=2):
+    def __init__(self, bam_path, fasta, options, chroms, references, lengths, device="cuda", index=None, threads=0, depth=2,
+                 engine=None, header_text=""):
         self.bam_path, self.fasta, self.options = bam_path, fasta, options
+        self.header_text = header_text
+        # where the BGZF blocks are inflated: "cpu" = libdeflate on host threads (io.bam.BamStream), "gpu" = on the device
+        # (ingest_gpu.DeviceDecoder); default: the device when the host is short of CPU time and the file has a linear index
+        self.engine = engine or os.environ.get("SVX_INGEST", "auto")
         self.references, self.lengths = list(references), list(lengths)
         self.chroms = list(chroms)
         self.device, self.index, self.threads = device, index, threads
@@ -107,7 +112,7 @@ class ChromosomeFeed:
         self.fresh = []                                        # (key, meta) not yet announced to the helpers
         self.error = None
         self.finished = False
-        self.stats = {"decode_wait_s": 0.0, "upload_scan_s": 0.0, "handover_wait_s": 0.0, "cigar_bytes": 0, "records": 0,
+        self.stats = {"engine": None, "decode_wait_s": 0.0, "upload_scan_s": 0.0, "handover_wait_s": 0.0, "cigar_bytes": 0, "records": 0,
                       "first_ready_s": None, "last_ready_s": None}
         self._t0 = time.perf_counter()
         self._stop = False
@@ -120,6 +125,7 @@ class ChromosomeFeed:
             if n == 0:
                 return np.empty(0, dtype)
             return np.lib.format.open_memmap(os.path.join(d, name + ".npy"), mode="w+", dtype=dtype, shape=(n,))
+        alloc.dir = d
         return alloc
 
     def _run(self):
@@ -145,15 +151,56 @@ class ChromosomeFeed:
                         self.fn = self.feed._alloc_in(next_dir())
                     return self.fn(name, dtype, n)
 
-            stream = BamStream(self.bam_path, with_seq=self.with_seq, threads=self.threads, tids=tids, index=self.index, alloc=Alloc(self))
             ingest_stream = torch.cuda.Stream(device=self.device, priority=-1) if torch.cuda.is_available() else None
-            it = iter(stream)
+            if ingest_stream is None:
+                raise RuntimeError("ChromosomeFeed needs the GPU (svx_cigar_scan); there is no CPU fallback")
+
+            def host_parts(which):                             # BGZF inflate on host threads
+                stream = BamStream(self.bam_path, with_seq=self.with_seq, threads=self.threads, tids=which, index=self.index, alloc=Alloc(self))
+                try:
+                    for table in stream:
+                        table._shm_dir = self._dir
+                        yield table, None
+                finally:
+                    stream.close()
+
+            def device_parts(which):                           # BGZF inflate + record packing on the device
+                from .ingest_gpu import DeviceDecoder, DeviceIngestError
+
+                def alloc_for():
+                    return self._alloc_in(next_dir())
+                dec = self.decoder = DeviceDecoder(self.bam_path, self.index, self.references, self.lengths, self.header_text, self.device,
+                                                   threads=min(8, max(1, self.threads)), alloc_for=alloc_for)
+                if not dec.usable(which):
+                    yield from host_parts(which)
+                    return
+                for group in dec.groups(which):
+                    try:
+                        with torch.cuda.stream(ingest_stream):
+                            parts = dec.decode_group(group)
+                    except DeviceIngestError as exc:           # CG-tag CIGARs, an index that does not fit: the host reader takes the group
+                        import logging
+                        logging.warning("device ingestion of references %s failed (%s): decoding them on the host", group, exc)
+                        yield from host_parts(group)
+                        continue
+                    for table, arrays in parts:
+                        yield table, arrays
+
+            engine = self.engine
+            if engine == "auto":
+                usable, _visible = effective_cpus()
+                engine = "gpu" if (self.index is not None and not self.with_seq and usable < 48) else "cpu"
+            if engine == "gpu" and (self.index is None or self.with_seq):
+                engine = "cpu"
+            self.stats["engine"] = engine
+            it = device_parts(tids) if engine == "gpu" else host_parts(tids)
             while not self._stop:
                 t0 = time.perf_counter()
-                table = next(it, None)
+                item = next(it, None)
                 self.stats["decode_wait_s"] += time.perf_counter() - t0
-                if table is None:
+                if item is None:
                     break
+                table, arrays = item
                 tid = int(table.tid[0])
                 while want and want[0] != tid:                 # chromosomes of this rank without a record in the file
                     self._emit_empty(want.pop(0))
@@ -161,12 +208,12 @@ class ChromosomeFeed:
                     break
                 want.pop(0)
                 t0 = time.perf_counter()
-                if ingest_stream is not None:
-                    with torch.cuda.stream(ingest_stream):
+                with torch.cuda.stream(ingest_stream):
+                    if arrays is None:
                         sample = Sample.from_table(table, self.fasta, self.options.min_sv_size, self.device)
-                else:
-                    raise RuntimeError("ChromosomeFeed needs the GPU (svx_cigar_scan); there is no CPU fallback")
-                d = self._dir
+                    else:
+                        sample = Sample.from_device(table, self.fasta, self.options.min_sv_size, *arrays)
+                d = table._shm_dir
                 np.save(os.path.join(d, "gaps.npy"), sample.gaps)
                 np.save(os.path.join(d, "gap_off.npy"), sample.gap_off)
                 np.save(os.path.join(d, "stats.npy"), sample.stats)
@@ -178,7 +225,8 @@ class ChromosomeFeed:
                 self._put((self.references[tid], sample, meta))
             while want and not self._stop:
                 self._emit_empty(want.pop(0))
-            stream.close()
+            if getattr(self, "decoder", None) is not None:
+                self.stats["device_decoder"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in self.decoder.stats.items()}
         except BaseException as exc:                           # noqa: BLE001 -- surfaces in the owner thread (poll / get)
             self.error = exc
         finally:

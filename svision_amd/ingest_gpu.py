@@ -1,0 +1,189 @@
+"""Device-side BAM ingestion: the compressed file goes to the GPU as it is, BGZF blocks are inflated there
+(svx_bgzf_inflate, one lane per block), the records are located through the .bai linear index and their fixed fields,
+QNAMEs and CIGAR words are packed on the device (svx_bam_walk_*).  The packed CIGARs -- the input of svx_cigar_scan --
+never leave HBM; the host receives the small per-record arrays its collection step needs.
+
+Why: DEFLATE decoding is the cost of ingestion (a HiFi BAM inflates to ~22 KB per read, ~0.6 GB/s per host core), and the
+GPU boxes this was built on give a container the CPU time of 16 cores (svision_amd.ingest.effective_cpus): ~10 GB/s of
+inflated data, a quarter of what the device pipeline consumes.  The same data inflates at ~45 GB/s on the MI355X.
+Replaces pysam's AlignmentFile.fetch (run_collection.py:23-26) like the host reader (io.bam.BamStream), which stays the
+engine for files without a linear index, for --hash / --graph (read bases wanted) and for CG-tag CIGARs.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import _lib, kernels
+from .io.bam import AlignmentTable, read_bai_linear
+
+FIRST_GROUP_BYTES = 192 << 20            # the first launch is small: the pipeline starts after ~0.1 s
+GROUP_BYTES = 2 << 30                    # later groups: enough blocks (~80 k) to fill the device
+
+
+class DeviceIngestError(RuntimeError):
+    pass
+
+
+class DeviceDecoder:
+    def __init__(self, path, index, references, lengths, header_text, device, threads=8, alloc_for=None):
+        self.path, self.references, self.lengths, self.header_text = path, list(references), list(lengths), header_text
+        self.device, self.threads = torch.device(device), max(1, int(threads))
+        self.alloc_for = alloc_for                               # callable() -> alloc(name, dtype, n) of the next part (shared memory)
+        self.lib = _lib.load()
+        self.spans = read_bai_linear(index)
+        self.size = os.path.getsize(path)
+        self.pinned = None
+        self.stats = {"read_s": 0.0, "h2d_inflate_s": 0.0, "walk_s": 0.0, "d2h_s": 0.0, "names_s": 0.0, "blocks": 0, "bytes_in": 0, "bytes_inflated": 0}
+
+    def usable(self, tids):
+        return all(t < len(self.spans) and (self.spans[t] is None or self.spans[t][2].size > 0) for t in tids)
+
+    def groups(self, tids):
+        """Chromosomes that have records, in file order, cut into runs of about FIRST_GROUP_BYTES / GROUP_BYTES compressed bytes."""
+        have = sorted((self.spans[t][0], t) for t in tids if t < len(self.spans) and self.spans[t] is not None)
+        out, cur, cur_bytes, limit = [], [], 0, FIRST_GROUP_BYTES
+        for _v, t in have:
+            lo, hi, _lin = self.spans[t]
+            nbytes = (hi >> 16) - (lo >> 16) + 65536
+            if cur and cur_bytes + nbytes > limit:
+                out.append(cur)
+                cur, cur_bytes, limit = [], 0, GROUP_BYTES
+            cur.append(t)
+            cur_bytes += nbytes
+        if cur:
+            out.append(cur)
+        return out
+
+    def _pinned(self, n):
+        if self.pinned is None or self.pinned.numel() < n:
+            self.pinned = torch.empty(max(n, 64 << 20), dtype=torch.uint8, pin_memory=True)
+        return self.pinned
+
+    def decode_group(self, tids):
+        """-> [(AlignmentTable on the host, (d_cigar int32, d_cig_off int64 [n+1], d_pos int32))] for the chromosomes of one group."""
+        import time
+        lib, dev = self.lib, self.device
+        spans = [self.spans[t] for t in tids]
+        c0 = min(s[0] >> 16 for s in spans)
+        c1 = min(self.size, max(s[1] >> 16 for s in spans) + 65536 + 64)
+        nbytes = c1 - c0
+        t0 = time.perf_counter()
+        pin = self._pinned(nbytes + 64)
+        if lib.svx_read_range(self.path.encode(), c0, nbytes, pin.data_ptr(), self.threads) != 0:
+            raise DeviceIngestError(lib.svx_bam_error().decode())
+        pin[nbytes:nbytes + 64].zero_()
+        cap = nbytes // 28 + 16
+        src_off, coff = np.empty(cap, np.uint64), np.empty(cap, np.uint64)
+        src_len, isize = np.empty(cap, np.uint32), np.empty(cap, np.uint32)
+        used = np.zeros(1, np.uint64)
+        nb = int(lib.svx_bgzf_index(pin.data_ptr(), nbytes, c0, cap, src_off.ctypes.data, src_len.ctypes.data, isize.ctypes.data,
+                                    coff.ctypes.data, used.ctypes.data))
+        if nb <= 0:
+            raise DeviceIngestError("no BGZF block at file offset %d" % c0)
+        src_off, src_len, isize, coff = src_off[:nb], src_len[:nb], isize[:nb], coff[:nb]
+        t1 = time.perf_counter()
+        self.stats["read_s"] += t1 - t0
+        padded = (nbytes + 31) // 16 * 16
+        d_comp = torch.empty(padded, dtype=torch.uint8, device=dev)
+        d_comp.copy_(pin[:padded], non_blocking=True)
+        d_raw, d_status = kernels.bgzf_inflate(d_comp, src_off, src_len, isize)
+        if int(d_status.max().item()) != 0:
+            raise DeviceIngestError("%d corrupt BGZF blocks" % int(d_status.ne(0).sum().item()))
+        del d_comp
+        t2 = time.perf_counter()
+        self.stats["h2d_inflate_s"] += t2 - t1
+        self.stats["blocks"] += nb
+        self.stats["bytes_in"] += int(nbytes)
+        self.stats["bytes_inflated"] += int(d_raw.numel())
+        dst = np.zeros(nb + 1, np.uint64)
+        dst[1:] = np.cumsum(isize.astype(np.uint64))
+
+        def inflated_offset(voffs):
+            c = voffs >> np.uint64(16)
+            idx = np.searchsorted(coff, c)
+            at_end = idx >= nb                                   # the virtual offset of the end of the data: behind the last block
+            idx = np.minimum(idx, nb - 1)
+            ok = at_end | (coff[idx] == c)
+            if not ok.all():
+                raise DeviceIngestError("the index points between two BGZF blocks")
+            return np.where(at_end, dst[nb], dst[idx] + (voffs & np.uint64(0xFFFF)))
+
+        out = []
+        for t, (lo, hi, linear) in zip(tids, spans):
+            seeds = linear[(linear >= np.uint64(lo)) & (linear < np.uint64(hi))]
+            voffs = np.unique(np.concatenate([np.asarray([lo], np.uint64), seeds, np.asarray([hi], np.uint64)]))
+            starts = np.unique(inflated_offset(voffs))           # (two virtual offsets of one byte: a block boundary)
+            out.append(self._walk(t, d_raw, starts))
+        return out
+
+    def _walk(self, tid, d_raw, starts):
+        import time
+        lib, dev = self.lib, self.device
+        st = kernels._stream_ptr(dev)
+        t0 = time.perf_counter()
+        n_starts = int(starts.size) - 1
+        d_starts = torch.from_numpy(starts.view(np.int64)).to(dev)
+        d_counts = torch.empty((n_starts, 4), dtype=torch.int64, device=dev)
+        _lib.check(lib.svx_bam_walk_count(d_raw.data_ptr(), d_starts.data_ptr(), n_starts, d_counts.data_ptr(), st), "svx_bam_walk_count")
+        counts = d_counts.cpu().numpy()
+        bad = counts[:, 3] != 0
+        if bad.any():
+            code = int(counts[bad, 3][0])
+            raise DeviceIngestError({1: "the linear index does not match the records", 2: "malformed BAM record", 3: "CG-tag CIGAR"}.get(code, "walk error %d" % code))
+        base = np.zeros((n_starts, 3), np.uint64)
+        base[1:] = np.cumsum(counts[:-1, :3], axis=0).astype(np.uint64)
+        n, words, name_bytes = (int(v) for v in counts[:, :3].sum(axis=0))
+        d_base = torch.from_numpy(base.view(np.int64)).to(dev)
+        d_tid = torch.empty(n, dtype=torch.int32, device=dev)
+        d_pos = torch.empty(n, dtype=torch.int32, device=dev)
+        d_flag = torch.empty(n, dtype=torch.int16, device=dev)
+        d_mapq = torch.empty(n, dtype=torch.uint8, device=dev)
+        d_lseq = torch.empty(n, dtype=torch.int32, device=dev)
+        d_cig_off = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        d_cigar = torch.empty(max(words, 1), dtype=torch.int32, device=dev)
+        d_name_off = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        d_names = torch.empty(max(name_bytes, 1), dtype=torch.uint8, device=dev)
+        _lib.check(lib.svx_bam_walk_extract(d_raw.data_ptr(), d_starts.data_ptr(), n_starts, d_base.data_ptr(), d_tid.data_ptr(), d_pos.data_ptr(),
+                                            d_flag.data_ptr(), d_mapq.data_ptr(), d_lseq.data_ptr(), d_cig_off.data_ptr(), d_cigar.data_ptr(),
+                                            d_name_off.data_ptr(), d_names.data_ptr(), st), "svx_bam_walk_extract")
+        d_cig_off[n] = words
+        d_name_off[n] = name_bytes
+        t1 = time.perf_counter()
+        alloc = self.alloc_for() if self.alloc_for is not None else (lambda _name, dtype, k: np.empty(k, dtype))
+
+        def to_host(name, d, dtype):
+            host = alloc(name, dtype, d.numel())
+            if d.numel():
+                torch.from_numpy(host).copy_(d)                  # (staged through the runtime's pinned bounce buffer)
+            return host
+        tid_h = to_host("tid", d_tid, np.int32)
+        pos_h = to_host("pos", d_pos, np.int32)
+        l_seq_h = to_host("l_seq", d_lseq, np.int32)
+        flag_h = alloc("flag", np.uint16, n)
+        if n:
+            torch.from_numpy(flag_h.view(np.int16)).copy_(d_flag)
+        mapq_h = to_host("mapq", d_mapq, np.uint8)
+        cig_off_h = to_host("cig_off", d_cig_off, np.int64)
+        cigar_h = alloc("cigar", np.uint32, words)
+        if words:
+            torch.from_numpy(cigar_h.view(np.int32)).copy_(d_cigar[:words])
+        name_off_h = d_name_off.cpu().numpy()
+        names_h = d_names[:name_bytes].cpu().numpy()
+        t2 = time.perf_counter()
+        name_id = alloc("name_id", np.int32, n)
+        uniq = np.empty(max(name_bytes, 1), np.uint8)
+        ub = np.zeros(1, np.uint64)
+        n_unique = int(lib.svx_name_ids(names_h.ctypes.data, name_off_h.ctypes.data, n, name_id.ctypes.data, uniq.ctypes.data, ub.ctypes.data))
+        blob = alloc("names", np.uint8, int(ub[0]))
+        blob[:] = uniq[:int(ub[0])]
+        name_list = blob.tobytes().decode().split("\n")[:-1] if n_unique else []
+        t3 = time.perf_counter()
+        self.stats["walk_s"] += t1 - t0
+        self.stats["d2h_s"] += t2 - t1
+        self.stats["names_s"] += t3 - t2
+        table = AlignmentTable(self.references, self.lengths, tid_h, pos_h, flag_h, mapq_h, l_seq_h, name_id, name_list, cigar_h, cig_off_h,
+                               self.header_text)
+        table._names_blob = blob
+        table._shm_dir = getattr(alloc, "dir", None)
+        return table, (d_cigar[:max(words, 1)], d_cig_off, d_pos)

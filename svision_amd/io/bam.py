@@ -341,6 +341,37 @@ def read_bam(path, with_seq=False, threads=0, tids=None, index=None):
     return table
 
 
+def read_bai_linear(path):
+    """.bai -> per reference None or (first virtual offset, last virtual offset, linear index uint64 array): the span of
+    its records as in :func:`read_bai` plus the 16 kb linear index (SAMv1 5.1.3: for every 16 kb of the reference the
+    virtual offset of the first record overlapping it, 0 where htslib left a gap)."""
+    with open(path, "rb") as f:
+        raw = f.read()
+    if raw[:4] != b"BAI\x01":
+        raise ValueError("%s is not a BAI index" % path)
+    n_ref = struct.unpack_from("<i", raw, 4)[0]
+    p = 8
+    out = []
+    for _ in range(n_ref):
+        n_bin = struct.unpack_from("<i", raw, p)[0]
+        p += 4
+        lo, hi = None, None
+        for _b in range(n_bin):
+            bin_id, n_chunk = struct.unpack_from("<Ii", raw, p)
+            p += 8
+            if bin_id != 37450 and n_chunk:
+                chunks = np.frombuffer(raw, "<u8", 2 * n_chunk, p).reshape(-1, 2)
+                lo = int(chunks[:, 0].min()) if lo is None else min(lo, int(chunks[:, 0].min()))
+                hi = int(chunks[:, 1].max()) if hi is None else max(hi, int(chunks[:, 1].max()))
+            p += 16 * n_chunk
+        n_intv = struct.unpack_from("<i", raw, p)[0]
+        p += 4
+        linear = np.frombuffer(raw, "<u8", n_intv, p).copy()
+        p += 8 * n_intv
+        out.append(None if lo is None else (lo, hi, linear))
+    return out
+
+
 def read_bam_header(path):
     """Header text + reference dictionary only (an AlignmentTable without records); no index needed."""
     from .. import _lib

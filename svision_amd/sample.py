@@ -42,6 +42,16 @@ class Sample:
         return cls(table, fasta, gaps, gap_off, stats, min_sv, device_buffers=(d_cigar, d_off, d_pos, res))
 
     @classmethod
+    def from_device(cls, table, fasta, min_sv, d_cigar, d_off, d_pos):
+        """The packed arrays are already in HBM (device-side ingestion, svision_amd/ingest_gpu.py): scan them in place."""
+        from . import kernels
+        res = kernels.cigar_scan(d_cigar, d_off, d_pos, min_sv)
+        gaps, gap_off, stats = res.to_host()
+        from .segmentplot import run_hash_lineplot
+        run_hash_lineplot.DEVICE = d_cigar.device
+        return cls(table, fasta, gaps, gap_off, stats, min_sv, device_buffers=(d_cigar, d_off, d_pos, res))
+
+    @classmethod
     def with_scan(cls, table, fasta, min_sv, scan):
         """Attach an externally computed scan (tests inject the oracle's here)."""
         gaps, gap_off, stats = scan

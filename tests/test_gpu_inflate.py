@@ -77,3 +77,52 @@ def test_damaged_blocks_are_flagged():
     short[-4:] = struct.pack("<I", 50001)                        # ISIZE says one byte more than the stream holds
     got, status = _inflate_on_device(bytes(good) + bytes(bad) + bytes(short) + good)
     assert status[0] == 0 and status[3] == 0 and status[1] != 0 and status[2] != 0
+
+
+def _same_table(a, b):
+    for f in ("tid", "pos", "flag", "mapq", "l_seq", "name_id", "cigar", "cig_off"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    assert a.names == b.names and a.references == b.references and a.lengths == b.lengths
+
+
+def test_device_decoder_equals_the_host_decoder(tmp_path):
+    """ingest_gpu.DeviceDecoder (read -> upload -> svx_bgzf_inflate -> svx_bam_walk_* through the .bai linear index) gives,
+    chromosome by chromosome, the tables of the host decoder, and the packed CIGARs it leaves in HBM are the same words."""
+    from svision_amd import synth
+    from svision_amd.ingest_gpu import DeviceDecoder, DeviceIngestError
+    cfg = synth.SimConfig(contigs=[("c1", 900_000), ("c2", 50_000), ("c3", 600_000), ("c4", 300_000)], coverage=12, read_len_mean=9000,
+                          read_len_sd=1500, sv_spacing=20_000, sv_min_gap=9_000, sv_max=3000, seed=9)
+    table, _g, _ = synth.simulate(cfg, with_genome=False)
+    table = table.subset(np.flatnonzero(table.tid != 1))                # a reference without records
+    segs = [bam.encode_reference_segment(table.subset(np.flatnonzero(table.tid == t)), seq="random", seed=t) for t in (0, 2, 3)]
+    path = str(tmp_path / "dev.bam")
+    bam.write_bam_segments(path, table.references, table.lengths, segs)
+    head = bam.read_bam_header(path)
+    for first_group in (1 << 10, 1 << 40):                               # every chromosome its own launch / all in one
+        import svision_amd.ingest_gpu as ig
+        ig.FIRST_GROUP_BYTES = ig.GROUP_BYTES = first_group
+        dec = DeviceDecoder(path, path + ".bai", head.references, head.lengths, head.header_text, "cuda:0", threads=3)
+        assert dec.usable([0, 1, 2, 3])
+        groups = dec.groups([0, 1, 2, 3])
+        assert sorted(t for g in groups for t in g) == [0, 2, 3]
+        got = {}
+        for g in groups:
+            for tb, (d_cigar, d_off, d_pos) in dec.decode_group(g):
+                t = int(tb.tid[0])
+                got[t] = tb
+                assert np.array_equal(d_cigar.cpu().numpy().view(np.uint32)[:tb.cigar.size], tb.cigar)
+                assert np.array_equal(d_off.cpu().numpy(), tb.cig_off) and np.array_equal(d_pos.cpu().numpy(), tb.pos)
+        for t in (0, 2, 3):
+            _same_table(got[t], bam.read_bam(path, tids=[t]))
+    # the golden BAM written by the plain writer (own .bai), and an index that does not fit the file
+    plain = str(tmp_path / "plain.bam")
+    bam.write_bam(plain, bam.read_bam(os.path.join(helpers.GOLDEN, "collect_small.bam")), index=True)
+    head = bam.read_bam_header(plain)
+    dec = DeviceDecoder(plain, plain + ".bai", head.references, head.lengths, head.header_text, "cuda:0")
+    for g in dec.groups([0, 1]):
+        for tb, _arrays in dec.decode_group(g):
+            _same_table(tb, bam.read_bam(plain, tids=[int(tb.tid[0])]))
+    wrong = DeviceDecoder(path, plain + ".bai", head.references, head.lengths, head.header_text, "cuda:0")
+    with pytest.raises(DeviceIngestError):
+        for g in wrong.groups([0, 1]):
+            wrong.decode_group(g)
