@@ -116,76 +116,51 @@ class ChromosomeFeed:
                       "first_ready_s": None, "last_ready_s": None}
         self._t0 = time.perf_counter()
         self._stop = False
+        self._slot_lock, self._free_slots, self._n_slots = threading.Lock(), [], 0
         self.thread = threading.Thread(target=self._run, name="svx-feed", daemon=True)
         self.thread.start()
 
-    # ---- feeder thread ---------------------------------------------------------------------------------------------
-    def _alloc_in(self, d):
+    # ---- shared-memory slots ---------------------------------------------------------------------------------------
+    # A chromosome's arrays live in the files of one slot directory; a released slot is handed to a later chromosome and
+    # its files are overwritten in place: their pages stay allocated (a fresh tmpfs page costs a fault and a memset --
+    # writing 270 MB of new files took 0.19 s, a sixth of a 20-window job).
+    def _slot_alloc(self):
+        with self._slot_lock:
+            d = self._free_slots.pop() if self._free_slots else None
+            if d is None:
+                d = os.path.join(self.root, "s%d" % self._n_slots)
+                self._n_slots += 1
+                os.makedirs(d)
+        arrays = {}
+
         def alloc(name, dtype, n):
+            dtype = np.dtype(dtype)
+            arrays[name] = (dtype.str, int(n))
             if n == 0:
                 return np.empty(0, dtype)
-            return np.lib.format.open_memmap(os.path.join(d, name + ".npy"), mode="w+", dtype=dtype, shape=(n,))
-        alloc.dir = d
+            path = os.path.join(d, name + ".bin")
+            need = int(n) * dtype.itemsize
+            mode = "r+" if os.path.exists(path) and os.path.getsize(path) >= need else "w+"
+            if mode == "w+" and os.path.exists(path):
+                os.remove(path)
+            return np.memmap(path, dtype=dtype, mode=mode, shape=(int(n),))
+        alloc.dir, alloc.arrays = d, arrays
         return alloc
 
+    def _slot_free(self, d):
+        with self._slot_lock:
+            self._free_slots.append(d)
+
     def _run(self):
+        """Stage B of the feeder (this thread): QNAME ids, upload (host engine) + device scan, hand-over.  Stage A (a thread
+        of its own, :meth:`_decode`) reads / inflates / packs the next chromosome meanwhile."""
         import torch
+        decoded = queue.Queue(maxsize=2)
         try:
             tids = [self.references.index(c) for c in self.chroms]
             want = list(tids)
-            seq = [0]
-
-            def next_dir():
-                d = os.path.join(self.root, "c%d" % seq[0])
-                seq[0] += 1
-                os.makedirs(d)
-                self._dir = d
-                return d
-
-            class Alloc:                                       # one directory per part, created when the part arrives
-                def __init__(self, feed):
-                    self.feed, self.fn = feed, None
-
-                def __call__(self, name, dtype, n):
-                    if name == "tid":                          # first array of a part (io.bam._table_from_handle)
-                        self.fn = self.feed._alloc_in(next_dir())
-                    return self.fn(name, dtype, n)
-
-            ingest_stream = torch.cuda.Stream(device=self.device, priority=-1) if torch.cuda.is_available() else None
-            if ingest_stream is None:
+            if not torch.cuda.is_available():
                 raise RuntimeError("ChromosomeFeed needs the GPU (svx_cigar_scan); there is no CPU fallback")
-
-            def host_parts(which):                             # BGZF inflate on host threads
-                stream = BamStream(self.bam_path, with_seq=self.with_seq, threads=self.threads, tids=which, index=self.index, alloc=Alloc(self))
-                try:
-                    for table in stream:
-                        table._shm_dir = self._dir
-                        yield table, None
-                finally:
-                    stream.close()
-
-            def device_parts(which):                           # BGZF inflate + record packing on the device
-                from .ingest_gpu import DeviceDecoder, DeviceIngestError
-
-                def alloc_for():
-                    return self._alloc_in(next_dir())
-                dec = self.decoder = DeviceDecoder(self.bam_path, self.index, self.references, self.lengths, self.header_text, self.device,
-                                                   threads=min(8, max(1, self.threads)), alloc_for=alloc_for)
-                if not dec.usable(which):
-                    yield from host_parts(which)
-                    return
-                for group in dec.groups(which):
-                    try:
-                        with torch.cuda.stream(ingest_stream):
-                            parts = dec.decode_group(group)
-                    except DeviceIngestError as exc:           # CG-tag CIGARs, an index that does not fit: the host reader takes the group
-                        import logging
-                        logging.warning("device ingestion of references %s failed (%s): decoding them on the host", group, exc)
-                        yield from host_parts(group)
-                        continue
-                    for table, arrays in parts:
-                        yield table, arrays
-
             engine = self.engine
             if engine == "auto":
                 usable, _visible = effective_cpus()
@@ -193,35 +168,48 @@ class ChromosomeFeed:
             if engine == "gpu" and (self.index is None or self.with_seq):
                 engine = "cpu"
             self.stats["engine"] = engine
-            it = device_parts(tids) if engine == "gpu" else host_parts(tids)
+            stage_a = threading.Thread(target=self._decode, args=(engine, tids, decoded), name="svx-decode", daemon=True)
+            stage_a.start()
+            scan_stream = torch.cuda.Stream(device=self.device, priority=-1)
             while not self._stop:
                 t0 = time.perf_counter()
-                item = next(it, None)
+                try:
+                    item = decoded.get(timeout=0.2)
+                except queue.Empty:
+                    self.stats["decode_wait_s"] += time.perf_counter() - t0
+                    continue
                 self.stats["decode_wait_s"] += time.perf_counter() - t0
                 if item is None:
                     break
+                if isinstance(item, BaseException):
+                    raise item
                 table, arrays = item
+                t0 = time.perf_counter()
+                if callable(table):                            # device engine: the QNAME ids are still to be computed
+                    table = table()
                 tid = int(table.tid[0])
                 while want and want[0] != tid:                 # chromosomes of this rank without a record in the file
                     self._emit_empty(want.pop(0))
                 if not want:
                     break
                 want.pop(0)
-                t0 = time.perf_counter()
-                with torch.cuda.stream(ingest_stream):
+                with torch.cuda.stream(scan_stream):
                     if arrays is None:
                         sample = Sample.from_table(table, self.fasta, self.options.min_sv_size, self.device)
                     else:
                         sample = Sample.from_device(table, self.fasta, self.options.min_sv_size, *arrays)
-                d = table._shm_dir
-                np.save(os.path.join(d, "gaps.npy"), sample.gaps)
-                np.save(os.path.join(d, "gap_off.npy"), sample.gap_off)
-                np.save(os.path.join(d, "stats.npy"), sample.stats)
+                alloc = table._alloc
+                for name, arr in (("gaps", sample.gaps), ("gap_off", sample.gap_off), ("stats", sample.stats)):
+                    arr = np.ascontiguousarray(arr)
+                    out = alloc(name, arr.dtype, arr.size)
+                    if arr.size:
+                        out[:] = arr.reshape(-1)
                 self.stats["upload_scan_s"] += time.perf_counter() - t0
                 self.stats["cigar_bytes"] += int(table.cigar.nbytes)
                 self.stats["records"] += len(table)
-                meta = {"dir": d, "references": self.references, "lengths": self.lengths, "min_sv": self.options.min_sv_size,
-                        "n": len(table), "with_seq": self.with_seq, "header_text": table.header_text}
+                meta = {"dir": alloc.dir, "arrays": dict(alloc.arrays), "references": self.references, "lengths": self.lengths,
+                        "min_sv": self.options.min_sv_size, "n": len(table), "with_seq": self.with_seq, "header_text": table.header_text,
+                        "stats_shape": list(np.shape(sample.stats))}
                 self._put((self.references[tid], sample, meta))
             while want and not self._stop:
                 self._emit_empty(want.pop(0))
@@ -229,8 +217,70 @@ class ChromosomeFeed:
                 self.stats["device_decoder"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in self.decoder.stats.items()}
         except BaseException as exc:                           # noqa: BLE001 -- surfaces in the owner thread (poll / get)
             self.error = exc
+            self._stop = True
+            try:
+                while True:                                    # let stage A run into its stop flag
+                    decoded.get_nowait()
+            except queue.Empty:
+                pass
         finally:
             self.handover.put(None)
+
+    def _decode(self, engine, tids, decoded):
+        """Stage A: chromosome after chromosome as (table or a callable finishing it, device arrays or None) into ``decoded``."""
+        import torch
+
+        def put(item):
+            while not self._stop:
+                try:
+                    decoded.put(item, timeout=0.2)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+
+        def host_parts(which):                                 # BGZF inflate on host threads (libdeflate)
+            state = {"alloc": None, "used": True}
+
+            def alloc(name, dtype, n):                         # one slot per part: "tid" is the first array of a part (io.bam._table_from_handle)
+                if name == "tid" and state["used"]:           # (a part the stream skipped leaves its slot to the next one)
+                    state["alloc"], state["used"] = self._slot_alloc(), False
+                return state["alloc"](name, dtype, n)
+            stream = BamStream(self.bam_path, with_seq=self.with_seq, threads=self.threads, tids=which, index=self.index, alloc=alloc)
+            try:
+                for table in stream:
+                    table._alloc, state["used"] = state["alloc"], True
+                    if not put((table, None)):
+                        return
+            finally:
+                stream.close()
+
+        try:
+            if engine == "gpu":                                # BGZF inflate + record packing on the device
+                from .ingest_gpu import DeviceDecoder, DeviceIngestError
+                ingest_stream = torch.cuda.Stream(device=self.device, priority=-1)
+                dec = self.decoder = DeviceDecoder(self.bam_path, self.index, self.references, self.lengths, self.header_text, self.device,
+                                                   threads=min(8, max(1, self.threads)), alloc_for=self._slot_alloc)
+                if not dec.usable(tids):
+                    host_parts(tids)
+                else:
+                    for group in dec.groups(tids):
+                        done = 0
+                        try:
+                            with torch.cuda.stream(ingest_stream):
+                                for part in dec.decode_group(group):
+                                    if not put(part):
+                                        return
+                                    done += 1
+                        except DeviceIngestError as exc:       # CG-tag CIGARs, an index that does not fit: the host reader takes over
+                            import logging
+                            logging.warning("device ingestion of references %s failed (%s): decoding them on the host", group[done:], exc)
+                            host_parts(group[done:])
+            else:
+                host_parts(tids)
+            put(None)
+        except BaseException as exc:                           # noqa: BLE001
+            put(exc)
 
     def _emit_empty(self, tid):
         meta = {"dir": None, "references": self.references, "lengths": self.lengths, "min_sv": self.options.min_sv_size, "n": 0,
@@ -297,7 +347,7 @@ class ChromosomeFeed:
         sample.device_buffers = None
         self.samples[chrom] = (key, None, None)
         if meta is not None and meta["dir"] is not None:
-            shutil.rmtree(meta["dir"], ignore_errors=True)
+            self._slot_free(meta["dir"])
 
     def close(self):
         self._stop = True
@@ -316,10 +366,12 @@ def load_shared_sample(meta, fasta):
     d = meta["dir"]
     if d is None:
         return empty_sample(meta["references"], meta["lengths"], fasta, meta["min_sv"], meta["header_text"])
+    arrays = meta["arrays"]
 
     def arr(name, dtype):
-        path = os.path.join(d, name + ".npy")
-        return np.load(path, mmap_mode="c") if os.path.exists(path) else np.empty(0, dtype)
+        if name not in arrays or arrays[name][1] == 0:
+            return np.empty(0, dtype)
+        return np.memmap(os.path.join(d, name + ".bin"), dtype=np.dtype(dtype), mode="c", shape=(arrays[name][1],))
     names_blob = arr("names", np.uint8)
     names = bytes(names_blob).decode().split("\n")[:-1] if names_blob.size else []
     cig_off = arr("cig_off", np.int64)
@@ -330,5 +382,7 @@ def load_shared_sample(meta, fasta):
     table = AlignmentTable(meta["references"], meta["lengths"], arr("tid", np.int32), arr("pos", np.int32), arr("flag", np.uint16),
                            arr("mapq", np.uint8), arr("l_seq", np.int32), arr("name_id", np.int32), names, arr("cigar", np.uint32), cig_off,
                            meta["header_text"], seq_packed, seq_off)
-    gaps, gap_off, stats = (np.load(os.path.join(d, k + ".npy"), mmap_mode="c") for k in ("gaps", "gap_off", "stats"))
-    return Sample.with_scan(table, fasta, meta["min_sv"], (gaps, gap_off, stats))
+    from . import kernels
+    gaps = arr("gaps", kernels.GAP_DTYPE)
+    stats = np.asarray(arr("stats", np.int32)).reshape(meta["stats_shape"])
+    return Sample.with_scan(table, fasta, meta["min_sv"], (gaps, arr("gap_off", np.int64), stats))

@@ -18,7 +18,8 @@ from . import _lib, kernels
 from .io.bam import AlignmentTable, read_bai_linear
 
 FIRST_GROUP_BYTES = 192 << 20            # the first launch is small: the pipeline starts after ~0.1 s
-GROUP_BYTES = 2 << 30                    # later groups: enough blocks (~80 k) to fill the device
+GROUP_BYTES = 24 << 30                   # later groups: as many blocks as possible per launch (a lane decodes one block in ~0.1 s
+                                         # whatever the launch size; 24 GB compressed inflate to ~58 GB of HBM)
 
 
 class DeviceIngestError(RuntimeError):
@@ -61,7 +62,9 @@ class DeviceDecoder:
         return self.pinned
 
     def decode_group(self, tids):
-        """-> [(AlignmentTable on the host, (d_cigar int32, d_cig_off int64 [n+1], d_pos int32))] for the chromosomes of one group."""
+        """Generator over the chromosomes of one group: (finish, (d_cigar int32, d_cig_off int64 [n+1], d_pos int32)) where
+        ``finish()`` -> AlignmentTable on the host (the QNAME ids are computed there: host work the caller can overlap
+        with the next chromosome's device work).  The group's blocks are inflated in ONE launch before the first yield."""
         import time
         lib, dev = self.lib, self.device
         spans = [self.spans[t] for t in tids]
@@ -109,13 +112,11 @@ class DeviceDecoder:
                 raise DeviceIngestError("the index points between two BGZF blocks")
             return np.where(at_end, dst[nb], dst[idx] + (voffs & np.uint64(0xFFFF)))
 
-        out = []
         for t, (lo, hi, linear) in zip(tids, spans):
             seeds = linear[(linear >= np.uint64(lo)) & (linear < np.uint64(hi))]
             voffs = np.unique(np.concatenate([np.asarray([lo], np.uint64), seeds, np.asarray([hi], np.uint64)]))
             starts = np.unique(inflated_offset(voffs))           # (two virtual offsets of one byte: a block boundary)
-            out.append(self._walk(t, d_raw, starts))
-        return out
+            yield self._walk(t, d_raw, starts)
 
     def _walk(self, tid, d_raw, starts):
         import time
@@ -171,19 +172,23 @@ class DeviceDecoder:
         name_off_h = d_name_off.cpu().numpy()
         names_h = d_names[:name_bytes].cpu().numpy()
         t2 = time.perf_counter()
-        name_id = alloc("name_id", np.int32, n)
-        uniq = np.empty(max(name_bytes, 1), np.uint8)
-        ub = np.zeros(1, np.uint64)
-        n_unique = int(lib.svx_name_ids(names_h.ctypes.data, name_off_h.ctypes.data, n, name_id.ctypes.data, uniq.ctypes.data, ub.ctypes.data))
-        blob = alloc("names", np.uint8, int(ub[0]))
-        blob[:] = uniq[:int(ub[0])]
-        name_list = blob.tobytes().decode().split("\n")[:-1] if n_unique else []
-        t3 = time.perf_counter()
         self.stats["walk_s"] += t1 - t0
         self.stats["d2h_s"] += t2 - t1
-        self.stats["names_s"] += t3 - t2
-        table = AlignmentTable(self.references, self.lengths, tid_h, pos_h, flag_h, mapq_h, l_seq_h, name_id, name_list, cigar_h, cig_off_h,
-                               self.header_text)
-        table._names_blob = blob
-        table._shm_dir = getattr(alloc, "dir", None)
-        return table, (d_cigar[:max(words, 1)], d_cig_off, d_pos)
+
+        def finish():
+            t2 = time.perf_counter()
+            name_id = alloc("name_id", np.int32, n)
+            uniq = np.empty(max(name_bytes, 1), np.uint8)
+            ub = np.zeros(1, np.uint64)
+            n_unique = int(lib.svx_name_ids(names_h.ctypes.data, name_off_h.ctypes.data, n, name_id.ctypes.data, uniq.ctypes.data, ub.ctypes.data))
+            blob = alloc("names", np.uint8, int(ub[0]))
+            blob[:] = uniq[:int(ub[0])]
+            name_list = blob.tobytes().decode().split("\n")[:-1] if n_unique else []
+            self.stats["names_s"] += time.perf_counter() - t2
+            table = AlignmentTable(self.references, self.lengths, tid_h, pos_h, flag_h, mapq_h, l_seq_h, name_id, name_list, cigar_h, cig_off_h,
+                                   self.header_text)
+            table._names_blob = blob
+            table._alloc = alloc
+            table._shm_dir = getattr(alloc, "dir", None)
+            return table
+        return finish, (d_cigar[:max(words, 1)], d_cig_off, d_pos)

@@ -107,7 +107,8 @@ def test_device_decoder_equals_the_host_decoder(tmp_path):
         assert sorted(t for g in groups for t in g) == [0, 2, 3]
         got = {}
         for g in groups:
-            for tb, (d_cigar, d_off, d_pos) in dec.decode_group(g):
+            for finish, (d_cigar, d_off, d_pos) in dec.decode_group(g):
+                tb = finish()
                 t = int(tb.tid[0])
                 got[t] = tb
                 assert np.array_equal(d_cigar.cpu().numpy().view(np.uint32)[:tb.cigar.size], tb.cigar)
@@ -120,9 +121,10 @@ def test_device_decoder_equals_the_host_decoder(tmp_path):
     head = bam.read_bam_header(plain)
     dec = DeviceDecoder(plain, plain + ".bai", head.references, head.lengths, head.header_text, "cuda:0")
     for g in dec.groups([0, 1]):
-        for tb, _arrays in dec.decode_group(g):
+        for finish, _arrays in dec.decode_group(g):
+            tb = finish()
             _same_table(tb, bam.read_bam(plain, tids=[int(tb.tid[0])]))
     wrong = DeviceDecoder(path, plain + ".bai", head.references, head.lengths, head.header_text, "cuda:0")
     with pytest.raises(DeviceIngestError):
         for g in wrong.groups([0, 1]):
-            wrong.decode_group(g)
+            list(wrong.decode_group(g))
