@@ -131,6 +131,9 @@ class ChromosomeFeed:
                 d = os.path.join(self.root, "s%d" % self._n_slots)
                 self._n_slots += 1
                 os.makedirs(d)
+        flag = os.path.join(d, "cigar.ready")
+        if os.path.exists(flag):
+            os.remove(flag)
         arrays = {}
 
         def alloc(name, dtype, n):
@@ -171,6 +174,8 @@ class ChromosomeFeed:
             stage_a = threading.Thread(target=self._decode, args=(engine, tids, decoded), name="svx-decode", daemon=True)
             stage_a.start()
             scan_stream = torch.cuda.Stream(device=self.device, priority=-1)
+            spill = queue.Queue()
+            threading.Thread(target=self._spill, args=(spill,), name="svx-spill", daemon=True).start()
             while not self._stop:
                 t0 = time.perf_counter()
                 try:
@@ -210,6 +215,10 @@ class ChromosomeFeed:
                 meta = {"dir": alloc.dir, "arrays": dict(alloc.arrays), "references": self.references, "lengths": self.lengths,
                         "min_sv": self.options.min_sv_size, "n": len(table), "with_seq": self.with_seq, "header_text": table.header_text,
                         "stats_shape": list(np.shape(sample.stats))}
+                if arrays is not None:                         # device engine: the host copy of the CIGAR words follows later
+                    meta["lazy_cigar"] = int(table.cigar.size)
+                    meta["spilled"] = threading.Event()
+                    spill.put((table, meta["spilled"]))
                 self._put((self.references[tid], sample, meta))
             while want and not self._stop:
                 self._emit_empty(want.pop(0))
@@ -224,7 +233,30 @@ class ChromosomeFeed:
             except queue.Empty:
                 pass
         finally:
+            try:
+                spill.put(None)
+            except NameError:
+                pass
             self.handover.put(None)
+
+    def _spill(self, jobs):
+        """Stage C: host copies of the device-decoded CIGAR words (ingest_gpu.spill_cigar), after the hand-over."""
+        import torch
+        from .ingest_gpu import spill_cigar
+        stream = torch.cuda.Stream(device=self.device, priority=-1)
+        while True:
+            job = jobs.get()
+            if job is None:
+                return
+            table, done = job
+            try:
+                with torch.cuda.stream(stream):
+                    spill_cigar(table)
+                table._d_cigar = None
+            except BaseException as exc:                       # noqa: BLE001 -- a helper that needs the words would wait for ever
+                self.error = self.error or exc
+            finally:
+                done.set()
 
     def _decode(self, engine, tids, decoded):
         """Stage A: chromosome after chromosome as (table or a callable finishing it, device arrays or None) into ``decoded``."""
@@ -337,7 +369,8 @@ class ChromosomeFeed:
     def take_fresh(self):
         """(key, chrom, meta) of the chromosomes that arrived since the last call: what the helpers must be sent."""
         out, self.fresh = self.fresh, []
-        return out
+        # (the meta of a chromosome goes through a pipe: without the owner-side event)
+        return [(k, c, None if m is None else {a: b for a, b in m.items() if a != "spilled"}) for k, c, m in out]
 
     def release(self, chrom):
         """The chromosome is done (its windows voted and stitched): free its device buffers and shared memory."""
@@ -347,6 +380,8 @@ class ChromosomeFeed:
         sample.device_buffers = None
         self.samples[chrom] = (key, None, None)
         if meta is not None and meta["dir"] is not None:
+            if meta.get("spilled") is not None:
+                meta["spilled"].wait(timeout=120)              # the slot must not be reused under a running spill
             self._slot_free(meta["dir"])
 
     def close(self):
@@ -382,6 +417,9 @@ def load_shared_sample(meta, fasta):
     table = AlignmentTable(meta["references"], meta["lengths"], arr("tid", np.int32), arr("pos", np.int32), arr("flag", np.uint16),
                            arr("mapq", np.uint8), arr("l_seq", np.int32), arr("name_id", np.int32), names, arr("cigar", np.uint32), cig_off,
                            meta["header_text"], seq_packed, seq_off)
+    if meta.get("lazy_cigar") is not None:                     # device engine: the words arrive in the slot a little later
+        from .ingest_gpu import LazyCigar
+        table.cigar = LazyCigar(meta["lazy_cigar"], os.path.join(d, "cigar.bin"), os.path.join(d, "cigar.ready"))
     from . import kernels
     gaps = arr("gaps", kernels.GAP_DTYPE)
     stats = np.asarray(arr("stats", np.int32)).reshape(meta["stats_shape"])

@@ -26,6 +26,54 @@ class DeviceIngestError(RuntimeError):
     pass
 
 
+class LazyCigar:
+    """Stand-in for ``AlignmentTable.cigar`` while the words exist on the device only.  ``attach(array)`` (owner process,
+    after the spill) or ``path`` + ``ready`` (helper processes: the file the owner spills to and its completion flag)."""
+
+    def __init__(self, n_words, path=None, ready=None):
+        self.size, self.nbytes, self.path, self.ready, self._arr = int(n_words), 4 * int(n_words), path, ready, None
+
+    def attach(self, arr):
+        self._arr = arr
+
+    def _get(self):
+        if self._arr is None:
+            import time
+            if self.path is None:
+                raise RuntimeError("the CIGAR words of this table are on the device only")
+            t0 = time.time()
+            while not os.path.exists(self.ready):              # the owner spills them right after the hand-over
+                if time.time() - t0 > 120:
+                    raise RuntimeError("the CIGAR spill %s never completed" % self.path)
+                time.sleep(0.001)
+            self._arr = np.memmap(self.path, dtype=np.uint32, mode="r", shape=(self.size,)) if self.size else np.empty(0, np.uint32)
+        return self._arr
+
+    def __getitem__(self, key):
+        return self._get()[key]
+
+    def __len__(self):
+        return self.size
+
+    def __array__(self, dtype=None, copy=None):
+        a = self._get()
+        return np.asarray(a, dtype) if dtype is not None else np.asarray(a)
+
+
+def spill_cigar(table):
+    """Owner process, off the critical path: the device CIGAR words of a device-decoded table -> its shared-memory slot."""
+    d_cigar, alloc, lazy = table._d_cigar, table._alloc, table.cigar
+    host = alloc("cigar", np.uint32, lazy.size)
+    if lazy.size:
+        torch.from_numpy(host.view(np.int32)).copy_(d_cigar[:lazy.size])
+        if hasattr(host, "flush"):
+            host.flush()
+    lazy.attach(host)
+    if getattr(alloc, "dir", None) is not None:                # the flag the helper processes wait for (LazyCigar._get)
+        with open(os.path.join(alloc.dir, "cigar.ready"), "w"):
+            pass
+
+
 class DeviceDecoder:
     def __init__(self, path, index, references, lengths, header_text, device, threads=8, alloc_for=None):
         self.path, self.references, self.lengths, self.header_text = path, list(references), list(lengths), header_text
@@ -166,9 +214,10 @@ class DeviceDecoder:
             torch.from_numpy(flag_h.view(np.int16)).copy_(d_flag)
         mapq_h = to_host("mapq", d_mapq, np.uint8)
         cig_off_h = to_host("cig_off", d_cig_off, np.int64)
-        cigar_h = alloc("cigar", np.uint32, words)
-        if words:
-            torch.from_numpy(cigar_h.view(np.int32)).copy_(d_cigar[:words])
+        # the CIGAR words stay in HBM (svx_cigar_scan reads them there).  The host has one rare use for them -- comparing
+        # duplicated records by value (collection.classes.Seg.same_value) -- and gets its copy off the critical path:
+        # spill_cigar() below, called by the feed after the chromosome has been handed to the pipeline
+        cigar_h = LazyCigar(words)
         name_off_h = d_name_off.cpu().numpy()
         names_h = d_names[:name_bytes].cpu().numpy()
         t2 = time.perf_counter()
@@ -185,10 +234,12 @@ class DeviceDecoder:
             blob[:] = uniq[:int(ub[0])]
             name_list = blob.tobytes().decode().split("\n")[:-1] if n_unique else []
             self.stats["names_s"] += time.perf_counter() - t2
-            table = AlignmentTable(self.references, self.lengths, tid_h, pos_h, flag_h, mapq_h, l_seq_h, name_id, name_list, cigar_h, cig_off_h,
-                                   self.header_text)
+            table = AlignmentTable(self.references, self.lengths, tid_h, pos_h, flag_h, mapq_h, l_seq_h, name_id, name_list, np.empty(0, np.uint32),
+                                   cig_off_h, self.header_text)
+            table.cigar = cigar_h                                # (the constructor wants an array)
             table._names_blob = blob
             table._alloc = alloc
             table._shm_dir = getattr(alloc, "dir", None)
+            table._d_cigar = d_cigar
             return table
         return finish, (d_cigar[:max(words, 1)], d_cig_off, d_pos)

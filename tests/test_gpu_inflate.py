@@ -109,6 +109,10 @@ def test_device_decoder_equals_the_host_decoder(tmp_path):
         for g in groups:
             for finish, (d_cigar, d_off, d_pos) in dec.decode_group(g):
                 tb = finish()
+                assert tb.cigar.size == int(d_off[-1].item())
+                with pytest.raises(RuntimeError):
+                    tb.cigar[0]                                # the words are on the device only ...
+                ig.spill_cigar(tb)                             # ... until the feed spills them to the table's slot
                 t = int(tb.tid[0])
                 got[t] = tb
                 assert np.array_equal(d_cigar.cpu().numpy().view(np.uint32)[:tb.cigar.size], tb.cigar)
@@ -123,6 +127,7 @@ def test_device_decoder_equals_the_host_decoder(tmp_path):
     for g in dec.groups([0, 1]):
         for finish, _arrays in dec.decode_group(g):
             tb = finish()
+            ig.spill_cigar(tb)
             _same_table(tb, bam.read_bam(plain, tids=[int(tb.tid[0])]))
     wrong = DeviceDecoder(path, plain + ".bai", head.references, head.lengths, head.header_text, "cuda:0")
     with pytest.raises(DeviceIngestError):
