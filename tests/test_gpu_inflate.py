@@ -133,3 +133,34 @@ def test_device_decoder_equals_the_host_decoder(tmp_path):
     with pytest.raises(DeviceIngestError):
         for g in wrong.groups([0, 1]):
             list(wrong.decode_group(g))
+
+
+def test_command_line_with_device_ingest_equals_host_ingest(tmp_path):
+    """SVX_INGEST=gpu: the whole command line (-t 1 and -t 3) with the BGZF blocks inflated and the records packed on the
+    device writes the VCF of the default run (host inflate); duplicated records included (their by-value comparison reads the
+    CIGAR words the device engine spills to shared memory after the hand-over)."""
+    import subprocess
+    import sys
+    from oracle import alexnet_ref
+    from svision_amd.network import tf_checkpoint as ck
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prefix = str(tmp_path / "m.ckpt")
+    ck.write_checkpoint(prefix, alexnet_ref.random_params(seed=7))
+    for name in ("collect_small", "dup_small"):
+        fasta = helpers.load_golden_fasta(name + ".fa.gz")
+        fa = str(tmp_path / (name + ".fa"))
+        bam.write_fasta(fa, {n: fasta._seq[n] for n in fasta.references})
+        path = str(tmp_path / (name + ".bam"))
+        bam.write_bam(path, bam.read_bam(os.path.join(helpers.GOLDEN, name + ".bam")), index=True)
+        outs = {}
+        for engine, t in (("cpu", "1"), ("gpu", "1"), ("gpu", "3")):
+            out = str(tmp_path / ("%s_%s_%s" % (name, engine, t)))
+            r = subprocess.run([sys.executable, os.path.join(root, "SVision"), "-o", out, "-b", path, "-m", prefix, "-g", fa, "-n", "HGi", "-s", "3",
+                                "--window_size", "150000", "--batch_size", "64", "-t", t, "--debug"], capture_output=True, text=True, timeout=600,
+                               env=dict(os.environ, PYTHONPATH=root, SVX_INGEST=engine, SVX_TIMING="1"))
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+            assert ("'engine': '%s'" % engine) in r.stdout
+            outs[(engine, t)] = {rel: open(os.path.join(out, rel)).read() for rel in ["HGi.svision.s3.vcf"] +
+                                 ["segments/" + f for f in sorted(os.listdir(os.path.join(out, "segments")))]}
+        assert outs[("cpu", "1")] == outs[("gpu", "1")] == outs[("gpu", "3")]
+        assert outs[("cpu", "1")]["HGi.svision.s3.vcf"].count("\n") > 30
