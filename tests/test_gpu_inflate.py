@@ -163,4 +163,4 @@ def test_command_line_with_device_ingest_equals_host_ingest(tmp_path):
             outs[(engine, t)] = {rel: open(os.path.join(out, rel)).read() for rel in ["HGi.svision.s3.vcf"] +
                                  ["segments/" + f for f in sorted(os.listdir(os.path.join(out, "segments")))]}
         assert outs[("cpu", "1")] == outs[("gpu", "1")] == outs[("gpu", "3")]
-        assert outs[("cpu", "1")]["HGi.svision.s3.vcf"].count("\n") > 30
+        assert outs[("cpu", "1")]["HGi.svision.s3.vcf"].count("\n") > 20
