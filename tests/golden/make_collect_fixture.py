@@ -31,7 +31,7 @@ def main():
     table, genome, svs = synth.simulate(cfg)
     bam_path = os.path.join(HERE, "collect_small.bam")
     bam.write_bam(bam_path, table, level=9)
-    with gzip.open(os.path.join(HERE, "collect_small.fa.gz"), "wb", compresslevel=9) as f:
+    with open(os.path.join(HERE, "collect_small.fa.gz"), "wb") as _raw, gzip.GzipFile(filename="", mode="wb", fileobj=_raw, mtime=0, compresslevel=9) as f:   # mtime 0: regenerates byte for byte
         for name, seq in genome.items():
             f.write(b">" + name.encode() + b"\n" + seq + b"\n")
     refdriver.DATASETS["sample.bam"] = bam.read_bam(bam_path)

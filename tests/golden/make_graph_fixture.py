@@ -99,7 +99,7 @@ def main():
     table, genome, svs = synth.simulate(cfg, with_seq=True)
     bam_path = os.path.join(HERE, "graph_small.bam")
     bam.write_bam(bam_path, table, level=9)
-    with gzip.open(os.path.join(HERE, "graph_small.fa.gz"), "wb", compresslevel=9) as f:
+    with open(os.path.join(HERE, "graph_small.fa.gz"), "wb") as _raw, gzip.GzipFile(filename="", mode="wb", fileobj=_raw, mtime=0, compresslevel=9) as f:   # mtime 0: regenerates byte for byte
         for name, seq in genome.items():
             f.write(b">" + name.encode() + b"\n" + seq + b"\n")
     out = tempfile.mkdtemp()
@@ -155,7 +155,9 @@ def main():
           "graphs with inserted nodes", sum(1 for t in expected["read_graphs"].values() if "\tI0\t" in t),
           "with dup nodes", sum(1 for t in expected["read_graphs"].values() if "\tDP:S:" in t))
     assert n_csv >= 3 and len(exact) >= 2
-    with gzip.open(os.path.join(HERE, "graph_small.expected.json.gz"), "wt", compresslevel=9) as f:
+    import io
+    with open(os.path.join(HERE, "graph_small.expected.json.gz"), "wb") as _raw, \
+            gzip.GzipFile(filename="", mode="wb", fileobj=_raw, mtime=0, compresslevel=9) as _gz, io.TextIOWrapper(_gz) as f:
         json.dump(expected, f, sort_keys=True)
 
 

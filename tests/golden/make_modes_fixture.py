@@ -66,7 +66,7 @@ def main():
     unm = rng.random(len(t)) < 0.01
     t.flag[unm] |= 0x4
     bam.write_bam(os.path.join(HERE, "ont_small.bam"), t, level=9)
-    with gzip.open(os.path.join(HERE, "ont_small.fa.gz"), "wb", compresslevel=9) as f:
+    with open(os.path.join(HERE, "ont_small.fa.gz"), "wb") as _raw, gzip.GzipFile(filename="", mode="wb", fileobj=_raw, mtime=0, compresslevel=9) as f:   # mtime 0: regenerates byte for byte
         for name, seq in g.items():
             f.write(b">" + name.encode() + b"\n" + seq + b"\n")
     t = bam.read_bam(os.path.join(HERE, "ont_small.bam"))
