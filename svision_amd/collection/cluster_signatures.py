@@ -18,6 +18,30 @@ from scipy.cluster.hierarchy import fcluster, linkage
 
 from .classes import Cluster
 
+try:                                                          # SciPy's own compiled cores, without the per-call validation wrappers
+    from scipy.cluster import _hierarchy as _hc
+    from scipy.cluster.hierarchy import _LINKAGE_METHODS
+    _AVERAGE = _LINKAGE_METHODS["average"]
+    if not (hasattr(_hc, "nn_chain") and hasattr(_hc, "cluster_dist")):
+        _hc = None
+except Exception:                                             # noqa: BLE001 -- another SciPy layout: the public functions below
+    _hc = None
+
+
+def average_linkage_labels(dist, n, threshold):
+    """fcluster(linkage(dist, "average"), threshold, "distance") for a condensed matrix of ``n`` observations.  The same two
+    compiled routines the public functions end in (scipy/cluster/hierarchy.py: ``_hierarchy.nn_chain`` for method "average",
+    ``_hierarchy.cluster_dist`` for criterion "distance"), called directly: a window clusters ~75 small partitions and the
+    wrappers' array-API plumbing and ``is_valid_linkage`` passes cost more than the clustering (≈25 of 90 ms per window in
+    the build container's profile).  Anything unusual -- non-finite distances, another SciPy -- takes the public path, which
+    raises what upstream would see."""
+    if _hc is None or not np.isfinite(dist).all() or dist.size != n * (n - 1) // 2:
+        return fcluster(linkage(dist, method="average"), threshold, criterion="distance")
+    z = _hc.nn_chain(np.ascontiguousarray(dist, np.float64), int(n), _AVERAGE)
+    labels = np.zeros(n, dtype="i")
+    _hc.cluster_dist(np.asarray(z), labels, float(threshold), int(n))
+    return labels
+
 
 def partition_and_cluster(signatures, chrom, sample, options):
     partitions = signature_partition(signatures, options)
@@ -86,8 +110,7 @@ def cluster_partitions(partitions, chrom, sample, options):
         if len(part) == 1:
             groups = [part]
         else:
-            z = linkage(next(dists), method="average")
-            labels = fcluster(z, options.cluster_max_distance, criterion="distance")
+            labels = average_linkage_labels(next(dists), len(part), options.cluster_max_distance)
             groups = [[] for _ in range(int(labels.max()))]
             for sig, lab in zip(part, labels):
                 groups[lab - 1].append(sig)

@@ -13,7 +13,7 @@ cache = "/tmp/prof_collect_workload.pkl"
 if os.path.exists(cache):
     table, genome = pickle.load(open(cache, "rb"))
 else:
-    table, genome = bench._simulate_contig(("chr21", 46709983, 30, 1))
+    table, genome, _seg = bench._simulate_contig(dict(name="chr21", length=46709983, coverage=30, seed=1, kind=None))
     pickle.dump((table, genome), open(cache, "wb"))
 opts = bench.options_ns(64)
 fasta = Fasta(sequences={"chr21": genome})
