@@ -8,10 +8,11 @@
 // are decoded on the device, one lane each, from the compressed bytes uploaded as they sit in the file:
 //
 //   * a lane owns its block from the first bit to the last byte: no cross-lane dependency, no barrier, no atomics;
-//   * Huffman decoding is canonical (RFC 1951 3.2.2): the per-length code counts of the block in hand live in
-//     REGISTERS (fifteen 10-bit counts packed into five dwords per alphabet), the walk over the lengths is unrolled,
-//     and only the final symbol lookup goes to the lane's private slice of LDS (356 B per lane: one wave per
-//     workgroup, seven workgroups per CU);
+//   * Huffman decoding is canonical (RFC 1951 3.2.2) and branch-free: the left-aligned code limits of the fifteen code
+//     lengths of the block in hand live in REGISTERS, a symbol's length is one plus the number of limits its next 15
+//     bits reach (fourteen compare / add-with-carry pairs: no divergence between the lanes of a wave, whose blocks are
+//     at unrelated places of their streams), and the symbol comes from the lane's private slice of LDS (420 B per lane:
+//     one wave per workgroup, six workgroups per CU);
 //   * input: a 64-bit bit buffer per lane fed from 16-byte loads issued a whole vector ahead of their use (every lane
 //     streams its own block: a load is a round trip to L2 or HBM, not an L1 hit); output: literals are gathered into
 //     an aligned dword before they are stored, matches are copied byte by byte from the lane's own earlier output
@@ -25,7 +26,7 @@
 namespace {
 
 constexpr int LANES = 64;                 // one wave per workgroup: the LDS slice of a lane is indexed by its lane id
-constexpr int LIT_SYMS = 288, DIST_SYMS = 32, LANE_DWORDS = 9 + (LIT_SYMS + DIST_SYMS) / 4;     // 89 dwords = 356 B of LDS per lane
+constexpr int LIT_SYMS = 288, DIST_SYMS = 32, LANE_DWORDS = 9 + (LIT_SYMS + DIST_SYMS) / 4 + 16;     // 105 dwords = 420 B of LDS per lane
 
 __constant__ uint16_t LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
 __constant__ uint8_t LEN_EXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -118,47 +119,55 @@ struct ByteSyms {
     __device__ __forceinline__ void put(int i, int sym) { lo[i] = (uint8_t)sym; }
 };
 
-// canonical Huffman decode of one symbol: walks the code lengths 1..15 with the counts in registers, then one LDS read
+// Decoder state of one alphabet: for every code length L the left-aligned (15-bit) code one past the last code of that
+// length -- the canonical codes of length L are exactly the 15-bit prefixes in [lim[L-2], lim[L-1]) -- in fifteen
+// registers (static indices only), and in the lane's LDS slice base[L] = (table slot of the first symbol of length L) -
+// (first code of length L), so that a symbol is  syms[(peek >> (15 - L)) + base[L]].
+struct Dec {
+    uint32_t lim[15];
+    int16_t* base;                        // LDS, [16]
+};
+
+// One symbol, branch-free: the next 15 bits MSB-first (`peek`), its code length = 1 + the number of limits it reaches
+// (fourteen compare + add-with-carry pairs instead of the divergent walk over the lengths: the wave paid every symbol
+// for its slowest lane's code), then two LDS reads.  -1: not a code of this alphabet.
 template <class Syms>
-__device__ __forceinline__ int decode_symbol(BitReader& br, const Counts& c, const Syms& syms)
+__device__ __forceinline__ int decode_symbol(BitReader& br, const Dec& d, const Syms& syms)
 {
     br.refill();
-    uint32_t bitsrc = (uint32_t)br.buf;
-    int code = 0, first = 0, index = 0;
+    const uint32_t peek = __brev((uint32_t)br.buf) >> 17;
+    int len = 1;
 #pragma unroll
-    for (int len = 1; len <= 15; ++len) {
-        code |= (int)(bitsrc & 1u);
-        bitsrc >>= 1;
-        const int count = (int)c.get(len);
-        if (code - count < first) {
-            br.drop(len);
-            return syms.get(index + (code - first));
-        }
-        index += count;
-        first += count;
-        first <<= 1;
-        code <<= 1;
-    }
-    return -1;                                                  // not a code of this alphabet
+    for (int k = 0; k < 14; ++k) len += peek >= d.lim[k] ? 1 : 0;
+    if (peek >= d.lim[14]) return -1;
+    br.drop(len);
+    return syms.get((int)(peek >> (15 - len)) + (int)d.base[len]);
 }
 
-// code lengths -> counts (registers) + symbols sorted by (length, symbol) in the lane's LDS slice (RFC 1951 3.2.2)
+// code lengths -> the limits (registers), base[] and the symbols sorted by (length, symbol) in the lane's LDS slice
+// (RFC 1951 3.2.2)
 template <class Syms>
-__device__ __forceinline__ bool build(const uint8_t* lens, int n, Counts& c, Syms& syms)
+__device__ __forceinline__ bool build(const uint8_t* lens, int n, Dec& d, Syms& syms)
 {
+    Counts c;
     c.clear();
     syms.clear();
     for (int s = 0; s < n; ++s) if (lens[s]) c.add(lens[s]);
     int left = 1;                                               // over-subscription check
     Counts offs;                                                // first table slot of every length (same packing)
     offs.clear();
-    uint32_t run = 0;
+    uint32_t run = 0, code = 0;
 #pragma unroll
     for (int len = 1; len <= 15; ++len) {
+        const uint32_t count = c.get(len);
         left <<= 1;
-        left -= (int)c.get(len);
+        left -= (int)count;
         offs.add(len, run);
-        run += c.get(len);
+        d.base[len] = (int16_t)((int)run - (int)code);
+        run += count;
+        code += count;
+        d.lim[len - 1] = code << (15 - len);                    // (an over-subscribed code overflows 15 bits: rejected below)
+        code <<= 1;
     }
     if (left < 0) return false;
     for (int s = 0; s < n; ++s) {
@@ -202,14 +211,17 @@ void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const uint64_t* __res
     __shared__ uint32_t lds[LANES * LANE_DWORDS];
     const uint32_t b = blockIdx.x * LANES + threadIdx.x;
     if (b >= n_blocks) return;
-    uint32_t* mine = lds + threadIdx.x * LANE_DWORDS;         // [9 mask dwords][288 literal bytes][32 distance bytes]
+    uint32_t* mine = lds + threadIdx.x * LANE_DWORDS;         // [9 mask dwords][288 literal bytes][32 distance bytes][2 x 16 bases]
     LitSyms lit_syms{reinterpret_cast<uint8_t*>(mine + 9), mine};
     ByteSyms dist_syms{reinterpret_cast<uint8_t*>(mine + 9) + LIT_SYMS};
+    Dec lc, dc, cc;
+    lc.base = reinterpret_cast<int16_t*>(mine + 9 + (LIT_SYMS + DIST_SYMS) / 4);
+    dc.base = lc.base + 16;
+    cc.base = dc.base;                                          // (the code-length code borrows the distance slices)
     BitReader br;
     br.init(comp, src_off[b], src_len[b]);
     Writer w{out, dst_off[b], dst_off[b], dst_off[b + 1], 0u, 0};
     int err = INF_OK;
-    Counts lc, dc;
     uint8_t lens[LIT_SYMS + DIST_SYMS];
     bool last = w.hi == w.lo;                                   // an empty block (the EOF marker): nothing to decode
     while (!last && err == INF_OK) {
@@ -236,7 +248,6 @@ void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const uint64_t* __res
                 uint8_t cl[19];
                 for (int i = 0; i < 19; ++i) cl[i] = 0;
                 for (int i = 0; i < ncode; ++i) cl[CLEN_ORDER[i]] = (uint8_t)br.bits(3);
-                Counts cc;
                 if (!build(cl, 19, cc, dist_syms)) { err = INF_BAD_TABLE; break; }     // (the code-length code borrows the distance slice)
                 int i = 0;
                 while (i < nlen + ndist) {

@@ -291,24 +291,22 @@ class ChromosomeFeed:
         try:
             if engine == "gpu":                                # BGZF inflate + record packing on the device
                 from .ingest_gpu import DeviceDecoder, DeviceIngestError
-                ingest_stream = torch.cuda.Stream(device=self.device, priority=-1)
                 dec = self.decoder = DeviceDecoder(self.bam_path, self.index, self.references, self.lengths, self.header_text, self.device,
                                                    threads=min(8, max(1, self.threads)), alloc_for=self._slot_alloc)
                 if not dec.usable(tids):
                     host_parts(tids)
                 else:
-                    for group in dec.groups(tids):
-                        done = 0
-                        try:
-                            with torch.cuda.stream(ingest_stream):
-                                for part in dec.decode_group(group):
-                                    if not put(part):
-                                        return
-                                    done += 1
-                        except DeviceIngestError as exc:       # CG-tag CIGARs, an index that does not fit: the host reader takes over
-                            import logging
-                            logging.warning("device ingestion of references %s failed (%s): decoding them on the host", group[done:], exc)
-                            host_parts(group[done:])
+                    order = [t for _v, t in sorted((dec.spans[t][0], t) for t in tids if t < len(dec.spans) and dec.spans[t] is not None)]
+                    done = 0
+                    try:
+                        for part in dec.parts_pipelined(tids):
+                            if not put(part):
+                                return
+                            done += 1
+                    except DeviceIngestError as exc:           # CG-tag CIGARs, an index that does not fit: the host reader takes over
+                        import logging
+                        logging.warning("device ingestion failed at reference %s (%s): decoding the rest on the host", order[done] if done < len(order) else "-", exc)
+                        host_parts(order[done:])
             else:
                 host_parts(tids)
             put(None)

@@ -18,6 +18,7 @@ from . import _lib, kernels
 from .io.bam import AlignmentTable, read_bai_linear
 
 FIRST_GROUP_BYTES = 192 << 20            # the first launch is small: the pipeline starts after ~0.1 s
+PIPE_GROUP_BYTES = 768 << 20             # parts_pipelined: ~30 k blocks per launch, three launches in flight on three streams
 GROUP_BYTES = 24 << 30                   # later groups: as many blocks as possible per launch (a lane decodes one block in ~0.1 s
                                          # whatever the launch size; 24 GB compressed inflate to ~58 GB of HBM)
 
@@ -108,6 +109,250 @@ class DeviceDecoder:
         if self.pinned is None or self.pinned.numel() < n:
             self.pinned = torch.empty(max(n, 64 << 20), dtype=torch.uint8, pin_memory=True)
         return self.pinned
+
+    # ---- pipelined form: a reader thread, up to `depth` groups in flight on streams of their own ------------------------
+    def parts_pipelined(self, tids, depth=3):
+        """Generator like :meth:`decode_group` over ALL chromosomes of ``tids``, with the steps overlapped: a reader thread
+        fills pinned buffers a few groups ahead; every group is uploaded, inflated and counted on one of ``depth`` streams
+        without a host synchronisation (a lane needs ~0.1 s for its block whatever the launch size, so launches of ~30 k
+        blocks are staggered rather than made large: the first chromosomes arrive after one such latency, the later ones
+        at the rate the device decodes); per group ONE read-back (block status + walk counts), per chromosome ONE."""
+        import collections
+        import queue
+        import threading
+        import time
+        lib, dev = self.lib, self.device
+        have = sorted((self.spans[t][0], t) for t in tids if t < len(self.spans) and self.spans[t] is not None)
+        groups, cur, cur_bytes, limit = [], [], 0, FIRST_GROUP_BYTES
+        for _v, t in have:
+            lo, hi, _lin = self.spans[t]
+            nbytes = (hi >> 16) - (lo >> 16) + 65536
+            if cur and cur_bytes + nbytes > limit:
+                groups.append(cur)
+                cur, cur_bytes, limit = [], 0, PIPE_GROUP_BYTES
+            cur.append(t)
+            cur_bytes += nbytes
+        if cur:
+            groups.append(cur)
+        q = queue.Queue(maxsize=depth)
+        stop = threading.Event()
+
+        def read_group(group):
+            spans = [self.spans[t] for t in group]
+            c0 = min(s[0] >> 16 for s in spans)
+            c1 = min(self.size, max(s[1] >> 16 for s in spans) + 65536 + 64)
+            nbytes = c1 - c0
+            t0 = time.perf_counter()
+            pin = torch.empty(nbytes + 64, dtype=torch.uint8, pin_memory=True)
+            if lib.svx_read_range(self.path.encode(), c0, nbytes, pin.data_ptr(), self.threads) != 0:
+                raise DeviceIngestError(lib.svx_bam_error().decode())
+            pin[nbytes:nbytes + 64].zero_()
+            cap = nbytes // 28 + 16
+            src_off, coff = np.empty(cap, np.uint64), np.empty(cap, np.uint64)
+            src_len, isize = np.empty(cap, np.uint32), np.empty(cap, np.uint32)
+            used = np.zeros(1, np.uint64)
+            nb = int(lib.svx_bgzf_index(pin.data_ptr(), nbytes, c0, cap, src_off.ctypes.data, src_len.ctypes.data, isize.ctypes.data,
+                                        coff.ctypes.data, used.ctypes.data))
+            if nb <= 0:
+                raise DeviceIngestError("no BGZF block at file offset %d" % c0)
+            src_off, src_len, isize, coff = src_off[:nb], src_len[:nb], isize[:nb], coff[:nb]
+            dst = np.zeros(nb + 1, np.uint64)
+            dst[1:] = np.cumsum(isize.astype(np.uint64))
+
+            def inflated_offset(voffs):
+                c = voffs >> np.uint64(16)
+                idx = np.searchsorted(coff, c)
+                at_end = idx >= nb
+                idx = np.minimum(idx, nb - 1)
+                if not (at_end | (coff[idx] == c)).all():
+                    raise DeviceIngestError("the index points between two BGZF blocks")
+                return np.where(at_end, dst[nb], dst[idx] + (voffs & np.uint64(0xFFFF)))
+            starts = []
+            for lo, hi, linear in spans:
+                seeds = linear[(linear >= np.uint64(lo)) & (linear < np.uint64(hi))]
+                voffs = np.unique(np.concatenate([np.asarray([lo], np.uint64), seeds, np.asarray([hi], np.uint64)]))
+                starts.append(np.unique(inflated_offset(voffs)))
+            # one pinned block of small tables: payload offsets, payload sizes, inflated offsets, then every chromosome's starts
+            n_starts = [int(a.size) - 1 for a in starts]
+            words = 3 * nb + 1 + sum(a.size for a in starts) + 8
+            tab = torch.empty(words, dtype=torch.int64, pin_memory=True)
+            tv = tab.numpy()
+            tv[:nb] = src_off.view(np.int64)
+            tv[nb:2 * nb] = src_len.astype(np.int64)
+            tv[2 * nb:3 * nb + 1] = dst.view(np.int64)
+            at, start_at = 3 * nb + 1, []
+            for a in starts:
+                tv[at:at + a.size] = a.view(np.int64)
+                start_at.append(at)
+                at += a.size
+            self.stats["read_s"] += time.perf_counter() - t0
+            self.stats["blocks"] += nb
+            self.stats["bytes_in"] += int(nbytes)
+            self.stats["bytes_inflated"] += int(dst[nb])
+            return {"group": group, "pin": pin, "nbytes": nbytes, "nb": nb, "total": int(dst[nb]), "tab": tab, "start_at": start_at, "n_starts": n_starts}
+
+        def reader():
+            try:
+                for g in groups:
+                    item = read_group(g)
+                    while not stop.is_set():
+                        try:
+                            q.put(item, timeout=0.2)
+                            break
+                        except queue.Full:
+                            continue
+                    if stop.is_set():
+                        return
+                q.put(None)
+            except BaseException as exc:                         # noqa: BLE001
+                q.put(exc)
+
+        def launch(item, stream):
+            nb, nbytes = item["nb"], item["nbytes"]
+            with torch.cuda.stream(stream):
+                padded = (nbytes + 31) // 16 * 16
+                d_comp = torch.empty(padded, dtype=torch.uint8, device=dev)
+                d_comp.copy_(item["pin"][:padded], non_blocking=True)
+                d_tab = item["tab"].to(dev, non_blocking=True)
+                d_raw = torch.empty(max(item["total"], 16), dtype=torch.uint8, device=dev)
+                d_status = torch.zeros(nb, dtype=torch.int32, device=dev)
+                d_len = d_tab[nb:2 * nb].to(torch.int32)
+                st = kernels._stream_ptr(dev)
+                _lib.check(lib.svx_bgzf_inflate(d_comp.data_ptr(), d_tab.data_ptr(), d_len.data_ptr(), d_tab[2 * nb:].data_ptr(), nb, d_raw.data_ptr(),
+                                                d_status.data_ptr(), st), "svx_bgzf_inflate")
+                total_starts = sum(item["n_starts"])
+                d_counts = torch.empty((total_starts + 1, 4), dtype=torch.int64, device=dev)
+                row = 0
+                for at, n in zip(item["start_at"], item["n_starts"]):
+                    _lib.check(lib.svx_bam_walk_count(d_raw.data_ptr(), d_tab[at:].data_ptr(), n, d_counts[row:].data_ptr(), st), "svx_bam_walk_count")
+                    row += n
+                d_counts[total_starts, 0] = d_status.max()
+                h_counts = torch.empty((total_starts + 1, 4), dtype=torch.int64, pin_memory=True)
+                h_counts.copy_(d_counts, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+            item.update(d_raw=d_raw, d_tab=d_tab, d_comp=d_comp, h_counts=h_counts, event=ev, stream=stream)
+            return item
+
+        def finish_group(item):
+            t0 = time.perf_counter()
+            item["event"].synchronize()
+            item["d_comp"] = None
+            self.stats["h2d_inflate_s"] += time.perf_counter() - t0
+            counts = item["h_counts"].numpy()
+            if int(counts[-1, 0]) != 0:
+                raise DeviceIngestError("corrupt BGZF blocks in references %s" % item["group"])
+            d_raw, d_tab, stream = item["d_raw"], item["d_tab"], item["stream"]
+            pending, row = [], 0
+            t0 = time.perf_counter()
+            with torch.cuda.stream(stream):
+                st = kernels._stream_ptr(dev)
+                for at, n_starts in zip(item["start_at"], item["n_starts"]):
+                    c = counts[row:row + n_starts]
+                    row += n_starts
+                    bad = c[:, 3] != 0
+                    if bad.any():
+                        code = int(c[bad, 3][0])
+                        raise DeviceIngestError({1: "the linear index does not match the records", 2: "malformed BAM record", 3: "CG-tag CIGAR"}.get(code, "walk error %d" % code))
+                    n, words, name_bytes = (int(v) for v in c[:, :3].sum(axis=0))
+                    base = torch.zeros((n_starts, 3), dtype=torch.int64, pin_memory=True)
+                    base.numpy()[1:] = np.cumsum(c[:-1, :3], axis=0)
+                    d_base = base.to(dev, non_blocking=True)
+                    # one device buffer for everything the host wants: [cig_off n+1][name_off n+1][tid n][pos n][l_seq n][flag n][mapq n][names]
+                    sect = [8 * (n + 1), 8 * (n + 1), 4 * n, 4 * n, 4 * n, 2 * n, n, name_bytes]
+                    offs = np.zeros(len(sect) + 1, np.int64)
+                    offs[1:] = np.cumsum([(v + 15) // 16 * 16 for v in sect])
+                    d_pack = torch.empty(int(offs[-1]) + 16, dtype=torch.uint8, device=dev)
+
+                    def view(k, dtype, count):
+                        return d_pack[int(offs[k]):int(offs[k]) + count * torch.empty(0, dtype=dtype).element_size()].view(dtype)
+                    d_cig_off, d_name_off = view(0, torch.int64, n + 1), view(1, torch.int64, n + 1)
+                    d_tid, d_pos, d_lseq = view(2, torch.int32, n), view(3, torch.int32, n), view(4, torch.int32, n)
+                    d_flag, d_mapq, d_names = view(5, torch.int16, n), view(6, torch.uint8, n), view(7, torch.uint8, max(name_bytes, 1))
+                    d_cigar = torch.empty(max(words, 1), dtype=torch.int32, device=dev)
+                    _lib.check(lib.svx_bam_walk_extract(d_raw.data_ptr(), d_tab[at:].data_ptr(), n_starts, d_base.data_ptr(), d_tid.data_ptr(),
+                                                        d_pos.data_ptr(), d_flag.data_ptr(), d_mapq.data_ptr(), d_lseq.data_ptr(), d_cig_off.data_ptr(),
+                                                        d_cigar.data_ptr(), d_name_off.data_ptr(), d_names.data_ptr(), st), "svx_bam_walk_extract")
+                    d_cig_off[n:].fill_(words)
+                    d_name_off[n:].fill_(name_bytes)
+                    h_pack = torch.empty(int(offs[-1]) + 16, dtype=torch.uint8, pin_memory=True)
+                    h_pack.copy_(d_pack, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    # device copies svx_cigar_scan keeps: own tensors (the pack goes away with this chromosome's read-back)
+                    pending.append((ev, h_pack, offs, n, words, name_bytes, d_cigar, d_cig_off.clone(), d_pos.clone(), base, d_pack))
+            self.stats["walk_s"] += time.perf_counter() - t0
+            for ev, h_pack, offs, n, words, name_bytes, d_cigar, d_cig_off, d_pos, _base, _d_pack in pending:
+                t0 = time.perf_counter()
+                ev.synchronize()
+                self.stats["d2h_s"] += time.perf_counter() - t0
+                yield self._make_finish(h_pack.numpy(), offs, n, words, name_bytes, d_cigar), (d_cigar, d_cig_off, d_pos)
+            item["d_raw"] = item["d_tab"] = None
+
+        th = threading.Thread(target=reader, name="svx-read", daemon=True)
+        th.start()
+        streams = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(depth)]
+        inflight, done, k = collections.deque(), False, 0
+        try:
+            while True:
+                while not done and len(inflight) < depth:
+                    try:
+                        item = q.get(block=not inflight, timeout=None if not inflight else 0)
+                    except queue.Empty:
+                        break
+                    if item is None:
+                        done = True
+                        break
+                    if isinstance(item, BaseException):
+                        raise item
+                    inflight.append(launch(item, streams[k % depth]))
+                    k += 1
+                if not inflight:
+                    break
+                yield from finish_group(inflight.popleft())
+        finally:
+            stop.set()
+
+    def _make_finish(self, hp, offs, n, words, name_bytes, d_cigar):
+        """The host side of one device-decoded chromosome: packed read-back -> shared-memory arrays, QNAME ids, table."""
+        lib = self.lib
+
+        def sect(k, dtype, count):
+            return hp[int(offs[k]):int(offs[k]) + count * np.dtype(dtype).itemsize].view(dtype)
+
+        def finish():
+            import time
+            t0 = time.perf_counter()
+            alloc = self.alloc_for() if self.alloc_for is not None else (lambda _name, dtype, k: np.empty(k, dtype))
+
+            def keep(name, dtype, src):
+                out = alloc(name, dtype, src.size)
+                if src.size:
+                    out[:] = src
+                return out
+            cig_off_h = keep("cig_off", np.int64, sect(0, np.int64, n + 1))
+            name_off_h = sect(1, np.int64, n + 1)
+            tid_h, pos_h, l_seq_h = keep("tid", np.int32, sect(2, np.int32, n)), keep("pos", np.int32, sect(3, np.int32, n)), keep("l_seq", np.int32, sect(4, np.int32, n))
+            flag_h, mapq_h = keep("flag", np.uint16, sect(5, np.uint16, n)), keep("mapq", np.uint8, sect(6, np.uint8, n))
+            names_h = np.ascontiguousarray(sect(7, np.uint8, name_bytes))
+            name_id = alloc("name_id", np.int32, n)
+            uniq = np.empty(max(name_bytes, 1), np.uint8)
+            ub = np.zeros(1, np.uint64)
+            name_off_c = np.ascontiguousarray(name_off_h)
+            n_unique = int(lib.svx_name_ids(names_h.ctypes.data, name_off_c.ctypes.data, n, name_id.ctypes.data, uniq.ctypes.data, ub.ctypes.data))
+            blob = alloc("names", np.uint8, int(ub[0]))
+            blob[:] = uniq[:int(ub[0])]
+            name_list = blob.tobytes().decode().split("\n")[:-1] if n_unique else []
+            self.stats["names_s"] += time.perf_counter() - t0
+            table = AlignmentTable(self.references, self.lengths, tid_h, pos_h, flag_h, mapq_h, l_seq_h, name_id, name_list, np.empty(0, np.uint32),
+                                   cig_off_h, self.header_text)
+            table.cigar = LazyCigar(words)
+            table._names_blob = blob
+            table._alloc = alloc
+            table._shm_dir = getattr(alloc, "dir", None)
+            table._d_cigar = d_cigar
+            return table
+        return finish
 
     def decode_group(self, tids):
         """Generator over the chromosomes of one group: (finish, (d_cigar int32, d_cig_off int64 [n+1], d_pos int32)) where

@@ -164,3 +164,30 @@ def test_command_line_with_device_ingest_equals_host_ingest(tmp_path):
                                  ["segments/" + f for f in sorted(os.listdir(os.path.join(out, "segments")))]}
         assert outs[("cpu", "1")] == outs[("gpu", "1")] == outs[("gpu", "3")]
         assert outs[("cpu", "1")]["HGi.svision.s3.vcf"].count("\n") > 20
+
+
+def test_pipelined_device_decoder_equals_the_host_decoder(tmp_path):
+    """DeviceDecoder.parts_pipelined (reader thread, several groups in flight on their own streams, one read-back per
+    group and per chromosome) == the host decoder, chromosome by chromosome, for several group sizes."""
+    from svision_amd import synth
+    import svision_amd.ingest_gpu as ig
+    cfg = synth.SimConfig(contigs=[("c%d" % i, 260_000 + 70_000 * (i % 3)) for i in range(7)], coverage=10, read_len_mean=9000, read_len_sd=1500,
+                          sv_spacing=20_000, sv_min_gap=9_000, sv_max=3000, seed=21)
+    table, _g, _ = synth.simulate(cfg, with_genome=False)
+    table = table.subset(np.flatnonzero(table.tid != 4))
+    tids = [0, 1, 2, 3, 5, 6]
+    segs = [bam.encode_reference_segment(table.subset(np.flatnonzero(table.tid == t)), seq="random", seed=t) for t in tids]
+    path = str(tmp_path / "pipe.bam")
+    bam.write_bam_segments(path, table.references, table.lengths, segs)
+    head = bam.read_bam_header(path)
+    for first, later in ((1 << 10, 1 << 10), (1 << 20, 3 << 20), (1 << 40, 1 << 40)):
+        ig.FIRST_GROUP_BYTES, ig.PIPE_GROUP_BYTES = first, later
+        dec = ig.DeviceDecoder(path, path + ".bai", head.references, head.lengths, head.header_text, "cuda:0", threads=3)
+        got = []
+        for finish, (d_cigar, d_off, d_pos) in dec.parts_pipelined(list(range(7))):
+            tb = finish()
+            ig.spill_cigar(tb)
+            got.append(int(tb.tid[0]))
+            _same_table(tb, bam.read_bam(path, tids=[got[-1]]))
+            assert np.array_equal(d_off.cpu().numpy(), tb.cig_off) and np.array_equal(d_pos.cpu().numpy(), tb.pos)
+        assert got == tids
