@@ -59,6 +59,11 @@ GRCH38 = (("chr1", 248956422), ("chr2", 242193529), ("chr3", 198295559), ("chr4"
 LAYER_FLOP = {"conv2": 447_897_600, "conv3": 299_040_768, "conv4": 224_280_576, "conv5": 149_520_384, "fc": 109_092_864}
 LAYER_PIX = {"conv2": 729, "conv3": 169, "conv4": 169, "conv5": 169}
 WINDOW = 10_000_000
+try:                                              # the round's rocprofv3 PMC passes over the device stage (tools/r03_profile.sh)
+    with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as _f:
+        TRAFFIC = json.load(_f)
+except (OSError, ValueError):
+    TRAFFIC = {}
 
 
 def random_weights(seed=0):
@@ -376,9 +381,12 @@ def main():
                      "executed_flop_per_image": executed_flop, "active_fraction": {k: round(v, 4) for k, v in frac.items()},
                      "algorithmic_tflops": CNN_FLOP * sum_dev_images / world / max(dev_s, 1e-9) / 1e12,
                      "algorithmic_speedup": CNN_FLOP / executed_flop,
-                     "traffic": None,
-                     "traffic_note": "PMC counters cannot be read inside this process; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                     "the same stage are summarised in profiles/r02_pmc_traffic.md",
+                     "traffic": TRAFFIC.get("bytes"),
+                     "traffic_note": ("HBM / fabric bytes per launch of %d images (the unit `achieved` is quoted per launch of as well: %.1f GFLOP executed), "
+                                      "%.3g read + %.3g written, against %.3g algorithmic (%.2fx); PMC counters cannot be read inside this process: "
+                                      % (TRAFFIC["images_per_launch"], executed_flop * TRAFFIC["images_per_launch"] / 1e9, TRAFFIC["read_bytes"],
+                                         TRAFFIC["written_bytes"], TRAFFIC["algorithmic_bytes"], TRAFFIC["bytes"] / TRAFFIC["algorithmic_bytes"])
+                                      + TRAFFIC["source"]) if TRAFFIC else "no PMC summary under profiles/",
                      "ms_per_batch": ms_batch, "batches": sum_dev_images / B, "device_busy_frac": dev_s / dt},
     }
     if e2e_block is not None:
