@@ -625,8 +625,8 @@ class CpuBaselinePool:
         """Every process takes 1/P of the sites of one window (round-robin over the windows) and at most `images_per_proc`
         of their images: about 10-30 s of wall time; value = sites classified by the pool / wall time."""
         P = len(self.conns)
-        if images_per_proc is None:                           # ~25 s of wall: a 1-thread process classifies 15-25 images per second
-            images_per_proc = 192 if P >= 64 else 384
+        if images_per_proc is None:                           # ~20 s of wall: a 1-thread process classifies 15-80 images per second
+            images_per_proc = 192 if P >= 64 else 1536
         per_win = max(1, P // max(len(windows), 1))
         t0 = time.perf_counter()
         for i, c in enumerate(self.conns):
