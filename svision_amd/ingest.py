@@ -101,8 +101,9 @@ class ChromosomeFeed:
         self.header_text = header_text
         # where the BGZF blocks are inflated: "cpu" = libdeflate on host threads (io.bam.BamStream, the default), "gpu" = on the
         # device (ingest_gpu.DeviceDecoder: needs a .bai with its linear index; not with --hash / --graph).  The device
-        # kernels inflate 4-5x faster than a 16-CPU container (46 vs 10 GB/s), but their orchestration still runs in Python
-        # threads next to the GPU-feeding one and end to end the host engine is ahead: opt-in for now
+        # kernels inflate 3-6x faster than a 16-CPU container, but their time adds to the CNN's on the one GPU and their
+        # host side (page cache -> pinned memory, per-chromosome hand-over) is bound by the same CPU quota: end to end the
+        # two engines are level on such a box (DESIGN.md section 5 "Device-side ingestion"), so the device engine is opt-in
         self.engine = engine or os.environ.get("SVX_INGEST", "cpu")
         self.references, self.lengths = list(references), list(lengths)
         self.chroms = list(chroms)
