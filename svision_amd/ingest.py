@@ -222,11 +222,14 @@ class ChromosomeFeed:
                     meta["lazy_cigar"] = int(table.cigar.size)
                     meta["spilled"] = threading.Event()
                     spill.put((table, meta["spilled"]))
+                if getattr(self, "decoder", None) is not None:
+                    self.decoder._mark("handed over %s (scan + slot writes)" % self.references[tid])
                 self._put((self.references[tid], sample, meta))
             while want and not self._stop:
                 self._emit_empty(want.pop(0))
             if getattr(self, "decoder", None) is not None:
                 self.stats["device_decoder"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in self.decoder.stats.items()}
+                self.stats["device_decoder"]["trace"] = ["%.3f %s" % (t + (self.decoder._t0 - self._t0), w) for t, w in self.decoder.trace[:40]]
         except BaseException as exc:                           # noqa: BLE001 -- surfaces in the owner thread (poll / get)
             self.error = exc
             self._stop = True

@@ -85,6 +85,13 @@ class DeviceDecoder:
         self.size = os.path.getsize(path)
         self.pinned = None
         self.stats = {"read_s": 0.0, "h2d_inflate_s": 0.0, "walk_s": 0.0, "d2h_s": 0.0, "names_s": 0.0, "blocks": 0, "bytes_in": 0, "bytes_inflated": 0}
+        import time
+        self._t0, self.trace = time.perf_counter(), []          # (seconds since construction, what) of the first events (SVX_TIMING)
+
+    def _mark(self, what):
+        import time
+        if len(self.trace) < 60:
+            self.trace.append((round(time.perf_counter() - self._t0, 4), what))
 
     def usable(self, tids):
         return all(t < len(self.spans) and (self.spans[t] is None or self.spans[t][2].size > 0) for t in tids)
@@ -143,7 +150,9 @@ class DeviceDecoder:
             c1 = min(self.size, max(s[1] >> 16 for s in spans) + 65536 + 64)
             nbytes = c1 - c0
             t0 = time.perf_counter()
+            self._mark("read %s: start" % group[:2])
             pin = torch.empty(nbytes + 64, dtype=torch.uint8, pin_memory=True)
+            self._mark("read: pinned %d MB" % (nbytes >> 20))
             if lib.svx_read_range(self.path.encode(), c0, nbytes, pin.data_ptr(), self.threads) != 0:
                 raise DeviceIngestError(lib.svx_bam_error().decode())
             pin[nbytes:nbytes + 64].zero_()
@@ -189,6 +198,7 @@ class DeviceDecoder:
             self.stats["blocks"] += nb
             self.stats["bytes_in"] += int(nbytes)
             self.stats["bytes_inflated"] += int(dst[nb])
+            self._mark("read: done, %d blocks" % nb)
             return {"group": group, "pin": pin, "nbytes": nbytes, "nb": nb, "total": int(dst[nb]), "tab": tab, "start_at": start_at, "n_starts": n_starts}
 
         def reader():
@@ -232,11 +242,13 @@ class DeviceDecoder:
                 ev = torch.cuda.Event()
                 ev.record()
             item.update(d_raw=d_raw, d_tab=d_tab, d_comp=d_comp, h_counts=h_counts, event=ev, stream=stream)
+            self._mark("launched %s" % item["group"][:2])
             return item
 
         def finish_group(item):
             t0 = time.perf_counter()
             item["event"].synchronize()
+            self._mark("inflate + count done %s" % item["group"][:2])
             item["d_comp"] = None
             self.stats["h2d_inflate_s"] += time.perf_counter() - t0
             counts = item["h_counts"].numpy()
@@ -286,6 +298,7 @@ class DeviceDecoder:
                 t0 = time.perf_counter()
                 ev.synchronize()
                 self.stats["d2h_s"] += time.perf_counter() - t0
+                self._mark("packed read-back done")
                 yield self._make_finish(h_pack.numpy(), offs, n, words, name_bytes, d_cigar), (d_cigar, d_cig_off, d_pos)
             item["d_raw"] = item["d_tab"] = None
 
@@ -344,6 +357,7 @@ class DeviceDecoder:
             blob[:] = uniq[:int(ub[0])]
             name_list = blob.tobytes().decode().split("\n")[:-1] if n_unique else []
             self.stats["names_s"] += time.perf_counter() - t0
+            self._mark("finish(): slot copies + QNAME ids %.1f ms" % ((time.perf_counter() - t0) * 1e3))
             table = AlignmentTable(self.references, self.lengths, tid_h, pos_h, flag_h, mapq_h, l_seq_h, name_id, name_list, np.empty(0, np.uint32),
                                    cig_off_h, self.header_text)
             table.cigar = LazyCigar(words)
