@@ -317,7 +317,11 @@ def main():
 
     dev_ms = hot.device_busy_ms()            # time with at least one batch in flight (HIP events on the batches' streams)
     dev_images = hot.device_images
-    e2e_block = run_from_file(args, e2e, hot, run, fasta, opts, dev, sync_all, cores, world, workers, grouped) if e2e is not None else None
+    e2e_block = e2e_device = None
+    if e2e is not None:
+        e2e_block = run_from_file(args, e2e, hot, run, fasta, opts, dev, sync_all, cores, world, workers, grouped, engine=os.environ.get("SVX_INGEST", "cpu"), keep=True)
+        # the same leg with the other ingest engine (BGZF inflate + record packing on the device), reported beside it
+        e2e_device = run_from_file(args, e2e, hot, run, fasta, opts, dev, sync_all, cores, world, workers, grouped, engine="gpu", keep=False)
     executed = net.executed.cpu().numpy().astype(np.float64)         # [conv2, conv3, conv4, conv5 pixels, images]
     totals = torch.tensor([sites, images, dt, dev_ms, dev_images] + executed.tolist(), dtype=torch.float64, device=dev)
     if grouped:
@@ -393,6 +397,9 @@ def main():
         e2e_block["resident_sites_per_s"] = line["value"]
         e2e_block["ratio_to_resident"] = e2e_block["value"] / max(line["value"], 1e-9)
         line["e2e"] = e2e_block
+        if e2e_device is not None:
+            e2e_device["ratio_to_resident"] = e2e_device["value"] / max(line["value"], 1e-9)
+            line["e2e_device_ingest"] = e2e_device
     if rank == 0 and not args.no_calibration:
         line["roofline_kernels"] = kernel_calibration(hot, sample, net, dev, B * max(1, args.launch_batches), windows[0])
     hot.close()
@@ -404,7 +411,7 @@ def main():
         tdist.destroy_process_group()
 
 
-def run_from_file(args, e2e, hot, run, fasta, opts, dev, sync_all, cores, world, workers, grouped):
+def run_from_file(args, e2e, hot, run, fasta, opts, dev, sync_all, cores, world, workers, grouped, engine="cpu", keep=False):
     """The file-inclusive leg (wall of Step 1 + Step 2 with the BAM on local disk): a timed region of its
     own that starts with nothing but the file -- svx_bam_stream_* reads and inflates it on host threads chromosome by
     chromosome, every chromosome is uploaded and scanned on the device when it arrives and handed to the helpers through
@@ -419,7 +426,7 @@ def run_from_file(args, e2e, hot, run, fasta, opts, dev, sync_all, cores, world,
     resident = hot.feed
     sync_all()
     t0 = time.perf_counter()
-    feed = ChromosomeFeed(e2e["path"], fasta, opts, refs, refs, lens, device=dev, index=e2e["path"] + ".bai", threads=threads)
+    feed = ChromosomeFeed(e2e["path"], fasta, opts, refs, refs, lens, device=dev, index=e2e["path"] + ".bai", threads=threads, engine=engine)
     hot.feed = feed
     try:
         sites, images, records, scores = run(e2e["windows"], rescan=False)
@@ -432,7 +439,8 @@ def run_from_file(args, e2e, hot, run, fasta, opts, dev, sync_all, cores, world,
             hot.release(chrom)
         feed.close()
         hot.feed = resident
-        shutil.rmtree(e2e["dir"], ignore_errors=True)
+        if not keep:
+            shutil.rmtree(e2e["dir"], ignore_errors=True)
     dev_ms = hot.device_busy_ms()
     tot = torch.tensor([sites, images, len(e2e["windows"]), e2e["bytes"], e2e["inflated"], dev_ms], dtype=torch.float64, device=dev)
     if grouped:
@@ -442,7 +450,7 @@ def run_from_file(args, e2e, hot, run, fasta, opts, dev, sync_all, cores, world,
         dt = float(tmax.item())
     tot = tot.cpu().numpy()
     st = feed.stats
-    return {"value": float(tot[0]) / dt, "unit": "sites/s", "seconds": dt, "windows": int(tot[2]), "sites": int(tot[0]), "images": int(tot[1]),
+    return {"ingest_engine": st.get("engine"), "value": float(tot[0]) / dt, "unit": "sites/s", "seconds": dt, "windows": int(tot[2]), "sites": int(tot[0]), "images": int(tot[1]),
             "bam_bytes": int(tot[3]), "inflated_bytes": int(tot[4]), "compressed_GB_per_s": float(tot[3]) / dt / 1e9,
             "inflated_GB_per_s": float(tot[4]) / dt / 1e9, "inflate_threads_per_rank": threads, "device_busy_frac": float(tot[5]) * 1e-3 / world / dt,
             "rank0_feed": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in st.items()},

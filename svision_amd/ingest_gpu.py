@@ -141,7 +141,7 @@ class DeviceDecoder:
             cur_bytes += nbytes
         if cur:
             groups.append(cur)
-        q = queue.Queue(maxsize=depth)
+        q = queue.Queue(maxsize=1)
         stop = threading.Event()
         pinned_free, pinned_lock = [], threading.Lock()        # pinned buffers whose upload has completed: reused by the reader
                                                                 # (a fresh 0.7 GB of pinned memory costs ~45 ms each time)
@@ -316,24 +316,35 @@ class DeviceDecoder:
         th = threading.Thread(target=reader, name="svx-read", daemon=True)
         th.start()
         streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
-        inflight, done, k = collections.deque(), False, 0
+        inflight = collections.deque()
+        state = {"done": False, "k": 0}
+
+        def pump(block):
+            """Launch what the reader has ready, up to `depth` groups in flight; block only when nothing is in flight."""
+            while not state["done"] and len(inflight) < depth:
+                try:
+                    item = q.get(block=block and not inflight, timeout=None)
+                except queue.Empty:
+                    return
+                if item is None:
+                    state["done"] = True
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                inflight.append(launch(item, streams[state["k"] % depth]))
+                state["k"] += 1
+
         try:
             while True:
-                while not done and len(inflight) < depth:
-                    try:
-                        item = q.get(block=not inflight, timeout=None if not inflight else 0)
-                    except queue.Empty:
-                        break
-                    if item is None:
-                        done = True
-                        break
-                    if isinstance(item, BaseException):
-                        raise item
-                    inflight.append(launch(item, streams[k % depth]))
-                    k += 1
+                pump(block=True)
                 if not inflight:
                     break
-                yield from finish_group(inflight.popleft())
+                head = inflight[0]
+                while not head["event"].query():               # keep launching while the oldest group is still on the device
+                    pump(block=False)
+                    time.sleep(0.0005)
+                inflight.popleft()
+                yield from finish_group(head)
         finally:
             stop.set()
 
