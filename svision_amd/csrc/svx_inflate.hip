@@ -217,22 +217,7 @@ struct Writer {
     }
     __device__ __forceinline__ void copy(uint32_t dist, uint32_t len)        // caller checked the bounds
     {
-        if (dist >= len + 4) {
-            // the source lies wholly in bytes already stored (the pending ones are the last < 4): eight independent byte loads
-            // at a time -- one round trip to L2 per eight bytes instead of a load -> store -> load chain per byte -- and the
-            // bytes leave through the dword gatherer like literals.  Short matches are everywhere in real data (a level-1
-            // encoder takes every 3-byte repeat of the 4-letter alphabet): SQ_INSTS_VMEM_RD was 7 per decoded symbol.
-            const uint8_t* src = base + pos - dist;
-            for (uint32_t i = 0; i < len; i += 8) {
-                uint32_t b[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) b[k] = i + k < len ? src[i + k] : 0u;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) if (i + k < len) literal(b[k]);
-            }
-            return;
-        }
-        flush();                                                // overlapping or very near: byte by byte, in order
+        flush();
         for (uint32_t i = 0; i < len; ++i, ++pos) base[pos] = base[pos - dist];
     }
 };
