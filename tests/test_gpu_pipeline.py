@@ -166,8 +166,8 @@ def test_streaming_cli_equals_file_based_cli(checkpoint, tmp_path, extra):
         assert outs["stream"][k] == outs["files"][k], k
 
 
-@pytest.mark.parametrize("threads", ["1", "3"])
-def test_two_ranks_from_an_indexed_bam_equal_one_rank(checkpoint, tmp_path, threads):
+@pytest.mark.parametrize("threads,engine", [("1", "cpu"), ("3", "cpu"), ("3", "gpu")])
+def test_two_ranks_from_an_indexed_bam_equal_one_rank(checkpoint, tmp_path, threads, engine):
     """The whole multi-rank command line from files: two torchrun ranks (gloo here: one GPU is shared, RCCL refuses
     duplicate devices; the driver's multi-GPU runs use nccl) each decode only their chromosomes through the .bai, stream
     them through the device path, and the single exchange gives rank 0 the merged VCF of the one-rank run, byte for byte."""
@@ -183,7 +183,7 @@ def test_two_ranks_from_an_indexed_bam_equal_one_rank(checkpoint, tmp_path, thre
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     args = ["-b", path, "-m", prefix, "-g", fa, "-n", "HGtest", "-s", "3", "--window_size", "150000", "--batch_size", "64"]
     one = cli.run(cli.parse_arguments(["-o", str(tmp_path / "one")] + args))
-    env = dict(os.environ, PYTHONPATH=root, SVX_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT="29641")
+    env = dict(os.environ, PYTHONPATH=root, SVX_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", SVX_INGEST=engine)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29641", os.path.join(root, "SVision"), "-o", str(tmp_path / "two"), "-t", threads] + args
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
