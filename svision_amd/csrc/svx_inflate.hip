@@ -21,6 +21,7 @@
 // Integer exact by construction: the result is the byte stream zlib / libdeflate produce (tests/test_gpu_inflate.py).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/svx.h"
 
 namespace {
@@ -319,6 +320,275 @@ void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const uint64_t* __res
     status[b] = (uint32_t)err;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// One WAVE per BGZF block, uniform control flow.
+//
+// The lane-per-block kernel above pays, in almost every iteration, for whichever of its 64 unrelated streams happens to
+// refill its bit buffer, store or copy a match (PMC: 7 vector-memory loads per decoded symbol, SQ_WAIT_ANY 70 %).  Here a
+// wave owns ONE block: the bit buffer, the table walk and every branch are wave-uniform (the compiler keeps them on the
+// scalar unit and in scalar branches), and the 64 lanes are the wide parts of the job:
+//   * input: the stream's next 256 bytes sit in one VGPR (lane i holds dword i), fetched with one coalesced load, the
+//     following 256 bytes already on their way; the bit buffer takes its dwords with v_readlane;
+//   * Huffman decoding: 10-bit (literal / length) and 8-bit (distance) first-level tables in LDS, entry = symbol << 4 |
+//     code length; longer codes (rare) walk the canonical limits;
+//   * output: a 64-byte line is gathered in one VGPR (lane = byte) and leaves as one coalesced store; a match copies up to
+//     min(length, distance, bytes left in the line) bytes per step, every lane fetching its source byte from the line
+//     in hand (ds_bpermute) or from the bytes this wave stored earlier.
+constexpr int W_LIT_BITS = 10, W_DIST_BITS = 8;
+struct WaveLds {
+    uint16_t lit_tab[1 << W_LIT_BITS];      // (symbol << 4) | length; 0 = a longer code
+    uint16_t dist_tab[1 << W_DIST_BITS];
+    uint16_t lit_syms[LIT_SYMS];            // symbols sorted by (length, symbol): the canonical fallback
+    uint16_t dist_syms[DIST_SYMS];
+    uint32_t lit_lim[16], dist_lim[16];     // [L - 1] = left-aligned 15-bit limit of length L
+    int32_t lit_base[16], dist_base[16];    // [L] = first slot of length L - first code of length L
+    uint8_t lens[LIT_SYMS + DIST_SYMS];
+    uint8_t cl[32];
+};
+
+struct WaveReader {
+    const uint32_t* words;
+    uint32_t cur, nxt;                      // VGPRs: lane i = dword i of the chunk in hand / of the next one
+    uint64_t chunk_next, word_end;          // (uniform) index of the first dword of the chunk behind `nxt`; one past the last dword
+    int k;                                  // (uniform) next dword of `cur`
+    uint64_t buf;                           // (uniform) unread bits, LSB first
+    int cnt;
+    int64_t fed, limit;
+    __device__ __forceinline__ uint32_t fetch(uint64_t first)
+    {
+        const uint64_t i = first + threadIdx.x;
+        return i < word_end ? words[i] : 0u;
+    }
+    __device__ __forceinline__ void init(const uint8_t* base, uint64_t byte_off, uint64_t byte_len)
+    {
+        words = reinterpret_cast<const uint32_t*>(base);
+        const uint64_t w0 = byte_off >> 2;
+        word_end = (byte_off + byte_len + 3) >> 2;
+        cur = fetch(w0);
+        nxt = fetch(w0 + 64);
+        chunk_next = w0 + 128;
+        k = 0; buf = 0; cnt = 0;
+        refill();
+        const int skip = (int)(byte_off & 3) * 8;
+        buf >>= skip;
+        cnt -= skip;
+        fed = 0;
+        limit = (int64_t)byte_len * 8;
+    }
+    __device__ __forceinline__ void refill()
+    {
+        if (cnt <= 32) {
+            const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)cur, k);
+            if (++k == 64) { cur = nxt; nxt = fetch(chunk_next); chunk_next += 64; k = 0; }
+            buf |= (uint64_t)v << cnt;
+            cnt += 32;
+        }
+    }
+    __device__ __forceinline__ void drop(int n) { buf >>= n; cnt -= n; fed += n; }
+    __device__ __forceinline__ uint32_t bits(int n)
+    {
+        refill();
+        const uint32_t v = (uint32_t)buf & ((1u << n) - 1u);
+        drop(n);
+        return v;
+    }
+    __device__ __forceinline__ bool exhausted() const { return fed > limit; }
+};
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// canonical tables of one alphabet from its code lengths (all uniform; a wave builds ~4 of these per block)
+__device__ __forceinline__ bool wave_build(const uint8_t* lens, int n, uint16_t* tab, int tab_bits, uint16_t* syms, uint32_t* lim, int32_t* base)
+{
+    int count[16];
+#pragma unroll
+    for (int L = 0; L < 16; ++L) count[L] = 0;
+    for (int s = 0; s < n; ++s) {
+        const int L = uni((int)lens[s]);
+#pragma unroll
+        for (int q = 1; q < 16; ++q) count[q] += L == q ? 1 : 0;
+    }
+    int left = 1, run = 0, code = 0;
+    int first[16], slot[16];
+#pragma unroll
+    for (int L = 1; L <= 15; ++L) {
+        left <<= 1;
+        left -= count[L];
+        first[L] = code;
+        slot[L] = run;
+        base[L] = run - code;
+        run += count[L];
+        code += count[L];
+        lim[L - 1] = (uint32_t)code << (15 - L);
+        code <<= 1;
+    }
+    if (left < 0) return false;
+    const int tab_n = 1 << tab_bits;
+    for (int i = threadIdx.x; i < tab_n; i += LANES) tab[i] = 0;
+    __builtin_amdgcn_s_waitcnt(0xc07f);                         // lgkmcnt(0): the clears land before the entries (same wave, in order)
+    for (int s = 0; s < n; ++s) {
+        const int L = uni((int)lens[s]);
+        if (L == 0) continue;
+        int c = 0, at = 0;
+#pragma unroll
+        for (int q = 1; q < 16; ++q) if (L == q) { c = first[q]++; at = slot[q]++; }
+        syms[at] = (uint16_t)s;
+        if (L <= tab_bits) {                                   // every table index whose low L bits are the code, LSB first
+            const uint32_t r = __brev((uint32_t)c) >> (32 - L);
+            const uint16_t e = (uint16_t)((s << 4) | L);
+            for (uint32_t i = r + ((uint32_t)threadIdx.x << L); i < (uint32_t)tab_n; i += (uint32_t)LANES << L) tab[i] = e;
+        }
+    }
+    return true;
+}
+
+// one symbol: first-level table, else the canonical walk (uniform)
+__device__ __forceinline__ int wave_symbol(WaveReader& br, const uint16_t* tab, int tab_bits, const uint16_t* syms, const uint32_t* lim,
+                                           const int32_t* base)
+{
+    br.refill();
+    const int e = uni((int)tab[(uint32_t)br.buf & ((1u << tab_bits) - 1u)]);
+    if (e) { br.drop(e & 15); return e >> 4; }
+    const uint32_t peek = __brev((uint32_t)br.buf) >> 17;
+    for (int L = tab_bits + 1; L <= 15; ++L)
+        if (peek < (uint32_t)uni((int)lim[L - 1])) {
+            br.drop(L);
+            return uni((int)syms[(int)(peek >> (15 - L)) + uni(base[L])]);
+        }
+    return -1;
+}
+
+struct WaveWriter {
+    uint8_t* base;
+    uint64_t lo, pos, hi;                   // (uniform) the block's byte range and the next byte
+    uint32_t line;                          // VGPR: lane j = byte (pos & ~63) + j of the line in hand
+    __device__ __forceinline__ void store_line(uint64_t upto)   // bytes [max(lo, line start), upto) of the line leave
+    {
+        const uint64_t l0 = (upto - 1) & ~63ull;
+        const uint64_t a = l0 + threadIdx.x;
+        if (a >= lo && a < upto) base[a] = (uint8_t)line;
+    }
+    __device__ __forceinline__ void literal(uint32_t b)
+    {
+        if ((pos & 63) == threadIdx.x) line = b;
+        ++pos;
+        if ((pos & 63) == 0) store_line(pos);
+    }
+    __device__ __forceinline__ void copy(uint32_t dist, uint32_t len)
+    {
+        while (len) {
+            const uint32_t j0 = (uint32_t)(pos & 63);
+            uint32_t n = 64 - j0;
+            if (n > len) n = len;
+            if (n > dist) n = dist;                             // the sources of a step lie in front of it
+            const uint64_t l0 = pos & ~63ull;
+            const int j = (int)threadIdx.x;
+            const bool mine = (uint32_t)j >= j0 && (uint32_t)j < j0 + n;
+            const int64_t a = (int64_t)l0 + j - (int64_t)dist;  // source byte of lane j
+            const int from_line = __builtin_amdgcn_ds_bpermute(((j - (int)dist) & 63) << 2, (int)line);
+            uint32_t v = (uint32_t)from_line & 255u;
+            if (mine && a < (int64_t)l0) v = base[a];           // stored by this wave earlier (program order, same L1)
+            if (mine) line = v;
+            pos += n;
+            len -= n;
+            if ((pos & 63) == 0) store_line(pos);
+        }
+    }
+    __device__ __forceinline__ void finish() { if (pos & 63) store_line(pos); }
+};
+
+__global__ __launch_bounds__(LANES)
+void bgzf_inflate_wave_kernel(const uint8_t* __restrict__ comp, const uint64_t* __restrict__ src_off, const uint32_t* __restrict__ src_len,
+                              const uint64_t* __restrict__ dst_off, uint32_t n_blocks, uint8_t* out, uint32_t* __restrict__ status)
+{
+    __shared__ WaveLds t;
+    const uint32_t b = blockIdx.x;
+    WaveReader br;
+    br.init(comp, src_off[b], src_len[b]);
+    WaveWriter w{out, dst_off[b], dst_off[b], dst_off[b + 1], 0u};
+    int err = INF_OK;
+    bool last = w.hi == w.lo;
+    while (!last && err == INF_OK) {
+        last = br.bits(1) != 0;
+        const uint32_t type = br.bits(2);
+        if (type == 0) {
+            br.bits(br.cnt & 7);
+            const uint32_t len = br.bits(16), nlen = br.bits(16);
+            if ((len ^ nlen) != 0xffffu) { err = INF_BAD_STORED; break; }
+            if (w.pos + len > w.hi) { err = INF_OUT_OVERRUN; break; }
+            for (uint32_t i = 0; i < len; ++i) w.literal(br.bits(8));
+        } else if (type == 1 || type == 2) {
+            if (type == 1) {
+                for (int s = threadIdx.x; s < 288; s += LANES) t.lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+                if (threadIdx.x < 30) t.lens[LIT_SYMS + threadIdx.x] = 5;
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                wave_build(t.lens, 288, t.lit_tab, W_LIT_BITS, t.lit_syms, t.lit_lim, t.lit_base);
+                wave_build(t.lens + LIT_SYMS, 30, t.dist_tab, W_DIST_BITS, t.dist_syms, t.dist_lim, t.dist_base);
+            } else {
+                const int nlen = (int)br.bits(5) + 257, ndist = (int)br.bits(5) + 1, ncode = (int)br.bits(4) + 4;
+                if (nlen > 286 || ndist > 30) { err = INF_BAD_TABLE; break; }
+                if (threadIdx.x < 32) t.cl[threadIdx.x] = 0;
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                for (int i = 0; i < ncode; ++i) { const uint32_t v = br.bits(3); if (threadIdx.x == 0) t.cl[CLEN_ORDER[i]] = (uint8_t)v; }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                // the code-length code borrows the distance tables (7-bit codes: an 8-bit table holds them all)
+                if (!wave_build(t.cl, 19, t.dist_tab, W_DIST_BITS, t.dist_syms, t.dist_lim, t.dist_base)) { err = INF_BAD_TABLE; break; }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                int i = 0;
+                while (i < nlen + ndist) {
+                    const int sym = wave_symbol(br, t.dist_tab, W_DIST_BITS, t.dist_syms, t.dist_lim, t.dist_base);
+                    if (sym < 0) { err = INF_BAD_TABLE; break; }
+                    int value = sym, rep = 1;
+                    if (sym == 16) {
+                        if (i == 0) { err = INF_BAD_TABLE; break; }
+                        const int jx = i - 1;
+                        value = uni((int)t.lens[jx < nlen ? jx : LIT_SYMS + (jx - nlen)]);
+                        rep = 3 + (int)br.bits(2);
+                    } else if (sym == 17) { value = 0; rep = 3 + (int)br.bits(3); }
+                    else if (sym == 18) { value = 0; rep = 11 + (int)br.bits(7); }
+                    if (i + rep > nlen + ndist) { err = INF_BAD_TABLE; break; }
+                    if ((int)threadIdx.x < rep) {               // up to 138 repeats: lanes 0..63 twice, then once more
+                        for (int r = threadIdx.x; r < rep; r += LANES) { const int x = i + r; t.lens[x < nlen ? x : LIT_SYMS + (x - nlen)] = (uint8_t)value; }
+                    }
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    i += rep;
+                }
+                if (err != INF_OK) break;
+                if (uni((int)t.lens[256]) == 0) { err = INF_BAD_TABLE; break; }
+                if (!wave_build(t.lens, nlen, t.lit_tab, W_LIT_BITS, t.lit_syms, t.lit_lim, t.lit_base) ||
+                    !wave_build(t.lens + LIT_SYMS, ndist, t.dist_tab, W_DIST_BITS, t.dist_syms, t.dist_lim, t.dist_base)) { err = INF_BAD_TABLE; break; }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            for (;;) {
+                const int sym = wave_symbol(br, t.lit_tab, W_LIT_BITS, t.lit_syms, t.lit_lim, t.lit_base);
+                if (sym < 256) {
+                    if (sym < 0) { err = INF_BAD_CODE; break; }
+                    if (w.pos >= w.hi) { err = INF_OUT_OVERRUN; break; }
+                    w.literal((uint32_t)sym);
+                    continue;
+                }
+                if (sym == 256) break;
+                const int li = sym - 257;
+                if (li >= 29) { err = INF_BAD_CODE; break; }
+                const uint32_t len = LEN_BASE[li] + br.bits(LEN_EXTRA[li]);
+                const int ds = wave_symbol(br, t.dist_tab, W_DIST_BITS, t.dist_syms, t.dist_lim, t.dist_base);
+                if (ds < 0 || ds >= 30) { err = INF_BAD_CODE; break; }
+                const uint32_t dist = DIST_BASE[ds] + br.bits(DIST_EXTRA[ds]);
+                if (dist > w.pos - w.lo) { err = INF_BAD_DIST; break; }
+                if (w.pos + len > w.hi) { err = INF_OUT_OVERRUN; break; }
+                w.copy(dist, len);
+            }
+            if (br.exhausted()) err = INF_IN_OVERRUN;
+        } else {
+            err = INF_BAD_TYPE;
+        }
+    }
+    w.finish();
+    if (err == INF_OK && w.pos != w.hi) err = INF_SHORT;
+    if (threadIdx.x == 0) status[b] = (uint32_t)err;
+}
+
 }  // namespace
 
 // BGZF blocks -> their inflated bytes, all blocks of a launch in parallel (one lane per block).
@@ -334,7 +604,12 @@ extern "C" int svx_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_src_off
     if (n_blocks == 0) return SVX_OK;
     if (!d_comp || !d_src_off || !d_src_len || !d_dst_off || !d_out || !d_status) return SVX_EINVAL;
     if (reinterpret_cast<uintptr_t>(d_comp) & 15u) return SVX_EINVAL;
-    hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((n_blocks + LANES - 1) / LANES), dim3(LANES), 0, static_cast<hipStream_t>(stream),
-                       d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, d_out, d_status);
+    static const bool wave_per_block = getenv("SVX_INFLATE_LANES") == nullptr;     // A/B switch: the lane-per-block kernel
+    if (wave_per_block)
+        hipLaunchKernelGGL(bgzf_inflate_wave_kernel, dim3(n_blocks), dim3(LANES), 0, static_cast<hipStream_t>(stream),
+                           d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, d_out, d_status);
+    else
+        hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((n_blocks + LANES - 1) / LANES), dim3(LANES), 0, static_cast<hipStream_t>(stream),
+                           d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, d_out, d_status);
     return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
 }
