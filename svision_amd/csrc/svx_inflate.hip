@@ -29,10 +29,19 @@ namespace {
 constexpr int LANES = 64;                 // one wave per workgroup: the LDS slice of a lane is indexed by its lane id
 constexpr int LIT_SYMS = 288, DIST_SYMS = 32, LANE_DWORDS = 9 + (LIT_SYMS + DIST_SYMS) / 4 + 16;     // 105 dwords = 420 B of LDS per lane
 
-__constant__ uint16_t LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__constant__ uint8_t LEN_EXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__constant__ uint16_t DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__constant__ uint8_t DIST_EXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+// (the tables of the RFC, kept for the compile-time check below)
+constexpr uint16_t LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+constexpr uint8_t LEN_EXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+constexpr uint16_t DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+constexpr uint8_t DIST_EXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+// base value and extra bits of a length code (257..285 -> li = 0..28) and of a distance code (0..29), RFC 1951 3.2.5, as
+// arithmetic: a table in constant memory costs a match four dependent vector loads through L2 (its index differs per lane, or
+// sits in a VGPR), and a level-1 encoder emits a match every few symbols.
+__device__ __forceinline__ uint32_t len_extra(int li) { return li < 8 || li == 28 ? 0u : (uint32_t)(li >> 2) - 1u; }
+__device__ __forceinline__ uint32_t len_base(int li) { return li < 8 ? 3u + (uint32_t)li : li == 28 ? 258u : 3u + ((4u + ((uint32_t)li & 3u)) << ((uint32_t)(li >> 2) - 1u)); }
+__device__ __forceinline__ uint32_t dist_extra(int ds) { return ds < 4 ? 0u : (uint32_t)(ds >> 1) - 1u; }
+__device__ __forceinline__ uint32_t dist_base(int ds) { return ds < 4 ? 1u + (uint32_t)ds : 1u + ((2u + ((uint32_t)ds & 1u)) << ((uint32_t)(ds >> 1) - 1u)); }
+
 __constant__ uint8_t CLEN_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 // per-length code counts of one alphabet, lengths 1..15, 10 bits each (a count is at most 288): three per dword.
@@ -302,10 +311,10 @@ void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const uint64_t* __res
                 if (sym == 256) break;
                 const int li = sym - 257;
                 if (li >= 29) { err = INF_BAD_CODE; break; }
-                const uint32_t len = LEN_BASE[li] + br.bits(LEN_EXTRA[li]);
+                const uint32_t len = len_base(li) + br.bits((int)len_extra(li));
                 const int ds = decode_symbol(br, dc, dist_syms);
                 if (ds < 0 || ds >= 30) { err = INF_BAD_CODE; break; }
-                const uint32_t dist = DIST_BASE[ds] + br.bits(DIST_EXTRA[ds]);
+                const uint32_t dist = dist_base(ds) + br.bits((int)dist_extra(ds));
                 if (dist > w.pos - w.lo) { err = INF_BAD_DIST; break; }
                 if (w.pos + len > w.hi) { err = INF_OUT_OVERRUN; break; }
                 w.copy(dist, len);
@@ -443,20 +452,26 @@ __device__ __forceinline__ bool wave_build(const uint8_t* lens, int n, uint16_t*
     return true;
 }
 
+// the canonical walk for a code longer than the first-level table (rare): out of line, so that its LDS reads are not hoisted
+// into every iteration of the symbol loop (they were: five LDS reads per symbol instead of one)
+__device__ __attribute__((noinline)) int wave_long_symbol(uint32_t peek, int tab_bits, const uint16_t* syms, const uint32_t* lim, const int32_t* base)
+{
+    for (int L = tab_bits + 1; L <= 15; ++L)
+        if (peek < lim[L - 1]) return (L << 16) | (int)syms[(int)(peek >> (15 - L)) + base[L]];
+    return -1;
+}
+
 // one symbol: first-level table, else the canonical walk (uniform)
 __device__ __forceinline__ int wave_symbol(WaveReader& br, const uint16_t* tab, int tab_bits, const uint16_t* syms, const uint32_t* lim,
                                            const int32_t* base)
 {
     br.refill();
     const int e = uni((int)tab[(uint32_t)br.buf & ((1u << tab_bits) - 1u)]);
-    if (e) { br.drop(e & 15); return e >> 4; }
-    const uint32_t peek = __brev((uint32_t)br.buf) >> 17;
-    for (int L = tab_bits + 1; L <= 15; ++L)
-        if (peek < (uint32_t)uni((int)lim[L - 1])) {
-            br.drop(L);
-            return uni((int)syms[(int)(peek >> (15 - L)) + uni(base[L])]);
-        }
-    return -1;
+    if (__builtin_expect(e != 0, 1)) { br.drop(e & 15); return e >> 4; }
+    const int r = uni(wave_long_symbol(__brev((uint32_t)br.buf) >> 17, tab_bits, syms, lim, base));
+    if (r < 0) return -1;
+    br.drop(r >> 16);
+    return r & 0xffff;
 }
 
 struct WaveWriter {
@@ -571,10 +586,10 @@ void bgzf_inflate_wave_kernel(const uint8_t* __restrict__ comp, const uint64_t* 
                 if (sym == 256) break;
                 const int li = sym - 257;
                 if (li >= 29) { err = INF_BAD_CODE; break; }
-                const uint32_t len = LEN_BASE[li] + br.bits(LEN_EXTRA[li]);
+                const uint32_t len = len_base(li) + br.bits((int)len_extra(li));
                 const int ds = wave_symbol(br, t.dist_tab, W_DIST_BITS, t.dist_syms, t.dist_lim, t.dist_base);
                 if (ds < 0 || ds >= 30) { err = INF_BAD_CODE; break; }
-                const uint32_t dist = DIST_BASE[ds] + br.bits(DIST_EXTRA[ds]);
+                const uint32_t dist = dist_base(ds) + br.bits((int)dist_extra(ds));
                 if (dist > w.pos - w.lo) { err = INF_BAD_DIST; break; }
                 if (w.pos + len > w.hi) { err = INF_OUT_OVERRUN; break; }
                 w.copy(dist, len);
@@ -613,3 +628,22 @@ extern "C" int svx_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_src_off
                            d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, d_out, d_status);
     return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
 }
+
+// compile-time check of the arithmetic length / distance tables against the RFC's
+namespace {
+constexpr bool tables_agree()
+{
+    for (int li = 0; li < 29; ++li) {
+        const unsigned e = li < 8 || li == 28 ? 0u : (unsigned)(li >> 2) - 1u;
+        const unsigned b = li < 8 ? 3u + (unsigned)li : li == 28 ? 258u : 3u + ((4u + ((unsigned)li & 3u)) << ((unsigned)(li >> 2) - 1u));
+        if (e != LEN_EXTRA[li] || b != LEN_BASE[li]) return false;
+    }
+    for (int ds = 0; ds < 30; ++ds) {
+        const unsigned e = ds < 4 ? 0u : (unsigned)(ds >> 1) - 1u;
+        const unsigned b = ds < 4 ? 1u + (unsigned)ds : 1u + ((2u + ((unsigned)ds & 1u)) << ((unsigned)(ds >> 1) - 1u));
+        if (e != DIST_EXTRA[ds] || b != DIST_BASE[ds]) return false;
+    }
+    return true;
+}
+static_assert(tables_agree(), "length / distance code arithmetic differs from RFC 1951 3.2.5");
+}  // namespace
