@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SVX_VERSION 320            /* 0.2.1: + active-row masks out of svx_alexnet_active_sets, into svx_bias_relu_pool_lrn */
+#define SVX_VERSION 330            /* 0.2.1: + active-row masks out of svx_alexnet_active_sets, into svx_bias_relu_pool_lrn */
 
 #define SVX_OK            0
 #define SVX_EINVAL       (-1)      /* bad argument (null pointer, bad layout...) */
@@ -267,6 +267,9 @@ void           svx_bam_close(void* handle);
  * anything else = corrupt (the caller falls back to the host decoder). */
 int            svx_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len,
                                 const uint64_t* d_dst_off, uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, void* stream);
+/* the same contract, one WAVE per block (uniform control flow; scalar-issue bound: slower at >= 10^5 blocks, level below) */
+int            svx_bgzf_inflate_wave(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len,
+                                     const uint64_t* d_dst_off, uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, void* stream);
 
 /* BAM records in an inflated stream on the device -> packed arrays (svx_bamdev.hip).  d_starts [n_starts + 1]: byte
  * offsets in d_raw of known record starts (from the .bai linear index), ascending, the last entry = end of the part.

@@ -383,7 +383,7 @@ def bgzf_block_table(raw):
     return (np.asarray(src_off, np.uint64), np.asarray(src_len, np.uint32), np.asarray(isize, np.uint32), np.asarray(block_off, np.uint64))
 
 
-def bgzf_inflate(d_comp, src_off, src_len, isize):
+def bgzf_inflate(d_comp, src_off, src_len, isize, wave=False):
     """d_comp: uint8 device tensor holding the compressed bytes (16-byte aligned, padded to a multiple of 16); src_off / src_len / isize: host
     arrays of :func:`bgzf_block_table` (or the native reader's).  -> (uint8 device tensor with the inflated stream,
     int32 device tensor [n] status: 0 = ok).  See include/svx.h svx_bgzf_inflate."""
@@ -402,7 +402,7 @@ def bgzf_inflate(d_comp, src_off, src_len, isize):
         d_src = torch.from_numpy(np.ascontiguousarray(src_off, np.uint64).view(np.int64)).to(dev)
         d_len = torch.from_numpy(np.ascontiguousarray(src_len, np.uint32).view(np.int32)).to(dev)
         d_dst = torch.from_numpy(dst.view(np.int64)).to(dev)
-        rc = lib.svx_bgzf_inflate(d_comp.data_ptr(), d_src.data_ptr(), d_len.data_ptr(), d_dst.data_ptr(), n, d_out.data_ptr(),
-                                  d_status.data_ptr(), _stream_ptr(dev))
+        fn = lib.svx_bgzf_inflate_wave if wave else lib.svx_bgzf_inflate     # the two implementations of one contract
+        rc = fn(d_comp.data_ptr(), d_src.data_ptr(), d_len.data_ptr(), d_dst.data_ptr(), n, d_out.data_ptr(), d_status.data_ptr(), _stream_ptr(dev))
         _lib.check(rc, "svx_bgzf_inflate")
     return d_out[:total], d_status[:n]

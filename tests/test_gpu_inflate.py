@@ -23,16 +23,17 @@ def _block(payload, level=6, strategy=zlib.Z_DEFAULT_STRATEGY):
             + struct.pack("<II", zlib.crc32(payload) & 0xFFFFFFFF, len(payload)))
 
 
-def _inflate_on_device(raw):
+def _inflate_on_device(raw, wave=False):
     raw = np.frombuffer(raw, np.uint8)
     src_off, src_len, isize, _blk = kernels.bgzf_block_table(raw)
     padded = np.zeros((raw.size + 31) // 16 * 16, np.uint8)
     padded[:raw.size] = raw
-    out, status = kernels.bgzf_inflate(torch.from_numpy(padded).cuda(), src_off, src_len, isize)
+    out, status = kernels.bgzf_inflate(torch.from_numpy(padded).cuda(), src_off, src_len, isize, wave=wave)
     return out.cpu().numpy().tobytes(), status.cpu().numpy()
 
 
-def test_every_block_type_and_match_shape():
+@pytest.mark.parametrize("wave", [False, True])
+def test_every_block_type_and_match_shape(wave):
     rng = np.random.default_rng(3)
     text = (b"ACGTTGCA" * 40 + bytes(rng.integers(0, 256, 300, dtype=np.uint8))) * 20
     far = bytes(rng.integers(0, 256, 32768, dtype=np.uint8))
@@ -48,12 +49,13 @@ def test_every_block_type_and_match_shape():
                                 (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE)):
             blocks.append(_block(p, level, strategy))
             want.append(p)
-    got, status = _inflate_on_device(b"".join(blocks))
+    got, status = _inflate_on_device(b"".join(blocks), wave)
     assert not status.any(), status.tolist()
     assert got == b"".join(want)
 
 
-def test_golden_and_synthetic_bams_inflate_like_zlib(tmp_path):
+@pytest.mark.parametrize("wave", [False, True])
+def test_golden_and_synthetic_bams_inflate_like_zlib(tmp_path, wave):
     from svision_amd import synth
     paths = [os.path.join(helpers.GOLDEN, n) for n in ("collect_small.bam", "ont_small.bam", "hash_collect.bam")]
     table, _g, _ = synth.simulate(synth.SimConfig(contigs=[("c1", 400_000)], coverage=20, seed=4), with_genome=False)
@@ -62,12 +64,13 @@ def test_golden_and_synthetic_bams_inflate_like_zlib(tmp_path):
     bam.write_bam_segments(p, table.references, table.lengths, [seg])
     for path in paths + [p]:
         raw = open(path, "rb").read()
-        got, status = _inflate_on_device(raw)
+        got, status = _inflate_on_device(raw, wave)
         assert not status.any()
         assert got == bam.bgzf_decompress(raw), path
 
 
-def test_damaged_blocks_are_flagged():
+@pytest.mark.parametrize("wave", [False, True])
+def test_damaged_blocks_are_flagged(wave):
     rng = np.random.default_rng(5)
     good = _block(bytes(rng.integers(65, 70, 50000, dtype=np.uint8)))
     bad = bytearray(good)
@@ -75,7 +78,7 @@ def test_damaged_blocks_are_flagged():
         bad[i] ^= 0x5a                                            # garbage inside the DEFLATE payload
     short = bytearray(good)
     short[-4:] = struct.pack("<I", 50001)                        # ISIZE says one byte more than the stream holds
-    got, status = _inflate_on_device(bytes(good) + bytes(bad) + bytes(short) + good)
+    got, status = _inflate_on_device(bytes(good) + bytes(bad) + bytes(short) + good, wave)
     assert status[0] == 0 and status[3] == 0 and status[1] != 0 and status[2] != 0
 
 

@@ -1,9 +1,11 @@
-"""GPU BGZF inflate rate on a synthetic HiFi-like BAM (svx_bgzf_inflate, one lane per block)."""
+"""GPU BGZF inflate rate on a synthetic HiFi-like BAM: svx_bgzf_inflate (one lane per block), or with the argument
+`wave` svx_bgzf_inflate_wave (one wave per block)."""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import numpy as np, torch
 from svision_amd import kernels, synth
 from svision_amd.io import bam
+WAVE = "wave" in sys.argv[1:]
 path = "/tmp/scal.bam"
 if not os.path.exists(path):
     table, _g, _ = synth.simulate(synth.SimConfig(contigs=[("c%d" % i, 10_000_000) for i in range(4)], coverage=30.0, seed=2), with_genome=False)
@@ -16,7 +18,7 @@ pin = torch.from_numpy(padded).pin_memory()
 torch.cuda.synchronize(); t = time.time(); d = pin.cuda(non_blocking=True); torch.cuda.synchronize(); print("H2D %.1f MB in %.1f ms" % (raw.size / 1e6, (time.time() - t) * 1e3))
 for rep in range(3):
     torch.cuda.synchronize(); t = time.time()
-    out, status = kernels.bgzf_inflate(d, src_off, src_len, isize)
+    out, status = kernels.bgzf_inflate(d, src_off, src_len, isize, wave=WAVE)
     torch.cuda.synchronize(); dt = time.time() - t
     print("inflate %.1f MB -> %.1f MB in %.1f ms = %.1f GB/s inflated; bad blocks %d" % (raw.size / 1e6, out.numel() / 1e6, dt * 1e3, out.numel() / dt / 1e9, int(status.ne(0).sum())))
 # the same blocks four times over: does the rate follow the number of lanes?
@@ -24,7 +26,6 @@ k = 4
 src4 = np.concatenate([src_off] * k); len4 = np.concatenate([src_len] * k); isz4 = np.concatenate([isize] * k)
 for rep in range(2):
     torch.cuda.synchronize(); t = time.time()
-    out, status = kernels.bgzf_inflate(d, src4, len4, isz4)
+    out, status = kernels.bgzf_inflate(d, src4, len4, isz4, wave=WAVE)
     torch.cuda.synchronize(); dt = time.time() - t
     print("x%d: %d blocks -> %.1f MB in %.1f ms = %.1f GB/s inflated; bad blocks %d" % (k, len(isz4), out.numel() / 1e6, dt * 1e3, out.numel() / dt / 1e9, int(status.ne(0).sum())))
-want = bam.bgzf_decompress(raw.tobytes()[:50_000_000 if raw.size > 50_000_000 else raw.size]) if False else None
