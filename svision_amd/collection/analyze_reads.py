@@ -9,7 +9,7 @@ The ``--hash`` branches (:731-790, :898-929) re-align unmapped / inserted read p
 the k-mer aligner of :mod:`svision_amd.segmentplot` and add the hits as helper segments.
 """
 from ..segmentplot.run_hash_lineplot import hashplot_unmapped
-from .classes import Seg, Signature, by_read_pos
+from .classes import _TABLE, Seg, Signature, by_read_pos
 
 
 def shift_left(ref_seq, ref_start, target_start, target_end):
@@ -244,7 +244,7 @@ def analyze_between_aligns(primary, supplementary, table, options, sample=None):
     if not options.contig and len(supplementary) > 4:
         return [], []
     flag, pos = table.flag, table.pos
-    Seg.table = table
+    _TABLE[0] = table
     p_rev = bool(flag[primary] & 0x10)
     qlen = int(table.l_seq[primary])                       # supplementary records inherit the primary's SEQ
     majors, minors, same_strand = [], [], []

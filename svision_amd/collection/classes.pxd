@@ -1,0 +1,9 @@
+# Static types for classes.py (Cython "augmenting .pxd": the .py source stays plain Python and runs unchanged when interpreted).
+cdef class Seg:
+    cdef public long q_start, q_end, ref_start, ref_end, ref_id, qual, aln
+    cdef public bint is_reverse, is_supplementary, derived
+    cdef public object type, read_seq
+    cpdef Seg copy(self)
+    cpdef bint same_value(self, Seg o)
+
+cpdef tuple by_read_pos(Seg seg)

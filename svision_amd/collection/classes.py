@@ -10,11 +10,15 @@ comparison is used.
 """
 
 
+_TABLE = [None]                   # AlignmentTable the `aln` indices point into (set by analyze_between_aligns)
+BY_VALUE = [True]                 # tests/test_dup_golden.py switches it off to show that its fixture needs the by-value comparison
+
+
 class Seg:
-    """One aligned piece of a read in read/reference coordinates."""
+    """One aligned piece of a read in read/reference coordinates.  Compiled as an extension type (classes.pxd: C integer
+    fields); the same source runs interpreted when the host build is absent."""
     __slots__ = ("q_start", "q_end", "ref_start", "ref_end", "ref_id", "is_reverse",
                  "is_supplementary", "type", "qual", "aln", "read_seq", "derived")
-    table = None                  # AlignmentTable the `aln` indices point into (set by analyze_between_aligns)
 
     def __init__(self, q_start, q_end, ref_start, ref_end, ref_id, is_reverse,
                  is_supplementary=False, type=None, qual=0, aln=-1, derived=False):
@@ -41,6 +45,8 @@ class Seg:
         (None here), the CIGAR string of whole records ('' for pieces cut out of one) and, implicitly, the read."""
         if self is o:
             return True
+        if not BY_VALUE[0]:
+            return False
         if (self.q_start, self.q_end, self.ref_start, self.ref_end, self.ref_id, self.is_reverse, self.is_supplementary,
                 self.type, self.qual, self.derived, self.aln < 0) != \
                 (o.q_start, o.q_end, o.ref_start, o.ref_end, o.ref_id, o.is_reverse, o.is_supplementary,
@@ -48,7 +54,7 @@ class Seg:
             return False
         if self.derived or self.aln < 0 or self.aln == o.aln:
             return True
-        t = Seg.table
+        t = _TABLE[0]
         if t is None:
             return False
         a, b = t.cigar[t.cig_off[self.aln]:t.cig_off[self.aln + 1]], t.cigar[t.cig_off[o.aln]:t.cig_off[o.aln + 1]]

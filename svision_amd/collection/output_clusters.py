@@ -99,16 +99,23 @@ def proc_one_cluster(cluster, options=None):
     return cluster, lines
 
 
-def collect_pair_lines(clusters, options):
-    """Site filter of writer_cluster_to_file (:46-51) + per-cluster pair extraction."""
-    out = []
+def iter_pair_lines(clusters, options):
+    """Site filter of writer_cluster_to_file (:46-51) + per-cluster pair extraction, one list of PairLines per kept
+    cluster, in cluster order (the streaming pipeline hands a window's lines on while later clusters are still worked on)."""
     for cl in clusters:
         if int(cl.cend) - int(cl.cstart) > options.max_sv_size:
             continue
         if cl.read_num >= options.min_support:
-            out.extend(proc_one_cluster(cl, options)[1])
+            yield proc_one_cluster(cl, options)[1]
             if getattr(options, "graph", False) is True:      # :57-67
                 write_cluster_graphs(cl, options)
+
+
+def collect_pair_lines(clusters, options):
+    """All PairLines of a window's clusters, in TSV order."""
+    out = []
+    for lines in iter_pair_lines(clusters, options):
+        out.extend(lines)
     return out
 
 

@@ -26,7 +26,7 @@ import numpy as np
 import torch
 
 from . import kernels
-from .collection.output_clusters import collect_pair_lines
+from .collection.output_clusters import collect_pair_lines, iter_pair_lines
 from .collection.run_collection import detect_window
 from .network.create_batch import PAD_DATA, parse_data_fields
 from .network.predict import Predict, SiteVoter
@@ -49,6 +49,26 @@ def _collect_lines(sample, options, chrom, start, end):
     except Exception as exc:                                  # noqa: BLE001 -- the reference catches everything
         logging.error("[ERROR]: %s. window %s:%s-%s skipped (reference behaviour)", exc, chrom, start, end)
         return []
+
+
+def _collect_parts(sample, options, chrom, start, end, emit, granule=256):
+    """:func:`_collect_lines` for the streaming pipeline: the window's lines are handed to ``emit`` in parts of at least
+    ``granule`` lines (whole clusters) while the later clusters are still being worked on.  -> (all lines, ok); a window
+    whose collection raises anywhere contributes nothing (ok False: parts already handed on are to be dropped)."""
+    lines, sent = [], 0
+    try:
+        _sigs, clusters = detect_window(options, sample, chrom, start, end)
+        for part in iter_pair_lines(clusters, options):
+            lines.extend(part)
+            if len(lines) - sent >= granule:
+                emit(lines[sent:])
+                sent = len(lines)
+        if len(lines) > sent:
+            emit(lines[sent:])
+        return lines, True
+    except Exception as exc:                                  # noqa: BLE001 -- the reference catches everything
+        logging.error("[ERROR]: %s. window %s:%s-%s skipped (reference behaviour)", exc, chrom, start, end)
+        return [], False
 
 
 def edge_margin(sample):
@@ -346,7 +366,9 @@ _POOL_STATE = {}
 
 def _worker_main(conn):
     """Helper process: never touches the GPU.  Protocol on the duplex pipe:
-       owner -> ("win", wid, key, chrom, start, end, scan of the window's rows or None)   helper -> ("rec", wid, records int32[n,12])
+       owner -> ("win", wid, key, chrom, start, end, scan of the window's rows or None)
+                    helper -> ("part", wid, records int32[k,12]) ... as the clusters are worked through, then
+                    helper -> ("rec", wid, n images of the window, ok)
        owner -> ("pred", wid, classes, probs)      helper -> ("done", wid, vcf, scores, n_sites, n_images, tsv, head, tail, ...)
        owner -> ("scan", min_sv, gaps.npy, gap_off.npy, stats.npy)   (HelperPool.attach_scan: helpers forked before the scan)
        owner -> ("chrom", key, meta) / ("drop", key)   a chromosome of a file-driven run arrives in / leaves shared memory
@@ -392,10 +414,13 @@ def _worker_main(conn):
             smp = samples[key]
             if scan is not None:
                 smp.apply_window_scan(*scan)
-            lines = _collect_lines(smp, options, chrom, start, end)
-            recs = np.asarray([ln.record() for ln in lines], np.int32).reshape(-1, 12)
+
+            def emit(part, wid=wid):
+                conn.send(("part", wid, np.asarray([ln.record() for ln in part], np.int32).reshape(-1, 12)))
+
+            lines, ok = _collect_parts(smp, options, chrom, start, end, emit)
             held[wid] = (chrom, lines, start, end, time.perf_counter() - t0, smp)
-            conn.send(("rec", wid, recs))
+            conn.send(("rec", wid, len(lines), ok))
         elif msg[0] == "pred":
             _t, wid, classes, probs = msg
             chrom, lines, start, end, t_collect, smp = held.pop(wid)
@@ -487,6 +512,14 @@ class PooledHotPath(HotPath):
     def run_windows(self, windows, rescan=True):
         """Yields WindowResults (completion order).  Each helper holds one window at a time.
 
+        The device side is one **stream of images**: the helpers hand a window's records on in parts (whole clusters,
+        >= 256 lines) while they work through the later clusters, the parts of all windows queue up in arrival order and
+        leave in launches of 256 images whatever window they belong to -- every image is independent of its neighbours
+        in every kernel (``DeviceStage``), so the grouping changes no result; what it removes is the per-window tail of
+        128- / 64-image launches with their padding, and the wait for a window's last cluster before its first launch.
+        Fewer than 256 images are launched (padded to the reference's batch) only when the device would otherwise idle,
+        when a part has waited ``flush_after`` seconds, or when nothing more can arrive.
+
         ``self.owner_profile`` afterwards: where this (GPU-owning) thread spent its time -- seconds per phase of the
         loop, the scans found ready on entry, the host seconds the helpers report for collection and vote, and when the
         first launch / last read-back / last result happened (SVX_TIMING=1 python bench.py prints it)."""
@@ -495,8 +528,15 @@ class PooledHotPath(HotPath):
         nxt = 0
         idle = list(range(len(self.conns)))
         busy = {}                     # conn index -> wid
-        ready = collections.deque()   # (conn index, WindowResult with records) waiting for the device
-        inflight = collections.deque()  # (conn index, WindowResult) enqueued on the device
+        wins = {}                     # wid -> state of a window whose predictions are not complete yet
+        pending = collections.deque()   # [wid, offset in the window, records] not launched yet, arrival order
+        pending_images = 0
+        inflight = collections.deque()  # (launch group as a WindowResult, [(wid, window offset, group offset, count)])
+        inflight_images = 0
+        collecting = 0                # windows sent to a helper whose last part has not arrived
+        granule = 4 * self.batch if 4 * self.batch in self.stage.sizes else max(self.stage.sizes)
+        cap_images = max(1, self.max_inflight) * 8 * granule
+        flush_after = 0.002
         scans = collections.deque()     # handles of the window scans enqueued ahead (Sample.rescan_window_async)
         ahead = min(16, len(self.conns) + 2)    # every helper can turn idle in one burst; a scan takes ~15 ms on the saturated device
         remaining = len(windows)
@@ -508,6 +548,38 @@ class PooledHotPath(HotPath):
             now = clock()
             prof[key] += now - since
             return now
+
+        def take(n):
+            """The first ``n`` pending images as one launch group."""
+            nonlocal pending_images
+            recs, mapping, off = [], [], 0
+            while off < n:
+                seg = pending[0]
+                k = min(n - off, int(seg[2].shape[0]))
+                recs.append(seg[2][:k])
+                mapping.append((seg[0], seg[1], off, k))
+                off += k
+                if k == seg[2].shape[0]:
+                    pending.popleft()
+                else:
+                    seg[1] += k
+                    seg[2] = seg[2][k:]
+            pending_images -= n
+            group = WindowResult()
+            group.records = recs[0] if len(recs) == 1 else np.concatenate(recs)
+            group.n_images, group.lines, group.packed = n, None, None
+            return group, mapping
+
+        def complete(wid):
+            """All predictions of a window are here: its helper votes."""
+            w = wins.pop(wid)
+            if w["chunks"]:
+                w["chunks"].sort(key=lambda c: c[0])
+                classes = np.concatenate([c[1] for c in w["chunks"]])
+                probs = np.concatenate([c[2] for c in w["chunks"]])
+            else:
+                classes, probs = np.empty(0, np.int64), np.empty((0, 5), np.float32)
+            self.conns[w["ci"]].send(("pred", wid, classes, probs))
 
         while remaining:
             t = clock()
@@ -538,39 +610,74 @@ class PooledHotPath(HotPath):
                     lap("scan.apply", t_s)
                 self.conns[ci].send(("win", nxt, key, chrom, start, end, scan))
                 busy[ci] = nxt
+                wins[nxt] = {"ci": ci, "total": None, "got": 0, "seen": 0, "chunks": []}
+                collecting += 1
                 nxt += 1
             t = lap("scan+send", t)
-            while ready and len(inflight) < self.max_inflight:
-                ci, res = ready.popleft()
+            while pending_images and inflight_images < cap_images:
+                room = cap_images - inflight_images
+                if pending_images >= granule:
+                    n = min(pending_images, room, 2 * granule) // granule * granule    # small groups: a window's predictions return as soon as its own launches are done
+                    if n == 0:
+                        break
+                elif not inflight or collecting == 0 or clock() - pending[0][3] > flush_after:
+                    n = pending_images                                # the device would idle / nothing else can arrive / it has waited
+                    prof["launch.partial"] += 1
+                else:
+                    break
+                group, mapping = take(n)
                 prof.setdefault("first_launch_at", clock() - t_loop)
-                inflight.append((ci, self.launch(res)))
+                inflight.append((self.launch(group), mapping))
+                inflight_images += n
             t = lap("launch", t)
-            while inflight and (inflight[0][1].n_images == 0 or inflight[0][1].done_event.query()):
-                ci, res = inflight.popleft()
-                classes, probs = self.fetch_predictions(res)
-                self.conns[ci].send(("pred", busy[ci], classes, probs))
+            while inflight and inflight[0][0].done_event.query():
+                group, mapping = inflight.popleft()
+                inflight_images -= group.n_images
+                classes, probs = self.fetch_predictions(group)
+                for wid, w_off, g_off, k in mapping:
+                    w = wins.get(wid)
+                    if w is None or w.get("drop"):
+                        continue
+                    w["chunks"].append((w_off, classes[g_off:g_off + k], probs[g_off:g_off + k]))
+                    w["got"] += k
+                    if w["total"] is not None and w["got"] == w["total"]:
+                        complete(wid)
                 prof["last_fetch_at"] = clock() - t_loop
             t = lap("fetch+send", t)
             waiting = [self.conns[ci] for ci in busy]
-            if not waiting and not inflight and not ready and nxt < len(windows):
+            if not waiting and not inflight and not pending and nxt < len(windows):
                 self.feed.poll(block=True)                            # nothing to do but wait for the next chromosome
                 lap("feed.wait", t)
                 continue
-            got = mpc.wait(waiting, timeout=0.0005 if inflight else (0.002 if nxt < len(windows) and idle else 0.05))
+            got = mpc.wait(waiting, timeout=0.0005 if inflight or pending else (0.002 if nxt < len(windows) and idle else 0.05))
             lap("wait", t)
-            if not got and not inflight and not ready:
+            if not got and not inflight and not pending:
                 dead = [ci for ci in busy if not self.procs[ci].is_alive()]
                 if dead:
                     raise RuntimeError("host helper process %s died while holding window %s" % (dead, [busy[ci] for ci in dead]))
             for c in got:
                 ci = self.conns.index(c)
                 msg = c.recv()
-                if msg[0] == "rec":
-                    res = WindowResult()
-                    res.chrom, res.start, res.end = windows[msg[1]]
-                    res.records, res.n_images, res.lines, res.packed = msg[2], int(msg[2].shape[0]), None, None
-                    res.t_device = None
-                    ready.append((ci, res))
+                if msg[0] == "part":
+                    w = wins[msg[1]]
+                    pending.append([msg[1], w["seen"], msg[2], clock()])
+                    w["seen"] += int(msg[2].shape[0])
+                    pending_images += int(msg[2].shape[0])
+                elif msg[0] == "rec":
+                    _t, wid, n_images, ok = msg
+                    w = wins[wid]
+                    collecting -= 1
+                    if not ok:                                        # the window's collection failed after parts had left: drop them
+                        for seg in [seg for seg in pending if seg[0] == wid]:
+                            pending.remove(seg)
+                            pending_images -= int(seg[2].shape[0])
+                        w["drop"], w["chunks"] = True, []
+                        complete(wid)
+                        wins[wid] = {"drop": True}                    # launches of it still in flight are ignored (entry never removed: wids are not reused)
+                        continue
+                    w["total"] = n_images
+                    if w["got"] == n_images:
+                        complete(wid)
                 else:
                     _t, wid, vcf, scores, n_sites, n_images, tsv, head, tail, host_s, edges = msg
                     prof["helper.collect_s"] += host_s[0]             # host seconds inside the helpers
