@@ -2,8 +2,9 @@
 
 The reference's collection is interpreted Python and so is this package's mirror of it (SURVEY 8(a'): same functions, same
 order of operations).  The six modules below are where a 10 Mb window spends its ~90 ms of host time; compiled as they
-are -- pure-Python mode, no type annotations, no semantic change -- they take 1.5x less (tools/exp/prof_collect.py), and an
-extension module next to its ``.py`` source is what ``import`` picks up.  Without the build the ``.py`` files run: same
+are -- pure-Python mode, no type annotations, no semantic change -- they take 1.5x less (tools/exp/prof_collect.py); since round 3 the hot ones
+carry static types in augmenting ``.pxd`` files next to them (segments and coordinates as C structs / longs: another 2x,
+same source, same results), and an extension module next to its ``.py`` source is what ``import`` picks up.  Without the build the ``.py`` files run: same
 results, slower.  Outputs (``*.so``, generated ``*.c``) are git-ignored; the ``.so`` files travel with the snapshot like
 ``libsvx.so``."""
 import os
@@ -14,13 +15,24 @@ MODULES = ["collection/analyze_reads.py", "collection/collect_signatures.py", "c
            "segmentplot/classes.py", "network/predict.py"]
 
 
-STAMP = "_host_build.json"               # sha1 of every source the extension modules were compiled from
+STAMP = "_host_build.json"               # per module: sha1 of the sources its extension module was compiled from (_source_hash)
 
 
-def _sha1(path):
+def _source_hash(here, m):
+    """sha1 of everything the extension module of ``m`` was compiled from: its ``.py`` and the ``.pxd`` files of ALL the
+    modules (they declare the extension types' C layout, which the modules share: a changed ``classes.pxd`` makes every
+    binary stale, not only its own).  Without any ``.pxd`` this is the sha1 of the ``.py``."""
     import hashlib
-    with open(path, "rb") as f:
-        return hashlib.sha1(f.read()).hexdigest()
+    h = hashlib.sha1()
+    with open(os.path.join(here, m), "rb") as f:
+        h.update(f.read())
+    for other in MODULES:
+        pxd = os.path.join(here, other[:-3] + ".pxd")
+        if os.path.exists(pxd):
+            h.update(other.encode())
+            with open(pxd, "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
 
 
 def stale_modules(here=None):
@@ -41,7 +53,7 @@ def stale_modules(here=None):
             sos = [n for n in os.listdir(d) if n.startswith(base + ".") and n.endswith(".so")]
         except OSError:
             continue
-        if sos and stamp.get(m) != _sha1(src):
+        if sos and stamp.get(m) != _source_hash(here, m):
             stale.append((m, sos))
     return stale
 
@@ -116,7 +128,7 @@ def build(quiet=True):
         setup(name="svision_amd_host", ext_modules=ext,
               script_args=["build_ext", "--inplace", "--build-temp", tmp, "--build-lib", tmp] + (["-q"] if quiet else []))
         with open(os.path.join(here, STAMP), "w") as f:
-            json.dump({m: _sha1(os.path.join(here, m)) for m in MODULES}, f, indent=0, sort_keys=True)
+            json.dump({m: _source_hash(here, m) for m in MODULES}, f, indent=0, sort_keys=True)
     finally:
         os.chdir(cwd)
         shutil.rmtree(tmp, ignore_errors=True)

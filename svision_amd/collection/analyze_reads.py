@@ -79,16 +79,27 @@ def trim_segs(segs, first, last):
                 seg.ref_start = right_most - length
 
 
+def _among(seg, others):
+    """``seg in others`` with the by-value comparison of segments."""
+    for h in others:
+        if seg.same_value(h):
+            return True
+    return False
+
+
 def _signature(chrom, qname, sig_type, first_bkp, segs, helpers, trim_first, trim_last, mechanism="None",
                extend_end=0):
     """Shared tail of every analyze_gap branch: breakpoints of the helper segments in read
     order, extreme coordinates, trim, Signature."""
     bkps = [first_bkp]
+    left, right = first_bkp[0], first_bkp[1]
     for seg in segs:
-        if any(seg.same_value(h) for h in helpers):           # `align in help_aligns` (:225): by value
+        if _among(seg, helpers):                              # `align in help_aligns` (:225): by value
             bkps.append([seg.ref_start, seg.ref_end, seg.ref_end - seg.ref_start])
-    left = min(b[0] for b in bkps)
-    right = max(b[1] for b in bkps)
+            if seg.ref_start < left:
+                left = seg.ref_start
+            if seg.ref_end > right:
+                right = seg.ref_end
     trim_segs(segs, trim_first, trim_last)
     return Signature(chrom, left, right + extend_end, sig_type, qname, segs, bkps, mechanism)
 
@@ -236,30 +247,35 @@ def _hash_hits_to_segs(hits, read_offset, ref_offset, like, read_seq):
     return out
 
 
-def analyze_between_aligns(primary, supplementary, table, options, sample=None):
+def _fields(table, a):
+    """(flag, leading clip, trailing clip, pos, reference span, tid, mapq, l_seq) of record ``a`` as Python ints."""
+    return (int(table.flag[a]), int(table.lead_clip[a]), int(table.trail_clip[a]), int(table.pos[a]), int(table.ref_span[a]),
+            int(table.tid[a]), int(table.mapq[a]), int(table.l_seq[a]))
+
+
+def analyze_between_aligns(primary, supplementary, table, options, sample=None, cols=None):
     """Primary + supplementary alignments of one read -> (major, minor) segments (:619-801).
 
     ``primary``/``supplementary`` are record indices into ``table`` (an AlignmentTable with the
-    device scan attached).  Query coordinates are expressed on the primary's strand."""
+    device scan attached).  Query coordinates are expressed on the primary's strand.  ``cols``: {record index:
+    :func:`_fields` tuple} prepared by the caller for the records of a whole window."""
     if not options.contig and len(supplementary) > 4:
         return [], []
-    flag, pos = table.flag, table.pos
     _TABLE[0] = table
-    p_rev = bool(flag[primary] & 0x10)
-    qlen = int(table.l_seq[primary])                       # supplementary records inherit the primary's SEQ
+    first = cols[primary] if cols is not None else _fields(table, primary)
+    p_rev = bool(first[0] & 0x10)
+    qlen = first[7]                                        # supplementary records inherit the primary's SEQ
     majors, minors, same_strand = [], [], []
     keep_seq = options.hash or getattr(options, "graph", False)           # the bases of every segment (--hash re-aligns them, --graph prints them)
     whole_seq = table.query_sequence(primary) if keep_seq else None
     for a in [primary] + list(supplementary):
-        a_rev = bool(flag[a] & 0x10)
-        lead, trail = int(table.lead_clip[a]), int(table.trail_clip[a])
+        flag, lead, trail, r0, span, tid, mapq, _l = cols[a] if cols is not None else _fields(table, a)
+        a_rev = bool(flag & 0x10)
         if a_rev != p_rev:
             q_start, q_end = trail, qlen - lead              # qlen - query_alignment_end, qlen - query_alignment_start
         else:
             q_start, q_end = lead, qlen - trail
-        r0 = int(pos[a])
-        seg = Seg(q_start, q_end, r0, r0 + int(table.ref_span[a]), int(table.tid[a]), a_rev != p_rev,
-                  bool(flag[a] & 0x800), qual=int(table.mapq[a]), aln=int(a))
+        seg = Seg(q_start, q_end, r0, r0 + span, tid, a_rev != p_rev, bool(flag & 0x800), qual=mapq, aln=int(a))
         if keep_seq:
             seg.read_seq = whole_seq[q_start:q_end]           # :667 (TypeError on SEQ '*', as upstream)
         if seg.is_reverse:
@@ -271,8 +287,12 @@ def analyze_between_aligns(primary, supplementary, table, options, sample=None):
         same_strand[0].type = "main"
         return same_strand, minors                            # (:685-691 returns before the --hash block)
     ordered = sorted(same_strand, key=by_read_pos)
-    left_most = min(s.ref_start for s in ordered)
-    right_most = max(s.ref_end for s in ordered)
+    left_most, right_most = ordered[0].ref_start, ordered[0].ref_end
+    for base in ordered:
+        if base.ref_start < left_most:
+            left_most = base.ref_start
+        if base.ref_end > right_most:
+            right_most = base.ref_end
     last = len(ordered) - 1
     for i, base in enumerate(ordered):
         covered = False
@@ -319,6 +339,14 @@ def _hash_between(majors, minors, options, sample):
             minors.extend(_hash_hits_to_segs(hits, read_start, ref_start, cur, piece))
 
 
+def _piece(out, seg, q0, q1, r0, r1):
+    """A main segment cut out of alignment ``seg`` between two of its long gaps (:932-948)."""
+    new = Seg(q0, q1, r0, r1, seg.ref_id, False, seg.is_supplementary, "main", seg.qual, seg.aln, derived=True)
+    if seg.read_seq is not None:                              # :943 the piece's own bases (read by --graph)
+        new.read_seq = seg.read_seq[q0 - seg.q_start:q1 - seg.q_start]
+    out.append(new)
+
+
 def analyze_inside_align(seg, gaps, options=None, sample=None):
     """Split one major segment at its long CIGAR gaps (:857-948).  ``gaps`` are this
     alignment's SvxGap records (kind, read_pos, ref_pos, len in op order) from the device scan;
@@ -328,22 +356,16 @@ def analyze_inside_align(seg, gaps, options=None, sample=None):
         return None, None
     out = []
     vrp = seg.q_start
-
-    def piece(q0, q1, r0, r1):
-        out.append(Seg(q0, q1, r0, r1, seg.ref_id, False, seg.is_supplementary, "main", seg.qual, seg.aln, derived=True))
-        if seg.read_seq is not None:                          # :943 the piece's own bases (read by --graph)
-            out[-1].read_seq = seg.read_seq[q0 - seg.q_start:q1 - seg.q_start]
-
-    first_ref = int(gaps[0]["ref_pos"])
+    rows = gaps.tolist()                                   # (aln, op, read_pos, ref_pos, len, kind) tuples of kernels.GAP_DTYPE
+    first_ref = rows[0][3]
     m = first_ref - seg.ref_start
-    piece(vrp, vrp + m, seg.ref_start, first_ref - 1)
+    _piece(out, seg, vrp, vrp + m, seg.ref_start, first_ref - 1)
     vrp += m
     prev_end = None
-    for g in gaps:
-        kind, ref_pos, length = int(g["kind"]), int(g["ref_pos"]), int(g["len"])
+    for _aln, _op, _read_pos, ref_pos, length, kind in rows:
         if prev_end is not None:
             m = ref_pos - prev_end
-            piece(vrp + 1, vrp + m + 1, prev_end, ref_pos)
+            _piece(out, seg, vrp + 1, vrp + m + 1, prev_end, ref_pos)
             vrp += m
         if kind == 1:
             vrp += length
@@ -351,7 +373,7 @@ def analyze_inside_align(seg, gaps, options=None, sample=None):
         else:
             prev_end = ref_pos + length
     m = seg.ref_end - prev_end
-    piece(vrp + 1, vrp + m + 1, prev_end, seg.ref_end)
+    _piece(out, seg, vrp + 1, vrp + m + 1, prev_end, seg.ref_end)
     helpers = []
     if options is not None and options.hash:                   # :898-929 re-align every long insertion
         ref_seq = None

@@ -7,3 +7,8 @@ cdef class Seg:
     cpdef bint same_value(self, Seg o)
 
 cpdef tuple by_read_pos(Seg seg)
+
+cimport cython
+
+@cython.locals(first=Seg, s=Seg, q0=long, r0=long, last=long, i=long, main=list, other=list)
+cpdef tuple _segs_cords(list segs)

@@ -103,22 +103,29 @@ class Signature:
     def get_segs_cords(self):
         """classes.py:72-117: rebase every segment on the first one (in place) and split
         them into main (first, last) and other coordinate triples."""
-        segs = self.sorted_aligns
-        q0, r0 = segs[0].q_start, segs[0].ref_start
-        main, other = [], []
-        last = len(segs) - 1
-        for i, s in enumerate(segs):
-            s.ref_start -= r0
-            s.ref_end -= r0
-            s.q_start -= q0
-            s.q_end -= q0
-            if i == 0 or i == last:
-                main.append([[s.q_start, s.q_end], [s.ref_start, s.ref_end], 0])
-            elif s.is_reverse:
-                other.append([[s.q_end, s.q_start], [s.ref_start, s.ref_end], 1])
-            else:
-                other.append([[s.q_start, s.q_end], [s.ref_start, s.ref_end], 0])
-        return segs[-1].ref_end, segs[-1].q_end, main, other
+        return _segs_cords(self.sorted_aligns)
+
+
+def _segs_cords(segs):
+    """Body of :meth:`Signature.get_segs_cords` (a module-level function so that the compiled module can type it)."""
+    first = segs[0]
+    q0, r0 = first.q_start, first.ref_start
+    main, other = [], []
+    last = len(segs) - 1
+    i = 0
+    for s in segs:
+        s.ref_start -= r0
+        s.ref_end -= r0
+        s.q_start -= q0
+        s.q_end -= q0
+        if i == 0 or i == last:
+            main.append([[s.q_start, s.q_end], [s.ref_start, s.ref_end], 0])
+        elif s.is_reverse:
+            other.append([[s.q_end, s.q_start], [s.ref_start, s.ref_end], 1])
+        else:
+            other.append([[s.q_start, s.q_end], [s.ref_start, s.ref_end], 0])
+        i += 1
+    return s.ref_end, s.q_end, main, other
 
 
 class Cluster:

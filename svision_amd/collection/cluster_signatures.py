@@ -28,6 +28,14 @@ except Exception:                                             # noqa: BLE001 -- 
     _hc = None
 
 
+try:
+    import cython as _cython
+    _COMPILED = bool(_cython.compiled)
+except ImportError:                                           # interpreted and no Cython on the machine
+    _COMPILED = False
+_NAN, _INF = float("nan"), float("inf")
+
+
 def average_linkage_labels(dist, n, threshold):
     """fcluster(linkage(dist, "average"), threshold, "distance") for a condensed matrix of ``n`` observations.  The same two
     compiled routines the public functions end in (scipy/cluster/hierarchy.py: ``_hierarchy.nn_chain`` for method "average",
@@ -65,16 +73,52 @@ def signature_partition(signatures, options):
 
 def span_position_distance_condensed(starts, ends, normalizer=1000):
     """Condensed pairwise matrix of span_position_distance (:132-141) in pdist order."""
-    n = len(starts)
-    i, j = np.triu_indices(n, k=1)
     s = np.asarray(starts, np.float64)
     e = np.asarray(ends, np.float64)
+    if _COMPILED:                                             # the same IEEE operations pair by pair, as C loops (cluster_signatures.pxd)
+        out = np.empty(len(s) * (len(s) - 1) // 2, np.float64)
+        _condensed_loops(s, e, float(normalizer), out)
+        return out
+    n = len(starts)
+    i, j = np.triu_indices(n, k=1)
     span = e - s
     centre = np.floor_divide(s + e, 2)
     pos = np.minimum(np.minimum(np.abs(s[i] - s[j]), np.abs(e[i] - e[j])), np.abs(centre[i] - centre[j])) / normalizer
     with np.errstate(invalid="ignore", divide="ignore"):
         spd = np.abs(span[i] - span[j]) / np.maximum(span[i], span[j])
     return pos + spd
+
+
+def _condensed_loops(s, e, normalizer, out):
+    """out[k] = span_position_distance of the k-th pair (i < j, row-major): min(|ds|, |de|, |dcentre|) / normalizer +
+    |dspan| / max(span).  A zero ``max(span)`` gives what IEEE division gives NumPy: nan for 0 / 0, inf otherwise."""
+    n = s.shape[0]
+    k = 0
+    for i in range(n):
+        si, ei = s[i], e[i]
+        spi = ei - si
+        ci = (si + ei) // 2.0
+        for j in range(i + 1, n):
+            sj, ej = s[j], e[j]
+            spj = ej - sj
+            cj = (sj + ej) // 2.0
+            pos = abs(si - sj)
+            d = abs(ei - ej)
+            if d < pos:
+                pos = d
+            d = abs(ci - cj)
+            if d < pos:
+                pos = d
+            num = abs(spi - spj)
+            den = spi if spi > spj else spj
+            if den != 0.0:
+                spd = num / den
+            elif num == 0.0:
+                spd = _NAN
+            else:
+                spd = _INF
+            out[k] = pos / normalizer + spd
+            k += 1
 
 
 def condensed_distances(parts, sample):

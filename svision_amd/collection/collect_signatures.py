@@ -16,6 +16,19 @@ from .classes import by_read_pos
 from .graph import build_graph
 
 
+def _emit(ctx, cur, nxt, helpers, next_is_last):
+    """Type the junction cur -> nxt of one read (on private copies) and keep its Signature, if any."""
+    signatures, want_graph, whole_seq, chrom_of, fetch_ref, sample, options, qname = ctx
+    cur, nxt = cur.copy(), nxt.copy()
+    graph = None
+    if want_graph:                                            # before analyze_gap shifts / trims anything (:236-237, :298-302)
+        graph = build_graph(cur, nxt, helpers, options.min_sv_size, whole_seq, chrom_of, sample.fetch_ref_str, qname, next_is_last)
+    sig = analyze_gap(cur, nxt, chrom_of, fetch_ref, options, qname, helpers)
+    if sig is not None:
+        sig.set_graph(graph)
+        signatures.append(sig)
+
+
 def analyze_alignments(rows, sample, options, part_num=0):
     """rows: record indices of one fetch window, in file order -> list[Signature] in
     read-first-occurrence order (the order of the reference's ``reads_dict``)."""
@@ -49,24 +62,31 @@ def analyze_alignments(rows, sample, options, part_num=0):
     bounds = np.searchsorted(sel_inv, cand_ids, side="left"), np.searchsorted(sel_inv, cand_ids, side="right")
 
     chrom_of = sample.chrom_of
-    fetch_ref = sample.fetch_ref
+    fetch_ref = getattr(sample, "fetch_ref_view", None) or sample.fetch_ref
     signatures = []
-    for rid, lo, hi in zip(cand_ids, bounds[0], bounds[1]):
-        recs = sel_rows[lo:hi]
+    # the fields the per-read analysis reads, as Python values (one vectorised pass instead of NumPy scalar accesses per read)
+    row_list = sel_rows.tolist()
+    cols = dict(zip(row_list, zip(table.flag[sel_rows].tolist(), table.lead_clip[sel_rows].tolist(),
+                                  table.trail_clip[sel_rows].tolist(), table.pos[sel_rows].tolist(),
+                                  table.ref_span[sel_rows].tolist(), table.tid[sel_rows].tolist(),
+                                  table.mapq[sel_rows].tolist(), table.l_seq[sel_rows].tolist())))
+    names = table.names
+    want_graph = getattr(options, "graph", False)
+    for rid, lo, hi in zip(uniq[cand_ids].tolist(), bounds[0].tolist(), bounds[1].tolist()):
         primary = -1
         supp = []
-        for a in recs:                                       # the last non-supplementary record wins (:172-178)
-            if table.flag[a] & 0x800:
-                supp.append(int(a))
+        for a in row_list[lo:hi]:                            # the last non-supplementary record wins (:172-178)
+            if cols[a][0] & 0x800:
+                supp.append(a)
             else:
-                primary = int(a)
+                primary = a
         if primary < 0:
             continue
-        if table.l_seq[primary] == 0:
+        if cols[primary][7] == 0:
             # SEQ '*' on the primary: the reference slices None (analyze_reads.py:667) and the window fails
             raise TypeError("'NoneType' object is not subscriptable")
-        qname = table.names[int(uniq[rid])]
-        majors, minors = analyze_between_aligns(primary, supp, table, options, sample)
+        qname = names[rid]
+        majors, minors = analyze_between_aligns(primary, supp, table, options, sample, cols)
         segs = list(minors)
         for seg in majors:                                    # :201-216
             pieces, helpers = analyze_inside_align(seg, sample.gaps_of(seg.aln), options, sample)
@@ -80,29 +100,18 @@ def analyze_alignments(rows, sample, options, part_num=0):
         if n < 2:
             continue
 
-        want_graph = getattr(options, "graph", False)
         whole_seq = table.query_sequence(primary) if want_graph else None
-
-        def emit(cur, nxt, helpers=(), next_is_last=True):
-            cur, nxt = cur.copy(), nxt.copy()
-            graph = None
-            if want_graph:                                    # before analyze_gap shifts / trims anything (:236-237, :298-302)
-                graph = build_graph(cur, nxt, helpers, options.min_sv_size, whole_seq, chrom_of, sample.fetch_ref_str, qname,
-                                    next_is_last)
-            sig = analyze_gap(cur, nxt, chrom_of, fetch_ref, options, qname, helpers)
-            if sig is not None:
-                sig.set_graph(graph)
-                signatures.append(sig)
-
+        ctx = (signatures, want_graph, whole_seq, chrom_of, fetch_ref, sample, options, qname)
         if n == 2:
-            emit(segs[0], segs[1])
+            _emit(ctx, segs[0], segs[1], (), True)
             continue
         if segs[0].is_reverse:                                # :250-261
-            emit(segs[0], segs[1])
+            _emit(ctx, segs[0], segs[1], (), True)
         if segs[-1].is_reverse:                               # :263-274
-            emit(segs[-2], segs[-1])
+            _emit(ctx, segs[-2], segs[-1], (), True)
         main_idx = [i for i, s in enumerate(segs) if s.type == "main"]
-        for p, (i, j) in enumerate(zip(main_idx[:-1], main_idx[1:])):         # :287-308
+        for p in range(len(main_idx) - 1):                    # :287-308
+            i, j = main_idx[p], main_idx[p + 1]
             if segs[j].q_start - segs[i].q_end >= -25:
-                emit(segs[i], segs[j], segs[i + 1:j], p == len(main_idx) - 2)
+                _emit(ctx, segs[i], segs[j], segs[i + 1:j], p == len(main_idx) - 2)
     return signatures

@@ -894,6 +894,12 @@ class Fasta:
         seq = self._seq[name]
         return seq[max(0, int(start)):max(0, min(len(seq), int(end)))]
 
+    def fetch_view(self, name, start, end):
+        """:meth:`fetch_bytes` without the copy: a memoryview of the same bytes (len() and integer indexing like bytes)."""
+        seq = self._seq[name]
+        lo, hi = max(0, int(start)), max(0, min(len(seq), int(end)))
+        return memoryview(seq)[lo:hi] if isinstance(seq, (bytes, bytearray)) else seq[lo:hi]
+
 
 def write_fasta(path, sequences, width=60):
     with open(path, "wb") as f:

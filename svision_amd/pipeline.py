@@ -82,27 +82,51 @@ def edge_margin(sample):
     return m
 
 
-def _vote(sample, options, chrom, lines, classes, probs, start=None, end=None):
-    """Vote of ONE window [start, end): -> (VCF text, score text of its interior sites, n_sites, head, tail).  The first /
-    last site is returned unwritten (predict.SiteVoter(hold_edges=True)) when it lies within :func:`edge_margin` of the
-    window's start / end and a neighbouring window exists: such a site can span the boundary, and the chromosome's
+class WindowVote:
+    """Vote of ONE window [start, end), fed in TSV order as the predictions arrive (``feed``) and closed by ``finish`` ->
+    (VCF text, score text of its interior sites, n_sites, head, tail).  The first / last site is returned unwritten
+    (predict.SiteVoter(hold_edges=True)) when it lies within :func:`edge_margin` of the window's start / end and a
+    neighbouring window exists: such a site can span the boundary, and the chromosome's
     :class:`~svision_amd.network.predict.ChromosomeVote` writes it once, as the reference's vote over the concatenated
     TSV does (predict.py:235-247)."""
-    vcf, score = io.StringIO(), io.StringIO()
-    n_sites, head, tail = 0, None, None
+
+    def __init__(self, sample, options, chrom, lines, start=None, end=None):
+        self.lines, self.fed = lines, 0
+        self.vcf, self.score = io.StringIO(), io.StringIO()
+        self.voter = None
+        if lines:
+            hold = None
+            if start is not None:
+                m = edge_margin(sample)
+                clen = sample.table.lengths[sample.table.get_tid(chrom)]
+                hold = (start + m if start > 0 else float("-inf"), end - m if end < clen else float("inf"))
+            self.voter = SiteVoter(Predict(chrom, None), self.vcf, self.score, options, sample, hold_edges=True, hold_range=hold)
+
+    def feed(self, classes, probs):
+        """Predictions of the next ``len(classes)`` lines."""
+        k = len(classes)
+        if k:
+            self.voter.feed_batch([ln.label() for ln in self.lines[self.fed:self.fed + k]], classes, probs)
+            self.fed += k
+
+    def finish(self):
+        n_sites, head, tail = 0, None, None
+        if self.voter is not None:
+            if self.fed != len(self.lines):
+                raise RuntimeError("window vote closed after %d of %d predictions" % (self.fed, len(self.lines)))
+            self.voter.finish()
+            head, tail = self.voter.head, self.voter.tail
+            # candidate sites = distinct region keys of the segment TSV (SURVEY 8(d)), whatever the CNN says
+            n_sites = len({ln.region for ln in self.lines})
+        return self.vcf.getvalue(), self.score.getvalue(), n_sites, head, tail
+
+
+def _vote(sample, options, chrom, lines, classes, probs, start=None, end=None):
+    """:class:`WindowVote` in one go."""
+    vote = WindowVote(sample, options, chrom, lines, start, end)
     if lines:
-        hold = None
-        if start is not None:
-            m = edge_margin(sample)
-            clen = sample.table.lengths[sample.table.get_tid(chrom)]
-            hold = (start + m if start > 0 else float("-inf"), end - m if end < clen else float("inf"))
-        voter = SiteVoter(Predict(chrom, None), vcf, score, options, sample, hold_edges=True, hold_range=hold)
-        voter.feed_batch([ln.label() for ln in lines], classes, probs)
-        voter.finish()
-        head, tail = voter.head, voter.tail
-        # candidate sites = distinct region keys of the segment TSV (SURVEY 8(d)), whatever the CNN says
-        n_sites = len({ln.region for ln in lines})
-    return vcf.getvalue(), score.getvalue(), n_sites, head, tail
+        vote.feed(classes[:len(lines)], probs[:len(lines)])
+    return vote.finish()
 
 
 def _edge_regions(lines):
@@ -369,7 +393,8 @@ def _worker_main(conn):
        owner -> ("win", wid, key, chrom, start, end, scan of the window's rows or None)
                     helper -> ("part", wid, records int32[k,12]) ... as the clusters are worked through, then
                     helper -> ("rec", wid, n images of the window, ok)
-       owner -> ("pred", wid, classes, probs)      helper -> ("done", wid, vcf, scores, n_sites, n_images, tsv, head, tail, ...)
+       owner -> ("pred", wid, classes, probs, last)  the window's predictions, in TSV order, in one or more messages
+                    helper -> ("done", wid, vcf, scores, n_sites, n_images, tsv, head, tail, ...)   after the last one
        owner -> ("scan", min_sv, gaps.npy, gap_off.npy, stats.npy)   (HelperPool.attach_scan: helpers forked before the scan)
        owner -> ("chrom", key, meta) / ("drop", key)   a chromosome of a file-driven run arrives in / leaves shared memory
                                                         (ingest.ChromosomeFeed); key None = the Sample of the fork / "scan"
@@ -419,15 +444,23 @@ def _worker_main(conn):
                 conn.send(("part", wid, np.asarray([ln.record() for ln in part], np.int32).reshape(-1, 12)))
 
             lines, ok = _collect_parts(smp, options, chrom, start, end, emit)
-            held[wid] = (chrom, lines, start, end, time.perf_counter() - t0, smp)
+            held[wid] = [WindowVote(smp, options, chrom, lines, start, end), time.perf_counter() - t0, 0.0]
             conn.send(("rec", wid, len(lines), ok))
         elif msg[0] == "pred":
-            _t, wid, classes, probs = msg
-            chrom, lines, start, end, t_collect, smp = held.pop(wid)
+            _t, wid, classes, probs, last = msg
+            state = held[wid]
+            vote = state[0]
             t0 = time.perf_counter()
-            vcf, scores, n_sites, head, tail = _vote(smp, options, chrom, lines, classes, probs, start, end)
+            if vote.lines:                                    # (a window whose collection failed has none: whatever was predicted is dropped)
+                vote.feed(classes, probs)
+            if not last:
+                state[2] += time.perf_counter() - t0
+                continue
+            vcf, scores, n_sites, head, tail = vote.finish()
+            lines = vote.lines
             tsv = "".join(ln.text() for ln in lines) if _POOL_STATE.get("want_tsv") else None
-            conn.send(("done", wid, vcf, scores, n_sites, len(lines), tsv, head, tail, (t_collect, time.perf_counter() - t0), _edge_regions(lines)))
+            del held[wid]
+            conn.send(("done", wid, vcf, scores, n_sites, len(lines), tsv, head, tail, (state[1], state[2] + time.perf_counter() - t0), _edge_regions(lines)))
             n_done += 1
             if n_done % 128 == 0:
                 gc.collect()
@@ -570,16 +603,25 @@ class PooledHotPath(HotPath):
             group.n_images, group.lines, group.packed = n, None, None
             return group, mapping
 
-        def complete(wid):
-            """All predictions of a window are here: its helper votes."""
-            w = wins.pop(wid)
-            if w["chunks"]:
-                w["chunks"].sort(key=lambda c: c[0])
-                classes = np.concatenate([c[1] for c in w["chunks"]])
-                probs = np.concatenate([c[2] for c in w["chunks"]])
-            else:
+        def forward(wid):
+            """Send the predictions that have arrived for a window on to its helper, which votes as they come.  Only
+            once the helper has reported the window's size: until then it is collecting, not reading its pipe, and a
+            send could block this thread on a full pipe."""
+            w = wins[wid]
+            if w["total"] is None:
+                return
+            last = w["got"] == w["total"]
+            chunks, w["chunks"] = w["chunks"], []
+            if chunks:
+                classes = chunks[0][1] if len(chunks) == 1 else np.concatenate([c[1] for c in chunks])
+                probs = chunks[0][2] if len(chunks) == 1 else np.concatenate([c[2] for c in chunks])
+            elif last:
                 classes, probs = np.empty(0, np.int64), np.empty((0, 5), np.float32)
-            self.conns[w["ci"]].send(("pred", wid, classes, probs))
+            else:
+                return
+            self.conns[w["ci"]].send(("pred", wid, classes, probs, last))
+            if last:
+                del wins[wid]
 
         while remaining:
             t = clock()
@@ -634,14 +676,16 @@ class PooledHotPath(HotPath):
                 group, mapping = inflight.popleft()
                 inflight_images -= group.n_images
                 classes, probs = self.fetch_predictions(group)
+                touched = {}
                 for wid, w_off, g_off, k in mapping:
                     w = wins.get(wid)
                     if w is None or w.get("drop"):
                         continue
-                    w["chunks"].append((w_off, classes[g_off:g_off + k], probs[g_off:g_off + k]))
+                    w["chunks"].append((w_off, classes[g_off:g_off + k], probs[g_off:g_off + k]))     # groups complete in launch order: window order
                     w["got"] += k
-                    if w["total"] is not None and w["got"] == w["total"]:
-                        complete(wid)
+                    touched[wid] = True
+                for wid in touched:
+                    forward(wid)
                 prof["last_fetch_at"] = clock() - t_loop
             t = lap("fetch+send", t)
             waiting = [self.conns[ci] for ci in busy]
@@ -671,13 +715,12 @@ class PooledHotPath(HotPath):
                         for seg in [seg for seg in pending if seg[0] == wid]:
                             pending.remove(seg)
                             pending_images -= int(seg[2].shape[0])
-                        w["drop"], w["chunks"] = True, []
-                        complete(wid)
+                        w["chunks"], w["total"], w["got"] = [], 0, 0
+                        forward(wid)                                  # an empty last message: the helper votes on no lines
                         wins[wid] = {"drop": True}                    # launches of it still in flight are ignored (entry never removed: wids are not reused)
                         continue
                     w["total"] = n_images
-                    if w["got"] == n_images:
-                        complete(wid)
+                    forward(wid)
                 else:
                     _t, wid, vcf, scores, n_sites, n_images, tsv, head, tail, host_s, edges = msg
                     prof["helper.collect_s"] += host_s[0]             # host seconds inside the helpers

@@ -154,6 +154,11 @@ class Sample:
             raise ValueError("invalid coordinates: start (%d) > stop (%d)" % (start, end))
         return self.fasta.fetch_bytes(chrom, start, end)
 
+    def fetch_ref_view(self, chrom, start, end):
+        """:meth:`fetch_ref` without copying the span (the left-alignment of analyze_gap reads a few bases of tens of kb)."""
+        if start < 0 or end < start:
+            raise ValueError("invalid coordinates: start (%d) > stop (%d)" % (start, end))
+        return self.fasta.fetch_view(chrom, start, end)
 
     def fetch_ref_str(self, chrom, start, end):
         """The same as text (the --hash re-aligner works on str)."""

@@ -72,3 +72,12 @@ def test_import_guard_runs_the_source_of_a_stale_module_and_touches_nothing(tmp_
         del sys.meta_path[:len(sys.meta_path) - n_finders]
         for k in [k for k in sys.modules if k.startswith("fakepkg")]:
             del sys.modules[k]
+
+
+def test_a_changed_pxd_makes_every_extension_module_stale(tmp_path):
+    """The .pxd files declare the C layout of the extension types the modules share."""
+    _layout(str(tmp_path), True)
+    assert build_host.stale_modules(str(tmp_path)) == []
+    with open(os.path.join(tmp_path, build_host.MODULES[2][:-3] + ".pxd"), "w") as f:
+        f.write("cdef class X:\n    cdef public long a\n")
+    assert len(build_host.stale_modules(str(tmp_path))) == len(build_host.MODULES)

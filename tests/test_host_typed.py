@@ -1,0 +1,48 @@
+"""The statically typed forms of the host collection (augmenting .pxd files, svision_amd/build_host.py) against their plain
+NumPy / Python forms.  The golden and fuzz fixtures pin the results of the whole step against the reference; these pin the
+two implementations of one function against each other on inputs the fixtures do not hold (zero spans, ties, huge values)."""
+import numpy as np
+import pytest
+
+from svision_amd.collection import cluster_signatures as cs
+
+
+def _numpy_form(starts, ends):
+    saved = cs._COMPILED
+    cs._COMPILED = False
+    try:
+        return cs.span_position_distance_condensed(starts, ends)
+    finally:
+        cs._COMPILED = saved
+
+
+@pytest.mark.skipif(not cs._COMPILED, reason="host modules not compiled: only the NumPy form exists")
+def test_condensed_distance_loops_equal_the_numpy_form_bit_for_bit():
+    rng = np.random.default_rng(5)
+    cases = [([10, 10, 10], [10, 10, 20]),                    # zero spans: 0/0 -> nan, x/0 never (max > 0) ...
+             ([5, 7], [5, 7]),                                 # ... both zero: nan
+             ([0, 3], [0, 9]), ([1], [2]), ([], []),
+             ([2_000_000_000, 2_147_483_000, 17], [2_147_483_647, 2_147_483_647, 4_000_000_000])]
+    for _ in range(200):
+        n = int(rng.integers(2, 80))
+        s = rng.integers(0, 250_000_000, n)
+        e = s + rng.integers(0, 5, n) * rng.integers(0, 100_000, n)          # many zero spans and equal values
+        cases.append((s.tolist(), e.tolist()))
+    for starts, ends in cases:
+        got = cs.span_position_distance_condensed(starts, ends)
+        want = _numpy_form(starts, ends)
+        assert got.dtype == want.dtype == np.float64 and got.shape == want.shape
+        assert got.tobytes() == want.tobytes(), (starts, ends)               # bit for bit, NaNs included
+
+
+def test_segments_are_extension_types_when_compiled_and_compare_by_value():
+    from svision_amd.collection.classes import Seg
+    a = Seg(1, 5, 100, 104, 0, False, qual=60, aln=-1)
+    b = a.copy()
+    assert a is not b and a.same_value(b) and b.same_value(a)
+    b.ref_end += 1
+    assert not a.same_value(b)
+    with pytest.raises((AttributeError, TypeError)):
+        a.no_such_field = 1                                                  # __slots__ interpreted, C struct compiled
+    big = Seg(0, 2**40, 2**40, 2**41, 3, True)
+    assert big.ref_end - big.q_end == 2**40 and big.is_reverse is True
