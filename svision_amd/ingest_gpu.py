@@ -237,7 +237,7 @@ class DeviceDecoder:
                 d_status = torch.zeros(nb, dtype=torch.int32, device=dev)
                 d_len = d_tab[nb:2 * nb].to(torch.int32)
                 st = kernels._stream_ptr(dev)
-                _lib.check(lib.svx_bgzf_inflate(d_comp.data_ptr(), d_tab.data_ptr(), d_len.data_ptr(), d_tab[2 * nb:].data_ptr(), nb, d_raw.data_ptr(),
+                _lib.check(kernels.inflate_kernel_for(lib, nb)(d_comp.data_ptr(), d_tab.data_ptr(), d_len.data_ptr(), d_tab[2 * nb:].data_ptr(), nb, d_raw.data_ptr(),
                                                 d_status.data_ptr(), st), "svx_bgzf_inflate")
                 total_starts = sum(item["n_starts"])
                 d_counts = torch.empty((total_starts + 1, 4), dtype=torch.int64, device=dev)

@@ -383,7 +383,17 @@ def bgzf_block_table(raw):
     return (np.asarray(src_off, np.uint64), np.asarray(src_len, np.uint32), np.asarray(isize, np.uint32), np.asarray(block_off, np.uint64))
 
 
-def bgzf_inflate(d_comp, src_off, src_len, isize, wave=False):
+WAVE_KERNEL_BELOW = 20_000          # blocks per launch under which the wave-per-block inflate kernel is the faster one (see inflate_kernel_for)
+
+
+def inflate_kernel_for(lib, n_blocks):
+    """The faster of the two inflate kernels for a launch of ``n_blocks`` blocks.  One lane per block needs ~0.1 s whatever
+    the launch size up to 98 k blocks (1,536 resident waves); one wave per block needs ~17 ms per round of 5,120 blocks:
+    level at 28 k blocks, 3x ahead at the 7 k blocks of a small chromosome (measured: tools/exp/inflate_gpu_bench.py)."""
+    return lib.svx_bgzf_inflate_wave if n_blocks < WAVE_KERNEL_BELOW else lib.svx_bgzf_inflate
+
+
+def bgzf_inflate(d_comp, src_off, src_len, isize, wave=None):
     """d_comp: uint8 device tensor holding the compressed bytes (16-byte aligned, padded to a multiple of 16); src_off / src_len / isize: host
     arrays of :func:`bgzf_block_table` (or the native reader's).  -> (uint8 device tensor with the inflated stream,
     int32 device tensor [n] status: 0 = ok).  See include/svx.h svx_bgzf_inflate."""
@@ -402,7 +412,8 @@ def bgzf_inflate(d_comp, src_off, src_len, isize, wave=False):
         d_src = torch.from_numpy(np.ascontiguousarray(src_off, np.uint64).view(np.int64)).to(dev)
         d_len = torch.from_numpy(np.ascontiguousarray(src_len, np.uint32).view(np.int32)).to(dev)
         d_dst = torch.from_numpy(dst.view(np.int64)).to(dev)
-        fn = lib.svx_bgzf_inflate_wave if wave else lib.svx_bgzf_inflate     # the two implementations of one contract
+        # the two implementations of one contract: wave True / False picks one, None the faster one for this launch size
+        fn = inflate_kernel_for(lib, n) if wave is None else (lib.svx_bgzf_inflate_wave if wave else lib.svx_bgzf_inflate)
         rc = fn(d_comp.data_ptr(), d_src.data_ptr(), d_len.data_ptr(), d_dst.data_ptr(), n, d_out.data_ptr(), d_status.data_ptr(), _stream_ptr(dev))
         _lib.check(rc, "svx_bgzf_inflate")
     return d_out[:total], d_status[:n]

@@ -638,7 +638,8 @@ class PooledHotPath(HotPath):
                 scan = None
                 if rescan:                                            # device scan of the window's block: the helper collects on ITS result
                     t_s = clock()
-                    while len(scans) < ahead and nxt + len(scans) < len(windows):    # enqueued several windows ahead, read back here
+                    want = ahead if nxt else 1                        # the very first window leaves before the scans of the next ones are enqueued (0.25 ms each)
+                    while len(scans) < want and nxt + len(scans) < len(windows):     # enqueued several windows ahead, read back here
                         scans.append(self.sample.rescan_window_async(*windows[nxt + len(scans)]))
                     t_s = lap("scan.enqueue", t_s)
                     handle = scans.popleft()
@@ -659,7 +660,9 @@ class PooledHotPath(HotPath):
             while pending_images and inflight_images < cap_images:
                 room = cap_images - inflight_images
                 if pending_images >= granule:
-                    n = min(pending_images, room, 2 * granule) // granule * granule    # small groups: a window's predictions return as soon as its own launches are done
+                    # small groups: a window's predictions return as soon as its own launches are done (and, when nothing
+                    # is being collected any more, launch by launch: the last vote is what the job's end waits for)
+                    n = min(pending_images, room, granule if collecting == 0 and nxt >= len(windows) else 2 * granule) // granule * granule
                     if n == 0:
                         break
                 elif not inflight or collecting == 0 or clock() - pending[0][3] > flush_after:
