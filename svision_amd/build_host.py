@@ -12,7 +12,7 @@ import sys
 
 MODULES = ["collection/analyze_reads.py", "collection/collect_signatures.py", "collection/classes.py",
            "collection/output_clusters.py", "collection/cluster_signatures.py", "collection/graph.py",
-           "segmentplot/classes.py", "network/predict.py"]
+           "segmentplot/classes.py", "network/predict.py", "network/genotype.py"]
 
 
 STAMP = "_host_build.json"               # per module: sha1 of the sources its extension module was compiled from (_source_hash)

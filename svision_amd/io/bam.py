@@ -185,25 +185,33 @@ class AlignmentTable:
             self._run_max_end = {}
         return self._tid_bounds
 
-    def fetch(self, tid, start, end):
-        """Indices (file order) of records overlapping the half-open interval
-        [start, end) on reference ``tid`` -- pysam ``fetch(contig, start, end)``."""
+    def fetch_range(self, tid, start, end):
+        """(first, stop): the records overlapping [start, end) on reference ``tid`` are those rows of [first, stop) whose
+        :meth:`ref_end` lies behind ``start`` (what :meth:`fetch` returns as an index array)."""
         b = self._bounds()
         lo, hi = int(b[tid]), int(b[tid + 1])
         if lo == hi:
-            return np.empty(0, np.int64)
-        pos = self.pos[lo:hi]
-        info = np.iinfo(pos.dtype)
-
-        def key(v):                                                  # a needle of the array's own type: no converted copy of `pos`
-            return pos.dtype.type(min(max(int(v), info.min), info.max))
-        stop = lo + int(np.searchsorted(pos, key(end), side="left"))      # pos < end
+            return lo, lo
+        pos = self.pos
         ref_end = self.ref_end()
         if getattr(self, "_max_span", None) is None:                 # no record reaches farther than this behind its start
-            self._max_span = int((ref_end - self.pos).max()) if len(self.pos) else 0
-        first = lo + int(np.searchsorted(pos, key(start - self._max_span), side="left"))
+            self._max_span = int((ref_end - pos).max()) if len(pos) else 0
+        if getattr(self, "_pos_needle", None) is None:               # a needle of the array's own type: no converted copy of `pos`
+            info = np.iinfo(pos.dtype)
+            self._pos_needle = (pos.dtype.type, int(info.min), int(info.max))
+        make, mn, mx = self._pos_needle
+        stop = lo + int(pos[lo:hi].searchsorted(make(min(max(int(end), mn), mx)), side="left"))      # pos < end
+        first = lo + int(pos[lo:hi].searchsorted(make(min(max(int(start) - self._max_span, mn), mx)), side="left"))
+        return first, stop
+
+    def fetch(self, tid, start, end):
+        """Indices (file order) of records overlapping the half-open interval
+        [start, end) on reference ``tid`` -- pysam ``fetch(contig, start, end)``."""
+        first, stop = self.fetch_range(tid, start, end)
+        if first >= stop:
+            return np.empty(0, np.int64)
         idx = np.arange(first, stop, dtype=np.int64)
-        return idx[ref_end[first:stop] > start]
+        return idx[self.ref_end()[first:stop] > start]
 
     def count_overlaps(self, tid, starts, ends):
         """Vectorised number of records overlapping each [start, end): the per-cluster
