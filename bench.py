@@ -219,7 +219,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="candidate images per CNN batch (BASELINE configs[1])")
     ap.add_argument("--contig-len", type=int, default=CHR21)
     ap.add_argument("--coverage", type=float, default=30.0)
-    ap.add_argument("--workers", type=int, default=8, help="helper processes per rank for the Python host glue (capped at cores / ranks)")
+    ap.add_argument("--workers", type=int, default=0, help="helper processes per rank for the Python host glue (default: 8, capped at twice the usable CPUs per rank: a helper waits for its window's predictions between collection and vote)")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the per-batch graphs are replayed on")
     ap.add_argument("--inflight", type=int, default=6, help="windows enqueued on the device at once")
     ap.add_argument("--launch-batches", type=int, default=4, help="batches of --batch images per device launch (graph replay)")
@@ -238,7 +238,7 @@ def main():
     rank, world = sdist.env_rank()
     from svision_amd.ingest import decode_threads, effective_cpus
     cores, visible_cpus = effective_cpus()        # the cgroup's CPU-time quota, not the CPUs the container merely sees
-    workers = max(1, min(args.workers, cores // world))
+    workers = args.workers if args.workers > 0 else max(1, min(8, 2 * cores // world))
     # ---- untimed set-up.  Order matters: everything that forks (simulation pool, CPU-baseline pool, host helpers)
     # happens before the first HIP call (forking with a live GPU context makes the driver evict / restore the queues)
     parts, windows, strong, total_windows, e2e = build_workload(args, rank, world, cores)

@@ -117,6 +117,50 @@ def test_streaming_pipelines_agree(checkpoint):
     assert sum(v[3] for v in outs[0].values()) == 610 and sum(v[2] for v in outs[0].values()) > 20
 
 
+def test_a_window_that_fails_after_parts_have_left_contributes_nothing(checkpoint, monkeypatch):
+    """run_detect turns any exception of a window into a message and the window into nothing (run_collection.py:44-47).
+    In the streaming pipeline parts of such a window may already be on the device when its collection fails: they are
+    dropped, the other windows are untouched."""
+    from svision_amd import pipeline
+    from svision_amd.pipeline import PooledHotPath
+    from svision_amd.network.tf_checkpoint import read_checkpoint
+    prefix, _ = checkpoint
+    net = AlexNet(read_checkpoint(prefix), device="cuda:0")
+    windows = [("chrA", 0, 150_000), ("chrA", 150_000, 300_000), ("chrA", 300_000, 420_000), ("chrB", 0, 150_000), ("chrB", 150_000, 200_000)]
+    opts = helpers.default_options(min_support=3, batch_size=64, bam_path="<resident>")
+
+    def run():
+        hp = PooledHotPath(helpers.golden_sample(50, device="cuda:0"), opts, net, device="cuda:0", n_workers=3, n_streams=2)
+        try:
+            return {(r.chrom, r.start): (r.vcf, r.scores, r.n_sites, r.n_images, r.head, r.tail) for r in hp.run_windows(windows)}
+        finally:
+            hp.close()
+    want = run()
+    victim = max(want, key=lambda k: want[k][3])                 # the window with most images: several parts
+    assert want[victim][3] > 128
+    real, real_detect, current = pipeline.iter_pair_lines, pipeline.detect_window, []
+
+    def detect(options, sample, chrom, start, end, part_num=0):   # the helpers are forked after these patches: they inherit them
+        current[:] = [(chrom, start)]
+        return real_detect(options, sample, chrom, start, end, part_num)
+
+    def failing(clusters, options):
+        n = 0
+        for lines in real(clusters, options):
+            yield lines
+            n += len(lines)
+            if current[0] == victim and n > 96:
+                raise ValueError("start out of range (-1)")
+    monkeypatch.setattr(pipeline, "detect_window", detect)
+    monkeypatch.setattr(pipeline, "iter_pair_lines", failing)
+    monkeypatch.setattr(pipeline._collect_parts, "__defaults__", (32,))     # parts of >= 32 lines: some leave before the failure
+    got = run()
+    assert got[victim][:4] == ("", "", 0, 0) and got[victim][4] is None and got[victim][5] is None
+    for key in want:
+        if key != victim:
+            assert got[key] == want[key]
+
+
 def test_cli_hash_mode_on_device(checkpoint, tmp_path):
     """--hash end to end on the device path: BAM with read bases -> TSV identical to the reference's."""
     import json

@@ -46,3 +46,29 @@ def test_segments_are_extension_types_when_compiled_and_compare_by_value():
         a.no_such_field = 1                                                  # __slots__ interpreted, C struct compiled
     big = Seg(0, 2**40, 2**40, 2**41, 3, True)
     assert big.ref_end - big.q_end == 2**40 and big.is_reverse is True
+
+
+def test_collect_parts_hands_whole_clusters_on_and_drops_a_failing_window(monkeypatch, oracle_lib):
+    """pipeline._collect_parts: the parts are the window's lines in order; an exception anywhere makes the window empty."""
+    from svision_amd import pipeline
+    from tests import helpers
+    sample = helpers.golden_sample(50)
+    opts = helpers.default_options(min_support=3, batch_size=64, bam_path="<resident>")
+    want = pipeline._collect_lines(sample, opts, "chrA", 0, 150_000)
+    assert len(want) > 64
+    parts = []
+    lines, ok = pipeline._collect_parts(sample, opts, "chrA", 0, 150_000, parts.append, granule=32)
+    assert ok and len(parts) > 1 and all(len(p) >= 32 for p in parts[:-1])
+    flat = [ln for p in parts for ln in p]
+    assert [ln.text() for ln in flat] == [ln.text() for ln in want] == [ln.text() for ln in lines]
+    real = pipeline.iter_pair_lines
+
+    def failing(clusters, options):
+        for i, got in enumerate(real(clusters, options)):
+            if i == 3:
+                raise ValueError("start out of range (-1)")
+            yield got
+    monkeypatch.setattr(pipeline, "iter_pair_lines", failing)
+    parts = []
+    lines, ok = pipeline._collect_parts(sample, opts, "chrA", 0, 150_000, parts.append, granule=8)
+    assert (lines, ok) == ([], False) and parts                   # parts left before the failure: the owner drops them
