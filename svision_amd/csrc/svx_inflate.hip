@@ -224,19 +224,56 @@ struct Writer {
         ++nacc; ++pos;
         if (nacc == 4) { *reinterpret_cast<uint32_t*>(base + pos - 4) = acc; nacc = 0; acc = 0; }
     }
-    __device__ __forceinline__ void copy(uint32_t dist, uint32_t len)        // caller checked the bounds
+};
+
+// A match is copied in steps of up to eight bytes, ONE step per turn of the symbol loop: the step's source is fetched with
+// one unaligned 8-byte load at the top of the turn, the turn's Huffman decoding runs while it is on its way, and the bytes
+// leave with one unaligned 8-byte store.  (First versions copied a whole match byte by byte -- load, wait, store -- inside
+// the turn that decoded it: the 63 other lanes of the wave, whose blocks are at unrelated places of their streams, waited
+// for every byte's round trip; ~3,800 of the 4,800 cycles of an average turn.)
+//   * distance < 8: the eight bytes are the period of `dist` bytes repeated; afterwards the distance is replaced by its
+//     smallest multiple >= 8 (the output is periodic from pos - dist on, so the source may be any whole period back);
+//   * the eight-byte store may carry up to seven bytes of garbage behind the step's last byte: they land in this lane's own
+//     not yet written output (never behind the block's end: byte-wise there) and later stores of the same lane replace them.
+struct MatchCopy {
+    uint32_t len, dist;                   // bytes still to copy (0: none pending), their distance
+    uint64_t v;                           // the step's source bytes (fetch -> commit)
+    bool wide;                            // this step runs on 8-byte accesses
+    __device__ __forceinline__ void fetch(const Writer& w)
     {
-        flush();
-        for (uint32_t i = 0; i < len; ++i, ++pos) base[pos] = base[pos - dist];
+        wide = len != 0 && w.pos + 8 <= w.hi;              // (then the source's eight bytes end before the block does as well)
+        if (wide) __builtin_memcpy(&v, w.base + w.pos - dist, 8);
+    }
+    __device__ __forceinline__ void commit(Writer& w)
+    {
+        if (len == 0) return;
+        const uint32_t n = len < 8u ? len : 8u;
+        if (wide) {
+            if (dist < 8u) {
+                const uint32_t sh = 8u * dist;
+                uint64_t p = v & ((1ull << sh) - 1ull);
+                p |= p << sh;
+                if (2u * sh < 64u) p |= p << (2u * sh);
+                if (4u * sh < 64u) p |= p << (4u * sh);
+                v = p;
+                dist *= (7u + dist) / dist;                    // smallest multiple of the period that is >= 8
+            }
+            __builtin_memcpy(w.base + w.pos, &v, 8);
+        } else {
+            for (uint32_t i = 0; i < n; ++i) w.base[w.pos + i] = w.base[w.pos + i - dist];
+        }
+        w.pos += n;
+        len -= n;
     }
 };
 
 // status per block: 0 ok, else the reason
 enum { INF_OK = 0, INF_BAD_TYPE = 1, INF_BAD_STORED = 2, INF_BAD_TABLE = 3, INF_BAD_CODE = 4, INF_OUT_OVERRUN = 5, INF_IN_OVERRUN = 6, INF_SHORT = 7, INF_BAD_DIST = 8 };
+enum { ST_HEADER = 0, ST_SYMBOLS = 1, ST_DONE = 2 };
 
 __global__ __launch_bounds__(LANES)
 void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const uint64_t* __restrict__ src_off, const uint32_t* __restrict__ src_len,
-                         const uint64_t* __restrict__ dst_off, uint32_t n_blocks, uint8_t* __restrict__ out, uint32_t* __restrict__ status)
+                         const uint64_t* __restrict__ dst_off, uint32_t n_blocks, uint8_t* out, uint32_t* __restrict__ status)
 {
     __shared__ uint32_t lds[LANES * LANE_DWORDS];
     const uint32_t b = blockIdx.x * LANES + threadIdx.x;
@@ -251,20 +288,28 @@ void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const uint64_t* __res
     BitReader br;
     br.init(comp, src_off[b], src_len[b]);
     Writer w{out, dst_off[b], dst_off[b], dst_off[b + 1], 0u, 0};
+    MatchCopy mc{0u, 0u, 0ull, false};
     int err = INF_OK;
     __attribute__((aligned(16))) uint8_t lens[LIT_SYMS + DIST_SYMS];
-    bool last = w.hi == w.lo;                                   // an empty block (the EOF marker): nothing to decode
-    while (!last && err == INF_OK) {
-        last = br.bits(1) != 0;
-        const uint32_t type = br.bits(2);
-        if (type == 0) {                                        // stored: to the byte boundary, LEN, ~LEN, bytes
-            br.bits(br.cnt & 7);
-            const uint32_t len = br.bits(16), nlen = br.bits(16);
-            if ((len ^ nlen) != 0xffffu) { err = INF_BAD_STORED; break; }
-            if (w.pos + len > w.hi) { err = INF_OUT_OVERRUN; break; }
-            for (uint32_t i = 0; i < len; ++i) w.literal(br.bits(8));
-        } else if (type == 1 || type == 2) {
-            if (type == 1) {                                    // fixed code (RFC 1951 3.2.6)
+    bool last = false;
+    int state = w.hi == w.lo ? ST_DONE : ST_HEADER;             // an empty block (the EOF marker): nothing to decode
+    // One loop for the whole block, every lane in its own state: a lane that reaches the end of a DEFLATE block parses the
+    // next header while the others go on decoding (an inner symbol loop per DEFLATE block made every lane wait, at every
+    // block boundary, for the slowest of the wave).
+    while (state != ST_DONE) {
+        if (state == ST_HEADER) {
+            last = br.bits(1) != 0;
+            const uint32_t type = br.bits(2);
+            state = ST_SYMBOLS;
+            if (type == 0) {                                    // stored: to the byte boundary, LEN, ~LEN, bytes
+                br.bits(br.cnt & 7);
+                const uint32_t len = br.bits(16), nlen = br.bits(16);
+                if ((len ^ nlen) != 0xffffu) err = INF_BAD_STORED;
+                else if (w.pos + len > w.hi) err = INF_OUT_OVERRUN;
+                else for (uint32_t i = 0; i < len; ++i) w.literal(br.bits(8));
+                if (br.exhausted()) err = INF_IN_OVERRUN;
+                state = last ? ST_DONE : ST_HEADER;
+            } else if (type == 1) {                             // fixed code (RFC 1951 3.2.6)
                 for (int s = 0; s < 144; ++s) lens[s] = 8;
                 for (int s = 144; s < 256; ++s) lens[s] = 9;
                 for (int s = 256; s < 280; ++s) lens[s] = 7;
@@ -272,55 +317,64 @@ void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const uint64_t* __res
                 for (int s = 0; s < 30; ++s) lens[LIT_SYMS + s] = 5;
                 build(lens, 288, lc, lit_syms);
                 build(lens + LIT_SYMS, 30, dc, dist_syms);
-            } else {                                            // dynamic code (3.2.7)
+            } else if (type == 2) {                             // dynamic code (3.2.7)
                 const int nlen = (int)br.bits(5) + 257, ndist = (int)br.bits(5) + 1, ncode = (int)br.bits(4) + 4;
-                if (nlen > 286 || ndist > 30) { err = INF_BAD_TABLE; break; }
-                __attribute__((aligned(16))) uint8_t cl[32];
-                for (int i = 0; i < 32; ++i) cl[i] = 0;
-                for (int i = 0; i < ncode; ++i) cl[CLEN_ORDER[i]] = (uint8_t)br.bits(3);
-                if (!build(cl, 19, cc, dist_syms)) { err = INF_BAD_TABLE; break; }     // (the code-length code borrows the distance slice)
-                int i = 0;
-                while (i < nlen + ndist) {
-                    const int sym = decode_symbol(br, cc, dist_syms);
-                    if (sym < 0) { err = INF_BAD_TABLE; break; }
-                    if (sym < 16) { lens[i < nlen ? i : LIT_SYMS + (i - nlen)] = (uint8_t)sym; ++i; continue; }
-                    int prev = 0, rep;
-                    if (sym == 16) {
-                        if (i == 0) { err = INF_BAD_TABLE; break; }
-                        const int j = i - 1;
-                        prev = lens[j < nlen ? j : LIT_SYMS + (j - nlen)];
-                        rep = 3 + (int)br.bits(2);
-                    } else if (sym == 17) rep = 3 + (int)br.bits(3);
-                    else rep = 11 + (int)br.bits(7);
-                    if (i + rep > nlen + ndist) { err = INF_BAD_TABLE; break; }
-                    for (; rep > 0; --rep, ++i) lens[i < nlen ? i : LIT_SYMS + (i - nlen)] = (uint8_t)prev;
+                if (nlen > 286 || ndist > 30) err = INF_BAD_TABLE;
+                else {
+                    __attribute__((aligned(16))) uint8_t cl[32];
+                    for (int i = 0; i < 32; ++i) cl[i] = 0;
+                    for (int i = 0; i < ncode; ++i) cl[CLEN_ORDER[i]] = (uint8_t)br.bits(3);
+                    if (!build(cl, 19, cc, dist_syms)) err = INF_BAD_TABLE;     // (the code-length code borrows the distance slice)
+                    int i = 0;
+                    while (err == INF_OK && i < nlen + ndist) {
+                        const int sym = decode_symbol(br, cc, dist_syms);
+                        if (sym < 0) { err = INF_BAD_TABLE; break; }
+                        if (sym < 16) { lens[i < nlen ? i : LIT_SYMS + (i - nlen)] = (uint8_t)sym; ++i; continue; }
+                        int prev = 0, rep;
+                        if (sym == 16) {
+                            if (i == 0) { err = INF_BAD_TABLE; break; }
+                            const int j = i - 1;
+                            prev = lens[j < nlen ? j : LIT_SYMS + (j - nlen)];
+                            rep = 3 + (int)br.bits(2);
+                        } else if (sym == 17) rep = 3 + (int)br.bits(3);
+                        else rep = 11 + (int)br.bits(7);
+                        if (i + rep > nlen + ndist) { err = INF_BAD_TABLE; break; }
+                        for (; rep > 0; --rep, ++i) lens[i < nlen ? i : LIT_SYMS + (i - nlen)] = (uint8_t)prev;
+                    }
+                    if (err == INF_OK && lens[256] == 0) err = INF_BAD_TABLE;
+                    if (err == INF_OK && (!build(lens, nlen, lc, lit_syms) || !build(lens + LIT_SYMS, ndist, dc, dist_syms))) err = INF_BAD_TABLE;
                 }
-                if (err != INF_OK) break;
-                if (lens[256] == 0) { err = INF_BAD_TABLE; break; }
-                if (!build(lens, nlen, lc, lit_syms) || !build(lens + LIT_SYMS, ndist, dc, dist_syms)) { err = INF_BAD_TABLE; break; }
+            } else {
+                err = INF_BAD_TYPE;
             }
-            for (;;) {                                          // the symbols of the block
-                const int sym = decode_symbol(br, lc, lit_syms);
-                if (sym < 256) {
-                    if (sym < 0) { err = INF_BAD_CODE; break; }
-                    if (w.pos >= w.hi) { err = INF_OUT_OVERRUN; break; }
-                    w.literal((uint32_t)sym);
-                    continue;
-                }
-                if (sym == 256) break;
-                const int li = sym - 257;
-                if (li >= 29) { err = INF_BAD_CODE; break; }
-                const uint32_t len = len_base(li) + br.bits((int)len_extra(li));
-                const int ds = decode_symbol(br, dc, dist_syms);
-                if (ds < 0 || ds >= 30) { err = INF_BAD_CODE; break; }
-                const uint32_t dist = dist_base(ds) + br.bits((int)dist_extra(ds));
-                if (dist > w.pos - w.lo) { err = INF_BAD_DIST; break; }
-                if (w.pos + len > w.hi) { err = INF_OUT_OVERRUN; break; }
-                w.copy(dist, len);
-            }
-            if (br.exhausted()) err = INF_IN_OVERRUN;
+            if (err != INF_OK) state = ST_DONE;
+            continue;
+        }
+        // one turn of the symbol loop: a step of the pending match (if any) and -- unless more of it stays -- one symbol
+        mc.fetch(w);
+        int sym = -2;
+        if (mc.len <= 8u) sym = decode_symbol(br, lc, lit_syms);
+        mc.commit(w);
+        if (sym == -2) continue;
+        if (sym < 256) {
+            if (sym < 0) { err = INF_BAD_CODE; state = ST_DONE; }
+            else if (w.pos >= w.hi) { err = INF_OUT_OVERRUN; state = ST_DONE; }
+            else w.literal((uint32_t)sym);
+        } else if (sym == 256) {
+            if (br.exhausted()) { err = INF_IN_OVERRUN; state = ST_DONE; }
+            else state = last ? ST_DONE : ST_HEADER;
         } else {
-            err = INF_BAD_TYPE;
+            const int li = sym - 257;
+            if (li >= 29) { err = INF_BAD_CODE; state = ST_DONE; continue; }
+            const uint32_t len = len_base(li) + br.bits((int)len_extra(li));
+            const int ds = decode_symbol(br, dc, dist_syms);
+            if (ds < 0 || ds >= 30) { err = INF_BAD_CODE; state = ST_DONE; continue; }
+            const uint32_t dist = dist_base(ds) + br.bits((int)dist_extra(ds));
+            if (dist > w.pos - w.lo) { err = INF_BAD_DIST; state = ST_DONE; continue; }
+            if (w.pos + len > w.hi) { err = INF_OUT_OVERRUN; state = ST_DONE; continue; }
+            w.flush();                                          // the literals in hand are part of what the match may copy
+            mc.len = len;
+            mc.dist = dist;
         }
     }
     w.flush();
