@@ -229,7 +229,7 @@ class ChromosomeFeed:
                 self._emit_empty(want.pop(0))
             if getattr(self, "decoder", None) is not None:
                 self.stats["device_decoder"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in self.decoder.stats.items()}
-                self.stats["device_decoder"]["trace"] = ["%.3f %s" % (t + (self.decoder._t0 - self._t0), w) for t, w in self.decoder.trace[:40]]
+                self.stats["device_decoder"]["trace"] = ["%.3f %s" % (t + (self.decoder._t0 - self._t0), w) for t, w in self.decoder.trace[:120]]
         except BaseException as exc:                           # noqa: BLE001 -- surfaces in the owner thread (poll / get)
             self.error = exc
             self._stop = True

@@ -18,6 +18,7 @@ from . import _lib, kernels
 from .io.bam import AlignmentTable, read_bai_linear
 
 FIRST_GROUP_BYTES = 192 << 20            # the first launch is small: the pipeline starts after ~0.1 s
+STAGE_BYTES = 64 << 20                   # a pinned staging slot of the pipelined reader (ring of four)
 PIPE_GROUP_BYTES = 768 << 20             # parts_pipelined: ~30 k blocks per launch, three launches in flight on three streams
 GROUP_BYTES = 24 << 30                   # later groups: as many blocks as possible per launch (a lane decodes one block in ~0.1 s
                                          # whatever the launch size; 24 GB compressed inflate to ~58 GB of HBM)
@@ -90,7 +91,7 @@ class DeviceDecoder:
 
     def _mark(self, what):
         import time
-        if len(self.trace) < 60:
+        if len(self.trace) < 120:
             self.trace.append((round(time.perf_counter() - self._t0, 4), what))
 
     def usable(self, tids):
@@ -143,15 +144,22 @@ class DeviceDecoder:
             groups.append(cur)
         q = queue.Queue(maxsize=1)
         stop = threading.Event()
-        pinned_free, pinned_lock = [], threading.Lock()        # pinned buffers whose upload has completed: reused by the reader
-                                                                # (a fresh 0.7 GB of pinned memory costs ~45 ms each time)
+        # Staging: a ring of four pinned 64 MB slots.  A group's compressed bytes go to the device slot by slot -- read (8
+        # pread threads), index the BGZF blocks the slot holds, copy them to their place in the group's device buffer on a
+        # copy stream, reuse the slot once its copy is done.  (First version: one pinned buffer per group in flight --
+        # 3.7 GB of hipHostMalloc at 0.1 s per GB inside the run, during which every other HIP call of the process waited.)
+        ring, ring_at = [], [0]
+        copy_stream = torch.cuda.Stream(device=dev)
 
-        def pinned(nbytes):
-            with pinned_lock:
-                for i, buf in enumerate(pinned_free):
-                    if buf.numel() >= nbytes:
-                        return pinned_free.pop(i)
-            return torch.empty(max(nbytes, min(PIPE_GROUP_BYTES, 1 << 30) + (1 << 20)), dtype=torch.uint8, pin_memory=True)
+        def slot():
+            if len(ring) < 4:
+                ring.append([torch.empty(STAGE_BYTES, dtype=torch.uint8, pin_memory=True), None])
+                return ring[-1]
+            s_ = ring[ring_at[0] % 4]
+            ring_at[0] += 1
+            if s_[1] is not None:
+                s_[1].synchronize()
+            return s_
 
         def read_group(group):
             spans = [self.spans[t] for t in group]
@@ -160,20 +168,35 @@ class DeviceDecoder:
             nbytes = c1 - c0
             t0 = time.perf_counter()
             self._mark("read %s: start" % group[:2])
-            pin = pinned(nbytes + 64)
-            self._mark("read: pinned %d MB" % (nbytes >> 20))
-            if lib.svx_read_range(self.path.encode(), c0, nbytes, pin.data_ptr(), self.threads) != 0:
-                raise DeviceIngestError(lib.svx_bam_error().decode())
-            pin[nbytes:nbytes + 64].zero_()
-            cap = nbytes // 28 + 16
-            src_off, coff = np.empty(cap, np.uint64), np.empty(cap, np.uint64)
-            src_len, isize = np.empty(cap, np.uint32), np.empty(cap, np.uint32)
-            used = np.zeros(1, np.uint64)
-            nb = int(lib.svx_bgzf_index(pin.data_ptr(), nbytes, c0, cap, src_off.ctypes.data, src_len.ctypes.data, isize.ctypes.data,
-                                        coff.ctypes.data, used.ctypes.data))
-            if nb <= 0:
-                raise DeviceIngestError("no BGZF block at file offset %d" % c0)
-            src_off, src_len, isize, coff = src_off[:nb], src_len[:nb], isize[:nb], coff[:nb]
+            d_comp = torch.empty((nbytes + 31) // 16 * 16, dtype=torch.uint8, device=dev)
+            off, tables, copied = 0, [], None
+            while off < nbytes:
+                want = min(STAGE_BYTES, nbytes - off)
+                st_ = slot()
+                pin = st_[0]
+                if lib.svx_read_range(self.path.encode(), c0 + off, want, pin.data_ptr(), self.threads) != 0:
+                    raise DeviceIngestError(lib.svx_bam_error().decode())
+                cap = want // 28 + 16
+                so, co = np.empty(cap, np.uint64), np.empty(cap, np.uint64)
+                sl, isz = np.empty(cap, np.uint32), np.empty(cap, np.uint32)
+                used = np.zeros(1, np.uint64)
+                k = int(lib.svx_bgzf_index(pin.data_ptr(), want, c0 + off, cap, so.ctypes.data, sl.ctypes.data, isz.ctypes.data, co.ctypes.data,
+                                           used.ctypes.data))
+                if k < 0 or (k == 0 and off == 0):
+                    raise DeviceIngestError("no BGZF block at file offset %d" % (c0 + off))
+                if k == 0:
+                    break                                      # what is left of the range is the head of a block that ends behind it
+                u = int(used[0])
+                with torch.cuda.stream(copy_stream):
+                    d_comp[off:off + u].copy_(pin[:u], non_blocking=True)
+                    copied = torch.cuda.Event()
+                    copied.record()
+                st_[1] = copied
+                tables.append((so[:k] + np.uint64(off), sl[:k], isz[:k], co[:k]))
+                off += u                                       # (a block cut by the end of the slot is read again, at the head of the next one)
+            d_comp.record_stream(copy_stream)
+            src_off, src_len, isize, coff = (np.concatenate([t[i] for t in tables]) for i in range(4))
+            nb = int(src_off.size)
             dst = np.zeros(nb + 1, np.uint64)
             dst[1:] = np.cumsum(isize.astype(np.uint64))
 
@@ -208,7 +231,8 @@ class DeviceDecoder:
             self.stats["bytes_in"] += int(nbytes)
             self.stats["bytes_inflated"] += int(dst[nb])
             self._mark("read: done, %d blocks" % nb)
-            return {"group": group, "pin": pin, "nbytes": nbytes, "nb": nb, "total": int(dst[nb]), "tab": tab, "start_at": start_at, "n_starts": n_starts}
+            return {"group": group, "d_comp": d_comp, "copied": copied, "nbytes": nbytes, "nb": nb, "total": int(dst[nb]), "tab": tab, "start_at": start_at,
+                    "n_starts": n_starts}
 
         def reader():
             try:
@@ -228,10 +252,11 @@ class DeviceDecoder:
 
         def launch(item, stream):
             nb, nbytes = item["nb"], item["nbytes"]
+            self._mark("launch %s: start" % item["group"][:2])
             with torch.cuda.stream(stream):
-                padded = (nbytes + 31) // 16 * 16
-                d_comp = torch.empty(padded, dtype=torch.uint8, device=dev)
-                d_comp.copy_(item["pin"][:padded], non_blocking=True)
+                stream.wait_event(item["copied"])              # the last slot of the group's compressed bytes is on the device
+                d_comp = item["d_comp"]
+                d_comp.record_stream(stream)
                 d_tab = item["tab"].to(dev, non_blocking=True)
                 d_raw = torch.empty(max(item["total"], 16), dtype=torch.uint8, device=dev)
                 d_status = torch.zeros(nb, dtype=torch.int32, device=dev)
@@ -250,7 +275,7 @@ class DeviceDecoder:
                 h_counts.copy_(d_counts, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()
-            item.update(d_raw=d_raw, d_tab=d_tab, d_comp=d_comp, h_counts=h_counts, event=ev, stream=stream)
+            item.update(d_raw=d_raw, d_tab=d_tab, h_counts=h_counts, event=ev, stream=stream)
             self._mark("launched %s" % item["group"][:2])
             return item
 
@@ -259,8 +284,6 @@ class DeviceDecoder:
             item["event"].synchronize()
             self._mark("inflate + count done %s" % item["group"][:2])
             item["d_comp"] = None
-            with pinned_lock:                                   # the upload is behind us: the reader may overwrite the buffer
-                pinned_free.append(item.pop("pin"))
             self.stats["h2d_inflate_s"] += time.perf_counter() - t0
             counts = item["h_counts"].numpy()
             if int(counts[-1, 0]) != 0:
@@ -334,17 +357,61 @@ class DeviceDecoder:
                 inflight.append(launch(item, streams[state["k"] % depth]))
                 state["k"] += 1
 
+        # The launches are driven from a thread of their own: the consumer of this generator does host work per chromosome
+        # (QNAME ids, shared-memory copies, the upload for the scan: 3-80 ms) and a generator that launches only between two
+        # of its yields left the device without inflate work for as long.
+        out_q = queue.Queue(maxsize=8)
+
+        def put(x):
+            while not stop.is_set():
+                try:
+                    out_q.put(x, timeout=0.2)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+
+        def drive():
+            try:
+                while not stop.is_set():
+                    pump(block=True)
+                    if not inflight:
+                        break
+                    head = inflight[0]
+                    while not head["event"].query():           # keep launching while the oldest group is still on the device
+                        pump(block=False)
+                        time.sleep(0.0005)
+                    inflight.popleft()
+                    for part in finish_group(head):
+                        if not put(part):
+                            return
+                    self._mark("group %s finished" % head["group"][:2])
+                put(None)
+            except BaseException as exc:                         # noqa: BLE001 -- re-raised in the consumer's thread
+                put(exc)
+
+        def warm():
+            """The device buffers of the groups in flight, allocated once while the first read is still on its way (the caching
+            allocator hands them out again: the first hipMalloc of a gigabyte costs tens of milliseconds, on the launch path)."""
+            big = max((sum((self.spans[t][1] >> 16) - (self.spans[t][0] >> 16) + 65536 for t in g) for g in groups), default=0)
+            held = []
+            for _ in range(min(depth, len(groups))):
+                held.append(torch.empty(big + (1 << 20), dtype=torch.uint8, device=dev))
+                held.append(torch.empty(3 * big + (1 << 20), dtype=torch.uint8, device=dev))
+            del held
+            self._mark("warm: done")
+
+        threading.Thread(target=warm, name="svx-inflate-warm", daemon=True).start()
+        driver = threading.Thread(target=drive, name="svx-inflate-driver", daemon=True)
+        driver.start()
         try:
             while True:
-                pump(block=True)
-                if not inflight:
+                part = out_q.get()
+                if part is None:
                     break
-                head = inflight[0]
-                while not head["event"].query():               # keep launching while the oldest group is still on the device
-                    pump(block=False)
-                    time.sleep(0.0005)
-                inflight.popleft()
-                yield from finish_group(head)
+                if isinstance(part, BaseException):
+                    raise part
+                yield part
         finally:
             stop.set()
 
