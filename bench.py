@@ -172,8 +172,14 @@ def build_workload(args, rank, world, cores):
             k += 1
     if len(jobs) > 1:
         import multiprocessing as mp
-        with mp.get_context("fork").Pool(min(len(jobs), max(1, cores // world))) as pool:     # before the first HIP call
+        pool = mp.get_context("fork").Pool(min(len(jobs), max(1, cores // world)))     # before the first HIP call
+        try:
             made = pool.map(_simulate_contig, jobs, chunksize=1)
+        finally:
+            # close + join, not the context manager's terminate(): under rocprofv3 a forked worker inherits the tool's
+            # SIGTERM handler, which does not let it die, and the parent then waits for it for ever
+            pool.close()
+            pool.join()
     else:
         made = [_simulate_contig(j) for j in jobs]
     parts = [(j["name"], j["length"], t, g) for j, (t, g, _seg) in zip(jobs, made)]
