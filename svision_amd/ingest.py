@@ -224,6 +224,7 @@ class ChromosomeFeed:
                     spill.put((table, meta["spilled"]))
                 if getattr(self, "decoder", None) is not None:
                     self.decoder._mark("handed over %s (scan + slot writes)" % self.references[tid])
+                    self.decoder.first_handover.set()           # (the decoder holds its second launch back for this, ingest_gpu.py)
                 self._put((self.references[tid], sample, meta))
             while want and not self._stop:
                 self._emit_empty(want.pop(0))

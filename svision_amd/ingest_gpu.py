@@ -20,6 +20,7 @@ from .io.bam import AlignmentTable, read_bai_linear
 FIRST_GROUP_BYTES = 192 << 20            # the first launch is small: the pipeline starts after ~0.1 s
 STAGE_BYTES = 64 << 20                   # a pinned staging slot of the pipelined reader (ring of four)
 PIPE_GROUP_BYTES = 768 << 20             # parts_pipelined: ~30 k blocks per launch, three launches in flight on three streams
+LARGE_GROUP_BYTES = 2560 << 20           # parts_pipelined, from the third group on: ~95 k blocks, what the chip holds at once
 GROUP_BYTES = 24 << 30                   # later groups: as many blocks as possible per launch (a lane decodes one block in ~0.1 s
                                          # whatever the launch size; 24 GB compressed inflate to ~58 GB of HBM)
 
@@ -88,6 +89,8 @@ class DeviceDecoder:
         self.stats = {"read_s": 0.0, "h2d_inflate_s": 0.0, "walk_s": 0.0, "d2h_s": 0.0, "names_s": 0.0, "blocks": 0, "bytes_in": 0, "bytes_inflated": 0}
         import time
         self._t0, self.trace = time.perf_counter(), []          # (seconds since construction, what) of the first events (SVX_TIMING)
+        import threading
+        self.first_handover = threading.Event()                 # set by the consumer once the first chromosome's scan is through
 
     def _mark(self, what):
         import time
@@ -131,17 +134,25 @@ class DeviceDecoder:
         import time
         lib, dev = self.lib, self.device
         have = sorted((self.spans[t][0], t) for t in tids if t < len(self.spans) and self.spans[t] is not None)
-        groups, cur, cur_bytes, limit = [], [], 0, FIRST_GROUP_BYTES
+        # Group sizes: small, medium, then large.  A launch of the lane-per-block kernel takes 60-90 ms whether it holds 28 k
+        # or 98 k blocks (the blocks a chip holds at once), so once the pipeline behind has chromosomes to work on the launches
+        # are made as large as the chip; the first chromosomes and the last one travel in small groups (the wave-per-block
+        # kernel: ~3.5 ms per 1,000 blocks), the first to start the pipeline early, the last because everything waits for it.
+        def size_of(t):
+            return (self.spans[t][1] >> 16) - (self.spans[t][0] >> 16) + 65536
+        limits = [FIRST_GROUP_BYTES, PIPE_GROUP_BYTES]
+        groups, cur, cur_bytes = [], [], 0
         for _v, t in have:
-            lo, hi, _lin = self.spans[t]
-            nbytes = (hi >> 16) - (lo >> 16) + 65536
-            if cur and cur_bytes + nbytes > limit:
+            limit = limits[len(groups)] if len(groups) < len(limits) else LARGE_GROUP_BYTES
+            if cur and cur_bytes + size_of(t) > limit:
                 groups.append(cur)
-                cur, cur_bytes, limit = [], 0, PIPE_GROUP_BYTES
+                cur, cur_bytes = [], 0
             cur.append(t)
-            cur_bytes += nbytes
+            cur_bytes += size_of(t)
         if cur:
             groups.append(cur)
+        if groups and len(groups[-1]) > 1 and sum(size_of(t) for t in groups[-1]) > FIRST_GROUP_BYTES + size_of(groups[-1][-1]):
+            groups[-1:] = [groups[-1][:-1], groups[-1][-1:]]
         q = queue.Queue(maxsize=1)
         stop = threading.Event()
         # Staging: a ring of four pinned 64 MB slots.  A group's compressed bytes go to the device slot by slot -- read (8
@@ -328,6 +339,7 @@ class DeviceDecoder:
                     # device copies svx_cigar_scan keeps: own tensors (the pack goes away with this chromosome's read-back)
                     pending.append((ev, h_pack, offs, n, words, name_bytes, d_cigar, d_cig_off.clone(), d_pos.clone(), base, d_pack))
             self.stats["walk_s"] += time.perf_counter() - t0
+            yield None                                          # every chromosome's extraction is enqueued: the caller may launch the next group
             for ev, h_pack, offs, n, words, name_bytes, d_cigar, d_cig_off, d_pos, _base, _d_pack in pending:
                 t0 = time.perf_counter()
                 ev.synchronize()
@@ -338,13 +350,24 @@ class DeviceDecoder:
 
         th = threading.Thread(target=reader, name="svx-read", daemon=True)
         th.start()
-        streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+        # high priority: the ingest kernels and the CNN share the device and do not overlap; whatever the order, the device
+        # does the same work, but chromosomes that arrive early give the pipeline behind a backlog (and the per-chromosome
+        # kernels here are small: behind queued graph replays they would wait for tens of ms)
+        streams = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(depth)]
         inflight = collections.deque()
-        state = {"done": False, "k": 0}
+        state = {"done": False, "k": 0, "finished": 0, "hold_until": float("inf")}
 
         def pump(block):
             """Launch what the reader has ready, up to `depth` groups in flight; block only when nothing is in flight."""
             while not state["done"] and len(inflight) < depth:
+                # Nothing is launched behind the very first group until its chromosome is through (extracted here, scanned by the
+                # consumer; at most 0.15 s): kernels do not pre-empt each other, these steps are a few small kernels, and behind the
+                # second group's inflate launch they would wait 60-90 ms -- while the pipeline waits for exactly that chromosome.
+                if state["k"] == 1 and not (state["finished"] and self.first_handover.is_set()) and time.perf_counter() < state["hold_until"]:
+                    if inflight or not block:
+                        return                                  # (the caller goes on to finish the group in flight)
+                    time.sleep(0.0005)
+                    continue
                 try:
                     item = q.get(block=block and not inflight, timeout=None)
                 except queue.Empty:
@@ -356,6 +379,8 @@ class DeviceDecoder:
                     raise item
                 inflight.append(launch(item, streams[state["k"] % depth]))
                 state["k"] += 1
+                if state["k"] == 1:
+                    state["hold_until"] = time.perf_counter() + 0.15
 
         # The launches are driven from a thread of their own: the consumer of this generator does host work per chromosome
         # (QNAME ids, shared-memory copies, the upload for the scan: 3-80 ms) and a generator that launches only between two
@@ -378,13 +403,16 @@ class DeviceDecoder:
                     if not inflight:
                         break
                     head = inflight[0]
-                    while not head["event"].query():           # keep launching while the oldest group is still on the device
+                    while not head["event"].query():           # keep launching while the oldest group is still on the device ...
                         pump(block=False)
                         time.sleep(0.0005)
                     inflight.popleft()
                     for part in finish_group(head):
-                        if not put(part):
+                        if part is None:
+                            state["finished"] += 1              # (its extraction is enqueued: what is launched now runs behind it)
+                        elif not put(part):
                             return
+                        pump(block=False)                       # (a group of a dozen chromosomes takes tens of ms to finish)
                     self._mark("group %s finished" % head["group"][:2])
                 put(None)
             except BaseException as exc:                         # noqa: BLE001 -- re-raised in the consumer's thread
@@ -393,12 +421,12 @@ class DeviceDecoder:
         def warm():
             """The device buffers of the groups in flight, allocated once while the first read is still on its way (the caching
             allocator hands them out again: the first hipMalloc of a gigabyte costs tens of milliseconds, on the launch path)."""
-            big = max((sum((self.spans[t][1] >> 16) - (self.spans[t][0] >> 16) + 65536 for t in g) for g in groups), default=0)
-            held = []
-            for _ in range(min(depth, len(groups))):
-                held.append(torch.empty(big + (1 << 20), dtype=torch.uint8, device=dev))
-                held.append(torch.empty(3 * big + (1 << 20), dtype=torch.uint8, device=dev))
-            del held
+            for g in groups:                                   # in the order they will be asked for: compressed bytes, inflated bytes
+                nbytes = sum(size_of(t) for t in g)
+                if stop.is_set():
+                    break
+                for n in (nbytes + (1 << 20), 3 * nbytes + (1 << 20)):
+                    torch.empty(n, dtype=torch.uint8, device=dev)      # allocated and released at once: the block stays in the allocator's cache
             self._mark("warm: done")
 
         threading.Thread(target=warm, name="svx-inflate-warm", daemon=True).start()
