@@ -325,9 +325,11 @@ def main():
     dev_images = hot.device_images
     e2e_block = e2e_device = None
     if e2e is not None:
-        e2e_block = run_from_file(args, e2e, hot, run, fasta, opts, dev, sync_all, cores, world, workers, grouped, engine=os.environ.get("SVX_INGEST", "cpu"), keep=True)
-        # the same leg with the other ingest engine (BGZF inflate + record packing on the device), reported beside it
-        e2e_device = run_from_file(args, e2e, hot, run, fasta, opts, dev, sync_all, cores, world, workers, grouped, engine="gpu", keep=False)
+        e2e_block = run_from_file(args, e2e, hot, run, fasta, opts, dev, sync_all, cores, world, workers, grouped, engine=os.environ.get("SVX_INGEST", "auto"), keep=True)
+        # the same leg with the other ingest engine, reported beside it (default engine: BGZF inflate + record packing on the
+        # device; the other: libdeflate on the host's threads)
+        other = "cpu" if e2e_block["ingest_engine"] == "gpu" else "gpu"
+        e2e_device = run_from_file(args, e2e, hot, run, fasta, opts, dev, sync_all, cores, world, workers, grouped, engine=other, keep=False)
     executed = net.executed.cpu().numpy().astype(np.float64)         # [conv2, conv3, conv4, conv5 pixels, images]
     totals = torch.tensor([sites, images, dt, dev_ms, dev_images] + executed.tolist(), dtype=torch.float64, device=dev)
     if grouped:
@@ -405,7 +407,7 @@ def main():
         line["e2e"] = e2e_block
         if e2e_device is not None:
             e2e_device["ratio_to_resident"] = e2e_device["value"] / max(line["value"], 1e-9)
-            line["e2e_device_ingest"] = e2e_device
+            line["e2e_host_ingest" if e2e_device["ingest_engine"] == "cpu" else "e2e_device_ingest"] = e2e_device
     if rank == 0 and not args.no_calibration:
         line["roofline_kernels"] = kernel_calibration(hot, sample, net, dev, B * max(1, args.launch_batches), windows[0])
     hot.close()

@@ -73,8 +73,8 @@ def signature_partition(signatures, options):
 
 def span_position_distance_condensed(starts, ends, normalizer=1000):
     """Condensed pairwise matrix of span_position_distance (:132-141) in pdist order."""
-    s = np.asarray(starts, np.float64)
-    e = np.asarray(ends, np.float64)
+    s = np.ascontiguousarray(starts, np.float64)              # (columns of a 2-D array come in strided)
+    e = np.ascontiguousarray(ends, np.float64)
     if _COMPILED:                                             # the same IEEE operations pair by pair, as C loops (cluster_signatures.pxd)
         out = np.empty(len(s) * (len(s) - 1) // 2, np.float64)
         _condensed_loops(s, e, float(normalizer), out)

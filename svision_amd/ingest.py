@@ -99,12 +99,13 @@ class ChromosomeFeed:
                  engine=None, header_text=""):
         self.bam_path, self.fasta, self.options = bam_path, fasta, options
         self.header_text = header_text
-        # where the BGZF blocks are inflated: "cpu" = libdeflate on host threads (io.bam.BamStream, the default), "gpu" = on the
-        # device (ingest_gpu.DeviceDecoder: needs a .bai with its linear index; not with --hash / --graph).  The device
-        # kernels inflate 3-6x faster than a 16-CPU container, but their time adds to the CNN's on the one GPU and their
-        # host side (page cache -> pinned memory, per-chromosome hand-over) is bound by the same CPU quota: end to end the
-        # two engines are level on such a box (DESIGN.md section 5 "Device-side ingestion"), so the device engine is opt-in
-        self.engine = engine or os.environ.get("SVX_INGEST", "cpu")
+        # where the BGZF blocks are inflated: "gpu" = on the device (ingest_gpu.DeviceDecoder), "cpu" = libdeflate on host
+        # threads (io.bam.BamStream), "auto" (the default; SVX_INGEST overrides) = the device whenever it can: the file has a
+        # .bai with its linear index and the run needs no read bases (--hash / --graph).  On a 16-CPU GPU box the device engine
+        # takes 0.6 s for the 3.9 GB of the bench's 20-window file, the host engine 1.15 s (DESIGN.md section 5 "Device-side
+        # ingestion"); a file the device engine cannot take (CG-tag CIGARs, an index that does not match) falls back to the
+        # host engine chromosome by chromosome.
+        self.engine = engine or os.environ.get("SVX_INGEST", "auto")
         self.references, self.lengths = list(references), list(lengths)
         self.chroms = list(chroms)
         self.device, self.index, self.threads = device, index, threads
@@ -170,8 +171,8 @@ class ChromosomeFeed:
                 raise RuntimeError("ChromosomeFeed needs the GPU (svx_cigar_scan); there is no CPU fallback")
             engine = self.engine
             if engine == "auto":
-                engine = "cpu"
-            if engine == "gpu" and (self.index is None or self.with_seq):
+                engine = "gpu"
+            if engine == "gpu" and (self.index is None or self.with_seq or not str(self.device).startswith("cuda")):
                 engine = "cpu"
             self.stats["engine"] = engine
             stage_a = threading.Thread(target=self._decode, args=(engine, tids, decoded), name="svx-decode", daemon=True)

@@ -28,6 +28,8 @@ def test_condensed_distance_loops_equal_the_numpy_form_bit_for_bit():
         s = rng.integers(0, 250_000_000, n)
         e = s + rng.integers(0, 5, n) * rng.integers(0, 100_000, n)          # many zero spans and equal values
         cases.append((s.tolist(), e.tolist()))
+    two_d = np.sort(rng.integers(0, 1000, (40, 2)), axis=1).astype(np.float64)
+    cases.append((two_d[:, 0], two_d[:, 1]))                                 # strided views
     for starts, ends in cases:
         got = cs.span_position_distance_condensed(starts, ends)
         want = _numpy_form(starts, ends)
