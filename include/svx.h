@@ -260,14 +260,15 @@ void           svx_bam_close(void* handle);
 
 /* BGZF inflate on the device (svx_inflate.hip): every block of a launch decoded by one lane, all blocks in parallel.
  * Replaces the host-side DEFLATE decoding of htslib / pysam behind run_collection.py:23-26 where host cores are the
- * scarce resource.  d_comp: the compressed bytes as they sit in the file (4-byte aligned, readable up to the next
- * multiple of 4 behind the last payload); d_src_off / d_src_len [n]: byte offset in d_comp and size of every block's
+ * scarce resource.  d_comp: the compressed bytes as they sit in the file (16-byte aligned -- SVX_EINVAL otherwise --,
+ * readable up to the next multiple of 16 behind the last payload); d_src_off / d_src_len [n]: byte offset in d_comp and size of every block's
  * DEFLATE payload (behind the block header, in front of CRC32 + ISIZE); d_dst_off [n + 1]: running sum of the ISIZE
  * fields = where every block's bytes go in d_out; d_status [n]: 0 = the block inflated to exactly ISIZE bytes,
  * anything else = corrupt (the caller falls back to the host decoder). */
 int            svx_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len,
                                 const uint64_t* d_dst_off, uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, void* stream);
-/* the same contract, one WAVE per block (uniform control flow; scalar-issue bound: slower at >= 10^5 blocks, level below) */
+/* the same contract, one WAVE per block (uniform control flow; its time is proportional to the launch -- 17 ms per 5,120
+ * blocks -- where the lane kernel needs 60+ ms for one block as for 98 k: the faster one below ~20 k blocks per launch) */
 int            svx_bgzf_inflate_wave(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len,
                                      const uint64_t* d_dst_off, uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, void* stream);
 
