@@ -152,7 +152,22 @@ class ChromosomeFeed:
             if mode == "w+" and os.path.exists(path):
                 os.remove(path)
             return np.memmap(path, dtype=dtype, mode=mode, shape=(int(n),))
-        alloc.dir, alloc.arrays = d, arrays
+
+        def put(name, src):
+            """``alloc`` + copy in one step, through the file: a write() fills the slot's pages inside the kernel, where filling a
+            fresh mapping takes a page fault per 4 KB -- and a page fault waits for the process's mmap lock, which the first
+            hipMalloc / hipHostMalloc calls of a run (other threads: staging ring, device buffers) hold for milliseconds at a
+            time: the same 1 MB of copies took 15 ms per chromosome in a process's first run and 2 ms in its second."""
+            src = np.ascontiguousarray(src).reshape(-1)
+            arrays[name] = (src.dtype.str, int(src.size))
+            if src.size == 0:
+                return np.empty(0, src.dtype)
+            path = os.path.join(d, name + ".bin")
+            reuse = os.path.exists(path) and os.path.getsize(path) >= src.nbytes
+            with open(path, "r+b" if reuse else "wb") as f:
+                f.write(src.view(np.uint8))
+            return np.memmap(path, dtype=src.dtype, mode="r+", shape=(int(src.size),))
+        alloc.dir, alloc.arrays, alloc.put = d, arrays, put
         return alloc
 
     def _slot_free(self, d):
@@ -209,10 +224,7 @@ class ChromosomeFeed:
                         sample = Sample.from_device(table, self.fasta, self.options.min_sv_size, *arrays)
                 alloc = table._alloc
                 for name, arr in (("gaps", sample.gaps), ("gap_off", sample.gap_off), ("stats", sample.stats)):
-                    arr = np.ascontiguousarray(arr)
-                    out = alloc(name, arr.dtype, arr.size)
-                    if arr.size:
-                        out[:] = arr.reshape(-1)
+                    alloc.put(name, arr)
                 self.stats["upload_scan_s"] += time.perf_counter() - t0
                 self.stats["cigar_bytes"] += int(table.cigar.nbytes)
                 self.stats["records"] += len(table)

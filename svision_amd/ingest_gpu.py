@@ -302,42 +302,57 @@ class DeviceDecoder:
             d_raw, d_tab, stream = item["d_raw"], item["d_tab"], item["stream"]
             pending, row = [], 0
             t0 = time.perf_counter()
+            # Sizes first, then ONE device buffer and ONE pinned buffer per group for the packed arrays of all its chromosomes
+            # (and one device buffer for their CIGAR words): every first-time hipMalloc / hipHostMalloc of a run costs
+            # milliseconds during which the other threads' HIP calls -- and their page faults -- wait; per chromosome that
+            # was six of them.
+            plan, pack_at, word_at = [], 0, 0
+            for at, n_starts in zip(item["start_at"], item["n_starts"]):
+                c = counts[row:row + n_starts]
+                bad = c[:, 3] != 0
+                if bad.any():
+                    code = int(c[bad, 3][0])
+                    raise DeviceIngestError({1: "the linear index does not match the records", 2: "malformed BAM record", 3: "CG-tag CIGAR"}.get(code, "walk error %d" % code))
+                n, words, name_bytes = (int(v) for v in c[:, :3].sum(axis=0))
+                # [cig_off n+1][name_off n+1][tid n][pos n][l_seq n][flag n][mapq n][names]: everything the host wants
+                sect = [8 * (n + 1), 8 * (n + 1), 4 * n, 4 * n, 4 * n, 2 * n, n, name_bytes]
+                offs = np.zeros(len(sect) + 1, np.int64)
+                offs[1:] = np.cumsum([(v + 15) // 16 * 16 for v in sect])
+                size = (int(offs[-1]) + 16 + 255) // 256 * 256
+                plan.append((at, n_starts, row, n, words, name_bytes, offs, pack_at, size, word_at))
+                pack_at += size
+                word_at += (max(words, 1) + 63) // 64 * 64       # (svx_cigar_scan reads 16-byte quads: every chromosome starts aligned)
+                row += n_starts
+            base_all = torch.zeros((max(row, 1), 3), dtype=torch.int64, pin_memory=True)
+            for at, n_starts, r0, *_rest in plan:
+                base_all.numpy()[r0 + 1:r0 + n_starts] = np.cumsum(counts[r0:r0 + n_starts - 1, :3], axis=0)
             with torch.cuda.stream(stream):
                 st = kernels._stream_ptr(dev)
-                for at, n_starts in zip(item["start_at"], item["n_starts"]):
-                    c = counts[row:row + n_starts]
-                    row += n_starts
-                    bad = c[:, 3] != 0
-                    if bad.any():
-                        code = int(c[bad, 3][0])
-                        raise DeviceIngestError({1: "the linear index does not match the records", 2: "malformed BAM record", 3: "CG-tag CIGAR"}.get(code, "walk error %d" % code))
-                    n, words, name_bytes = (int(v) for v in c[:, :3].sum(axis=0))
-                    base = torch.zeros((n_starts, 3), dtype=torch.int64, pin_memory=True)
-                    base.numpy()[1:] = np.cumsum(c[:-1, :3], axis=0)
-                    d_base = base.to(dev, non_blocking=True)
-                    # one device buffer for everything the host wants: [cig_off n+1][name_off n+1][tid n][pos n][l_seq n][flag n][mapq n][names]
-                    sect = [8 * (n + 1), 8 * (n + 1), 4 * n, 4 * n, 4 * n, 2 * n, n, name_bytes]
-                    offs = np.zeros(len(sect) + 1, np.int64)
-                    offs[1:] = np.cumsum([(v + 15) // 16 * 16 for v in sect])
-                    d_pack = torch.empty(int(offs[-1]) + 16, dtype=torch.uint8, device=dev)
+                d_base_all = base_all.to(dev, non_blocking=True)
+                d_pack_all = torch.empty(max(pack_at, 256), dtype=torch.uint8, device=dev)
+                d_cigar_all = torch.empty(max(word_at, 64), dtype=torch.int32, device=dev)
+                h_pack_all = torch.empty(max(pack_at, 256), dtype=torch.uint8, pin_memory=True)
+                for at, n_starts, r0, n, words, name_bytes, offs, p0, size, w0 in plan:
+                    d_pack = d_pack_all[p0:p0 + size]
+                    d_base = d_base_all[r0:r0 + n_starts]
 
-                    def view(k, dtype, count):
+                    def view(k, dtype, count, d_pack=d_pack, offs=offs):
                         return d_pack[int(offs[k]):int(offs[k]) + count * torch.empty(0, dtype=dtype).element_size()].view(dtype)
                     d_cig_off, d_name_off = view(0, torch.int64, n + 1), view(1, torch.int64, n + 1)
                     d_tid, d_pos, d_lseq = view(2, torch.int32, n), view(3, torch.int32, n), view(4, torch.int32, n)
                     d_flag, d_mapq, d_names = view(5, torch.int16, n), view(6, torch.uint8, n), view(7, torch.uint8, max(name_bytes, 1))
-                    d_cigar = torch.empty(max(words, 1), dtype=torch.int32, device=dev)
+                    d_cigar = d_cigar_all[w0:w0 + max(words, 1)]
                     _lib.check(lib.svx_bam_walk_extract(d_raw.data_ptr(), d_tab[at:].data_ptr(), n_starts, d_base.data_ptr(), d_tid.data_ptr(),
                                                         d_pos.data_ptr(), d_flag.data_ptr(), d_mapq.data_ptr(), d_lseq.data_ptr(), d_cig_off.data_ptr(),
                                                         d_cigar.data_ptr(), d_name_off.data_ptr(), d_names.data_ptr(), st), "svx_bam_walk_extract")
                     d_cig_off[n:].fill_(words)
                     d_name_off[n:].fill_(name_bytes)
-                    h_pack = torch.empty(int(offs[-1]) + 16, dtype=torch.uint8, pin_memory=True)
+                    h_pack = h_pack_all[p0:p0 + size]
                     h_pack.copy_(d_pack, non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record()
-                    # device copies svx_cigar_scan keeps: own tensors (the pack goes away with this chromosome's read-back)
-                    pending.append((ev, h_pack, offs, n, words, name_bytes, d_cigar, d_cig_off.clone(), d_pos.clone(), base, d_pack))
+                    # device copies svx_cigar_scan keeps: own tensors (the pack goes away with this group's read-backs)
+                    pending.append((ev, h_pack, offs, n, words, name_bytes, d_cigar, d_cig_off.clone(), d_pos.clone(), base_all, d_pack))
             self.stats["walk_s"] += time.perf_counter() - t0
             yield None                                          # every chromosome's extraction is enqueued: the caller may launch the next group
             for ev, h_pack, offs, n, words, name_bytes, d_cigar, d_cig_off, d_pos, _base, _d_pack in pending:
@@ -456,6 +471,8 @@ class DeviceDecoder:
             alloc = self.alloc_for() if self.alloc_for is not None else (lambda _name, dtype, k: np.empty(k, dtype))
 
             def keep(name, dtype, src):
+                if hasattr(alloc, "put"):                       # a shared-memory slot: filled through the file (ingest._slot_alloc)
+                    return alloc.put(name, np.asarray(src, dtype))
                 out = alloc(name, dtype, src.size)
                 if src.size:
                     out[:] = src
@@ -469,10 +486,15 @@ class DeviceDecoder:
             uniq = np.empty(max(name_bytes, 1), np.uint8)
             ub = np.zeros(1, np.uint64)
             name_off_c = np.ascontiguousarray(name_off_h)
+            t1 = time.perf_counter()
+            self.stats["finish_copy_s"] = self.stats.get("finish_copy_s", 0.0) + (t1 - t0)
             n_unique = int(lib.svx_name_ids(names_h.ctypes.data, name_off_c.ctypes.data, n, name_id.ctypes.data, uniq.ctypes.data, ub.ctypes.data))
+            t2 = time.perf_counter()
+            self.stats["finish_ids_s"] = self.stats.get("finish_ids_s", 0.0) + (t2 - t1)
             blob = alloc("names", np.uint8, int(ub[0]))
             blob[:] = uniq[:int(ub[0])]
             name_list = blob.tobytes().decode().split("\n")[:-1] if n_unique else []
+            self.stats["finish_list_s"] = self.stats.get("finish_list_s", 0.0) + (time.perf_counter() - t2)
             self.stats["names_s"] += time.perf_counter() - t0
             self._mark("finish(): slot copies + QNAME ids %.1f ms" % ((time.perf_counter() - t0) * 1e3))
             table = AlignmentTable(self.references, self.lengths, tid_h, pos_h, flag_h, mapq_h, l_seq_h, name_id, name_list, np.empty(0, np.uint32),
@@ -606,9 +628,12 @@ class DeviceDecoder:
             uniq = np.empty(max(name_bytes, 1), np.uint8)
             ub = np.zeros(1, np.uint64)
             n_unique = int(lib.svx_name_ids(names_h.ctypes.data, name_off_h.ctypes.data, n, name_id.ctypes.data, uniq.ctypes.data, ub.ctypes.data))
+            t2 = time.perf_counter()
+            self.stats["finish_ids_s"] = self.stats.get("finish_ids_s", 0.0) + (t2 - t1)
             blob = alloc("names", np.uint8, int(ub[0]))
             blob[:] = uniq[:int(ub[0])]
             name_list = blob.tobytes().decode().split("\n")[:-1] if n_unique else []
+            self.stats["finish_list_s"] = self.stats.get("finish_list_s", 0.0) + (time.perf_counter() - t2)
             self.stats["names_s"] += time.perf_counter() - t2
             table = AlignmentTable(self.references, self.lengths, tid_h, pos_h, flag_h, mapq_h, l_seq_h, name_id, name_list, np.empty(0, np.uint32),
                                    cig_off_h, self.header_text)
