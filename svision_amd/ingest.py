@@ -154,19 +154,20 @@ class ChromosomeFeed:
             return np.memmap(path, dtype=dtype, mode=mode, shape=(int(n),))
 
         def put(name, src):
-            """``alloc`` + copy in one step, through the file: a write() fills the slot's pages inside the kernel, where filling a
-            fresh mapping takes a page fault per 4 KB -- and a page fault waits for the process's mmap lock, which the first
-            hipMalloc / hipHostMalloc calls of a run (other threads: staging ring, device buffers) hold for milliseconds at a
-            time: the same 1 MB of copies took 15 ms per chromosome in a process's first run and 2 ms in its second."""
+            """The device engine's way into a slot: the array is WRITTEN to the slot's file and the caller keeps using its own
+            copy -- no mapping is created in this process.  np.memmap here cost the first file-driven pass of a process two
+            stalls of 0.1-0.2 s: mmap() needs the address-space lock for writing, and while the process's first hipMalloc /
+            hipHostMalloc calls and the runtime's page pinning hold it, the caller -- the one thread every chromosome passes
+            through -- stood in mmap() (periodic stack dumps: numpy memmap.__new__, four in a row).  The helpers map the
+            files in their own processes, which have no HIP runtime."""
             src = np.ascontiguousarray(src).reshape(-1)
             arrays[name] = (src.dtype.str, int(src.size))
-            if src.size == 0:
-                return np.empty(0, src.dtype)
-            path = os.path.join(d, name + ".bin")
-            reuse = os.path.exists(path) and os.path.getsize(path) >= src.nbytes
-            with open(path, "r+b" if reuse else "wb") as f:
-                f.write(src.view(np.uint8))
-            return np.memmap(path, dtype=src.dtype, mode="r+", shape=(int(src.size),))
+            if src.size:
+                path = os.path.join(d, name + ".bin")
+                reuse = os.path.exists(path) and os.path.getsize(path) >= src.nbytes
+                with open(path, "r+b" if reuse else "wb") as f:
+                    f.write(src.view(np.uint8))
+            return src
         alloc.dir, alloc.arrays, alloc.put = d, arrays, put
         return alloc
 

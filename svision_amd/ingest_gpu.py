@@ -66,11 +66,17 @@ class LazyCigar:
 def spill_cigar(table):
     """Owner process, off the critical path: the device CIGAR words of a device-decoded table -> its shared-memory slot."""
     d_cigar, alloc, lazy = table._d_cigar, table._alloc, table.cigar
-    host = alloc("cigar", np.uint32, lazy.size)
-    if lazy.size:
-        torch.from_numpy(host.view(np.int32)).copy_(d_cigar[:lazy.size])
-        if hasattr(host, "flush"):
-            host.flush()
+    if hasattr(alloc, "put"):                                   # a shared-memory slot: read back into private memory, then written to the file
+        host = np.empty(lazy.size, np.uint32)
+        if lazy.size:
+            torch.from_numpy(host.view(np.int32)).copy_(d_cigar[:lazy.size])
+        alloc.put("cigar", host)
+    else:
+        host = alloc("cigar", np.uint32, lazy.size)
+        if lazy.size:
+            torch.from_numpy(host.view(np.int32)).copy_(d_cigar[:lazy.size])
+            if hasattr(host, "flush"):
+                host.flush()
     lazy.attach(host)
     if getattr(alloc, "dir", None) is not None:                # the flag the helper processes wait for (LazyCigar._get)
         with open(os.path.join(alloc.dir, "cigar.ready"), "w"):
@@ -470,9 +476,11 @@ class DeviceDecoder:
             t0 = time.perf_counter()
             alloc = self.alloc_for() if self.alloc_for is not None else (lambda _name, dtype, k: np.empty(k, dtype))
 
+            put = getattr(alloc, "put", None)                   # a shared-memory slot (ingest._slot_alloc): arrays are written to its files
+
             def keep(name, dtype, src):
-                if hasattr(alloc, "put"):                       # a shared-memory slot: filled through the file (ingest._slot_alloc)
-                    return alloc.put(name, np.asarray(src, dtype))
+                if put is not None:
+                    return put(name, np.asarray(src, dtype))        # (a view of the group's pinned read-back buffer, which lives as long as its views)
                 out = alloc(name, dtype, src.size)
                 if src.size:
                     out[:] = src
@@ -482,7 +490,7 @@ class DeviceDecoder:
             tid_h, pos_h, l_seq_h = keep("tid", np.int32, sect(2, np.int32, n)), keep("pos", np.int32, sect(3, np.int32, n)), keep("l_seq", np.int32, sect(4, np.int32, n))
             flag_h, mapq_h = keep("flag", np.uint16, sect(5, np.uint16, n)), keep("mapq", np.uint8, sect(6, np.uint8, n))
             names_h = np.ascontiguousarray(sect(7, np.uint8, name_bytes))
-            name_id = alloc("name_id", np.int32, n)
+            name_id = np.empty(n, np.int32) if put is not None else alloc("name_id", np.int32, n)
             uniq = np.empty(max(name_bytes, 1), np.uint8)
             ub = np.zeros(1, np.uint64)
             name_off_c = np.ascontiguousarray(name_off_h)
@@ -491,8 +499,12 @@ class DeviceDecoder:
             n_unique = int(lib.svx_name_ids(names_h.ctypes.data, name_off_c.ctypes.data, n, name_id.ctypes.data, uniq.ctypes.data, ub.ctypes.data))
             t2 = time.perf_counter()
             self.stats["finish_ids_s"] = self.stats.get("finish_ids_s", 0.0) + (t2 - t1)
-            blob = alloc("names", np.uint8, int(ub[0]))
-            blob[:] = uniq[:int(ub[0])]
+            if put is not None:
+                put("name_id", name_id)
+                blob = put("names", uniq[:int(ub[0])].copy())
+            else:
+                blob = alloc("names", np.uint8, int(ub[0]))
+                blob[:] = uniq[:int(ub[0])]
             name_list = blob.tobytes().decode().split("\n")[:-1] if n_unique else []
             self.stats["finish_list_s"] = self.stats.get("finish_list_s", 0.0) + (time.perf_counter() - t2)
             self.stats["names_s"] += time.perf_counter() - t0
@@ -628,12 +640,9 @@ class DeviceDecoder:
             uniq = np.empty(max(name_bytes, 1), np.uint8)
             ub = np.zeros(1, np.uint64)
             n_unique = int(lib.svx_name_ids(names_h.ctypes.data, name_off_h.ctypes.data, n, name_id.ctypes.data, uniq.ctypes.data, ub.ctypes.data))
-            t2 = time.perf_counter()
-            self.stats["finish_ids_s"] = self.stats.get("finish_ids_s", 0.0) + (t2 - t1)
             blob = alloc("names", np.uint8, int(ub[0]))
             blob[:] = uniq[:int(ub[0])]
             name_list = blob.tobytes().decode().split("\n")[:-1] if n_unique else []
-            self.stats["finish_list_s"] = self.stats.get("finish_list_s", 0.0) + (time.perf_counter() - t2)
             self.stats["names_s"] += time.perf_counter() - t2
             table = AlignmentTable(self.references, self.lengths, tid_h, pos_h, flag_h, mapq_h, l_seq_h, name_id, name_list, np.empty(0, np.uint32),
                                    cig_off_h, self.header_text)

@@ -26,3 +26,15 @@ for r in longs:
     c = collections.Counter()
     for n, d in ov: c[n] += d
     print("during the %.0f ms memcpy at -%.3f s: %d kernels, %.0f ms of kernel time:" % ((e - s) / 1e6, (t_end - s) / 1e9, len(ov), tot), c.most_common(5))
+# GPU idle gaps and long kernels in the last 2.5 s of the run (the two file-driven legs)
+ks = sorted(((int(k["Start_Timestamp"]), int(k["End_Timestamp"]), k["Kernel_Name"][:48]) for k in krows), key=lambda x: x[0])
+t_last = max(e for _s, e, _n in ks)
+ks = [k for k in ks if k[0] > t_last - 2.6e9]
+busy_until = ks[0][1]
+for s, e, n in ks:
+    if s - busy_until > 25e6:
+        print("GPU idle %.0f ms until -%.3f s (next kernel: %s)" % ((s - busy_until) / 1e6, (t_last - s) / 1e9, n))
+    busy_until = max(busy_until, e)
+for s, e, n in ks:
+    if e - s > 40e6:
+        print("kernel %.0f ms at -%.3f s: %s" % ((e - s) / 1e6, (t_last - s) / 1e9, n))
