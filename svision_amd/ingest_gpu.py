@@ -1,13 +1,15 @@
-"""Device-side BAM ingestion: the compressed file goes to the GPU as it is, BGZF blocks are inflated there
-(svx_bgzf_inflate, one lane per block), the records are located through the .bai linear index and their fixed fields,
-QNAMEs and CIGAR words are packed on the device (svx_bam_walk_*).  The packed CIGARs -- the input of svx_cigar_scan --
-never leave HBM; the host receives the small per-record arrays its collection step needs.
+"""Device-side BAM ingestion (the default engine, svision_amd.ingest.ChromosomeFeed): the compressed file goes to the GPU as
+it is -- through a ring of pinned 64 MB slots --, the BGZF blocks are inflated there (svx_bgzf_inflate: one lane per block,
+svx_bgzf_inflate_wave: one wave per block; kernels.inflate_kernel_for picks by launch size), the records are located through
+the .bai linear index and their fixed fields, QNAMEs and CIGAR words are packed on the device (svx_bam_walk_*).  The packed
+CIGARs -- the input of svx_cigar_scan -- never leave HBM; the host receives the small per-record arrays its collection step
+needs and hands them to the helper processes by WRITING them to shared-memory files (it never maps them: DESIGN.md section 5).
 
 Why: DEFLATE decoding is the cost of ingestion (a HiFi BAM inflates to ~22 KB per read, ~0.6 GB/s per host core), and the
 GPU boxes this was built on give a container the CPU time of 16 cores (svision_amd.ingest.effective_cpus): ~10 GB/s of
-inflated data, a quarter of what the device pipeline consumes.  The same data inflates at ~45 GB/s on the MI355X.
+inflated data, a quarter of what the device pipeline consumes.  The same data inflates at 55 GB/s on the MI355X.
 Replaces pysam's AlignmentFile.fetch (run_collection.py:23-26) like the host reader (io.bam.BamStream), which stays the
-engine for files without a linear index, for --hash / --graph (read bases wanted) and for CG-tag CIGARs.
+engine for files without a linear index, for --hash / --graph (read bases wanted), for CG-tag CIGARs and for SVX_INGEST=cpu.
 """
 import os
 
@@ -17,12 +19,11 @@ import torch
 from . import _lib, kernels
 from .io.bam import AlignmentTable, read_bai_linear
 
-FIRST_GROUP_BYTES = 192 << 20            # the first launch is small: the pipeline starts after ~0.1 s
+FIRST_GROUP_BYTES = 192 << 20            # the first launch is small (~7 k blocks: the wave-per-block kernel): the pipeline starts after ~0.1 s
 STAGE_BYTES = 64 << 20                   # a pinned staging slot of the pipelined reader (ring of four)
-PIPE_GROUP_BYTES = 768 << 20             # parts_pipelined: ~30 k blocks per launch, three launches in flight on three streams
+PIPE_GROUP_BYTES = 768 << 20             # parts_pipelined, second group: ~30 k blocks
 LARGE_GROUP_BYTES = 2560 << 20           # parts_pipelined, from the third group on: ~95 k blocks, what the chip holds at once
-GROUP_BYTES = 24 << 30                   # later groups: as many blocks as possible per launch (a lane decodes one block in ~0.1 s
-                                         # whatever the launch size; 24 GB compressed inflate to ~58 GB of HBM)
+GROUP_BYTES = 24 << 30                   # serial form (groups / decode_group): later groups as large as they come
 
 
 class DeviceIngestError(RuntimeError):
@@ -268,7 +269,7 @@ class DeviceDecoder:
                 q.put(exc)
 
         def launch(item, stream):
-            nb, nbytes = item["nb"], item["nbytes"]
+            nb = item["nb"]
             self._mark("launch %s: start" % item["group"][:2])
             with torch.cuda.stream(stream):
                 stream.wait_event(item["copied"])              # the last slot of the group's compressed bytes is on the device
