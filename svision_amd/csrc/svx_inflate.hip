@@ -167,7 +167,7 @@ __device__ __forceinline__ bool build(const uint8_t* lens, int n, Dec& d, Syms& 
     // decoded symbol).
     const uint4* lens16 = reinterpret_cast<const uint4*>(lens);
     const int chunks = (n + 15) >> 4;
-#pragma unroll 3
+#pragma unroll 1
     for (int q = 0; q < chunks; ++q) {
         const uint4 v = lens16[q];
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -194,7 +194,7 @@ __device__ __forceinline__ bool build(const uint8_t* lens, int n, Dec& d, Syms& 
         code <<= 1;
     }
     if (left < 0) return false;
-#pragma unroll 3
+#pragma unroll 1
     for (int q = 0; q < chunks; ++q) {
         const uint4 v = lens16[q];
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
