@@ -38,7 +38,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from svision_amd import dist as sdist, kernels, synth  # noqa: E402
+from svision_amd import build_host, dist as sdist, kernels, synth  # noqa: E402
 from svision_amd.io import bam  # noqa: E402
 from svision_amd.network.alexnet import AlexNet, checkpoint_shapes  # noqa: E402
 from svision_amd.pipeline import HelperPool, PooledHotPath  # noqa: E402
@@ -376,7 +376,7 @@ def main():
                    "rccl_world": world if grouped else 0, "dist_backend": (tdist.get_backend() if grouped else None),
                    "rank_mb": [round(v, 1) for v in getattr(args, "rank_mb", [])] or None,
                    "imbalance": (max(args.rank_mb) / (sum(args.rank_mb) / len(args.rank_mb)) if getattr(args, "rank_mb", None) else None),
-                   "host_workers_per_rank": workers, "host_cores": cores, "host_cpus_visible": visible_cpus, "streams": args.streams, "batches_per_launch": args.launch_batches,
+                   "host_workers_per_rank": workers, "host_modules_compiled": not build_host.compiled_state()[1], "host_cores": cores, "host_cpus_visible": visible_cpus, "streams": args.streams, "batches_per_launch": args.launch_batches,
                    "parallelism": "one process per GPU, chromosomes per rank, no data-path collective "
                                   "(score-range all_reduce + record gather once)"},
         "roofline": {"kernel": "device stage per batch of %d images (a graph replay carries --launch-batches of them): encode_conv1_kernel (rasterise + sparse conv1) + "

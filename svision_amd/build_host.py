@@ -35,6 +35,17 @@ def _source_hash(here, m):
     return h.hexdigest()
 
 
+def compiled_state(package="svision_amd"):
+    """-> (modules running compiled, modules running interpreted): which form of the host modules this process imports.
+    The command line logs it and bench.py reports it: without the build the same Python runs 2-4x slower, silently."""
+    import importlib
+    compiled, interpreted = [], []
+    for m in MODULES:
+        mod = importlib.import_module(package + "." + m[:-3].replace("/", "."))
+        (compiled if getattr(mod, "__file__", "").endswith(".so") else interpreted).append(m[:-3])
+    return compiled, interpreted
+
+
 def stale_modules(here=None):
     """-> [(module path relative to the package, [its extension files])] for every compiled host module whose ``.py``
     source is not the one it was compiled from.  Read-only (eight small files are hashed)."""

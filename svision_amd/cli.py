@@ -191,6 +191,10 @@ def run(options, sample=None, classifier=None):
             # from shared memory when the feed announces it
             from .pipeline import HelperPool
             pool = HelperPool(options.thread_num, options, fasta=fasta, want_tsv=True)
+        from .build_host import compiled_state
+        _compiled, _interp = compiled_state()
+        if _interp:
+            logging.warning("host modules running interpreted (2-4x slower collection and vote): %s -- build them with `python -m svision_amd.build_host`", ", ".join(_interp))
         _tick("header, FASTA index, fork helpers")
         # one process per GPU: every device tensor of this rank (scan buffers, weights, graphs) lives on its own GPU.
         # The process group comes up now (after the fork, before the first long phase), not when the first rank is done:

@@ -81,3 +81,8 @@ def test_a_changed_pxd_makes_every_extension_module_stale(tmp_path):
     with open(os.path.join(tmp_path, build_host.MODULES[2][:-3] + ".pxd"), "w") as f:
         f.write("cdef class X:\n    cdef public long a\n")
     assert len(build_host.stale_modules(str(tmp_path))) == len(build_host.MODULES)
+
+
+def test_compiled_state_lists_every_host_module_once():
+    compiled, interpreted = build_host.compiled_state()
+    assert sorted(compiled + interpreted) == sorted(m[:-3] for m in build_host.MODULES)
