@@ -194,3 +194,59 @@ def test_pipelined_device_decoder_equals_the_host_decoder(tmp_path):
             _same_table(tb, bam.read_bam(path, tids=[got[-1]]))
             assert np.array_equal(d_off.cpu().numpy(), tb.cig_off) and np.array_equal(d_pos.cpu().numpy(), tb.pos)
         assert got == tids
+
+
+def test_feed_falls_back_to_the_host_engine_where_the_device_engine_refuses(tmp_path, caplog):
+    """A record whose CIGAR sits in a CG:B,I tag (> 65535 operations) is something the device engine refuses (status 3 of
+    svx_bam_walk_count): the chromosomes before it come from the device engine, that chromosome and the rest from the host
+    engine, and the tables are what the host engine alone produces."""
+    import logging
+    from svision_amd import ingest, synth
+    cfg = synth.SimConfig(contigs=[("c1", 300_000), ("c2", 200_000), ("c3", 250_000)], coverage=6, read_len_mean=4000, read_len_sd=600,
+                          sv_spacing=9000, sv_min_gap=5000, sv_max=1000, seed=21)
+    table, genome, _ = synth.simulate(cfg)
+    # one very long CIGAR on c2 (tid 1)
+    n_ops = 66_000
+    ops = np.tile(np.array([7, 8], np.uint32), n_ops // 2)
+    words = (np.full(n_ops, 1, np.uint32) << 4) | ops                       # 1=1X1=1X...: 66,000 reference bases
+    first_c2 = int(np.flatnonzero(table.tid == 1)[0])
+    k, at = first_c2, int(table.cig_off[first_c2])
+
+    def ins(col, value):
+        return np.concatenate([col[:k], np.asarray([value], col.dtype), col[k:]])
+    n_cig = np.diff(np.asarray(table.cig_off))
+    cig_off = np.zeros(len(table) + 2, np.int64)
+    cig_off[1:] = np.cumsum(ins(n_cig, n_ops))
+    merged = bam.AlignmentTable(table.references, table.lengths, ins(table.tid, 1), ins(table.pos, int(table.pos[k])), ins(table.flag, 0),
+                                ins(table.mapq, 60), ins(table.l_seq, n_ops), ins(table.name_id, len(table.names)),
+                                list(table.names) + ["long_cigar_read"], np.concatenate([table.cigar[:at], words, table.cigar[at:]]), cig_off)
+    path = str(tmp_path / "cg.bam")
+    bam.write_bam(path, merged, index=True)
+    head = bam.read_bam_header(path)
+    fasta = bam.Fasta(sequences=genome)
+    opts = helpers.default_options(min_support=3, batch_size=64, bam_path=path)
+
+    def tables(engine):
+        feed = ingest.ChromosomeFeed(path, fasta, opts, head.references, head.references, head.lengths, device=torch.device("cuda:0"),
+                                     index=bam.find_index(path), threads=4, engine=engine)
+        out = {}
+        try:
+            for chrom in head.references:
+                _key, smp = feed.get(chrom, block=True)
+                t = smp.table
+                out[chrom] = (t.pos.copy(), t.flag.copy(), t.mapq.copy(), t.l_seq.copy(), np.asarray(t.cig_off).copy(), np.asarray(t.cigar).copy(),
+                              [t.names[i] for i in t.name_id], smp.stats.copy(), np.asarray(smp.gap_off).copy())
+                feed.release(chrom)
+        finally:
+            feed.close()
+        return out, dict(feed.stats)
+
+    with caplog.at_level(logging.WARNING):
+        got, stats = tables("gpu")
+    assert stats["engine"] == "gpu" and any("decoding the rest on the host" in r.getMessage() for r in caplog.records)
+    want, _ = tables("cpu")
+    assert list(got) == list(want) == ["c1", "c2", "c3"]
+    for chrom in want:
+        for a, b in zip(got[chrom], want[chrom]):
+            assert (a == b) if isinstance(a, list) else np.array_equal(a, b), chrom
+    assert "long_cigar_read" in got["c2"][6] and int(np.diff(got["c2"][4]).max()) == n_ops
