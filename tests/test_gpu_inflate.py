@@ -250,3 +250,38 @@ def test_feed_falls_back_to_the_host_engine_where_the_device_engine_refuses(tmp_
         for a, b in zip(got[chrom], want[chrom]):
             assert (a == b) if isinstance(a, list) else np.array_equal(a, b), chrom
     assert "long_cigar_read" in got["c2"][6] and int(np.diff(got["c2"][4]).max()) == n_ops
+
+
+def test_device_decoder_on_a_file_with_secondary_records_and_an_unmapped_tail(tmp_path):
+    """A coordinate-sorted file ends with its unmapped reads (tid -1, no CIGAR, behind the last reference's records) and holds
+    secondary records and records without a CIGAR: the device decoder's tables == the host decoder's, chromosome by chromosome
+    (the last chromosome's walk has to end where the unmapped reads begin)."""
+    from svision_amd import synth
+    import svision_amd.ingest_gpu as ig
+    cfg = synth.SimConfig(contigs=[("c1", 200_000), ("c2", 100_000), ("c3", 150_000)], coverage=10, read_len_mean=5000, read_len_sd=800,
+                          sv_spacing=6000, sv_min_gap=4000, sv_max=2000, seed=3)
+    t, _genome, _ = synth.simulate(cfg, with_genome=False)
+    extra = 7
+    flag = np.concatenate([t.flag, np.full(extra, 4, np.uint16)])
+    flag[[10, 20, 30]] |= 0x100
+    t2 = bam.AlignmentTable(t.references, t.lengths, np.concatenate([t.tid, np.full(extra, -1, np.int32)]),
+                            np.concatenate([t.pos, np.full(extra, -1, np.int32)]), flag, np.concatenate([t.mapq, np.zeros(extra, np.uint8)]),
+                            np.concatenate([t.l_seq, np.full(extra, 100, np.int32)]),
+                            np.concatenate([t.name_id, np.arange(len(t.names), len(t.names) + extra, dtype=np.int32)]),
+                            list(t.names) + ["unmapped%d" % i for i in range(extra)], t.cigar,
+                            np.concatenate([t.cig_off, np.full(extra, t.cig_off[-1], np.int64)]), "")
+    path = str(tmp_path / "u.bam")
+    bam.write_bam(path, t2, index=True)
+    head = bam.read_bam_header(path)
+    for first, later in ((1 << 10, 1 << 10), (1 << 40, 1 << 40)):
+        ig.FIRST_GROUP_BYTES, ig.PIPE_GROUP_BYTES = first, later
+        dec = ig.DeviceDecoder(path, bam.find_index(path), head.references, head.lengths, head.header_text, "cuda:0", threads=3)
+        assert dec.usable([0, 1, 2])
+        got = []
+        for finish, (_d_cigar, d_off, d_pos) in dec.parts_pipelined([0, 1, 2]):
+            tb = finish()
+            ig.spill_cigar(tb)
+            got.append(int(tb.tid[0]))
+            _same_table(tb, bam.read_bam(path, tids=[got[-1]]))
+            assert np.array_equal(d_off.cpu().numpy(), tb.cig_off) and np.array_equal(d_pos.cpu().numpy(), tb.pos)
+        assert got == [0, 1, 2]
