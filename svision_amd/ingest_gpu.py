@@ -22,7 +22,8 @@ from .io.bam import AlignmentTable, read_bai_linear
 FIRST_GROUP_BYTES = 192 << 20            # the first launch is small (~7 k blocks: the wave-per-block kernel): the pipeline starts after ~0.1 s
 STAGE_BYTES = 64 << 20                   # a pinned staging slot of the pipelined reader (ring of four)
 PIPE_GROUP_BYTES = 768 << 20             # parts_pipelined, second group: ~30 k blocks
-LARGE_GROUP_BYTES = 2560 << 20           # parts_pipelined, from the third group on: ~95 k blocks, what the chip holds at once
+LARGE_GROUP_BYTES = 2560 << 20           # parts_pipelined, from the third group on ...
+LARGE_GROUP_BLOCKS = 94_000              # ... but not more blocks than one round of the lane-per-block kernel holds (98,304)
 GROUP_BYTES = 24 << 30                   # serial form (groups / decode_group): later groups as large as they come
 
 
@@ -123,6 +124,23 @@ class DeviceDecoder:
             out.append(cur)
         return out
 
+    def _block_bytes(self, tid, sample=1 << 20):
+        """Mean size of a BGZF block in the file (a megabyte sampled at the start of reference ``tid``): the large groups are
+        cut to the number of blocks one round of the lane-per-block kernel holds, whatever the file's compression ratio."""
+        start = self.spans[tid][0] >> 16
+        n = int(min(sample, self.size - start))
+        if n <= 0:
+            return 28_000.0
+        buf = np.empty(n, np.uint8)
+        if self.lib.svx_read_range(self.path.encode(), start, n, buf.ctypes.data, 1) != 0:
+            return 28_000.0
+        cap = n // 28 + 16
+        so, co = np.empty(cap, np.uint64), np.empty(cap, np.uint64)
+        sl, isz = np.empty(cap, np.uint32), np.empty(cap, np.uint32)
+        used = np.zeros(1, np.uint64)
+        k = int(self.lib.svx_bgzf_index(buf.ctypes.data, n, start, cap, so.ctypes.data, sl.ctypes.data, isz.ctypes.data, co.ctypes.data, used.ctypes.data))
+        return float(used[0]) / k if k > 0 else 28_000.0
+
     def _pinned(self, n):
         if self.pinned is None or self.pinned.numel() < n:
             self.pinned = torch.empty(max(n, 64 << 20), dtype=torch.uint8, pin_memory=True)
@@ -148,9 +166,10 @@ class DeviceDecoder:
         def size_of(t):
             return (self.spans[t][1] >> 16) - (self.spans[t][0] >> 16) + 65536
         limits = [FIRST_GROUP_BYTES, PIPE_GROUP_BYTES]
+        large = min(LARGE_GROUP_BYTES, int(LARGE_GROUP_BLOCKS * self._block_bytes(have[0][1]))) if have else LARGE_GROUP_BYTES
         groups, cur, cur_bytes = [], [], 0
         for _v, t in have:
-            limit = limits[len(groups)] if len(groups) < len(limits) else LARGE_GROUP_BYTES
+            limit = limits[len(groups)] if len(groups) < len(limits) else large
             if cur and cur_bytes + size_of(t) > limit:
                 groups.append(cur)
                 cur, cur_bytes = [], 0
