@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SVX_VERSION 330            /* 0.2.1: + active-row masks out of svx_alexnet_active_sets, into svx_bias_relu_pool_lrn */
+#define SVX_VERSION 340            /* 0.2.1: + active-row masks out of svx_alexnet_active_sets, into svx_bias_relu_pool_lrn */
 
 #define SVX_OK            0
 #define SVX_EINVAL       (-1)      /* bad argument (null pointer, bad layout...) */
@@ -267,6 +267,14 @@ void           svx_bam_close(void* handle);
  * anything else = corrupt (the caller falls back to the host decoder). */
 int            svx_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len,
                                 const uint64_t* d_dst_off, uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, void* stream);
+/* svx_bgzf_inflate picks between two versions of the lane-per-block kernel by the size of the launch; by name:
+ * _lds: the lane's symbol tables in LDS (420 B per lane: 98,304 blocks on the chip at once; 64-74 ms per round),
+ * _private: the literal / length symbols in private memory (96 B of LDS per lane: 196,608 blocks at once; 68-125 ms),
+ * which takes the launches the first would need two rounds for. */
+int            svx_bgzf_inflate_lds(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len,
+                                    const uint64_t* d_dst_off, uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, void* stream);
+int            svx_bgzf_inflate_private(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len,
+                                        const uint64_t* d_dst_off, uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, void* stream);
 /* the same contract, one WAVE per block (uniform control flow; its time is proportional to the launch -- 17 ms per 5,120
  * blocks -- where the lane kernel needs 60+ ms for one block as for 98 k: the faster one below ~20 k blocks per launch) */
 int            svx_bgzf_inflate_wave(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len,

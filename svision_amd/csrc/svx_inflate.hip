@@ -21,12 +21,14 @@
 // Integer exact by construction: the result is the byte stream zlib / libdeflate produce (tests/test_gpu_inflate.py).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "../../include/svx.h"
 
 namespace {
 
 constexpr int LANES = 64;                 // one wave per workgroup: the LDS slice of a lane is indexed by its lane id
 constexpr int LIT_SYMS = 288, DIST_SYMS = 32, LANE_DWORDS = 9 + (LIT_SYMS + DIST_SYMS) / 4 + 16;     // 105 dwords = 420 B of LDS per lane
+constexpr int LANE_DWORDS_PRIV = DIST_SYMS / 4 + 16;        // 24 dwords = 96 B per lane when the literal / length symbols sit in private memory
 
 // (the tables of the RFC, kept for the compile-time check below)
 constexpr uint16_t LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
@@ -120,6 +122,16 @@ struct LitSyms {
     __device__ __forceinline__ int get(int i) const { return (int)lo[i] | (int)((hi[i >> 5] >> (i & 31)) & 1u) << 8; }
     __device__ __forceinline__ void clear() { for (int k = 0; k < 9; ++k) hi[k] = 0; }
     __device__ __forceinline__ void put(int i, int sym) { lo[i] = (uint8_t)sym; if (sym & 256) hi[i >> 5] |= 1u << (i & 31); }
+};
+// The same alphabet in the lane's PRIVATE memory (16-bit entries): the LDS slice shrinks to the distance symbols and the
+// bases -- 96 bytes per lane, twelve one-wave workgroups per CU instead of six.  A wave is slower (a private load is a trip
+// to L1 / L2 where the LDS read took ~100 cycles: 68 ms per block instead of 64), but 196,608 blocks are in flight at
+// once instead of 98,304: the variant for launches that would need a second round of the LDS version.
+struct PrivSyms {
+    uint16_t* v;                          // [288]
+    __device__ __forceinline__ int get(int i) const { return (int)v[i]; }
+    __device__ __forceinline__ void clear() {}
+    __device__ __forceinline__ void put(int i, int sym) { v[i] = (uint16_t)sym; }
 };
 struct ByteSyms {
     uint8_t* lo;
@@ -267,22 +279,31 @@ struct MatchCopy {
     }
 };
 
+template <bool PRIVATE_SYMS> struct LitStore;
+template <> struct LitStore<false> { static __device__ __forceinline__ LitSyms make(uint32_t* mine, uint16_t*) { return LitSyms{reinterpret_cast<uint8_t*>(mine + 9), mine}; } };
+template <> struct LitStore<true> { static __device__ __forceinline__ PrivSyms make(uint32_t*, uint16_t* priv) { return PrivSyms{priv}; } };
+template <bool PRIVATE_SYMS>
+__device__ __forceinline__ auto make_lit_syms(uint32_t* mine, uint16_t* priv) { return LitStore<PRIVATE_SYMS>::make(mine, priv); }
+
 // status per block: 0 ok, else the reason
 enum { INF_OK = 0, INF_BAD_TYPE = 1, INF_BAD_STORED = 2, INF_BAD_TABLE = 3, INF_BAD_CODE = 4, INF_OUT_OVERRUN = 5, INF_IN_OVERRUN = 6, INF_SHORT = 7, INF_BAD_DIST = 8 };
 enum { ST_HEADER = 0, ST_SYMBOLS = 1, ST_DONE = 2 };
 
+template <bool PRIVATE_SYMS>
 __global__ __launch_bounds__(LANES)
 void bgzf_inflate_kernel(const uint8_t* __restrict__ comp, const uint64_t* __restrict__ src_off, const uint32_t* __restrict__ src_len,
                          const uint64_t* __restrict__ dst_off, uint32_t n_blocks, uint8_t* out, uint32_t* __restrict__ status)
 {
-    __shared__ uint32_t lds[LANES * LANE_DWORDS];
+    constexpr int DW = PRIVATE_SYMS ? LANE_DWORDS_PRIV : LANE_DWORDS;
+    __shared__ uint32_t lds[LANES * DW];
     const uint32_t b = blockIdx.x * LANES + threadIdx.x;
     if (b >= n_blocks) return;
-    uint32_t* mine = lds + threadIdx.x * LANE_DWORDS;         // [9 mask dwords][288 literal bytes][32 distance bytes][2 x 16 bases]
-    LitSyms lit_syms{reinterpret_cast<uint8_t*>(mine + 9), mine};
-    ByteSyms dist_syms{reinterpret_cast<uint8_t*>(mine + 9) + LIT_SYMS};
+    uint32_t* mine = lds + threadIdx.x * DW;                  // [9 mask dwords][288 literal bytes][32 distance bytes][2 x 16 bases], or the last two only
+    uint16_t lit_private[PRIVATE_SYMS ? LIT_SYMS : 1];
+    typename std::conditional<PRIVATE_SYMS, PrivSyms, LitSyms>::type lit_syms = make_lit_syms<PRIVATE_SYMS>(mine, lit_private);
+    ByteSyms dist_syms{PRIVATE_SYMS ? reinterpret_cast<uint8_t*>(mine) : reinterpret_cast<uint8_t*>(mine + 9) + LIT_SYMS};
     Dec lc, dc, cc;
-    lc.base = reinterpret_cast<int16_t*>(mine + 9 + (LIT_SYMS + DIST_SYMS) / 4);
+    lc.base = reinterpret_cast<int16_t*>(PRIVATE_SYMS ? mine + DIST_SYMS / 4 : mine + 9 + (LIT_SYMS + DIST_SYMS) / 4);
     dc.base = lc.base + 16;
     cc.base = dc.base;                                          // (the code-length code borrows the distance slices)
     BitReader br;
@@ -666,15 +687,40 @@ void bgzf_inflate_wave_kernel(const uint8_t* __restrict__ comp, const uint64_t* 
 //   d_src_len   [n] payload bytes (BSIZE - xlen - 19)
 //   d_dst_off   [n + 1] byte offset in d_out of every block's inflated bytes: the running sum of the ISIZE fields
 //   d_status    [n] 0 = block decoded to exactly its ISIZE bytes; anything else: corrupt block (the host falls back)
-extern "C" int svx_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len, const uint64_t* d_dst_off,
-                                uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, void* stream)
+namespace {
+constexpr uint32_t ONE_ROUND_BLOCKS = 6u * 256u * LANES;       // the blocks the LDS version holds at once: six one-wave workgroups on each of 256 CUs
+template <bool PRIVATE_SYMS>
+int launch_lanes(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len, const uint64_t* d_dst_off,
+                 uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, void* stream)
 {
     if (n_blocks == 0) return SVX_OK;
     if (!d_comp || !d_src_off || !d_src_len || !d_dst_off || !d_out || !d_status) return SVX_EINVAL;
     if (reinterpret_cast<uintptr_t>(d_comp) & 15u) return SVX_EINVAL;
-    hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((n_blocks + LANES - 1) / LANES), dim3(LANES), 0, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(bgzf_inflate_kernel<PRIVATE_SYMS>, dim3((n_blocks + LANES - 1) / LANES), dim3(LANES), 0, static_cast<hipStream_t>(stream),
                        d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, d_out, d_status);
     return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
+}
+}  // namespace
+
+// A launch of more blocks than the LDS version holds at once would take it two rounds (98 k blocks: 74 ms, 113 k: 135 ms);
+// the private-memory version holds twice as many (113 k: 94 ms, 170 k: 125 ms against 146) and takes launches of that size.
+extern "C" int svx_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len, const uint64_t* d_dst_off,
+                                uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, void* stream)
+{
+    return n_blocks > ONE_ROUND_BLOCKS ? launch_lanes<true>(d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, d_out, d_status, stream)
+                                       : launch_lanes<false>(d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, d_out, d_status, stream);
+}
+
+// (the two versions by name: tests and measurements)
+extern "C" int svx_bgzf_inflate_lds(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len, const uint64_t* d_dst_off,
+                                    uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, void* stream)
+{
+    return launch_lanes<false>(d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, d_out, d_status, stream);
+}
+extern "C" int svx_bgzf_inflate_private(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len, const uint64_t* d_dst_off,
+                                        uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, void* stream)
+{
+    return launch_lanes<true>(d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, d_out, d_status, stream);
 }
 
 // The same contract with the wave-per-block kernel (uniform control flow: bit buffer and table walk on the scalar unit, the

@@ -7,7 +7,7 @@ needs and hands them to the helper processes by WRITING them to shared-memory fi
 
 Why: DEFLATE decoding is the cost of ingestion (a HiFi BAM inflates to ~22 KB per read, ~0.6 GB/s per host core), and the
 GPU boxes this was built on give a container the CPU time of 16 cores (svision_amd.ingest.effective_cpus): ~10 GB/s of
-inflated data, a quarter of what the device pipeline consumes.  The same data inflates at 55-76 GB/s on the MI355X.
+inflated data, a quarter of what the device pipeline consumes.  The same data inflates at 75-90 GB/s on the MI355X.
 Replaces pysam's AlignmentFile.fetch (run_collection.py:23-26) like the host reader (io.bam.BamStream), which stays the
 engine for files without a linear index, for --hash / --graph (read bases wanted), for CG-tag CIGARs and for SVX_INGEST=cpu.
 """

@@ -412,8 +412,14 @@ def bgzf_inflate(d_comp, src_off, src_len, isize, wave=None):
         d_src = torch.from_numpy(np.ascontiguousarray(src_off, np.uint64).view(np.int64)).to(dev)
         d_len = torch.from_numpy(np.ascontiguousarray(src_len, np.uint32).view(np.int32)).to(dev)
         d_dst = torch.from_numpy(dst.view(np.int64)).to(dev)
-        # the two implementations of one contract: wave True / False picks one, None the faster one for this launch size
-        fn = inflate_kernel_for(lib, n) if wave is None else (lib.svx_bgzf_inflate_wave if wave else lib.svx_bgzf_inflate)
+        # the implementations of one contract: wave None picks the fastest for this launch size, True / False the wave- / the
+        # lane-per-block kernel, "lds" / "private" one version of the latter by name
+        if wave is None:
+            fn = inflate_kernel_for(lib, n)
+        elif isinstance(wave, str):
+            fn = {"lds": lib.svx_bgzf_inflate_lds, "private": lib.svx_bgzf_inflate_private, "wave": lib.svx_bgzf_inflate_wave}[wave]
+        else:
+            fn = lib.svx_bgzf_inflate_wave if wave else lib.svx_bgzf_inflate
         rc = fn(d_comp.data_ptr(), d_src.data_ptr(), d_len.data_ptr(), d_dst.data_ptr(), n, d_out.data_ptr(), d_status.data_ptr(), _stream_ptr(dev))
         _lib.check(rc, "svx_bgzf_inflate")
     return d_out[:total], d_status[:n]

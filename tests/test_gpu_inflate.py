@@ -32,7 +32,7 @@ def _inflate_on_device(raw, wave=False):
     return out.cpu().numpy().tobytes(), status.cpu().numpy()
 
 
-@pytest.mark.parametrize("wave", [False, True])
+@pytest.mark.parametrize("wave", ["lds", "private", "wave"])
 def test_every_block_type_and_match_shape(wave):
     rng = np.random.default_rng(3)
     text = (b"ACGTTGCA" * 40 + bytes(rng.integers(0, 256, 300, dtype=np.uint8))) * 20
@@ -54,7 +54,7 @@ def test_every_block_type_and_match_shape(wave):
     assert got == b"".join(want)
 
 
-@pytest.mark.parametrize("wave", [False, True])
+@pytest.mark.parametrize("wave", ["lds", "private", "wave"])
 def test_golden_and_synthetic_bams_inflate_like_zlib(tmp_path, wave):
     from svision_amd import synth
     paths = [os.path.join(helpers.GOLDEN, n) for n in ("collect_small.bam", "ont_small.bam", "hash_collect.bam")]
@@ -69,7 +69,7 @@ def test_golden_and_synthetic_bams_inflate_like_zlib(tmp_path, wave):
         assert got == bam.bgzf_decompress(raw), path
 
 
-@pytest.mark.parametrize("wave", [False, True])
+@pytest.mark.parametrize("wave", ["lds", "private", "wave"])
 def test_damaged_blocks_are_flagged(wave):
     rng = np.random.default_rng(5)
     good = _block(bytes(rng.integers(65, 70, 50000, dtype=np.uint8)))

@@ -11,7 +11,7 @@ for k in (1, 2, 3, 4, 6, 8):
     best = 1e9
     for rep in range(2):
         torch.cuda.synchronize(); t = time.time()
-        out, status = kernels.bgzf_inflate(d, s, l, z, wave=False)
+        out, status = kernels.bgzf_inflate(d, s, l, z, wave=(sys.argv[1] if len(sys.argv) > 1 else False))
         torch.cuda.synchronize(); best = min(best, time.time() - t)
     print("x%d: %6d blocks %5d waves: %.1f ms = %.1f GB/s" % (k, len(z), (len(z) + 63) // 64, best * 1e3, out.numel() / best / 1e9), flush=True)
     del out
