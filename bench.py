@@ -261,6 +261,12 @@ def main():
     rank, world = sdist.init_from_env()
     sample = Sample.from_table(table, fasta, opts.min_sv_size, device=dev)
     pool.attach_scan(sample)
+    if e2e is not None:
+        # The file-inclusive legs run with a warm device allocator, as the resident leg runs after --warmup steps: the first large
+        # hipMalloc of a process on a box whose previous process has just exited costs 0.15-0.35 s (nothing else in the process
+        # gets a HIP call through meanwhile); one block of the size the legs' buffers add up to is allocated here and stays in
+        # the caching allocator, which cuts the legs' buffers out of it.
+        torch.empty(min(24 << 30, 6 * int(e2e["bytes"])), dtype=torch.uint8, device=dev)
     net = AlexNet(random_weights(0), device=dev)
     net.executed = torch.zeros(5, dtype=torch.int64, device=dev)     # executed conv pixels per layer + images, summed on the device
     hot = PooledHotPath(sample, opts, net, device=dev, n_streams=args.streams, max_inflight=args.inflight, launch_batches=args.launch_batches, pool=pool)

@@ -460,9 +460,12 @@ class DeviceDecoder:
                 put(exc)
 
         def warm():
-            """The device buffers of the groups in flight, allocated once while the first read is still on its way (the caching
-            allocator hands them out again: the first hipMalloc of a gigabyte costs tens of milliseconds, on the launch path)."""
-            for g in groups:                                   # in the order they will be asked for: compressed bytes, inflated bytes
+            """The device buffers of the first two groups, allocated while the first read is still on its way (the caching allocator
+            hands them out again): their hipMalloc calls would sit on the path to the first chromosome.  Only those: on some
+            boxes a first hipMalloc costs 15 ms per GB instead of 0.2 -- 0.3 s for the 22 GB of all groups, during which no
+            other HIP call of the process returns -- and the large groups' buffers are better allocated when their turn comes,
+            next to device work that is already queued."""
+            for g in groups[:2]:                               # in the order they will be asked for: compressed bytes, inflated bytes
                 nbytes = sum(size_of(t) for t in g)
                 if stop.is_set():
                     break
