@@ -317,16 +317,25 @@ class ChromosomeFeed:
                     host_parts(tids)
                 else:
                     order = [t for _v, t in sorted((dec.spans[t][0], t) for t in tids if t < len(dec.spans) and dec.spans[t] is not None)]
-                    done = 0
-                    try:
-                        for part in dec.parts_pipelined(tids):
-                            if not put(part):
-                                return
-                            done += 1
-                    except DeviceIngestError as exc:           # CG-tag CIGARs, an index that does not fit: the host reader takes over
-                        import logging
-                        logging.warning("device ingestion failed at reference %s (%s): decoding the rest on the host", order[done] if done < len(order) else "-", exc)
-                        host_parts(order[done:])
+                    import logging
+                    refusals = 0
+                    while order:
+                        done = 0
+                        try:
+                            for part in dec.parts_pipelined(order):
+                                if not put(part):
+                                    return
+                                done += 1
+                            break
+                        except DeviceIngestError as exc:
+                            # CG-tag CIGARs, an index that does not fit, a corrupt block: the host reader takes that reference
+                            # and the device engine goes on behind it -- three times; then the host reader takes the rest
+                            refusals += 1
+                            rest = order[done:] if refusals >= 3 else order[done:done + 1]
+                            logging.warning("device ingestion failed at reference %s (%s): decoding %s on the host", self.references[order[done]], exc,
+                                            "the rest" if len(rest) > 1 or refusals >= 3 else "it")
+                            host_parts(rest)
+                            order = order[done + len(rest):]
             else:
                 host_parts(tids)
             put(None)
