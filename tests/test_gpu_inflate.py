@@ -234,6 +234,10 @@ def test_feed_falls_back_to_the_host_engine_where_the_device_engine_refuses(tmp_
             for chrom in head.references:
                 _key, smp = feed.get(chrom, block=True)
                 t = smp.table
+                import time
+                t_end = time.time() + 30                      # a device-decoded table's CIGAR words reach the host a little later (the spill)
+                while getattr(t.cigar, "_arr", 0) is None and time.time() < t_end:
+                    time.sleep(0.005)
                 out[chrom] = (t.pos.copy(), t.flag.copy(), t.mapq.copy(), t.l_seq.copy(), np.asarray(t.cig_off).copy(), np.asarray(t.cigar).copy(),
                               [t.names[i] for i in t.name_id], smp.stats.copy(), np.asarray(smp.gap_off).copy())
                 feed.release(chrom)
