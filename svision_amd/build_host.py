@@ -86,8 +86,14 @@ class _SourceFirst:
 
 
 def guard_imports(package="svision_amd", here=None, log=None):
-    """Called on package import: stale extension modules are bypassed (their sources run interpreted) and reported."""
+    """Called on package import: stale extension modules are bypassed (their sources run interpreted) and reported.
+    ``SVX_HOST_INTERPRETED=1`` bypasses ALL of them: the same sources as plain Python (tests/test_host_typed.py runs the
+    golden collection and vote that way -- the form a machine without the build executes)."""
     here = here or os.path.dirname(os.path.abspath(__file__))
+    if os.environ.get("SVX_HOST_INTERPRETED"):
+        names = {package + "." + m[:-3].replace("/", "."): os.path.join(here, m) for m in MODULES}
+        sys.meta_path.insert(0, _SourceFirst(names))
+        return sorted(names)
     stale = stale_modules(here)
     if not stale:
         return []

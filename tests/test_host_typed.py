@@ -74,3 +74,22 @@ def test_collect_parts_hands_whole_clusters_on_and_drops_a_failing_window(monkey
     parts = []
     lines, ok = pipeline._collect_parts(sample, opts, "chrA", 0, 150_000, parts.append, granule=8)
     assert (lines, ok) == ([], False) and parts                   # parts left before the failure: the owner drops them
+
+
+def test_the_same_sources_interpreted_reproduce_the_golden_fixtures():
+    """The host modules are compiled with static types from sources that must stay plain Python: with SVX_HOST_INTERPRETED=1
+    every one of them is imported from its .py (what a machine without the build runs) and the reference-generated collection,
+    fuzz, duplicate-record and vote fixtures must come out the same."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import svision_amd.collection.classes as c, svision_amd.network.genotype as g, sys; "
+            "assert c.__file__.endswith('.py') and g.__file__.endswith('.py'), (c.__file__, g.__file__); "
+            "import pytest; sys.exit(pytest.main(['-x', '-q', '-m', 'not gpu', '-p', 'no:cacheprovider', "
+            "'tests/test_collection_golden.py', 'tests/test_fuzz_golden.py', 'tests/test_dup_golden.py', 'tests/test_boundary_golden.py', "
+            "'tests/test_predict_golden.py']))")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=1500,
+                       env=dict(os.environ, SVX_HOST_INTERPRETED="1", PYTHONPATH=root))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
