@@ -93,3 +93,35 @@ def test_the_same_sources_interpreted_reproduce_the_golden_fixtures():
                        env=dict(os.environ, SVX_HOST_INTERPRETED="1", PYTHONPATH=root))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_window_vote_fed_in_chunks_equals_the_vote_in_one_go(oracle_lib):
+    """pipeline.WindowVote: the predictions of a window arrive launch by launch; any chunking gives the vote of the whole."""
+    from svision_amd import pipeline
+    from tests import helpers
+    sample = helpers.golden_sample(50)
+    opts = helpers.default_options(min_support=3, batch_size=64, bam_path="<resident>")
+    rng = np.random.default_rng(11)
+    for chrom, start, end in (("chrA", 0, 150_000), ("chrA", 150_000, 300_000), ("chrB", 0, 200_000)):
+        lines = pipeline._collect_lines(sample, opts, chrom, start, end)
+        assert len(lines) > 40
+        probs = rng.random((len(lines), 5)).astype(np.float32)
+        probs /= probs.sum(1, keepdims=True)
+        classes = probs.argmax(1).astype(np.int64)
+        want = pipeline._vote(sample, opts, chrom, lines, classes, probs, start, end)
+        for sizes in ([1] * len(lines), [7, 64, 1, 256], [len(lines)]):
+            vote = pipeline.WindowVote(sample, opts, chrom, lines, start, end)
+            at, k = 0, 0
+            while at < len(lines):
+                n = min(sizes[k % len(sizes)], len(lines) - at)
+                vote.feed(classes[at:at + n], probs[at:at + n])
+                vote.feed(classes[:0], probs[:0])                 # an empty chunk changes nothing
+                at += n
+                k += 1
+            assert vote.finish() == want
+    empty = pipeline.WindowVote(sample, opts, "chrA", [], 0, 10)
+    assert empty.finish() == ("", "", 0, None, None)
+    short = pipeline.WindowVote(sample, opts, "chrA", lines[:10], 0, 150_000)
+    short.feed(classes[:4], probs[:4])
+    with pytest.raises(RuntimeError):
+        short.finish()                                            # closed before all predictions arrived
