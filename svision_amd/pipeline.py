@@ -515,6 +515,53 @@ class HelperPool:
             self._scan_dir = None
 
 
+class ImageQueue:
+    """The images of all windows that wait for the device, in arrival order: the helpers' parts go in (``add``), launch groups
+    of any size come out (``take``) together with where every image belongs -- (window id, offset in the window, offset in the
+    group, count) -- so that the predictions find their way back to the windows' votes."""
+
+    def __init__(self):
+        self.parts = collections.deque()      # [wid, offset in the window, records, arrival time]
+        self.images = 0
+        self.seen = {}                        # wid -> images of the window queued so far
+
+    def add(self, wid, records, now=0.0):
+        n = int(records.shape[0])
+        if n:
+            self.parts.append([wid, self.seen.get(wid, 0), records, now])
+            self.seen[wid] = self.seen.get(wid, 0) + n
+            self.images += n
+
+    def oldest(self):
+        return self.parts[0][3] if self.parts else None
+
+    def take(self, n):
+        """The first ``n`` queued images -> (records [n, 12], [(wid, window offset, group offset, count)])."""
+        if n > self.images or n <= 0:
+            raise ValueError("ImageQueue.take(%d) with %d images queued" % (n, self.images))
+        recs, mapping, off = [], [], 0
+        while off < n:
+            part = self.parts[0]
+            k = min(n - off, int(part[2].shape[0]))
+            recs.append(part[2][:k])
+            mapping.append((part[0], part[1], off, k))
+            off += k
+            if k == part[2].shape[0]:
+                self.parts.popleft()
+            else:
+                part[1] += k
+                part[2] = part[2][k:]
+        self.images -= n
+        return (recs[0] if len(recs) == 1 else np.concatenate(recs)), mapping
+
+    def drop(self, wid):
+        """Forget what is queued of a window (its collection failed after parts had left)."""
+        keep = collections.deque(p for p in self.parts if p[0] != wid)
+        self.images -= sum(int(p[2].shape[0]) for p in self.parts if p[0] == wid)
+        self.parts = keep
+        self.seen.pop(wid, None)
+
+
 class PooledHotPath(HotPath):
     """Owner process = device feeder; the helpers of a :class:`HelperPool` do the Python glue."""
 
@@ -562,8 +609,7 @@ class PooledHotPath(HotPath):
         idle = list(range(len(self.conns)))
         busy = {}                     # conn index -> wid
         wins = {}                     # wid -> state of a window whose predictions are not complete yet
-        pending = collections.deque()   # [wid, offset in the window, records] not launched yet, arrival order
-        pending_images = 0
+        pending = ImageQueue()        # the parts not launched yet
         inflight = collections.deque()  # (launch group as a WindowResult, [(wid, window offset, group offset, count)])
         inflight_images = 0
         collecting = 0                # windows sent to a helper whose last part has not arrived
@@ -584,23 +630,9 @@ class PooledHotPath(HotPath):
 
         def take(n):
             """The first ``n`` pending images as one launch group."""
-            nonlocal pending_images
-            recs, mapping, off = [], [], 0
-            while off < n:
-                seg = pending[0]
-                k = min(n - off, int(seg[2].shape[0]))
-                recs.append(seg[2][:k])
-                mapping.append((seg[0], seg[1], off, k))
-                off += k
-                if k == seg[2].shape[0]:
-                    pending.popleft()
-                else:
-                    seg[1] += k
-                    seg[2] = seg[2][k:]
-            pending_images -= n
+            records, mapping = pending.take(n)
             group = WindowResult()
-            group.records = recs[0] if len(recs) == 1 else np.concatenate(recs)
-            group.n_images, group.lines, group.packed = n, None, None
+            group.records, group.n_images, group.lines, group.packed = records, n, None, None
             return group, mapping
 
         def forward(wid):
@@ -653,20 +685,20 @@ class PooledHotPath(HotPath):
                     lap("scan.apply", t_s)
                 self.conns[ci].send(("win", nxt, key, chrom, start, end, scan))
                 busy[ci] = nxt
-                wins[nxt] = {"ci": ci, "total": None, "got": 0, "seen": 0, "chunks": []}
+                wins[nxt] = {"ci": ci, "total": None, "got": 0, "chunks": []}
                 collecting += 1
                 nxt += 1
             t = lap("scan+send", t)
-            while pending_images and inflight_images < cap_images:
+            while pending.images and inflight_images < cap_images:
                 room = cap_images - inflight_images
-                if pending_images >= granule:
+                if pending.images >= granule:
                     # small groups: a window's predictions return as soon as its own launches are done (and, when nothing
                     # is being collected any more, launch by launch: the last vote is what the job's end waits for)
-                    n = min(pending_images, room, granule if collecting == 0 and nxt >= len(windows) else 2 * granule) // granule * granule
+                    n = min(pending.images, room, granule if collecting == 0 and nxt >= len(windows) else 2 * granule) // granule * granule
                     if n == 0:
                         break
-                elif not inflight or collecting == 0 or clock() - pending[0][3] > flush_after:
-                    n = pending_images                                # the device would idle / nothing else can arrive / it has waited
+                elif not inflight or collecting == 0 or clock() - pending.oldest() > flush_after:
+                    n = pending.images                                # the device would idle / nothing else can arrive / it has waited
                     prof["launch.partial"] += 1
                 else:
                     break
@@ -692,13 +724,13 @@ class PooledHotPath(HotPath):
                 prof["last_fetch_at"] = clock() - t_loop
             t = lap("fetch+send", t)
             waiting = [self.conns[ci] for ci in busy]
-            if not waiting and not inflight and not pending and nxt < len(windows):
+            if not waiting and not inflight and not pending.images and nxt < len(windows):
                 self.feed.poll(block=True)                            # nothing to do but wait for the next chromosome
                 lap("feed.wait", t)
                 continue
-            got = mpc.wait(waiting, timeout=0.0005 if inflight or pending else (0.002 if nxt < len(windows) and idle else 0.05))
+            got = mpc.wait(waiting, timeout=0.0005 if inflight or pending.images else (0.002 if nxt < len(windows) and idle else 0.05))
             lap("wait", t)
-            if not got and not inflight and not pending:
+            if not got and not inflight and not pending.images:
                 dead = [ci for ci in busy if not self.procs[ci].is_alive()]
                 if dead:
                     raise RuntimeError("host helper process %s died while holding window %s" % (dead, [busy[ci] for ci in dead]))
@@ -706,18 +738,13 @@ class PooledHotPath(HotPath):
                 ci = self.conns.index(c)
                 msg = c.recv()
                 if msg[0] == "part":
-                    w = wins[msg[1]]
-                    pending.append([msg[1], w["seen"], msg[2], clock()])
-                    w["seen"] += int(msg[2].shape[0])
-                    pending_images += int(msg[2].shape[0])
+                    pending.add(msg[1], msg[2], clock())
                 elif msg[0] == "rec":
                     _t, wid, n_images, ok = msg
                     w = wins[wid]
                     collecting -= 1
                     if not ok:                                        # the window's collection failed after parts had left: drop them
-                        for seg in [seg for seg in pending if seg[0] == wid]:
-                            pending.remove(seg)
-                            pending_images -= int(seg[2].shape[0])
+                        pending.drop(wid)
                         w["chunks"], w["total"], w["got"] = [], 0, 0
                         forward(wid)                                  # an empty last message: the helper votes on no lines
                         wins[wid] = {"drop": True}                    # launches of it still in flight are ignored (entry never removed: wids are not reused)

@@ -125,3 +125,42 @@ def test_window_vote_fed_in_chunks_equals_the_vote_in_one_go(oracle_lib):
     short.feed(classes[:4], probs[:4])
     with pytest.raises(RuntimeError):
         short.finish()                                            # closed before all predictions arrived
+
+
+def test_image_queue_cuts_launch_groups_across_windows_and_maps_them_back():
+    """pipeline.ImageQueue: parts of several windows in arrival order -> groups of any size; the mapping puts every image's
+    prediction back at its place in its window."""
+    from svision_amd.pipeline import ImageQueue
+    rng = np.random.default_rng(3)
+    q = ImageQueue()
+    windows = {}                                                  # wid -> all its records, in order
+    arrivals = [(0, 300), (1, 5), (0, 17), (2, 700), (1, 256), (0, 1)]
+    for t, (wid, n) in enumerate(arrivals):
+        recs = rng.integers(0, 1000, (n, 12)).astype(np.int32)
+        q.add(wid, recs, now=float(t))
+        windows[wid] = recs if wid not in windows else np.concatenate([windows[wid], recs])
+    q.add(3, np.empty((0, 12), np.int32), now=9.0)                # an empty part is nothing
+    total = sum(n for _w, n in arrivals)
+    assert q.images == total and q.oldest() == 0.0
+    back = {wid: np.zeros_like(r) for wid, r in windows.items()}
+    seen = 0
+    for n in (256, 256, 64, 512, 1, total - 1089):
+        records, mapping = q.take(n)
+        assert records.shape == (n, 12) and sum(k for *_x, k in mapping) == n
+        for wid, w_off, g_off, k in mapping:
+            back[wid][w_off:w_off + k] = records[g_off:g_off + k]
+        seen += n
+        assert q.images == total - seen
+    assert q.images == 0 and q.oldest() is None
+    for wid in windows:
+        assert np.array_equal(back[wid], windows[wid])
+    with pytest.raises(ValueError):
+        q.take(1)
+    # a window whose collection failed: what is queued of it goes, the others stay in order
+    q = ImageQueue()
+    a, b, c = (rng.integers(0, 9, (n, 12)).astype(np.int32) for n in (10, 20, 30))
+    q.add(7, a); q.add(8, b); q.add(7, c)
+    q.drop(7)
+    assert q.images == 20
+    records, mapping = q.take(20)
+    assert np.array_equal(records, b) and mapping == [(8, 0, 0, 20)]
