@@ -13,6 +13,16 @@ from svision_amd import kernels
 from svision_amd.io import bam
 from tests import helpers
 
+
+@pytest.fixture(autouse=True)
+def _restore_group_sizes():
+    """Some tests shrink / blow up the decoder's group sizes: put the module's constants back behind every test."""
+    import svision_amd.ingest_gpu as ig
+    saved = {k: getattr(ig, k) for k in ("FIRST_GROUP_BYTES", "PIPE_GROUP_BYTES", "LARGE_GROUP_BYTES", "GROUP_BYTES")}
+    yield
+    for k, v in saved.items():
+        setattr(ig, k, v)
+
 pytestmark = pytest.mark.gpu
 
 
