@@ -284,7 +284,8 @@ int            svx_bgzf_inflate_wave(const uint8_t* d_comp, const uint64_t* d_sr
  * offsets in d_raw of known record starts (from the .bai linear index), ascending, the last entry = end of the part.
  *   svx_bam_walk_count    d_counts [n_starts][4] = records, CIGAR words, QNAME bytes (one separator per record) between
  *                         start i and start i + 1, and a status: 0 ok, 1 the walk misses the next start, 2 malformed
- *                         record, 3 CG-tag CIGAR (the caller decodes that part on the host)
+ *                         record.  A CIGAR of more than 65,535 operations is read from the record's CG:B,I tag
+ *                         (SAMv1 4.2.2), by both passes
  *   svx_bam_walk_extract  d_base [n_starts][3] = exclusive prefix sums of the first three counts; fills tid / pos / flag /
  *                         mapq / l_seq [records], cig_off / name_off [records] (offsets of each record's words / name),
  *                         cigar [words], names [bytes] ('\n' behind every name) */

@@ -13,7 +13,7 @@
 //   pass 2  svx_bam_walk_extract per start (a wave each): tid / pos / flag / mapq / l_seq, CIGAR words, QNAMEs ('\n'-separated)
 //
 // Integer exact: the arrays equal the host decoder's (svx_bam.cpp) element for element (tests/test_gpu_inflate.py).
-// Records with a CG:B,I long CIGAR (> 65535 operations) set a flag and the caller takes the host decoder for that part.
+// Records with a CG:B,I long CIGAR (> 65535 operations) are followed into their optional fields (find_cg_tag).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/svx.h"
@@ -27,8 +27,44 @@ __device__ __forceinline__ uint32_t ld32(const uint8_t* p)    // unaligned littl
     return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24;
 }
 
+// A CIGAR of more than 65,535 operations sits in the optional field CG:B,I and the record's own CIGAR is the placeholder
+// "<l_seq>S<span>N" (SAMv1 4.2.2).  -> the tag's words (and their number), or nullptr when the record has no such field.
+__device__ inline const uint8_t* find_cg_tag(const uint8_t* rec, uint32_t bs, uint32_t l_name, uint32_t n_cig, uint32_t l_seq, uint32_t* count)
+{
+    const uint8_t* q = rec + 32 + l_name + 4ull * n_cig + (l_seq + 1ull) / 2 + l_seq;
+    const uint8_t* end = rec + bs;
+    while (q + 3 <= end) {
+        const uint8_t t0 = q[0], t1 = q[1], type = q[2];
+        q += 3;
+        if (type == 'B') {
+            if (q + 5 > end) return nullptr;
+            const uint8_t sub = q[0];
+            const uint32_t n = ld32(q + 1);
+            const uint32_t width = sub == 'c' || sub == 'C' ? 1u : sub == 's' || sub == 'S' ? 2u : sub == 'i' || sub == 'I' || sub == 'f' ? 4u : 0u;
+            if (width == 0u || (uint64_t)(end - (q + 5)) < (uint64_t)n * width) return nullptr;
+            if (t0 == 'C' && t1 == 'G' && sub == 'I') { *count = n; return q + 5; }
+            q += 5 + (uint64_t)n * width;
+        } else if (type == 'Z' || type == 'H') {
+            while (q < end && *q) ++q;
+            ++q;
+        } else {
+            const uint32_t width = type == 'A' || type == 'c' || type == 'C' ? 1u : type == 's' || type == 'S' ? 2u : type == 'i' || type == 'I' || type == 'f' ? 4u : 0u;
+            if (width == 0u) return nullptr;
+            q += width;
+        }
+    }
+    return nullptr;
+}
+
+__device__ inline bool is_cg_placeholder(const uint8_t* rec, uint32_t l_name, uint32_t n_cig, uint32_t l_seq)
+{
+    if (n_cig != 2) return false;
+    const uint32_t w0 = ld32(rec + 32 + l_name), w1 = ld32(rec + 36 + l_name);
+    return (w0 & 15) == 4 && (w0 >> 4) == l_seq && (w1 & 15) == 3;
+}
+
 // counts per start: [0] records, [1] CIGAR words, [2] QNAME bytes (incl. one separator per record), [3] status
-// status: 0 ok, 1 walk does not end on the next start (index does not match the data), 2 malformed record, 3 long CIGAR
+// status: 0 ok, 1 walk does not end on the next start (index does not match the data), 2 malformed record
 __global__ __launch_bounds__(BLOCK)
 void bam_walk_count_kernel(const uint8_t* __restrict__ raw, const uint64_t* __restrict__ starts, uint32_t n_starts,
                            uint64_t* __restrict__ counts)
@@ -44,12 +80,12 @@ void bam_walk_count_kernel(const uint8_t* __restrict__ raw, const uint64_t* __re
         const uint8_t* rec = raw + p + 4;
         const uint32_t l_name = rec[8], n_cig = (uint32_t)rec[12] | (uint32_t)rec[13] << 8, l_seq = ld32(rec + 16);
         if (bs < 32 || p + 4 + bs > end || 32ull + l_name + 4ull * n_cig + (l_seq + 1ull) / 2 + l_seq > bs) { status = 2; break; }
-        if (n_cig == 2) {                                       // "<l_seq>S<span>N": the real CIGAR is in the CG tag
-            const uint32_t w0 = ld32(rec + 32 + l_name), w1 = ld32(rec + 36 + l_name);
-            if ((w0 & 15) == 4 && (w0 >> 4) == l_seq && (w1 & 15) == 3) { status = 3; break; }
+        uint32_t n_words = n_cig;
+        if (is_cg_placeholder(rec, l_name, n_cig, l_seq)) {     // "<l_seq>S<span>N": the real CIGAR is in the CG tag
+            if (find_cg_tag(rec, bs, l_name, n_cig, l_seq, &n_words) == nullptr) n_words = n_cig;     // (a look-alike without the tag is what it says: two operations, as in the host reader)
         }
         ++n;
-        words += n_cig;
+        words += n_words;
         name_bytes += l_name ? l_name : 1;                      // l_name counts the NUL: the bytes + one separator
         p += 4 + bs;
     }
@@ -82,7 +118,7 @@ void bam_walk_extract_kernel(const uint8_t* __restrict__ raw, const uint64_t* __
         const uint8_t* rec = raw + p + 4;
         const uint32_t bs = (uint32_t)__builtin_amdgcn_readfirstlane((int)ld32(raw + p));
         const uint32_t l_name = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec[8]);
-        const uint32_t n_cig = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)rec[12] | (uint32_t)rec[13] << 8));
+        uint32_t n_cig = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)rec[12] | (uint32_t)rec[13] << 8));
         if (lane == 0) {
             tid[k] = (int32_t)ld32(rec);
             pos[k] = (int32_t)ld32(rec + 4);
@@ -98,6 +134,12 @@ void bam_walk_extract_kernel(const uint8_t* __restrict__ raw, const uint64_t* __
         if (lane == 0) names[nb + nn] = '\n';
         nb += nn + 1;
         const uint8_t* cg = rec + 32 + l_name;
+        const uint32_t l_seq = (uint32_t)__builtin_amdgcn_readfirstlane((int)ld32(rec + 16));
+        if (is_cg_placeholder(rec, l_name, n_cig, l_seq)) {     // (uniform: every lane walks the same optional fields)
+            uint32_t n_real = 0;
+            const uint8_t* real = find_cg_tag(rec, bs, l_name, n_cig, l_seq, &n_real);
+            if (real != nullptr) { cg = real; n_cig = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_real); }
+        }
         for (uint32_t j = lane; j < n_cig; j += BLOCK) {
             uint32_t v;
             __builtin_memcpy(&v, cg + 4ull * j, 4);

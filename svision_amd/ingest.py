@@ -103,7 +103,7 @@ class ChromosomeFeed:
         # threads (io.bam.BamStream), "auto" (the default; SVX_INGEST overrides) = the device whenever it can: the file has a
         # .bai with its linear index and the run needs no read bases (--hash / --graph).  On a 16-CPU GPU box the device engine
         # takes 0.6 s for the 3.9 GB of the bench's 20-window file, the host engine 1.15 s (DESIGN.md section 5 "Device-side
-        # ingestion"); a file the device engine cannot take (CG-tag CIGARs, an index that does not match) falls back to the
+        # ingestion"); a reference the device engine cannot take (a linear index that does not match, a corrupt block) falls back to the
         # host engine chromosome by chromosome.
         self.engine = engine or os.environ.get("SVX_INGEST", "auto")
         self.references, self.lengths = list(references), list(lengths)
@@ -328,7 +328,7 @@ class ChromosomeFeed:
                                 done += 1
                             break
                         except DeviceIngestError as exc:
-                            # CG-tag CIGARs, an index that does not fit, a corrupt block: the host reader takes that reference
+                            # an index that does not fit, a corrupt block: the host reader takes that reference
                             # and the device engine goes on behind it -- three times; then the host reader takes the rest
                             refusals += 1
                             rest = order[done:] if refusals >= 3 else order[done:done + 1]

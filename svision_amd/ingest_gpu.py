@@ -9,7 +9,7 @@ Why: DEFLATE decoding is the cost of ingestion (a HiFi BAM inflates to ~22 KB pe
 GPU boxes this was built on give a container the CPU time of 16 cores (svision_amd.ingest.effective_cpus): ~10 GB/s of
 inflated data, a quarter of what the device pipeline consumes.  The same data inflates at 75-90 GB/s on the MI355X.
 Replaces pysam's AlignmentFile.fetch (run_collection.py:23-26) like the host reader (io.bam.BamStream), which stays the
-engine for files without a linear index, for --hash / --graph (read bases wanted), for CG-tag CIGARs and for SVX_INGEST=cpu.
+engine for files without a linear index, for --hash / --graph (read bases wanted) and for SVX_INGEST=cpu.
 """
 import os
 
@@ -338,7 +338,7 @@ class DeviceDecoder:
                 bad = c[:, 3] != 0
                 if bad.any():
                     code = int(c[bad, 3][0])
-                    raise DeviceIngestError({1: "the linear index does not match the records", 2: "malformed BAM record", 3: "CG-tag CIGAR"}.get(code, "walk error %d" % code))
+                    raise DeviceIngestError({1: "the linear index does not match the records", 2: "malformed BAM record"}.get(code, "walk error %d" % code))
                 n, words, name_bytes = (int(v) for v in c[:, :3].sum(axis=0))
                 # [cig_off n+1][name_off n+1][tid n][pos n][l_seq n][flag n][mapq n][names]: everything the host wants
                 sect = [8 * (n + 1), 8 * (n + 1), 4 * n, 4 * n, 4 * n, 2 * n, n, name_bytes]
@@ -612,7 +612,7 @@ class DeviceDecoder:
         bad = counts[:, 3] != 0
         if bad.any():
             code = int(counts[bad, 3][0])
-            raise DeviceIngestError({1: "the linear index does not match the records", 2: "malformed BAM record", 3: "CG-tag CIGAR"}.get(code, "walk error %d" % code))
+            raise DeviceIngestError({1: "the linear index does not match the records", 2: "malformed BAM record"}.get(code, "walk error %d" % code))
         base = np.zeros((n_starts, 3), np.uint64)
         base[1:] = np.cumsum(counts[:-1, :3], axis=0).astype(np.uint64)
         n, words, name_bytes = (int(v) for v in counts[:, :3].sum(axis=0))

@@ -206,21 +206,17 @@ def test_pipelined_device_decoder_equals_the_host_decoder(tmp_path):
         assert got == tids
 
 
-def test_feed_falls_back_to_the_host_engine_where_the_device_engine_refuses(tmp_path, caplog):
-    """A record whose CIGAR sits in a CG:B,I tag (> 65535 operations) is something the device engine refuses (status 3 of
-    svx_bam_walk_count): the chromosomes before it come from the device engine, that chromosome and the rest from the host
-    engine, and the tables are what the host engine alone produces."""
-    import logging
-    from svision_amd import ingest, synth
+def _bam_with_a_cg_tag_record(tmp_path):
+    """Three references; on the second one a record of 66,000 CIGAR operations (CG:B,I tag + placeholder, SAMv1 4.2.2)."""
+    from svision_amd import synth
     cfg = synth.SimConfig(contigs=[("c1", 300_000), ("c2", 200_000), ("c3", 250_000)], coverage=6, read_len_mean=4000, read_len_sd=600,
                           sv_spacing=9000, sv_min_gap=5000, sv_max=1000, seed=21)
     table, genome, _ = synth.simulate(cfg)
-    # one very long CIGAR on c2 (tid 1)
     n_ops = 66_000
     ops = np.tile(np.array([7, 8], np.uint32), n_ops // 2)
     words = (np.full(n_ops, 1, np.uint32) << 4) | ops                       # 1=1X1=1X...: 66,000 reference bases
-    first_c2 = int(np.flatnonzero(table.tid == 1)[0])
-    k, at = first_c2, int(table.cig_off[first_c2])
+    k = int(np.flatnonzero(table.tid == 1)[0])
+    at = int(table.cig_off[k])
 
     def ins(col, value):
         return np.concatenate([col[:k], np.asarray([value], col.dtype), col[k:]])
@@ -232,41 +228,85 @@ def test_feed_falls_back_to_the_host_engine_where_the_device_engine_refuses(tmp_
                                 list(table.names) + ["long_cigar_read"], np.concatenate([table.cigar[:at], words, table.cigar[at:]]), cig_off)
     path = str(tmp_path / "cg.bam")
     bam.write_bam(path, merged, index=True)
+    return path, genome, n_ops
+
+
+def _feed_tables(path, genome, engine):
+    """Every reference's table (+ scan) through ChromosomeFeed with one ingest engine -> ({reference: fields}, feed.stats)."""
+    import time
+    from svision_amd import ingest
     head = bam.read_bam_header(path)
     fasta = bam.Fasta(sequences=genome)
     opts = helpers.default_options(min_support=3, batch_size=64, bam_path=path)
+    feed = ingest.ChromosomeFeed(path, fasta, opts, head.references, head.references, head.lengths, device=torch.device("cuda:0"),
+                                 index=bam.find_index(path), threads=4, engine=engine)
+    out = {}
+    try:
+        for chrom in head.references:
+            _key, smp = feed.get(chrom, block=True)
+            t = smp.table
+            t_end = time.time() + 30                              # a device-decoded table's CIGAR words reach the host a little later (the spill)
+            while getattr(t.cigar, "_arr", 0) is None and time.time() < t_end:
+                time.sleep(0.005)
+            out[chrom] = (t.pos.copy(), t.flag.copy(), t.mapq.copy(), t.l_seq.copy(), np.asarray(t.cig_off).copy(), np.asarray(t.cigar).copy(),
+                          [t.names[i] for i in t.name_id], smp.stats.copy(), np.asarray(smp.gap_off).copy(), type(t.cigar).__name__)
+            feed.release(chrom)
+    finally:
+        feed.close()
+    return out, dict(feed.stats)
 
-    def tables(engine):
-        feed = ingest.ChromosomeFeed(path, fasta, opts, head.references, head.references, head.lengths, device=torch.device("cuda:0"),
-                                     index=bam.find_index(path), threads=4, engine=engine)
-        out = {}
-        try:
-            for chrom in head.references:
-                _key, smp = feed.get(chrom, block=True)
-                t = smp.table
-                import time
-                t_end = time.time() + 30                      # a device-decoded table's CIGAR words reach the host a little later (the spill)
-                while getattr(t.cigar, "_arr", 0) is None and time.time() < t_end:
-                    time.sleep(0.005)
-                out[chrom] = (t.pos.copy(), t.flag.copy(), t.mapq.copy(), t.l_seq.copy(), np.asarray(t.cig_off).copy(), np.asarray(t.cigar).copy(),
-                              [t.names[i] for i in t.name_id], smp.stats.copy(), np.asarray(smp.gap_off).copy(), type(t.cigar).__name__)
-                feed.release(chrom)
-        finally:
-            feed.close()
-        return out, dict(feed.stats)
 
-    with caplog.at_level(logging.WARNING):
-        got, stats = tables("gpu")
-    assert stats["engine"] == "gpu" and any("on the host" in r.getMessage() for r in caplog.records)
-    want, _ = tables("cpu")
-    assert list(got) == list(want) == ["c1", "c2", "c3"]
+def _same_feed_tables(got, want):
+    assert list(got) == list(want)
     for chrom in want:
         for a, b in zip(got[chrom][:-1], want[chrom][:-1]):
             assert (a == b) if isinstance(a, list) else np.array_equal(a, b), chrom
+
+
+def test_device_engine_follows_a_long_cigar_into_its_cg_tag(tmp_path):
+    """A CIGAR of more than 65,535 operations sits in the record's CG:B,I tag: svx_bam_walk_* read it there, like the host
+    reader (svx_bam.cpp find_long_cigar); every reference is decoded on the device and equals the host engine's."""
+    path, genome, n_ops = _bam_with_a_cg_tag_record(tmp_path)
+    got, stats = _feed_tables(path, genome, "gpu")
+    want, _ = _feed_tables(path, genome, "cpu")
+    assert stats["engine"] == "gpu" and {v[-1] for v in got.values()} == {"LazyCigar"} and {v[-1] for v in want.values()} == {"ndarray"}
+    _same_feed_tables(got, want)
+    assert "long_cigar_read" in got["c2"][6] and int(np.diff(got["c2"][4]).max()) == n_ops
+
+
+def test_feed_falls_back_to_the_host_engine_where_the_device_engine_refuses(tmp_path, caplog):
+    """An entry of the second reference's LINEAR index that points into the middle of a record: the host engine never reads
+    the linear index (it takes a reference's byte range from the bins), the device engine starts a record walk there, finds
+    that it does not end on the next entry and refuses the reference -- which then comes from the host reader, the one
+    behind it from the device engine again, and all tables are what the host engine alone produces."""
+    import logging
+    import shutil
+    import struct as st
+    path, genome, _n_ops = _bam_with_a_cg_tag_record(tmp_path)
+    want, _ = _feed_tables(path, genome, "cpu")
+    bai = bam.find_index(path)
+    raw = bytearray(open(bai, "rb").read())
+    at = 8                                                        # magic, n_ref
+    for ref in range(2):                                          # walk to reference 1's linear index
+        n_bin, = st.unpack_from("<i", raw, at); at += 4
+        for _ in range(n_bin):
+            _bin, n_chunk = st.unpack_from("<Ii", raw, at); at += 8 + 16 * n_chunk
+        n_intv, = st.unpack_from("<i", raw, at); at += 4
+        if ref == 0:
+            at += 8 * n_intv
+    vals = list(st.unpack_from("<%dQ" % n_intv, raw, at))
+    k = max(i for i in range(n_intv) if vals[i] and vals[i] != vals[-1])    # an entry in the middle of the reference's records
+    st.pack_into("<Q", raw, at + 8 * k, vals[k] + 5)               # five bytes into the record it pointed at
+    shutil.copy(path, str(tmp_path / "bad.bam"))
+    with open(str(tmp_path / "bad.bam.bai"), "wb") as f:
+        f.write(raw)
+    with caplog.at_level(logging.WARNING):
+        got, stats = _feed_tables(str(tmp_path / "bad.bam"), genome, "gpu")
+    assert stats["engine"] == "gpu" and any("on the host" in r.getMessage() for r in caplog.records)
+    _same_feed_tables(got, want)
     # who decoded what: the refused reference (and, in its group, the one in front of it) by the host reader, the one behind it
     # by the device engine again
-    assert got["c2"][-1] != "LazyCigar" and got["c3"][-1] == "LazyCigar" and {v[-1] for v in want.values()} == {"ndarray"}
-    assert "long_cigar_read" in got["c2"][6] and int(np.diff(got["c2"][4]).max()) == n_ops
+    assert got["c2"][-1] != "LazyCigar" and got["c3"][-1] == "LazyCigar"
 
 
 def test_device_decoder_on_a_file_with_secondary_records_and_an_unmapped_tail(tmp_path):
