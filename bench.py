@@ -135,10 +135,7 @@ def _simulate_contig(job):
         tid, prefix = job["e2e"]
         part = table if prefix >= length else table.subset(np.flatnonzero(table.pos < prefix))
         part.tid[:] = tid
-        if len(part) and int(np.diff(np.asarray(part.cig_off)).max()) > 65535:
-            segment = "skip"             # a CIGAR of more than 65,535 operations (ONT-like reads): the fast segment writer has no CG tags
-        else:
-            segment = bam.encode_reference_segment(part, seq="random", seed=seed)
+        segment = bam.encode_reference_segment(part, seq="random", seed=seed)
         if part is table:
             table.tid[:] = 0
     return table, genome[name], segment
@@ -197,9 +194,6 @@ def build_workload(args, rank, world, cores):
         d = tempfile.mkdtemp(prefix="svx_bench_bam_", dir=args.bam_dir)
         path = os.path.join(d, "rank%d.bam" % rank)
         segs = [seg for _t, _g, seg in made if seg is not None]
-        if any(isinstance(seg, str) for seg in segs):            # no file-inclusive leg for this workload (see _simulate_contig)
-            os.rmdir(d)
-            return parts, windows, strong, total_windows, None
         bam.write_bam_segments(path, names, [dict((j["name"], j["length"]) for j in jobs)[n] for n in names], segs, index=True)
         e2e = {"path": path, "dir": d, "references": names, "windows": [w for n in names for w in windows_of(n, e2e_prefix[n])],
                "bytes": os.path.getsize(path), "inflated": sum(s["inflated"] for s in segs)}

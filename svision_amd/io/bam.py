@@ -625,17 +625,18 @@ def reference_spans(table):
 def encode_record_stream(table, seq="random", seed=0):
     """The uncompressed BAM record stream of ``table`` -> (uint8 array, int64 offsets [n+1] of the records in it).
     ``seq``: 'random' = uniformly random bases (2 bits of entropy per base, like real reads) and HiFi-like binned
-    qualities (7 values, skewed); 'N' = N bases and 0xFF qualities (what :func:`write_bam` writes).  CIGARs of more than
-    65535 operations are not supported here."""
+    qualities (7 values, skewed); 'N' = N bases and 0xFF qualities (what :func:`write_bam` writes).  A CIGAR of more than
+    65535 operations goes into the record's CG:B,I tag behind the placeholder "<l_seq>S<span>N" (SAMv1 4.2.2)."""
     n = len(table)
-    n_cig = (table.cig_off[1:] - table.cig_off[:-1]).astype(np.int64)
-    if n and int(n_cig.max()) > 65535:
-        raise ValueError("encode_record_stream: CG-tag CIGARs are written by write_bam only")
+    n_real = (table.cig_off[1:] - table.cig_off[:-1]).astype(np.int64)
+    long_ = n_real > 65535
+    n_cig = np.where(long_, 2, n_real)                        # the words in the record's own CIGAR field
+    aux_len = np.where(long_, 8 + 4 * n_real, 0)              # "CG" "B" "I" count words
     names = [table.names[i].encode() + b"\x00" for i in table.name_id]
     l_name = np.fromiter((len(b) for b in names), np.int64, n)
     l_seq = table.l_seq.astype(np.int64)
     sq = (l_seq + 1) // 2
-    size = 32 + l_name + 4 * n_cig + sq + l_seq
+    size = 32 + l_name + 4 * n_cig + sq + l_seq + aux_len
     off = np.zeros(n + 1, np.int64)
     off[1:] = np.cumsum(size + 4)
     buf = np.empty(int(off[-1]), np.uint8)
@@ -655,7 +656,20 @@ def encode_record_stream(table, seq="random", seed=0):
             first[1:] = np.cumsum(lengths)[:-1]
             buf[np.repeat(starts - first, lengths) + np.arange(tot)] = payload
     scatter(off[:-1] + 36, l_name, np.frombuffer(b"".join(names), np.uint8))
-    scatter(off[:-1] + 36 + l_name, 4 * n_cig, table.cigar.astype("<u4").view(np.uint8))
+    words = table.cigar.astype("<u4")
+    if long_.any():                                           # the short records' words in one scatter, the long ones one by one
+        short = np.flatnonzero(~long_)
+        keep = np.repeat(~long_, n_real)
+        scatter((off[:-1] + 36 + l_name)[short], 4 * n_real[short], words[keep].view(np.uint8))
+        for i in np.flatnonzero(long_):
+            a = int(off[i] + 36 + l_name[i])
+            buf[a:a + 8] = np.array([(int(l_seq[i]) << 4) | 4, (int(span[i]) << 4) | 3], "<u4").view(np.uint8)
+            t = int(a + 8 + sq[i] + l_seq[i])
+            buf[t:t + 4] = np.frombuffer(b"CGBI", np.uint8)
+            buf[t + 4:t + 8] = np.array([int(n_real[i])], "<u4").view(np.uint8)
+            buf[t + 8:t + 8 + 4 * int(n_real[i])] = words[int(table.cig_off[i]):int(table.cig_off[i + 1])].view(np.uint8)
+    else:
+        scatter(off[:-1] + 36 + l_name, 4 * n_cig, words.view(np.uint8))
     at = off[:-1] + 36 + l_name + 4 * n_cig
     if seq == "N":
         for i in range(n):

@@ -406,3 +406,23 @@ def test_segment_writer_round_trip_and_index(tmp_path):
     bam.write_bam(plain, table, index=True)                         # both writers index the same record set
     a, b = bam.read_bai(path + ".bai"), bam.read_bai(plain + ".bai")
     assert [x is None for x in a] == [x is None for x in b]
+
+
+def test_fast_segment_writer_puts_long_cigars_into_cg_tags(tmp_path):
+    """encode_reference_segment / write_bam_segments (the bench's BAM writer): a CIGAR of more than 65,535 operations becomes
+    the placeholder + CG:B,I tag and the native reader gives the table back."""
+    n_ops = 70_001
+    ops = np.tile(np.array([7, 8, 7, 1, 7, 2], np.uint32), n_ops // 6 + 1)[:n_ops]
+    lens = (np.arange(n_ops, dtype=np.uint32) % 9) + 1
+    words = (lens << 4) | ops
+    qlen = int(lens[np.isin(ops, (7, 8, 1))].sum())
+    cig = np.concatenate([np.array([(5 << 4) | 7], np.uint32), words, np.array([(5 << 4) | 7], np.uint32)])
+    t = bam.AlignmentTable(["ctg"], [5_000_000], [0, 0, 0], [50, 100, 200], [0, 0, 0], [60, 60, 60], [5, qlen, 5], [0, 1, 2],
+                           ["a", "long", "short"], cig, [0, 1, n_ops + 1, n_ops + 2])
+    path = str(tmp_path / "cgfast.bam")
+    bam.write_bam_segments(path, t.references, t.lengths, [bam.encode_reference_segment(t, seq="random", seed=1)], index=True)
+    back = bam.read_bam(path)
+    assert back.cig_off.tolist() == [0, 1, n_ops + 1, n_ops + 2] and np.array_equal(back.cigar, cig)
+    assert back.l_seq.tolist() == [5, qlen, 5] and back.names == ["a", "long", "short"] and back.pos.tolist() == [50, 100, 200]
+    part = bam.read_bam(path, tids=[0])
+    assert np.array_equal(part.cigar, cig)
