@@ -161,6 +161,8 @@ def build_workload(args, rank, world, cores):
                      kind="contig" if args.workload == "contig" else None) for i, (n, l) in enumerate(contigs) if n in shard]
         strong = True
         total_windows = len(contigs) if args.workload == "contig" else sum(len(windows_of(n, l)) for n, l in contigs)
+        if args.e2e_windows and args.workload == "contig":
+            e2e_prefix = {n: length_of[n] for n in shard}               # --contig: one task per chromosome, the file holds all of them
         if args.e2e_windows and args.workload == "wg":
             # the file-inclusive leg runs on a bounded job: the same chromosomes, every one cut to its share of --e2e-windows
             small = dict(job_contigs(args.e2e_windows)) if total_windows > args.e2e_windows else length_of
@@ -195,7 +197,8 @@ def build_workload(args, rank, world, cores):
         path = os.path.join(d, "rank%d.bam" % rank)
         segs = [seg for _t, _g, seg in made if seg is not None]
         bam.write_bam_segments(path, names, [dict((j["name"], j["length"]) for j in jobs)[n] for n in names], segs, index=True)
-        e2e = {"path": path, "dir": d, "references": names, "windows": [w for n in names for w in windows_of(n, e2e_prefix[n])],
+        e2e = {"path": path, "dir": d, "references": names,
+               "windows": [(n, 0, e2e_prefix[n]) for n in names] if args.workload == "contig" else [w for n in names for w in windows_of(n, e2e_prefix[n])],
                "bytes": os.path.getsize(path), "inflated": sum(s["inflated"] for s in segs)}
     return parts, windows, strong, total_windows, e2e
 
