@@ -342,3 +342,36 @@ def test_device_decoder_on_a_file_with_secondary_records_and_an_unmapped_tail(tm
             _same_table(tb, bam.read_bam(path, tids=[got[-1]]))
             assert np.array_equal(d_off.cpu().numpy(), tb.cig_off) and np.array_equal(d_pos.cpu().numpy(), tb.pos)
         assert got == [0, 1, 2]
+
+
+def test_contig_mode_command_line_with_cg_tag_cigars_device_ingest_equals_host_ingest(tmp_path):
+    """--contig on assembly-like alignments whose CIGARs have more than 65,535 operations (CG:B,I tags): the command line
+    with the device ingest engine writes what it writes with the host engine."""
+    import subprocess
+    import sys
+    from oracle import alexnet_ref
+    from svision_amd import synth
+    from svision_amd.network import tf_checkpoint as ck
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prefix = str(tmp_path / "m.ckpt")
+    ck.write_checkpoint(prefix, alexnet_ref.random_params(seed=7))
+    cfg = synth.SimConfig(contigs=[("ctgA", 1_500_000), ("ctgB", 900_000)], coverage=2, read_len_mean=600_000, read_len_sd=100_000,
+                          err_rate=0.08, sv_spacing=40_000, sv_min_gap=20_000, sv_max=3000, seed=5)
+    table, genome, _ = synth.simulate(cfg)
+    assert int(np.diff(np.asarray(table.cig_off)).max()) > 65535
+    fa = str(tmp_path / "asm.fa")
+    bam.write_fasta(fa, genome)
+    path = str(tmp_path / "asm.bam")
+    bam.write_bam(path, table, index=True)
+    outs = {}
+    for engine, t in (("cpu", "1"), ("gpu", "1"), ("gpu", "3")):
+        out = str(tmp_path / ("out_%s_%s" % (engine, t)))
+        r = subprocess.run([sys.executable, os.path.join(root, "SVision"), "-o", out, "-b", path, "-m", prefix, "-g", fa, "-n", "ASM", "--contig",
+                            "--batch_size", "64", "-t", t, "--debug"], capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, PYTHONPATH=root, SVX_INGEST=engine, SVX_TIMING="1"))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        assert ("'engine': '%s'" % engine) in r.stdout and "on the host" not in r.stderr
+        vcf = [f for f in os.listdir(out) if f.endswith(".vcf")]
+        outs[(engine, t)] = {rel: open(os.path.join(out, rel)).read() for rel in vcf + ["segments/" + f for f in sorted(os.listdir(os.path.join(out, "segments")))]}
+    assert outs[("cpu", "1")] == outs[("gpu", "1")] == outs[("gpu", "3")]
+    assert sum(v.count("\n") for k, v in outs[("cpu", "1")].items() if k.startswith("segments/")) > 20
