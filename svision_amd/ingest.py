@@ -293,15 +293,18 @@ class ChromosomeFeed:
             return False
 
         def host_parts(which):                                 # BGZF inflate on host threads (libdeflate)
-            state = {"alloc": None, "used": True}
+            state = {"alloc": None, "used": True, "arrays": {}}
 
             def alloc(name, dtype, n):                         # one slot per part: "tid" is the first array of a part (io.bam._table_from_handle)
                 if name == "tid" and state["used"]:           # (a part the stream skipped leaves its slot to the next one)
-                    state["alloc"], state["used"] = self._slot_alloc(), False
-                return state["alloc"](name, dtype, n)
+                    state["alloc"], state["used"], state["arrays"] = self._slot_alloc(), False, {}
+                arr = state["arrays"][name] = np.empty(int(n), dtype)      # the decoder fills this process's own memory ...
+                return arr
             stream = BamStream(self.bam_path, with_seq=self.with_seq, threads=self.threads, tids=which, index=self.index, alloc=alloc)
             try:
                 for table in stream:
+                    for name, arr in state["arrays"].items():  # ... and the slot's files are written from it (no mapping in this process: _slot_alloc.put)
+                        state["alloc"].put(name, arr)
                     table._alloc, state["used"] = state["alloc"], True
                     if not put((table, None)):
                         return
