@@ -97,11 +97,14 @@ def guard_imports(package="svision_amd", here=None, log=None):
     stale = stale_modules(here)
     if not stale:
         return []
-    names = {package + "." + m[:-3].replace("/", "."): os.path.join(here, m) for m, _sos in stale}
+    # ONE stale module bypasses ALL of them: the typed modules cimport each other's extension types (Seg, Segment), so a
+    # compiled collect_signatures next to an interpreted classes dies at import (KeyError '__pyx_vtable__') -- a mixed
+    # state is not a state this package can run in.
+    names = {package + "." + m[:-3].replace("/", "."): os.path.join(here, m) for m in MODULES}
     sys.meta_path.insert(0, _SourceFirst(names))
     if log is not None:
-        log("svision_amd: compiled host modules older than their source are ignored, the .py files run interpreted "
-            "(rebuild with `python -m svision_amd.build_host`): " + ", ".join(m for m, _s in stale))
+        log("svision_amd: compiled host modules older than their source (" + ", ".join(m for m, _s in stale) + "): ALL host "
+            "modules run interpreted from their .py files (rebuild with `python -m svision_amd.build_host`)")
     return sorted(names)
 
 

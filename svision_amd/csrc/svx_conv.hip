@@ -37,6 +37,8 @@
 #include <stdint.h>
 #include "../../include/svx.h"
 
+#include "svx_shadow.hpp"
+
 namespace {
 
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -350,6 +352,7 @@ template <int KS>
 __global__ __launch_bounds__(THREADS, 2)
 void conv_wave_list_kernel(const ConvArgs a, int shape)
 {
+    SVX_SHADOW_ROOM();
     const int Mall = a.nimg * a.H * a.W;
     int Mtot = Mall;
     { const long long c = (long long)*a.pixel_count; if (c * 100 < (long long)Mall * SVX_CONV_DENSE_PCT) Mtot = (int)c; }

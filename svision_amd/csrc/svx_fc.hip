@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/svx.h"
+#include "svx_shadow.hpp"
 
 namespace {
 
@@ -56,6 +57,7 @@ template <int NA, int NB>
 __global__ __launch_bounds__(THREADS, 2)
 void fc_splitk_kernel(const FcArgs a)
 {
+    SVX_SHADOW_ROOM();
     const int n_tiles = a.N / (32 * NA), m_tiles = (a.M + 32 * NB - 1) / (32 * NB);
     const int total = m_tiles * a.splits * n_tiles;                 // neuron tile fastest: neighbours share the x slice
     const int wt = blockIdx.x * WAVES + (threadIdx.x >> 6);

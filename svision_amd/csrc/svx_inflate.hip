@@ -607,6 +607,7 @@ void bgzf_inflate_wave_kernel(const uint8_t* __restrict__ comp, const uint64_t* 
             if ((len ^ nlen) != 0xffffu) { err = INF_BAD_STORED; break; }
             if (w.pos + len > w.hi) { err = INF_OUT_OVERRUN; break; }
             for (uint32_t i = 0; i < len; ++i) w.literal(br.bits(8));
+            if (br.exhausted()) { err = INF_IN_OVERRUN; break; }   // a truncated payload is padded with zero bits: not a stored block
         } else if (type == 1 || type == 2) {
             if (type == 1) {
                 for (int s = threadIdx.x; s < 288; s += LANES) t.lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;

@@ -334,9 +334,15 @@ class ChromosomeFeed:
                             # an index that does not fit, a corrupt block: the host reader takes that reference
                             # and the device engine goes on behind it -- three times; then the host reader takes the rest
                             refusals += 1
-                            rest = order[done:] if refusals >= 3 else order[done:done + 1]
-                            logging.warning("device ingestion failed at reference %s (%s): decoding %s on the host", self.references[order[done]], exc,
-                                            "the rest" if len(rest) > 1 or refusals >= 3 else "it")
+                            # the references the error names (a group-wide failure: the whole group; a walk error: the one
+                            # chromosome) and whatever lies in front of them and has not been yielded; unnamed: the reference
+                            # the consumer waits for.  Parts must arrive in order (the feeder emits skipped references as empty).
+                            named = [order.index(t) for t in (getattr(exc, "tids", None) or []) if t in order[done:]]
+                            hi = max(named) + 1 if named else done + 1
+                            rest = order[done:] if refusals >= 3 else order[done:hi]
+                            logging.warning("device ingestion failed at reference %s (%s): decoding %s on the host",
+                                            ", ".join(self.references[t] for t in order[done:hi][-max(1, len(named)):]), exc,
+                                            "the rest of the file" if refusals >= 3 else "%d reference(s)" % len(rest))
                             host_parts(rest)
                             order = order[done + len(rest):]
             else:

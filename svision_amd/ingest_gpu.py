@@ -28,7 +28,12 @@ GROUP_BYTES = 24 << 30                   # serial form (groups / decode_group): 
 
 
 class DeviceIngestError(RuntimeError):
-    pass
+    """``tids``: the references the failure belongs to (None: unknown -- the reference the consumer waits for is blamed)."""
+    tids = None
+
+    def __init__(self, msg, tids=None):
+        super().__init__(msg)
+        self.tids = list(tids) if tids is not None else None
 
 
 class LazyCigar:
@@ -212,7 +217,7 @@ class DeviceDecoder:
                 st_ = slot()
                 pin = st_[0]
                 if lib.svx_read_range(self.path.encode(), c0 + off, want, pin.data_ptr(), self.threads) != 0:
-                    raise DeviceIngestError(lib.svx_bam_error().decode())
+                    raise DeviceIngestError(lib.svx_bam_error().decode(), group)
                 cap = want // 28 + 16
                 so, co = np.empty(cap, np.uint64), np.empty(cap, np.uint64)
                 sl, isz = np.empty(cap, np.uint32), np.empty(cap, np.uint32)
@@ -220,7 +225,7 @@ class DeviceDecoder:
                 k = int(lib.svx_bgzf_index(pin.data_ptr(), want, c0 + off, cap, so.ctypes.data, sl.ctypes.data, isz.ctypes.data, co.ctypes.data,
                                            used.ctypes.data))
                 if k < 0 or (k == 0 and off == 0):
-                    raise DeviceIngestError("no BGZF block at file offset %d" % (c0 + off))
+                    raise DeviceIngestError("no BGZF block at file offset %d" % (c0 + off), group)
                 if k == 0:
                     break                                      # what is left of the range is the head of a block that ends behind it
                 u = int(used[0])
@@ -246,10 +251,13 @@ class DeviceDecoder:
                     raise DeviceIngestError("the index points between two BGZF blocks")
                 return np.where(at_end, dst[nb], dst[idx] + (voffs & np.uint64(0xFFFF)))
             starts = []
-            for lo, hi, linear in spans:
+            for t_, (lo, hi, linear) in zip(group, spans):
                 seeds = linear[(linear >= np.uint64(lo)) & (linear < np.uint64(hi))]
                 voffs = np.unique(np.concatenate([np.asarray([lo], np.uint64), seeds, np.asarray([hi], np.uint64)]))
-                starts.append(np.unique(inflated_offset(voffs)))
+                try:
+                    starts.append(np.unique(inflated_offset(voffs)))
+                except DeviceIngestError as exc:
+                    raise DeviceIngestError(str(exc), [t_]) from None
             # one pinned block of small tables: payload offsets, payload sizes, inflated offsets, then every chromosome's starts
             n_starts = [int(a.size) - 1 for a in starts]
             words = 3 * nb + 1 + sum(a.size for a in starts) + 8
@@ -324,7 +332,7 @@ class DeviceDecoder:
             self.stats["h2d_inflate_s"] += time.perf_counter() - t0
             counts = item["h_counts"].numpy()
             if int(counts[-1, 0]) != 0:
-                raise DeviceIngestError("corrupt BGZF blocks in references %s" % item["group"])
+                raise DeviceIngestError("corrupt BGZF blocks in references %s" % item["group"], item["group"])
             d_raw, d_tab, stream = item["d_raw"], item["d_tab"], item["stream"]
             pending, row = [], 0
             t0 = time.perf_counter()
@@ -333,12 +341,12 @@ class DeviceDecoder:
             # milliseconds during which the other threads' HIP calls -- and their page faults -- wait; per chromosome that
             # was six of them.
             plan, pack_at, word_at = [], 0, 0
-            for at, n_starts in zip(item["start_at"], item["n_starts"]):
+            for tid_, at, n_starts in zip(item["group"], item["start_at"], item["n_starts"]):
                 c = counts[row:row + n_starts]
                 bad = c[:, 3] != 0
                 if bad.any():
                     code = int(c[bad, 3][0])
-                    raise DeviceIngestError({1: "the linear index does not match the records", 2: "malformed BAM record"}.get(code, "walk error %d" % code))
+                    raise DeviceIngestError({1: "the linear index does not match the records", 2: "malformed BAM record"}.get(code, "walk error %d" % code), [tid_])
                 n, words, name_bytes = (int(v) for v in c[:, :3].sum(axis=0))
                 # [cig_off n+1][name_off n+1][tid n][pos n][l_seq n][flag n][mapq n][names]: everything the host wants
                 sect = [8 * (n + 1), 8 * (n + 1), 4 * n, 4 * n, 4 * n, 2 * n, n, name_bytes]
@@ -351,7 +359,8 @@ class DeviceDecoder:
                 row += n_starts
             base_all = torch.zeros((max(row, 1), 3), dtype=torch.int64, pin_memory=True)
             for at, n_starts, r0, *_rest in plan:
-                base_all.numpy()[r0 + 1:r0 + n_starts] = np.cumsum(counts[r0:r0 + n_starts - 1, :3], axis=0)
+                if n_starts > 1:
+                    base_all.numpy()[r0 + 1:r0 + n_starts] = np.cumsum(counts[r0:r0 + n_starts - 1, :3], axis=0)
             with torch.cuda.stream(stream):
                 st = kernels._stream_ptr(dev)
                 d_base_all = base_all.to(dev, non_blocking=True)
@@ -375,10 +384,13 @@ class DeviceDecoder:
                     d_name_off[n:].fill_(name_bytes)
                     h_pack = h_pack_all[p0:p0 + size]
                     h_pack.copy_(d_pack, non_blocking=True)
+                    # device copies svx_cigar_scan keeps: own tensors (the pack goes away with this group's read-backs), made IN
+                    # FRONT of the event the consumer synchronises on: it scans on another stream and orders itself behind
+                    # this one through that event only
+                    keep_off, keep_pos = d_cig_off.clone(), d_pos.clone()
                     ev = torch.cuda.Event()
                     ev.record()
-                    # device copies svx_cigar_scan keeps: own tensors (the pack goes away with this group's read-backs)
-                    pending.append((ev, h_pack, offs, n, words, name_bytes, d_cigar, d_cig_off.clone(), d_pos.clone(), base_all, d_pack))
+                    pending.append((ev, h_pack, offs, n, words, name_bytes, d_cigar, keep_off, keep_pos, base_all, d_pack))
             self.stats["walk_s"] += time.perf_counter() - t0
             yield None                                          # every chromosome's extraction is enqueued: the caller may launch the next group
             for ev, h_pack, offs, n, words, name_bytes, d_cigar, d_cig_off, d_pos, _base, _d_pack in pending:
@@ -417,7 +429,11 @@ class DeviceDecoder:
                     state["done"] = True
                     return
                 if isinstance(item, BaseException):
-                    raise item
+                    # a LATER group failed in the reader: the groups in flight in front of it are healthy -- they are finished and
+                    # their chromosomes yielded first (drive() raises this once nothing is in flight any more), so that the
+                    # consumer's count of finished chromosomes points at the failing group and nothing decoded is thrown away
+                    state["error"], state["done"] = item, True
+                    return
                 inflight.append(launch(item, streams[state["k"] % depth]))
                 state["k"] += 1
                 if state["k"] == 1:
@@ -442,6 +458,8 @@ class DeviceDecoder:
                 while not stop.is_set():
                     pump(block=True)
                     if not inflight:
+                        if state.get("error") is not None:
+                            raise state["error"]
                         break
                     head = inflight[0]
                     while not head["event"].query():           # keep launching while the oldest group is still on the device ...

@@ -415,6 +415,7 @@ def _worker_main(conn):
     held = {}
     n_done = 0
     samples = {None: sample}
+    header_dict = None
     while True:
         msg = conn.recv()
         if msg[0] == "stop":
@@ -422,7 +423,12 @@ def _worker_main(conn):
         if msg[0] == "chrom":
             if msg[1] not in samples:
                 from .ingest import load_shared_sample
-                samples[msg[1]] = load_shared_sample(msg[2], sample.fasta if sample is not None else _POOL_STATE.get("fasta"))
+                meta = msg[2]
+                if "references" in meta:                      # the header's dictionary travels with a helper's first chromosome only
+                    header_dict = (meta["references"], meta["lengths"])
+                else:
+                    meta = dict(meta, references=header_dict[0], lengths=header_dict[1])
+                samples[msg[1]] = load_shared_sample(meta, sample.fasta if sample is not None else _POOL_STATE.get("fasta"))
             continue
         if msg[0] == "drop":
             samples.pop(msg[1], None)
@@ -573,6 +579,9 @@ class PooledHotPath(HotPath):
         self.max_inflight = max_inflight
         from .ingest import StaticFeed
         self.feed = feed if feed is not None else StaticFeed(sample)   # where a chromosome's Sample comes from
+        self._chrom_meta = {}                                          # key -> meta of the chromosomes of a file-driven run that are alive
+        self._helper_keys = [set() for _ in self.conns]                # per helper: the keys it has been told about
+        self._helper_has_dict = [False] * len(self.conns)              # per helper: has it received the header's sequence dictionary
 
     def release(self, chrom):
         """A chromosome of a file-driven run is finished (voted, stitched): the helpers unmap it, the feed frees it."""
@@ -581,9 +590,27 @@ class PooledHotPath(HotPath):
         except KeyError:
             return
         if key is not None:
-            for c in self.conns:
-                c.send(("drop", key))
+            self._chrom_meta.pop(key, None)
+            for ci, c in enumerate(self.conns):               # only the helpers that were told about it (see _announce)
+                if key in self._helper_keys[ci]:
+                    self._helper_keys[ci].discard(key)
+                    c.send(("drop", key))
         self.feed.release(chrom)
+
+    def _announce(self, ci, key):
+        """Tell helper ``ci`` where chromosome ``key`` lies in shared memory -- right in front of the first window of it that
+        the helper is given, i.e. while it is idle and reading its pipe.  (Until round 4 every arriving chromosome was
+        broadcast to every helper with blocking sends, busy ones included, its meta carrying the header's whole sequence
+        dictionary: a helper in the middle of a large window does not read its pipe while it sends parts of that window
+        to this thread -- a few such messages fill its socket buffer and both ends block for ever.  ADVICE r3.)"""
+        if key is None or key in self._helper_keys[ci]:
+            return
+        meta = self._chrom_meta[key]
+        if self._helper_has_dict[ci]:
+            meta = {k: v for k, v in meta.items() if k not in ("references", "lengths")}
+        self.conns[ci].send(("chrom", key, meta))
+        self._helper_has_dict[ci] = True
+        self._helper_keys[ci].add(key)
 
     def close(self):
         self.pool.close()
@@ -660,13 +687,13 @@ class PooledHotPath(HotPath):
             while idle and nxt < len(windows):
                 chrom, start, end = windows[nxt]
                 key, smp = self.feed.get(chrom, block=False)          # file-driven runs: is the chromosome decoded + scanned yet?
-                for k, _c, meta in self.feed.take_fresh():            # tell the helpers where it lies in shared memory
-                    for c in self.conns:
-                        c.send(("chrom", k, meta))
+                for k, _c, meta in self.feed.take_fresh():            # where it lies in shared memory: told to a helper with its first window of it
+                    self._chrom_meta[k] = meta
                 if smp is None:
                     prof["feed.not_ready"] += 1
                     break
                 ci = idle.pop()
+                self._announce(ci, key)
                 scan = None
                 if rescan:                                            # device scan of the window's block: the helper collects on ITS result
                     t_s = clock()

@@ -44,7 +44,13 @@ class Sample:
     @classmethod
     def from_device(cls, table, fasta, min_sv, d_cigar, d_off, d_pos):
         """The packed arrays are already in HBM (device-side ingestion, svision_amd/ingest_gpu.py): scan them in place."""
+        import torch
         from . import kernels
+        # the arrays were produced (and allocated) on the decoder's stream, whose event the caller has waited for; they are
+        # used on the caller's current stream from here on: the caching allocator must not hand their blocks out behind that
+        # stream's back when they are freed
+        for t in (d_cigar, d_off, d_pos):
+            t.record_stream(torch.cuda.current_stream(t.device))
         res = kernels.cigar_scan(d_cigar, d_off, d_pos, min_sv)
         gaps, gap_off, stats = res.to_host()
         from .segmentplot import run_hash_lineplot
