@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SVX_VERSION 340            /* 0.2.1: + active-row masks out of svx_alexnet_active_sets, into svx_bias_relu_pool_lrn */
+#define SVX_VERSION 350            /* 0.2.2: + svx_bgzf_crc32 (BGZF footer CRC32 verified on the device) */
 
 #define SVX_OK            0
 #define SVX_EINVAL       (-1)      /* bad argument (null pointer, bad layout...) */
@@ -275,6 +275,14 @@ int            svx_bgzf_inflate_lds(const uint8_t* d_comp, const uint64_t* d_src
                                     const uint64_t* d_dst_off, uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, void* stream);
 int            svx_bgzf_inflate_private(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len,
                                         const uint64_t* d_dst_off, uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, void* stream);
+/* CRC32 of every inflated block against the block's footer -- the four bytes behind its DEFLATE payload in d_comp (RFC 1952
+ * 2.3.1) -- what htslib checks on every block behind pysam's fetch (/root/reference/src/collection/run_collection.py:23-26).
+ * d_out / d_dst_off / d_comp / d_src_off / d_src_len: as svx_bgzf_inflate took and wrote them.  d_status [n]: left alone where
+ * the CRC agrees or a status is already set, SVX_INFLATE_BAD_CRC where it differs.  One wave per block, coalesced dword
+ * reads, one LDS look-up per byte (svx_crc.hip). */
+#define SVX_INFLATE_BAD_CRC 9
+int            svx_bgzf_crc32(const uint8_t* d_out, const uint64_t* d_dst_off, const uint8_t* d_comp, const uint64_t* d_src_off,
+                              const uint32_t* d_src_len, uint32_t n_blocks, uint32_t* d_status, void* stream);
 /* the same contract, one WAVE per block (uniform control flow; its time is proportional to the launch -- 17 ms per 5,120
  * blocks -- where the lane kernel needs 60+ ms for one block as for 98 k: the faster one below ~20 k blocks per launch) */
 int            svx_bgzf_inflate_wave(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len,

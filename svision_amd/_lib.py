@@ -51,6 +51,7 @@ SYMBOLS = {
     "svx_bgzf_inflate_wave": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
     "svx_bgzf_inflate_lds": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
     "svx_bgzf_inflate_private": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
+    "svx_bgzf_crc32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp]),
     "svx_bam_walk_count": (ctypes.c_int, [_vp, _vp, _u32, _vp, _vp]),
     "svx_bam_walk_extract": (ctypes.c_int, [_vp, _vp, _u32, _vp] + [_vp] * 9 + [_vp]),
     "svx_read_range": (ctypes.c_int, [ctypes.c_char_p, _u64, _u64, _vp, ctypes.c_int]),
@@ -73,7 +74,7 @@ class SvxMissing(SvxError):
 _lib = None
 
 
-ABI_VERSION = 340                     # SVX_VERSION of include/svx.h this binding was written against
+ABI_VERSION = 350                     # SVX_VERSION of include/svx.h this binding was written against
 
 
 def load():

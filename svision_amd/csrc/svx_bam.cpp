@@ -147,9 +147,11 @@ struct Deflate {
     using alloc_fn = void* (*)();
     using free_fn = void (*)(void*);
     using run_fn = int (*)(void*, const void*, size_t, void*, size_t, size_t*);
+    using crc_fn = uint32_t (*)(uint32_t, const void*, size_t);
     alloc_fn alloc = nullptr;
     free_fn release = nullptr;
     run_fn run = nullptr;
+    crc_fn crc = nullptr;                                     // libdeflate_crc32 (carry-less multiply: ~10 GB/s per core; zlib's table walk: ~1)
     Deflate()
     {
         if (getenv("SVX_BAM_ZLIB")) return;                  // A/B switch: force zlib
@@ -159,11 +161,21 @@ struct Deflate {
         alloc = (alloc_fn)dlsym(h, "libdeflate_alloc_decompressor");
         release = (free_fn)dlsym(h, "libdeflate_free_decompressor");
         run = (run_fn)dlsym(h, "libdeflate_deflate_decompress");
+        crc = (crc_fn)dlsym(h, "libdeflate_crc32");
         if (!alloc || !release || !run) alloc = nullptr;
     }
     bool fast() const { return alloc != nullptr; }
 };
 const Deflate& deflate_lib() { static const Deflate d; return d; }
+
+// The CRC32 of a BGZF block's inflated bytes against the one its footer carries (RFC 1952 2.3.1; htslib verifies it on
+// every block behind aln_file.fetch, run_collection.py:23-26).  SVX_BGZF_CRC=0 switches the check off.
+bool bgzf_crc_wanted() { static const bool on = [] { const char* e = getenv("SVX_BGZF_CRC"); return !(e && e[0] == '0'); }(); return on; }
+uint32_t crc32_of(const uint8_t* p, size_t n)
+{
+    if (deflate_lib().crc) return deflate_lib().crc(0, p, n);
+    return (uint32_t)crc32(crc32(0L, Z_NULL, 0), p, (uInt)n);
+}
 
 // one per worker thread and call
 struct BlockInflater {
@@ -353,8 +365,12 @@ bool inflate_chunk(const CChunk& c, RawBuf& out, Pool* pool, std::vector<OutBloc
     // slices from a shared counter, about eight per thread: the blocks of a chunk inflate at different speeds
     pool->run(c.blk.size(), std::max<size_t>(1, c.blk.size() / (8 * (size_t)pool->size())), [&](size_t lo, size_t hi) {
         thread_local BlockInflater inflate_block;
-        for (size_t i = lo; i < hi && ok; ++i)
-            if (!inflate_block(&c.bytes[c.blk[i].data], c.blk[i].csize, out.data() + ob[i].dst, ob[i].isize)) { ok = false; return; }
+        for (size_t i = lo; i < hi && ok; ++i) {
+            const uint8_t* payload = &c.bytes[c.blk[i].data];
+            if (!inflate_block(payload, c.blk[i].csize, out.data() + ob[i].dst, ob[i].isize)) { ok = false; return; }
+            // the block's footer follows its payload: CRC32 of the inflated bytes, ISIZE
+            if (bgzf_crc_wanted() && crc32_of(out.data() + ob[i].dst, ob[i].isize) != rd32(payload + c.blk[i].csize)) { ok = false; return; }
+        }
     });
     return ok;
 }
@@ -377,7 +393,7 @@ public:
         const double t0 = BamClock::now();
         const bool ok = inflate_chunk(cc_, out, pool_, &blocks_);
         g_clock.inflate += BamClock::now() - t0;
-        if (!ok) { err_ = "BGZF inflate failed"; return false; }
+        if (!ok) { err_ = "BGZF inflate failed (corrupt block or CRC32 mismatch)"; return false; }
         return true;
     }
 
@@ -723,7 +739,7 @@ struct Stream {
                 }
                 ch->buf.resize(HEAD);                           // the inflated bytes go behind the HEAD room
                 const double t0 = BamClock::now();
-                if (!inflate_chunk(it->c, ch->buf, inflate_pool.get(), &blocks)) { fail("BGZF inflate failed"); return; }
+                if (!inflate_chunk(it->c, ch->buf, inflate_pool.get(), &blocks)) { fail("BGZF inflate failed (corrupt block or CRC32 mismatch)"); return; }
                 t_inflate += BamClock::now() - t0;
                 ch->fresh = it->first;
                 ch->begin = HEAD + (it->first ? (size_t)(r.first & 0xffff) : 0);

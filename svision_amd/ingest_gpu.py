@@ -309,6 +309,9 @@ class DeviceDecoder:
                 st = kernels._stream_ptr(dev)
                 _lib.check(kernels.inflate_kernel_for(lib, nb)(d_comp.data_ptr(), d_tab.data_ptr(), d_len.data_ptr(), d_tab[2 * nb:].data_ptr(), nb, d_raw.data_ptr(),
                                                 d_status.data_ptr(), st), "svx_bgzf_inflate")
+                if kernels.bgzf_crc_wanted():                  # the footers' CRC32 (htslib checks it on every block): status 9 where one differs
+                    _lib.check(lib.svx_bgzf_crc32(d_raw.data_ptr(), d_tab[2 * nb:].data_ptr(), d_comp.data_ptr(), d_tab.data_ptr(), d_len.data_ptr(), nb,
+                                                  d_status.data_ptr(), st), "svx_bgzf_crc32")
                 total_starts = sum(item["n_starts"])
                 d_counts = torch.empty((total_starts + 1, 4), dtype=torch.int64, device=dev)
                 row = 0

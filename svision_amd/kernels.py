@@ -393,10 +393,20 @@ def inflate_kernel_for(lib, n_blocks):
     return lib.svx_bgzf_inflate_wave if n_blocks < WAVE_KERNEL_BELOW else lib.svx_bgzf_inflate
 
 
-def bgzf_inflate(d_comp, src_off, src_len, isize, wave=None):
+INFLATE_BAD_CRC = 9                 # SVX_INFLATE_BAD_CRC: the block inflated, but not to the bytes its footer's CRC32 was taken of
+
+
+def bgzf_crc_wanted():
+    """BGZF footers are verified (htslib does, behind pysam's fetch) unless SVX_BGZF_CRC=0."""
+    import os
+    return os.environ.get("SVX_BGZF_CRC", "1") != "0"
+
+
+def bgzf_inflate(d_comp, src_off, src_len, isize, wave=None, crc=None):
     """d_comp: uint8 device tensor holding the compressed bytes (16-byte aligned, padded to a multiple of 16); src_off / src_len / isize: host
     arrays of :func:`bgzf_block_table` (or the native reader's).  -> (uint8 device tensor with the inflated stream,
-    int32 device tensor [n] status: 0 = ok).  See include/svx.h svx_bgzf_inflate."""
+    int32 device tensor [n] status: 0 = ok, 9 = CRC32 mismatch).  ``crc``: verify the blocks' footers (svx_bgzf_crc32; default:
+    yes unless SVX_BGZF_CRC=0).  See include/svx.h svx_bgzf_inflate."""
     lib = _lib.load()
     _require_cuda(d_comp, "d_comp")
     if d_comp.dtype != torch.uint8:
@@ -422,4 +432,9 @@ def bgzf_inflate(d_comp, src_off, src_len, isize, wave=None):
             fn = lib.svx_bgzf_inflate_wave if wave else lib.svx_bgzf_inflate
         rc = fn(d_comp.data_ptr(), d_src.data_ptr(), d_len.data_ptr(), d_dst.data_ptr(), n, d_out.data_ptr(), d_status.data_ptr(), _stream_ptr(dev))
         _lib.check(rc, "svx_bgzf_inflate")
+        if bgzf_crc_wanted() if crc is None else crc:
+            # the blocks' footers (CRC32 of the inflated bytes) checked on the device: status 9 where one differs
+            rc = lib.svx_bgzf_crc32(d_out.data_ptr(), d_dst.data_ptr(), d_comp.data_ptr(), d_src.data_ptr(), d_len.data_ptr(), n,
+                                    d_status.data_ptr(), _stream_ptr(dev))
+            _lib.check(rc, "svx_bgzf_crc32")
     return d_out[:total], d_status[:n]

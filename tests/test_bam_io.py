@@ -426,3 +426,34 @@ def test_fast_segment_writer_puts_long_cigars_into_cg_tags(tmp_path):
     assert back.l_seq.tolist() == [5, qlen, 5] and back.names == ["a", "long", "short"] and back.pos.tolist() == [50, 100, 200]
     part = bam.read_bam(path, tids=[0])
     assert np.array_equal(part.cigar, cig)
+
+
+def test_host_engine_verifies_the_bgzf_crc(tmp_path):
+    """a damaged payload that keeps ISIZE (a flipped bit inside a STORED deflate block decodes fine) must
+    not go through: the host engine checks every block's CRC32 like htslib does behind pysam's fetch."""
+    import subprocess
+    import sys
+    cfg = synth.SimConfig(contigs=[("c1", 200_000)], coverage=6, read_len_mean=5000, read_len_sd=500, seed=11)
+    table, _g, _ = synth.simulate(cfg, with_genome=False)
+    good = str(tmp_path / "stored.bam")
+    bam.write_bam(good, table, level=0, index=True)              # level 0: stored blocks
+    assert len(bam.read_bam(good)) == len(table)
+    raw = bytearray(open(good, "rb").read())
+    from svision_amd import kernels
+    src_off, src_len, isize, _blk = kernels.bgzf_block_table(np.frombuffer(bytes(raw), np.uint8))
+    k = int(np.argmax(isize))                                     # a full block in the middle of the records
+    at = int(src_off[k]) + 5 + int(isize[k]) // 2                 # behind the stored block's 5-byte header: one data byte
+    # flip the lowest bit of a base / quality byte: the stream still decodes to ISIZE bytes and the record chain stays intact
+    raw[at] ^= 0x01
+    bad = str(tmp_path / "flipped.bam")
+    with open(bad, "wb") as f:
+        f.write(raw)
+    with pytest.raises(ValueError, match="CRC32"):
+        bam.read_bam(bad)
+    with pytest.raises(ValueError):
+        list(bam.BamStream(bad, threads=2))
+    # switched off (SVX_BGZF_CRC=0, what rounds 1-3 did) the file reads: the damage is invisible to everything but the CRC
+    code = ("import sys; sys.path.insert(0, %r); from svision_amd.io import bam; print(len(bam.read_bam(%r)))"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), bad))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, SVX_BGZF_CRC="0"))
+    assert r.returncode == 0 and r.stdout.strip() == str(len(table)), r.stderr[-1500:]

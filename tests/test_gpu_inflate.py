@@ -92,6 +92,28 @@ def test_damaged_blocks_are_flagged(wave):
     assert status[0] == 0 and status[3] == 0 and status[1] != 0 and status[2] != 0
 
 
+@pytest.mark.parametrize("wave", ["lds", "private", "wave"])
+def test_a_damaged_payload_that_keeps_isize_is_caught_by_the_crc(wave):
+    """a flipped bit that leaves the DEFLATE stream decodable and ISIZE right (here: inside a stored block)
+    went through both engines silently; htslib checks the footer's CRC32 on every block, and so does svx_bgzf_crc32."""
+    rng = np.random.default_rng(6)
+    payloads = [bytes(rng.integers(0, 256, n, dtype=np.uint8)) for n in (50000, 3, 1, 65280, 4, 4099)]
+    blocks = [bytearray(_block(p, level=0)) for p in payloads]            # level 0: stored blocks -- any payload byte may change
+    flipped = bytearray(blocks[0])
+    flipped[18 + 5 + 777] ^= 0x04                                          # one bit of one data byte (18-byte header, 5-byte stored-block header)
+    raw = bytes(blocks[0]) + bytes(flipped) + b"".join(bytes(b) for b in blocks[1:]) + bam._BGZF_EOF
+    got, status = _inflate_on_device(raw, wave)
+    want = [0, kernels.INFLATE_BAD_CRC] + [0] * (len(blocks) - 1) + [0]
+    assert status.tolist() == want
+    # and with the check switched off the damaged block passes (what rounds 1-3 did)
+    r = np.frombuffer(raw, np.uint8)
+    src_off, src_len, isize, _blk = kernels.bgzf_block_table(r)
+    padded = np.zeros((r.size + 31) // 16 * 16, np.uint8)
+    padded[:r.size] = r
+    _out, status = kernels.bgzf_inflate(torch.from_numpy(padded).cuda(), src_off, src_len, isize, wave=wave, crc=False)
+    assert not status.cpu().numpy().any()
+
+
 def _same_table(a, b):
     for f in ("tid", "pos", "flag", "mapq", "l_seq", "name_id", "cigar", "cig_off"):
         assert np.array_equal(getattr(a, f), getattr(b, f)), f
