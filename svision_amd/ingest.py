@@ -314,8 +314,10 @@ class ChromosomeFeed:
         try:
             if engine == "gpu":                                # BGZF inflate + record packing on the device
                 from .ingest_gpu import DeviceDecoder, DeviceIngestError
+                # pread threads of the device engine: copies out of the page cache, ~2 GB/s each (SVX_READ_THREADS overrides)
+                n_read = int(os.environ.get("SVX_READ_THREADS", "0")) or min(8, max(1, self.threads))
                 dec = self.decoder = DeviceDecoder(self.bam_path, self.index, self.references, self.lengths, self.header_text, self.device,
-                                                   threads=min(8, max(1, self.threads)), alloc_for=self._slot_alloc)
+                                                   threads=n_read, alloc_for=self._slot_alloc)
                 if not dec.usable(tids):
                     host_parts(tids)
                 else:

@@ -27,6 +27,27 @@ LARGE_GROUP_BLOCKS = 94_000              # ... but not more blocks than one roun
 GROUP_BYTES = 24 << 30                   # serial form (groups / decode_group): later groups as large as they come
 
 
+# The pinned staging slots outlive a decoder: a process that reads a second file (a service, a bench's warm-up pass) finds them
+# allocated -- hipHostMalloc costs ~0.1 s per GB and every other HIP call of the process waits for it.
+_STAGING = {"lock": None, "slots": [], "busy": False}
+
+
+def _staging_ring():
+    """-> (slots, release): the process-wide ring of pinned slots if no other decoder holds it, else a private one."""
+    import threading
+    if _STAGING["lock"] is None:
+        _STAGING["lock"] = threading.Lock()
+    with _STAGING["lock"]:
+        if not _STAGING["busy"]:
+            _STAGING["busy"] = True
+
+            def release():
+                with _STAGING["lock"]:
+                    _STAGING["busy"] = False
+            return _STAGING["slots"], release
+    return [], (lambda: None)
+
+
 class DeviceIngestError(RuntimeError):
     """``tids``: the references the failure belongs to (None: unknown -- the reference the consumer waits for is blamed)."""
     tids = None
@@ -92,6 +113,8 @@ def spill_cigar(table):
 
 class DeviceDecoder:
     def __init__(self, path, index, references, lengths, header_text, device, threads=8, alloc_for=None):
+        import time
+        self._t0, self.trace = time.perf_counter(), []          # (seconds since construction, what) of the first events (SVX_TIMING)
         self.path, self.references, self.lengths, self.header_text = path, list(references), list(lengths), header_text
         self.device, self.threads = torch.device(device), max(1, int(threads))
         self.alloc_for = alloc_for                               # callable() -> alloc(name, dtype, n) of the next part (shared memory)
@@ -100,8 +123,7 @@ class DeviceDecoder:
         self.size = os.path.getsize(path)
         self.pinned = None
         self.stats = {"read_s": 0.0, "h2d_inflate_s": 0.0, "walk_s": 0.0, "d2h_s": 0.0, "names_s": 0.0, "blocks": 0, "bytes_in": 0, "bytes_inflated": 0}
-        import time
-        self._t0, self.trace = time.perf_counter(), []          # (seconds since construction, what) of the first events (SVX_TIMING)
+        self._mark("index read")
         import threading
         self.first_handover = threading.Event()                 # set by the consumer once the first chromosome's scan is through
 
@@ -184,20 +206,26 @@ class DeviceDecoder:
             groups.append(cur)
         if groups and len(groups[-1]) > 1 and sum(size_of(t) for t in groups[-1]) > FIRST_GROUP_BYTES + size_of(groups[-1][-1]):
             groups[-1:] = [groups[-1][:-1], groups[-1][-1:]]
+        self._mark("groups cut: %s" % [len(g) for g in groups])
         q = queue.Queue(maxsize=1)
         stop = threading.Event()
         # Staging: a ring of four pinned 64 MB slots.  A group's compressed bytes go to the device slot by slot -- read (8
         # pread threads), index the BGZF blocks the slot holds, copy them to their place in the group's device buffer on a
         # copy stream, reuse the slot once its copy is done.  (First version: one pinned buffer per group in flight --
         # 3.7 GB of hipHostMalloc at 0.1 s per GB inside the run, during which every other HIP call of the process waited.)
-        ring, ring_at = [], [0]
+        ring, release_ring = _staging_ring()
+        ring[:] = [r for r in ring if r[0].numel() == STAGE_BYTES]
+        for r in ring:
+            r[1] = None
+        ring_at = [0]
         copy_stream = torch.cuda.Stream(device=dev)
 
         def slot():
-            if len(ring) < 4:
+            if ring_at[0] < 4 and len(ring) < 4:
+                ring_at[0] += 1
                 ring.append([torch.empty(STAGE_BYTES, dtype=torch.uint8, pin_memory=True), None])
                 return ring[-1]
-            s_ = ring[ring_at[0] % 4]
+            s_ = ring[ring_at[0] % len(ring)]
             ring_at[0] += 1
             if s_[1] is not None:
                 s_[1].synchronize()
@@ -507,6 +535,12 @@ class DeviceDecoder:
                 yield part
         finally:
             stop.set()
+            try:
+                th.join(timeout=10)                            # (an abandoned run: the reader may be in the middle of a group)
+                copy_stream.synchronize()                      # the slots go back to the process-wide ring: no copy may still read them
+            finally:
+                if not th.is_alive():
+                    release_ring()
 
     def _make_finish(self, hp, offs, n, words, name_bytes, d_cigar):
         """The host side of one device-decoded chromosome: packed read-back -> shared-memory arrays, QNAME ids, table."""

@@ -364,13 +364,15 @@ def read_bai_linear(path):
         n_bin = struct.unpack_from("<i", raw, p)[0]
         p += 4
         lo, hi = None, None
-        for _b in range(n_bin):
-            bin_id, n_chunk = struct.unpack_from("<Ii", raw, p)
+        unpack = struct.unpack_from
+        for _b in range(n_bin):                                # (plain ints: a whole-genome index has ~10^5 bins, a NumPy call per bin cost seconds)
+            bin_id, n_chunk = unpack("<Ii", raw, p)
             p += 8
             if bin_id != 37450 and n_chunk:
-                chunks = np.frombuffer(raw, "<u8", 2 * n_chunk, p).reshape(-1, 2)
-                lo = int(chunks[:, 0].min()) if lo is None else min(lo, int(chunks[:, 0].min()))
-                hi = int(chunks[:, 1].max()) if hi is None else max(hi, int(chunks[:, 1].max()))
+                vals = unpack("<%dQ" % (2 * n_chunk), raw, p)
+                b0, e1 = min(vals[0::2]), max(vals[1::2])
+                lo = b0 if lo is None or b0 < lo else lo
+                hi = e1 if hi is None or e1 > hi else hi
             p += 16 * n_chunk
         n_intv = struct.unpack_from("<i", raw, p)[0]
         p += 4

@@ -390,6 +390,11 @@ def inflate_kernel_for(lib, n_blocks):
     """The faster of the two inflate kernels for a launch of ``n_blocks`` blocks.  One lane per block needs ~0.1 s whatever
     the launch size up to 98 k blocks (1,536 resident waves); one wave per block needs ~17 ms per round of 5,120 blocks:
     level at 28 k blocks, 3x ahead at the 7 k blocks of a small chromosome (measured: tools/exp/inflate_gpu_bench.py)."""
+    import os
+    variant = os.environ.get("SVX_INFLATE_VARIANT")          # A/B switch: lds | private | wave | lane (default: by launch size)
+    if variant:
+        return {"lds": lib.svx_bgzf_inflate_lds, "private": lib.svx_bgzf_inflate_private, "wave": lib.svx_bgzf_inflate_wave,
+                "lane": lib.svx_bgzf_inflate}[variant]
     return lib.svx_bgzf_inflate_wave if n_blocks < WAVE_KERNEL_BELOW else lib.svx_bgzf_inflate
 
 

@@ -91,3 +91,29 @@ def test_exchange_over_rccl_equals_the_plain_run(expected, device_model, tmp_pat
     a = open(os.path.join(str(tmp_path / "plain"), "HGr.svision.s3.vcf")).read()
     b = open(os.path.join(str(tmp_path / "rccl"), "HGr.svision.s3.vcf")).read()
     assert a == b and a.count("\n") > 30
+
+
+def test_eight_ranks_on_the_miniature_equal_one_rank(miniature, device_model, tmp_path):
+    """the first contact with an 8-GPU node must not also be the first 8-rank run.  Eight torchrun ranks
+    on the one GPU of the box (gloo: RCCL refuses duplicate devices; the driver's multi-GPU runs use nccl), the 24
+    chromosomes LPT-sharded three to a rank, every rank streaming only its own byte ranges of the BAM through the device
+    ingest engine with the host budget of an eighth of the box (quota-aware sizing: helpers, pread threads): rank 0's merged VCF
+    is the one-rank run's, byte for byte, and every rank logs its shard."""
+    bam_path, fa, contigs = miniature
+    args = ["-b", bam_path, "-m", device_model, "-g", fa, "-t", "2"] + ARGS
+    one = _cli(["-o", str(tmp_path / "one")] + args)
+    assert one.returncode == 0, one.stdout + one.stderr
+    env = dict(os.environ, PYTHONPATH=ROOT, SVX_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT="29653",
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+           "--master-port", "29653", os.path.join(ROOT, "SVision"), "-o", str(tmp_path / "eight")] + args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-5000:]
+    a = open(os.path.join(str(tmp_path / "one"), "HGwg.svision.s4.vcf")).read()
+    b = open(os.path.join(str(tmp_path / "eight"), "HGwg.svision.s4.vcf")).read()
+    assert a == b and a.count("\n") > 200
+    logs = sorted(f for f in os.listdir(str(tmp_path / "eight")) if f.endswith(".log"))
+    assert len(logs) == 8                                          # one log per rank
+    from svision_amd import dist as sdist
+    shards = sdist.shard_chromosomes([n for n, _l in contigs], [l for _n, l in contigs], 8)
+    assert sorted(len(s) for s in shards) == [3] * 8               # LPT on 24 chromosomes: three each
