@@ -250,6 +250,9 @@ def main():
     ap.add_argument("--steps", type=int, default=None, help="windows of the job (wg: whole job, default 20 -- the windows the job's BAM is written for; with --resident all 322; cfg2 / ont: per rank, default 200)")
     ap.add_argument("--resident", action="store_true", help="`value` = the resident leg (alignments decoded and in HBM before the timed region; the headline of rounds 1-3): for jobs whose BAM would be too large to write during set-up (the whole genome: 62 GB)")
     ap.add_argument("--no-other-engine", action="store_true", help="skip the file-inclusive leg with the other ingest engine")
+    ap.add_argument("--e2e-sweep", default=None, help="experiments: further file-inclusive legs in the same process, one per ';'-separated set of "
+                                                      "comma-separated NAME=VALUE environment settings (e.g. 'SVX_STAGE_SLOTS=8;SVX_STAGE_SLOTS=8,SVX_PIPE_GROUP_MB=256'); "
+                                                      "a set may be repeated; their seconds go to stderr and to the line's `e2e_sweep`")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", choices=("cfg1", "cfg2", "wg", "ont", "contig"), default="wg",
                     help="wg: 24 GRCh38-length contigs sharded over the ranks (strong scaling, the default: the config the metric is quoted on); "
@@ -300,6 +303,7 @@ def main():
         # hipMalloc of a process on a box whose previous process has just exited costs 0.15-0.35 s (nothing else in the process
         # gets a HIP call through meanwhile); one block of the size the legs' buffers add up to is allocated here and stays in
         # the caching allocator, which cuts the legs' buffers out of it.
+        # (compressed bytes x 2.4 inflated x 1.5 for the two-kernel inflate's sequence streams + packed arrays, several groups in flight)
         torch.empty(min(24 << 30, 6 * int(e2e["bytes"])), dtype=torch.uint8, device=dev)
     net = AlexNet(random_weights(0), device=dev)
     net.executed = torch.zeros(5, dtype=torch.int64, device=dev)     # executed conv pixels per layer + images, summed on the device
@@ -400,6 +404,26 @@ def main():
     res_stage = stage_stats()
     tot, tmax = reduce_sum_max([sites, images, dt])
     res_sites, res_images, dt = float(tot[0]), float(tot[1]), float(tmax[2])
+    sweep = []
+    if e2e is not None and args.e2e_sweep:
+        for spec in args.e2e_sweep.split(";"):
+            env = dict(kv.split("=", 1) for kv in spec.split(",") if "=" in kv)
+            saved = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            try:
+                leg = run_from_file(args, e2e, hot, run, fasta, opts, dev, sync_all, cores, world, workers, grouped, engine=os.environ.get("SVX_INGEST", "auto"), keep=True)
+            finally:
+                for k, v in saved.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+            dd = leg["rank0_feed"].get("device_decoder", {})
+            sweep.append({"env": env, "seconds": leg["seconds"], "read_s": dd.get("read_s"), "pread_s": dd.get("pread_s"), "slot_wait_s": dd.get("slot_wait_s"),
+                          "last_ready_s": leg["rank0_feed"].get("last_ready_s"), "device_busy_frac": leg["device_busy_frac"]})
+            if rank == 0:
+                print("e2e sweep %s: %.3f s (read %s, pread %s, slot wait %s, last chromosome ready %s)" % (
+                    spec or "(default)", leg["seconds"], dd.get("read_s"), dd.get("pread_s"), dd.get("slot_wait_s"), leg["rank0_feed"].get("last_ready_s")), file=sys.stderr)
     if e2e is not None and not args.no_other_engine:
         # the file-inclusive leg with the other ingest engine, reported beside it (default engine: BGZF inflate + record packing
         # on the device; the other: libdeflate on the host's threads)
@@ -510,6 +534,8 @@ def main():
     if e2e_other is not None:
         e2e_other["ratio_to_resident"] = e2e_other["value"] / max(res_sites / dt, 1e-9)
         line["e2e_host_ingest" if e2e_other["ingest_engine"] == "cpu" else "e2e_device_ingest"] = e2e_other
+    if sweep:
+        line["e2e_sweep"] = sweep
     if calib:
         line["roofline_kernels"] = calib
     hot.close()

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SVX_VERSION 350            /* 0.2.2: + svx_bgzf_crc32 (BGZF footer CRC32 verified on the device) */
+#define SVX_VERSION 360            /* 0.3.0: + svx_bgzf_crc32 (BGZF footer CRC32 on the device), svx_bgzf_inflate_fast (two-kernel inflate) */
 
 #define SVX_OK            0
 #define SVX_EINVAL       (-1)      /* bad argument (null pointer, bad layout...) */
@@ -275,6 +275,16 @@ int            svx_bgzf_inflate_lds(const uint8_t* d_comp, const uint64_t* d_src
                                     const uint64_t* d_dst_off, uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, void* stream);
 int            svx_bgzf_inflate_private(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len,
                                         const uint64_t* d_dst_off, uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, void* stream);
+/* The same contract in two kernels (svx_inflate2.hip): (A) one WAVE per block decodes the Huffman code in parallel -- 64
+ * segments of the compressed bits per step, every lane from its segment's first bit, re-synchronised with its predecessor --
+ * and transcodes the tokens into a byte-aligned LZ sequence stream; (B) one LANE per block copies literals and matches
+ * from that stream.  d_ws: svx_bgzf_inflate_fast_ws_bytes(d_dst_off[n] - d_dst_off[0], n) bytes (16-byte aligned) for the
+ * sequence streams.  Same statuses; blocks whose stream would not fit its slot (pathological: hundreds of tiny DEFLATE
+ * blocks) are decoded by the wave-per-block kernel inside the call. */
+size_t         svx_bgzf_inflate_fast_ws_bytes(uint64_t inflated_bytes, uint32_t n_blocks);
+int            svx_bgzf_inflate_fast(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len,
+                                     const uint64_t* d_dst_off, uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status,
+                                     void* d_ws, uint64_t ws_bytes, void* stream);
 /* CRC32 of every inflated block against the block's footer -- the four bytes behind its DEFLATE payload in d_comp (RFC 1952
  * 2.3.1) -- what htslib checks on every block behind pysam's fetch (/root/reference/src/collection/run_collection.py:23-26).
  * d_out / d_dst_off / d_comp / d_src_off / d_src_len: as svx_bgzf_inflate took and wrote them.  d_status [n]: left alone where

@@ -589,10 +589,11 @@ struct WaveWriter {
 
 __global__ __launch_bounds__(LANES)
 void bgzf_inflate_wave_kernel(const uint8_t* __restrict__ comp, const uint64_t* __restrict__ src_off, const uint32_t* __restrict__ src_len,
-                              const uint64_t* __restrict__ dst_off, uint32_t n_blocks, uint8_t* out, uint32_t* __restrict__ status)
+                              const uint64_t* __restrict__ dst_off, uint32_t n_blocks, uint8_t* out, uint32_t* __restrict__ status, uint32_t only)
 {
     __shared__ WaveLds t;
     const uint32_t b = blockIdx.x;
+    if (only != 0u && uni((int)status[b]) != (int)only) return;     // (svx_bgzf_inflate_fast: the blocks it left over, those only)
     WaveReader br;
     br.init(comp, src_off[b], src_len[b]);
     WaveWriter w{out, dst_off[b], dst_off[b], dst_off[b + 1], 0u};
@@ -735,7 +736,17 @@ extern "C" int svx_bgzf_inflate_wave(const uint8_t* d_comp, const uint64_t* d_sr
     if (!d_comp || !d_src_off || !d_src_len || !d_dst_off || !d_out || !d_status) return SVX_EINVAL;
     if (reinterpret_cast<uintptr_t>(d_comp) & 15u) return SVX_EINVAL;
     hipLaunchKernelGGL(bgzf_inflate_wave_kernel, dim3(n_blocks), dim3(LANES), 0, static_cast<hipStream_t>(stream),
-                       d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, d_out, d_status);
+                       d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, d_out, d_status, 0u);
+    return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
+}
+
+// (library-internal) the wave-per-block kernel on the blocks whose status is `only`, which it replaces by its own verdict
+extern "C" __attribute__((visibility("hidden")))
+int svx_bgzf_inflate_wave_only(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len, const uint64_t* d_dst_off,
+                               uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, uint32_t only, void* stream)
+{
+    hipLaunchKernelGGL(bgzf_inflate_wave_kernel, dim3(n_blocks), dim3(LANES), 0, static_cast<hipStream_t>(stream),
+                       d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, d_out, d_status, only);
     return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
 }
 

@@ -1,0 +1,537 @@
+// svx_inflate2.hip -- BGZF inflate on gfx950 in two kernels: parallel Huffman decoding per block, then the LZ77 copies.
+//
+// The lane-per-block kernel of svx_inflate.hip pays ~300 instructions and two or three dependent memory round trips per
+// decoded symbol (420 B of LDS per lane hold its Huffman tables: 1.5 waves per SIMD, nobody to hide them): 64 ms per block
+// whatever the launch holds.  What is sequential in DEFLATE is the LZ77 window, not the Huffman code -- a decoder started
+// at an arbitrary bit re-synchronises with the true token boundaries within a few dozen bits (measured on BAM data:
+// median 50 bits, 99 % within 500; tools/exp/spec_inflate_sim.cpp is the CPU model of everything below).  So:
+//
+//   A. bgzf_tokens_kernel -- one WAVE per BGZF block.  Per DEFLATE block the wave parses the header (uniform, scalar bit
+//      buffer) and builds ONE set of look-up tables in LDS (10-bit literal/length root + sub-tables, 8-bit distance root:
+//      entries carry base value and extra-bit count); then the compressed bits are cut into chunks of 64 segments of
+//      SEG_BITS bits, staged in LDS, and lane i decodes segment i -- pass S1 from the segment's first bit (speculative: its
+//      last token boundary is almost always a true one), pass S2 from its predecessor's end, repeated for the lanes whose
+//      start moved until nothing moves (lane 0 is true, so lane k is true after <= k rounds; in practice 1.15); S2 also sizes
+//      every segment's output.  Pass S3 decodes once more and TRANSCODES: the tokens leave as byte-aligned LZ sequences,
+//      u32 header [literals:8 | match length:9 | distance - 1:15] + the literal bytes, every lane writing its own part of
+//      the block's stream (offsets by wave prefix sums).  No LZ77 copy happens here: nothing in this kernel waits for a
+//      store.
+//   B. bgzf_lz_kernel -- one LANE per block walks its sequence stream: literal runs and matches are copied in steps of up
+//      to eight bytes.  No tables, no LDS, ~40 VGPRs: every block of a launch is resident at once and a turn costs ~50
+//      instructions instead of ~300; 22 k steps per 64 KB block instead of 36 k turns.
+//
+// Byte-identical to zlib by construction (tests/test_gpu_inflate.py runs this pair through every case the other kernels
+// pass).  Blocks whose sequence stream would not fit its slot (1.5 x ISIZE + 1 KB: only pathological streams -- hundreds of
+// tiny DEFLATE blocks -- get there) are left to the wave-per-block kernel of svx_inflate.hip by the entry point.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "../../include/svx.h"
+
+namespace {
+
+constexpr int LANES = 64;
+constexpr int LB = 10, DB = 8;                       // root bits of the literal / length and the distance table
+constexpr int LIT_CAP = (1 << LB) + 512, DIST_CAP = (1 << DB) + 512;      // + sub-tables (zlib's ENOUGH for 286 / 30 symbols, 15-bit codes)
+constexpr int SEG_BITS = 512;                        // compressed bits per lane and chunk
+constexpr int CHUNK_WORDS = LANES * SEG_BITS / 32 + 8;                    // staged dwords: the chunk + what the last tokens may read behind it
+enum { K_BAD = 0, K_LIT = 1, K_LEN = 2, K_EOB = 3, K_SUB = 4 };
+enum { INF_OK = 0, INF_BAD_TYPE = 1, INF_BAD_STORED = 2, INF_BAD_TABLE = 3, INF_BAD_CODE = 4, INF_OUT_OVERRUN = 5, INF_IN_OVERRUN = 6, INF_SHORT = 7,
+       INF_BAD_DIST = 8, INF_TOKENS_OVERFLOW = 10 };
+
+__constant__ uint16_t LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__constant__ uint8_t LEN_EXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__constant__ uint16_t DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__constant__ uint8_t DIST_EXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__constant__ uint8_t CLEN_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+// table entry: bits 0..3 code bits consumed at this level, 4..7 kind, 8.. payload
+//   literal: 8..15 byte | length: 8..16 base, 17..19 extra bits | distance: 8..22 base, 23..26 extra bits | sub-table: 8..19 start, 20..23 bits
+struct LitPayload {
+    __device__ __forceinline__ uint32_t operator()(int s) const
+    {
+        if (s < 256) return (uint32_t)K_LIT << 4 | (uint32_t)s << 8;
+        if (s == 256) return (uint32_t)K_EOB << 4;
+        if (s - 257 >= 29) return (uint32_t)K_BAD << 4;
+        return (uint32_t)K_LEN << 4 | (uint32_t)LEN_BASE[s - 257] << 8 | (uint32_t)LEN_EXTRA[s - 257] << 17;
+    }
+};
+struct DistPayload {
+    __device__ __forceinline__ uint32_t operator()(int s) const
+    {
+        return s >= 30 ? (uint32_t)K_BAD << 4 : ((uint32_t)K_LEN << 4 | (uint32_t)DIST_BASE[s] << 8 | (uint32_t)DIST_EXTRA[s] << 23);
+    }
+};
+struct ClenPayload { __device__ __forceinline__ uint32_t operator()(int s) const { return (uint32_t)K_LIT << 4 | (uint32_t)s << 8; } };
+
+struct Lds {
+    uint32_t lit[LIT_CAP];                           // 6 KB
+    uint32_t dist[DIST_CAP];                         // 3 KB (also: the code-length code's table, scratch of the literal table's build)
+    uint32_t chunk[CHUNK_WORDS];                     // 4 KB: the compressed bytes of the chunk in hand
+    uint16_t code[320];                              // canonical code of every symbol
+    uint8_t lens[320];                               // code lengths: literal / length symbols at 0, distance symbols at 288
+    uint8_t cl[32];
+};
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ void lds_fence() { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); }   // lgkmcnt(0); one wave: in order
+
+// uniform bit reader for the block headers: the stream's next 256 bytes in one VGPR (lane i = dword i), the bit buffer scalar
+struct HeadReader {
+    const uint32_t* words;
+    uint32_t cur, nxt;
+    uint64_t chunk_next, word_end;
+    int k;
+    uint64_t buf;
+    int cnt;
+    uint32_t fed;                                    // bits handed out since seek()
+    __device__ __forceinline__ uint32_t fetch(uint64_t first) { const uint64_t i = first + threadIdx.x; return i < word_end ? words[i] : 0u; }
+    __device__ __forceinline__ void refill()
+    {
+        if (cnt <= 32) {
+            const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)cur, k);
+            if (++k == 64) { cur = nxt; nxt = fetch(chunk_next); chunk_next += 64; k = 0; }
+            buf |= (uint64_t)v << cnt;
+            cnt += 32;
+        }
+    }
+    // position the reader at bit `bit` of the stream that starts at byte address `base` and holds `bytes` bytes
+    __device__ __forceinline__ void seek(const uint8_t* base, uint32_t bytes, uint32_t bit)
+    {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(base) + (bit >> 3);
+        words = reinterpret_cast<const uint32_t*>(a & ~(uintptr_t)3);
+        word_end = ((reinterpret_cast<uintptr_t>(base) + bytes + 3) >> 2) - (reinterpret_cast<uintptr_t>(words) >> 2) + 1;   // (+ a dword of the footer: readable)
+        cur = fetch(0); nxt = fetch(64); chunk_next = 128;
+        k = 0; buf = 0; cnt = 0;
+        refill();
+        const int skip = (int)(a & 3) * 8 + (int)(bit & 7);
+        buf >>= skip; cnt -= skip;
+        fed = 0;
+    }
+    __device__ __forceinline__ uint32_t bits(int n)            // n <= 16
+    {
+        refill();
+        const uint32_t v = (uint32_t)buf & ((1u << n) - 1u);
+        buf >>= n; cnt -= n; fed += (uint32_t)n;
+        return v;
+    }
+};
+
+// Canonical Huffman tables of one alphabet, built by the wave: code lengths lens[0..n) (LDS) -> root table of 2^root entries +
+// sub-tables for longer codes, behind it.  `tmp`: 2^root bytes of scratch in LDS.  -> entries used, 0 = over-subscribed / too large.
+template <class Payload>
+__device__ int build_tables(const uint8_t* lens, int n, int root, uint32_t* tab, int cap, uint16_t* code_of, uint8_t* tmp, Payload payload)
+{
+    const int lane = threadIdx.x;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int count[16];
+#pragma unroll
+    for (int l = 0; l < 16; ++l) count[l] = 0;
+    for (int s0 = 0; s0 < n; s0 += LANES) {
+        const int l = s0 + lane < n ? (int)lens[s0 + lane] : 0;
+#pragma unroll
+        for (int q = 1; q < 16; ++q) count[q] += (int)__popcll(__ballot(l == q));
+    }
+    int next[16], left = 1, code = 0;
+    next[0] = 0;
+#pragma unroll
+    for (int l = 1; l <= 15; ++l) {
+        left = (left << 1) - count[l];
+        code = (code + (l > 1 ? count[l - 1] : 0)) << 1;
+        next[l] = code;
+    }
+    if (left < 0) return 0;
+    // codes in symbol order within each length
+    for (int s0 = 0; s0 < n; s0 += LANES) {
+        const int l = s0 + lane < n ? (int)lens[s0 + lane] : 0;
+        int mine = 0;
+#pragma unroll
+        for (int q = 1; q < 16; ++q) {
+            const unsigned long long m = __ballot(l == q);
+            if (l == q) mine = next[q] + (int)__popcll(m & lt);
+            next[q] += (int)__popcll(m);
+        }
+        if (s0 + lane < n) code_of[s0 + lane] = (uint16_t)mine;
+    }
+    const int nroot = 1 << root;
+    for (int i = lane; i < nroot; i += LANES) { tab[i] = 0; tmp[i] = 0; }
+    lds_fence();
+    // sub-table bits per root prefix: the longest code below it
+    for (int s = 0; s < n; ++s) {
+        const int l = uni((int)lens[s]);
+        if (l <= root) continue;
+        const uint32_t r = __brev((uint32_t)uni((int)code_of[s])) >> (32 - l);
+        const int pre = (int)(r & (uint32_t)(nroot - 1));
+        if (lane == 0 && (int)tmp[pre] < l - root) tmp[pre] = (uint8_t)(l - root);
+        lds_fence();
+    }
+    // allocate: exclusive prefix of 2^bits over the root entries (each lane owns nroot / 64 consecutive entries)
+    int top = nroot;
+    {
+        const int per = nroot / LANES, i0 = lane * per;
+        int mine = 0;
+        for (int i = 0; i < per; ++i) { const int b = tmp[i0 + i]; mine += b ? 1 << b : 0; }
+        int inc = mine;
+#pragma unroll
+        for (int o = 1; o < LANES; o <<= 1) { const int u = __shfl_up(inc, o, LANES); if (lane >= o) inc += u; }
+        const int total = __shfl(inc, LANES - 1, LANES);
+        if (nroot + total > cap) return 0;
+        int at = nroot + inc - mine;
+        for (int i = 0; i < per; ++i) {
+            const int b = tmp[i0 + i];
+            if (b) { tab[i0 + i] = (uint32_t)K_SUB << 4 | (uint32_t)at << 8 | (uint32_t)b << 20; at += 1 << b; }
+        }
+        for (int i = nroot + lane; i < nroot + total; i += LANES) tab[i] = 0;
+        top = nroot + total;
+    }
+    lds_fence();
+    // entries: symbol after symbol, the wave fills a symbol's replicas
+    for (int s = 0; s < n; ++s) {
+        const int l = uni((int)lens[s]);
+        if (l == 0) continue;
+        const uint32_t r = __brev((uint32_t)uni((int)code_of[s])) >> (32 - l);
+        if (l <= root) {
+            const uint32_t e = payload(s) | (uint32_t)l;
+            for (uint32_t i = r + ((uint32_t)lane << l); i < (uint32_t)nroot; i += (uint32_t)LANES << l) tab[i] = e;
+        } else {
+            const uint32_t p = tab[r & (uint32_t)(nroot - 1)];
+            const uint32_t start = (p >> 8) & 0xfffu, sb = (p >> 20) & 15u;
+            const uint32_t e = payload(s) | (uint32_t)(l - root);
+            for (uint32_t i = (r >> root) + ((uint32_t)lane << (l - root)); i < (1u << sb); i += (uint32_t)LANES << (l - root)) tab[start + i] = e;
+        }
+    }
+    lds_fence();
+    return top;
+}
+
+// >= 57 bits of the chunk from bit `rel` of the staged words (rel < 32 * (CHUNK_WORDS - 2))
+__device__ __forceinline__ uint64_t peek(const uint32_t* chunk, uint32_t rel)
+{
+    const uint32_t w = rel >> 5, sh = rel & 31u;
+    const uint32_t d0 = chunk[w], d1 = chunk[w + 1], d2 = chunk[w + 2];
+    const uint64_t lo = ((uint64_t)d1 << 32 | d0) >> sh;
+    return sh ? lo | (uint64_t)d2 << (64 - sh) : lo;
+}
+
+struct Tok { uint32_t kind, used, val, len, dist; };
+
+__device__ __forceinline__ Tok token(const Lds& t, uint32_t rel)
+{
+    const uint64_t bits = peek(t.chunk, rel);
+    uint32_t e = t.lit[(uint32_t)bits & ((1u << LB) - 1u)];
+    uint32_t used;
+    if (((e >> 4) & 15u) == K_SUB) {
+        e = t.lit[((e >> 8) & 0xfffu) + ((uint32_t)(bits >> LB) & ((1u << ((e >> 20) & 15u)) - 1u))];
+        used = LB + (e & 15u);
+    } else used = e & 15u;
+    Tok k{(e >> 4) & 15u, used, (e >> 8) & 255u, 0u, 0u};
+    if (k.kind != K_LEN) return k;
+    const uint32_t xb = (e >> 17) & 7u;
+    k.len = ((e >> 8) & 511u) + ((uint32_t)(bits >> used) & ((1u << xb) - 1u));
+    used += xb;
+    uint32_t d = t.dist[(uint32_t)(bits >> used) & ((1u << DB) - 1u)];
+    if (((d >> 4) & 15u) == K_SUB) {
+        d = t.dist[((d >> 8) & 0xfffu) + ((uint32_t)(bits >> (used + DB)) & ((1u << ((d >> 20) & 15u)) - 1u))];
+        used += DB + (d & 15u);
+    } else used += d & 15u;
+    if (((d >> 4) & 15u) != K_LEN) { k.kind = K_BAD; k.used = used; return k; }
+    const uint32_t db = (d >> 23) & 15u;
+    k.dist = ((d >> 8) & 0x7fffu) + ((uint32_t)(bits >> used) & ((1u << db) - 1u));
+    k.used = used + db;
+    return k;
+}
+
+__device__ __forceinline__ uint32_t wave_excl_sum(uint32_t v, uint32_t* total)
+{
+    const int lane = threadIdx.x;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < LANES; o <<= 1) { const uint32_t u = __shfl_up(inc, o, LANES); if (lane >= o) inc += u; }
+    *total = __shfl(inc, LANES - 1, LANES);
+    return inc - v;
+}
+
+// where block b's sequence stream lies in the workspace: 1.5 x its inflated bytes + 1 KB
+__host__ __device__ inline uint64_t stream_base(const uint64_t* dst_off, uint32_t b) { const uint64_t d = dst_off[b] - dst_off[0]; return d + (d >> 1) + 1024ull * b; }
+
+__device__ __forceinline__ void put32(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+
+__global__ __launch_bounds__(LANES)
+void bgzf_tokens_kernel(const uint8_t* __restrict__ comp, const uint64_t* __restrict__ src_off, const uint32_t* __restrict__ src_len,
+                        const uint64_t* __restrict__ dst_off, uint32_t n_blocks, uint8_t* __restrict__ streams, uint32_t* __restrict__ stream_len,
+                        uint32_t* __restrict__ status)
+{
+    __shared__ Lds t;
+    const uint32_t b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const uint8_t* src = comp + src_off[b];
+    const uint32_t nbytes = src_len[b], nbits = nbytes * 8u;
+    const uint32_t isize = (uint32_t)(dst_off[b + 1] - dst_off[b]);
+    uint8_t* stream = streams + stream_base(dst_off, b);
+    const uint32_t cap = (uint32_t)(stream_base(dst_off, b + 1) - stream_base(dst_off, b));
+    uint32_t P = 0, W = 0, Q = 0;                    // (uniform) bit position, bytes decoded, stream bytes written
+    int err = INF_OK;
+    bool last = isize == 0;                          // an empty block (the EOF marker): nothing to decode
+    HeadReader hr;
+    while (!last && err == INF_OK) {
+        hr.seek(src, nbytes, P);
+        last = hr.bits(1) != 0;
+        const uint32_t type = hr.bits(2);
+        if (type == 0) {                             // stored: to the byte boundary, LEN, ~LEN, bytes -> literal-only sequences
+            hr.bits((int)((P + hr.fed) & 7u ? 8u - ((P + hr.fed) & 7u) : 0u));
+            const uint32_t len = hr.bits(16), nlen = hr.bits(16);
+            P += hr.fed;
+            if ((len ^ nlen) != 0xffffu) { err = INF_BAD_STORED; break; }
+            if (W + len > isize) { err = INF_OUT_OVERRUN; break; }
+            if (P + 8u * len > nbits) { err = INF_IN_OVERRUN; break; }
+            const uint32_t nseq = (len + 254u) / 255u;
+            if (Q + len + 4u * nseq > cap) { err = INF_TOKENS_OVERFLOW; break; }
+            const uint8_t* from = src + (P >> 3);
+            for (uint32_t s = lane; s < nseq; s += LANES) {
+                const uint32_t n = min(255u, len - 255u * s);
+                uint8_t* q = stream + Q + 259u * s;
+                put32(q, n);
+                for (uint32_t i = 0; i < n; ++i) q[4 + i] = from[255u * s + i];
+            }
+            Q += len + 4u * nseq; W += len; P += 8u * len;
+            continue;
+        }
+        if (type == 3) { err = INF_BAD_TYPE; break; }
+        int nlen = 288, ndist = 30;
+        if (type == 1) {                             // fixed code (RFC 1951 3.2.6)
+            for (int s = lane; s < 288; s += LANES) t.lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+            if (lane < 32) t.lens[288 + lane] = lane < 30 ? 5 : 0;
+            lds_fence();
+        } else {                                     // dynamic code (3.2.7)
+            nlen = (int)hr.bits(5) + 257; ndist = (int)hr.bits(5) + 1;
+            const int ncode = (int)hr.bits(4) + 4;
+            if (nlen > 286 || ndist > 30) { err = INF_BAD_TABLE; break; }
+            if (lane < 32) t.cl[lane] = 0;
+            lds_fence();
+            for (int i = 0; i < ncode; ++i) { const uint32_t v = hr.bits(3); if (lane == 0) t.cl[CLEN_ORDER[i]] = (uint8_t)v; }
+            lds_fence();
+            // the code-length code: a 7-bit table in the distance table's place (scratch: the chunk buffer)
+            if (!build_tables(t.cl, 19, 7, t.dist, 128, t.code, reinterpret_cast<uint8_t*>(t.chunk), ClenPayload{})) { err = INF_BAD_TABLE; break; }
+            for (int s = lane; s < 320; s += LANES) t.lens[s] = 0;
+            lds_fence();
+            int i = 0;
+            while (i < nlen + ndist) {
+                hr.refill();
+                const uint32_t e = (uint32_t)uni((int)t.dist[(uint32_t)hr.buf & 127u]);
+                if (((e >> 4) & 15u) != K_LIT) { err = INF_BAD_TABLE; break; }
+                hr.buf >>= (e & 15u); hr.cnt -= (int)(e & 15u); hr.fed += e & 15u;
+                const int sym = (int)((e >> 8) & 255u);
+                int value = sym, rep = 1;
+                if (sym == 16) {
+                    if (i == 0) { err = INF_BAD_TABLE; break; }
+                    const int j = i - 1;
+                    value = uni((int)t.lens[j < nlen ? j : 288 + (j - nlen)]);
+                    rep = 3 + (int)hr.bits(2);
+                } else if (sym == 17) { value = 0; rep = 3 + (int)hr.bits(3); }
+                else if (sym == 18) { value = 0; rep = 11 + (int)hr.bits(7); }
+                if (i + rep > nlen + ndist) { err = INF_BAD_TABLE; break; }
+                for (int r = lane; r < rep; r += LANES) { const int x = i + r; t.lens[x < nlen ? x : 288 + (x - nlen)] = (uint8_t)value; }
+                lds_fence();
+                i += rep;
+            }
+            if (err != INF_OK) break;
+            if (uni((int)t.lens[256]) == 0) { err = INF_BAD_TABLE; break; }
+        }
+        P += hr.fed;
+        if (!build_tables(t.lens, nlen, LB, t.lit, LIT_CAP, t.code, reinterpret_cast<uint8_t*>(t.dist), LitPayload{}) ||
+            !build_tables(t.lens + 288, ndist, DB, t.dist, DIST_CAP, t.code, reinterpret_cast<uint8_t*>(t.chunk), DistPayload{})) { err = INF_BAD_TABLE; break; }
+        // ---- the block's tokens, chunk by chunk
+        bool eob = false;
+        while (!eob && err == INF_OK) {
+            if (P >= nbits) { err = INF_IN_OVERRUN; break; }
+            // stage the chunk: dword w of the buffer = bytes [4w, 4w + 4) from the byte that holds bit P
+            const uint32_t byte0 = P >> 3, bit0 = byte0 * 8u;
+            for (int w = lane; w < CHUNK_WORDS; w += LANES) {
+                uint32_t v = 0;
+                const uint32_t at = byte0 + 4u * (uint32_t)w;
+                if (at + 4u <= nbytes + 8u) __builtin_memcpy(&v, src + at, 4);      // (the 8-byte footer behind the payload is readable)
+                t.chunk[w] = v;
+            }
+            lds_fence();
+            const uint32_t q0 = P + (uint32_t)lane * SEG_BITS, q1 = q0 + SEG_BITS;   // this lane's segment
+            // S1: from the segment's first bit
+            uint32_t p = q0;
+            while (__any(p < q1 && p < nbits)) {
+                if (p < q1 && p < nbits) { const Tok k = token(t, p - bit0); p += k.kind == K_BAD ? 1u : k.used; }
+            }
+            // S2: from the predecessor's end; again for the lanes whose start moved
+            uint32_t start = (uint32_t)__shfl_up((int)p, 1, LANES);
+            if (lane == 0) start = P;
+            uint32_t f = 0, olen = 0, enc = 0, lit = 0, flag = 0;
+            bool dirty = true;
+            int first = LANES;
+            for (;;) {
+                bool run = dirty;
+                if (dirty) { p = start; olen = 0; enc = 0; lit = 0; flag = 0; }
+                while (__any(run)) {
+                    if (run) {
+                        if (p >= q1) { run = false; f = p; }
+                        else if (p >= nbits) { flag = 2; run = false; f = p; }
+                        else {
+                            const Tok k = token(t, p - bit0);
+                            if (k.kind == K_BAD) { flag = 2; run = false; f = p; }
+                            else {
+                                p += k.used;
+                                if (k.kind == K_EOB) { flag = 1; run = false; f = p; }
+                                else if (k.kind == K_LIT) { if (lit == 255u) { enc += 259u; lit = 0; } ++lit; ++olen; }
+                                else { enc += 4u + lit; lit = 0; olen += k.len; }
+                            }
+                        }
+                    }
+                }
+                const unsigned long long fm = __ballot(flag != 0);
+                first = fm ? __ffsll((long long)fm) - 1 : LANES;
+                const uint32_t prev = (uint32_t)__shfl_up((int)f, 1, LANES);
+                dirty = lane > 0 && lane <= first && prev != start;
+                if (dirty) start = prev;
+                if (!__any(dirty)) break;
+            }
+            if (first < LANES && uni((int)__shfl((int)flag, first, LANES)) == 2) { err = INF_BAD_CODE; break; }
+            const bool valid = lane <= first;
+            if (lit) enc += 4u + lit;
+            uint32_t tot_o, tot_e;
+            const uint32_t o = W + wave_excl_sum(valid ? olen : 0u, &tot_o);
+            const uint32_t qoff = Q + wave_excl_sum(valid ? enc : 0u, &tot_e);
+            if (W + tot_o > isize) { err = INF_OUT_OVERRUN; break; }
+            if (Q + tot_e > cap) { err = INF_TOKENS_OVERFLOW; break; }
+            // S3: transcode
+            {
+                uint8_t* hdr = stream + qoff;
+                uint32_t w = o, nl = 0;
+                bool bad_dist = false;
+                p = start;
+                bool run = valid;
+                while (__any(run)) {
+                    if (run) {
+                        if (p >= f) run = false;
+                        else {
+                            const Tok k = token(t, p - bit0);
+                            p += k.used;
+                            if (k.kind == K_LIT) {
+                                if (nl == 255u) { put32(hdr, 255u); hdr += 259; nl = 0; }
+                                hdr[4 + nl] = (uint8_t)k.val;
+                                ++nl; ++w;
+                            } else if (k.kind == K_LEN) {
+                                if (k.dist > w) { bad_dist = true; run = false; }
+                                put32(hdr, nl | k.len << 8 | (k.dist - 1u) << 17);
+                                hdr += 4 + nl; nl = 0; w += k.len;
+                            } else run = false;              // the end-of-block code
+                        }
+                    }
+                }
+                if (valid && nl) put32(hdr, nl);
+                if (__any(bad_dist)) { err = INF_BAD_DIST; break; }
+            }
+            W += tot_o; Q += tot_e;
+            if (first < LANES) { eob = true; P = (uint32_t)__shfl((int)f, first, LANES); }
+            else P = (uint32_t)__shfl((int)f, LANES - 1, LANES);
+        }
+    }
+    if (err == INF_OK && W != isize) err = INF_SHORT;
+    if (lane == 0) { status[b] = (uint32_t)err; stream_len[b] = Q; }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// B: one lane per block copies its sequences, every lane in its own state.  A turn is one dependent memory round trip, so a
+// turn does as much as the data allows: up to eight literal bytes (stream -> output) AND, when they are the run's last and
+// the match's source lies clear of them, the match's first eight bytes (output -> output) -- both loads leave together, both
+// stores follow; the header of the NEXT sequence is requested when a header is parsed and is there when it is needed.
+__global__ __launch_bounds__(256)
+void bgzf_lz_kernel(const uint8_t* __restrict__ streams, const uint32_t* __restrict__ stream_len, const uint64_t* __restrict__ dst_off,
+                    uint32_t n_blocks, uint8_t* out, uint32_t* __restrict__ status)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    if (status[b] != 0) return;
+    const uint8_t* p = streams + stream_base(dst_off, b);
+    const uint8_t* const p_end = p + stream_len[b];
+    const uint64_t lo = dst_off[b], hi = dst_off[b + 1];
+    uint64_t w = lo;
+    uint32_t lit = 0, mlen = 0, dist = 0, hn;
+    __builtin_memcpy(&hn, p, 4);                     // (behind the stream's end: the next slot or the workspace's slack)
+    int err = INF_OK;
+    for (;;) {
+        if (lit == 0 && mlen == 0) {                 // next sequence
+            if (p >= p_end) break;
+            const uint32_t h = hn;
+            p += 4;
+            lit = h & 255u; mlen = (h >> 8) & 511u; dist = (h >> 17) + 1u;
+            if (w + lit + mlen > hi || p + lit > p_end) { err = INF_OUT_OVERRUN; break; }
+            if (mlen && dist > w + lit - lo) { err = INF_BAD_DIST; break; }
+            __builtin_memcpy(&hn, p + lit, 4);       // the header behind this sequence's literals
+        }
+        const uint32_t nl = lit < 8u ? lit : 8u;
+        const uint32_t nm = (mlen && lit <= 8u) ? (mlen < 8u ? mlen : 8u) : 0u;       // the literals end in this turn (or there are none)
+        if (nl) {
+            // the match rides along when its eight source bytes lie clear of the eight bytes the literal store writes
+            const bool merged = nm && dist >= nl + 8u && w + nl + 8 <= hi;
+            if (w + 8 <= hi) {                       // wide: the (up to seven) bytes of garbage behind the literals land in this block's
+                uint64_t vl, vm = 0;                 // own not yet written output
+                __builtin_memcpy(&vl, p, 8);
+                if (merged) __builtin_memcpy(&vm, out + w + nl - dist, 8);
+                __builtin_memcpy(out + w, &vl, 8);
+                if (merged) __builtin_memcpy(out + w + nl, &vm, 8);
+            } else {
+                for (uint32_t i = 0; i < nl; ++i) out[w + i] = p[i];
+            }
+            p += nl; w += nl; lit -= nl;
+            if (merged) { w += nm; mlen -= nm; }
+        } else if (nm) {                             // a step of the match alone
+            if (w + 8 <= hi) {
+                uint64_t v;
+                __builtin_memcpy(&v, out + w - dist, 8);
+                if (dist < 8u) {                     // the period of `dist` bytes, repeated
+                    const uint32_t sh = 8u * dist;
+                    uint64_t q = v & ((1ull << sh) - 1ull);
+                    q |= q << sh;
+                    if (2u * sh < 64u) q |= q << (2u * sh);
+                    if (4u * sh < 64u) q |= q << (4u * sh);
+                    v = q;
+                    dist *= (0x2222348u >> (4u * (dist - 1u))) & 15u;      // smallest multiple of the period >= 8: 8 8 9 8 10 12 14
+                }
+                __builtin_memcpy(out + w, &v, 8);
+            } else {
+                for (uint32_t i = 0; i < nm; ++i) out[w + i] = out[w + i - dist];
+            }
+            w += nm; mlen -= nm;
+        }
+    }
+    if (err == INF_OK && w != hi) err = INF_SHORT;
+    if (err != INF_OK) status[b] = (uint32_t)err;
+}
+
+}  // namespace
+
+extern "C" size_t svx_bgzf_inflate_fast_ws_bytes(uint64_t inflated_bytes, uint32_t n_blocks)
+{
+    return (size_t)(inflated_bytes + (inflated_bytes >> 1) + 1024ull * n_blocks + 4ull * n_blocks + 256);
+}
+
+// The contract of svx_bgzf_inflate with a workspace (svx_bgzf_inflate_fast_ws_bytes(d_dst_off[n] - d_dst_off[0], n) bytes, 16-byte
+// aligned): the blocks' LZ sequence streams and their lengths live there between the two kernels.
+extern "C" __attribute__((visibility("hidden"))) int svx_bgzf_inflate_wave_only(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len, const uint64_t* d_dst_off,
+                                          uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, uint32_t only, void* stream);
+
+extern "C" int svx_bgzf_inflate_fast(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len, const uint64_t* d_dst_off,
+                                     uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, void* d_ws, uint64_t ws_bytes, void* stream)
+{
+    if (n_blocks == 0) return SVX_OK;
+    if (!d_comp || !d_src_off || !d_src_len || !d_dst_off || !d_out || !d_status || !d_ws) return SVX_EINVAL;
+    if (reinterpret_cast<uintptr_t>(d_ws) & 15u) return SVX_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    uint32_t* stream_len = static_cast<uint32_t*>(d_ws);
+    uint8_t* streams = static_cast<uint8_t*>(d_ws) + (((size_t)4 * n_blocks + 255) & ~(size_t)255);
+    (void)ws_bytes;
+    hipLaunchKernelGGL(bgzf_tokens_kernel, dim3(n_blocks), dim3(LANES), 0, st, d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, streams, stream_len, d_status);
+    static const bool only_a = getenv("SVX_INFLATE2_ONLY_A") != nullptr;     // measurements: kernel A alone (the output stays unwritten)
+    if (only_a) return SVX_OK;
+    hipLaunchKernelGGL(bgzf_lz_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, st, streams, stream_len, d_dst_off, n_blocks, d_out, d_status);
+    if (hipGetLastError() != hipSuccess) return SVX_ELAUNCH;
+    // the (pathological) blocks whose sequence stream did not fit its slot: the wave-per-block kernel, those blocks only
+    return svx_bgzf_inflate_wave_only(d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, d_out, d_status, INF_TOKENS_OVERFLOW, stream);
+}

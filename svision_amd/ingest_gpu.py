@@ -192,8 +192,12 @@ class DeviceDecoder:
         # kernel: ~3.5 ms per 1,000 blocks), the first to start the pipeline early, the last because everything waits for it.
         def size_of(t):
             return (self.spans[t][1] >> 16) - (self.spans[t][0] >> 16) + 65536
-        limits = [FIRST_GROUP_BYTES, PIPE_GROUP_BYTES]
-        large = min(LARGE_GROUP_BYTES, int(LARGE_GROUP_BLOCKS * self._block_bytes(have[0][1]))) if have else LARGE_GROUP_BYTES
+        def mb(name, default):                                 # (experiments: SVX_FIRST_GROUP_MB / SVX_PIPE_GROUP_MB / SVX_LARGE_GROUP_MB)
+            v = os.environ.get(name)
+            return int(v) << 20 if v else default
+        limits = [mb("SVX_FIRST_GROUP_MB", FIRST_GROUP_BYTES), mb("SVX_PIPE_GROUP_MB", PIPE_GROUP_BYTES)]
+        large = mb("SVX_LARGE_GROUP_MB", LARGE_GROUP_BYTES)
+        large = min(large, int(LARGE_GROUP_BLOCKS * self._block_bytes(have[0][1]))) if have else large
         groups, cur, cur_bytes = [], [], 0
         for _v, t in have:
             limit = limits[len(groups)] if len(groups) < len(limits) else large
@@ -218,17 +222,23 @@ class DeviceDecoder:
         for r in ring:
             r[1] = None
         ring_at = [0]
-        copy_stream = torch.cuda.Stream(device=dev)
+        # high priority like the ingest kernels' streams: where the runtime copies with a kernel of its own, that kernel must
+        # not queue up behind the CNN's launches (the ring then waits for its slots and the "reads" crawl at 10 GB/s while
+        # pread alone delivers 50: tools/exp/read_rate.py)
+        copy_stream = torch.cuda.Stream(device=dev, priority=-1)
+        n_slots = max(2, int(os.environ.get("SVX_STAGE_SLOTS", "4")))
 
         def slot():
-            if ring_at[0] < 4 and len(ring) < 4:
+            if ring_at[0] < n_slots and len(ring) < n_slots:
                 ring_at[0] += 1
                 ring.append([torch.empty(STAGE_BYTES, dtype=torch.uint8, pin_memory=True), None])
                 return ring[-1]
             s_ = ring[ring_at[0] % len(ring)]
             ring_at[0] += 1
             if s_[1] is not None:
+                t_w = time.perf_counter()
                 s_[1].synchronize()
+                self.stats["slot_wait_s"] = self.stats.get("slot_wait_s", 0.0) + (time.perf_counter() - t_w)
             return s_
 
         def read_group(group):
@@ -244,8 +254,10 @@ class DeviceDecoder:
                 want = min(STAGE_BYTES, nbytes - off)
                 st_ = slot()
                 pin = st_[0]
+                t_p = time.perf_counter()
                 if lib.svx_read_range(self.path.encode(), c0 + off, want, pin.data_ptr(), self.threads) != 0:
                     raise DeviceIngestError(lib.svx_bam_error().decode(), group)
+                self.stats["pread_s"] = self.stats.get("pread_s", 0.0) + (time.perf_counter() - t_p)
                 cap = want // 28 + 16
                 so, co = np.empty(cap, np.uint64), np.empty(cap, np.uint64)
                 sl, isz = np.empty(cap, np.uint32), np.empty(cap, np.uint32)
@@ -335,8 +347,8 @@ class DeviceDecoder:
                 d_status = torch.zeros(nb, dtype=torch.int32, device=dev)
                 d_len = d_tab[nb:2 * nb].to(torch.int32)
                 st = kernels._stream_ptr(dev)
-                _lib.check(kernels.inflate_kernel_for(lib, nb)(d_comp.data_ptr(), d_tab.data_ptr(), d_len.data_ptr(), d_tab[2 * nb:].data_ptr(), nb, d_raw.data_ptr(),
-                                                d_status.data_ptr(), st), "svx_bgzf_inflate")
+                kernels.launch_inflate(lib, kernels.inflate_variant_for(nb), d_comp.data_ptr(), d_tab.data_ptr(), d_len.data_ptr(), d_tab[2 * nb:].data_ptr(), nb,
+                                       d_raw.data_ptr(), d_status.data_ptr(), item["total"], dev)
                 if kernels.bgzf_crc_wanted():                  # the footers' CRC32 (htslib checks it on every block): status 9 where one differs
                     _lib.check(lib.svx_bgzf_crc32(d_raw.data_ptr(), d_tab[2 * nb:].data_ptr(), d_comp.data_ptr(), d_tab.data_ptr(), d_len.data_ptr(), nb,
                                                   d_status.data_ptr(), st), "svx_bgzf_crc32")

@@ -383,19 +383,34 @@ def bgzf_block_table(raw):
     return (np.asarray(src_off, np.uint64), np.asarray(src_len, np.uint32), np.asarray(isize, np.uint32), np.asarray(block_off, np.uint64))
 
 
-WAVE_KERNEL_BELOW = 20_000          # blocks per launch under which the wave-per-block inflate kernel is the faster one (see inflate_kernel_for)
+WAVE_KERNEL_BELOW = 20_000          # (lane-per-block era) blocks per launch under which the wave-per-block kernel beat the lane-per-block one
 
 
-def inflate_kernel_for(lib, n_blocks):
-    """The faster of the two inflate kernels for a launch of ``n_blocks`` blocks.  One lane per block needs ~0.1 s whatever
-    the launch size up to 98 k blocks (1,536 resident waves); one wave per block needs ~17 ms per round of 5,120 blocks:
-    level at 28 k blocks, 3x ahead at the 7 k blocks of a small chromosome (measured: tools/exp/inflate_gpu_bench.py)."""
+def inflate_variant_for(n_blocks):
+    """Which inflate implementation a launch of ``n_blocks`` blocks takes: "fast" -- the two-kernel form (svx_inflate2.hip:
+    parallel Huffman decoding per block + LZ copies; 0.5 + 0.65 ms per 1,000 blocks, proportional to the launch) -- unless
+    SVX_INFLATE_VARIANT names another (lds | private | wave | lane | fast; "auto": the round-3 choice between the lane- and
+    the wave-per-block kernel by launch size)."""
     import os
-    variant = os.environ.get("SVX_INFLATE_VARIANT")          # A/B switch: lds | private | wave | lane (default: by launch size)
-    if variant:
-        return {"lds": lib.svx_bgzf_inflate_lds, "private": lib.svx_bgzf_inflate_private, "wave": lib.svx_bgzf_inflate_wave,
-                "lane": lib.svx_bgzf_inflate}[variant]
-    return lib.svx_bgzf_inflate_wave if n_blocks < WAVE_KERNEL_BELOW else lib.svx_bgzf_inflate
+    variant = os.environ.get("SVX_INFLATE_VARIANT", "fast")
+    if variant == "auto":
+        return "wave" if n_blocks < WAVE_KERNEL_BELOW else "lane"
+    return variant
+
+
+def launch_inflate(lib, variant, comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, out_ptr, status_ptr, inflated_bytes, device):
+    """Enqueue one inflate launch on the current stream of ``device`` (the "fast" form takes its workspace from the caching
+    allocator: stream-ordered, so it may die with this call)."""
+    st = _stream_ptr(device)
+    if variant == "fast":
+        ws_bytes = int(lib.svx_bgzf_inflate_fast_ws_bytes(int(inflated_bytes), int(n_blocks)))
+        d_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+        rc = lib.svx_bgzf_inflate_fast(comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, out_ptr, status_ptr, d_ws.data_ptr(), ws_bytes, st)
+    else:
+        fn = {"lds": lib.svx_bgzf_inflate_lds, "private": lib.svx_bgzf_inflate_private, "wave": lib.svx_bgzf_inflate_wave,
+              "lane": lib.svx_bgzf_inflate}[variant]
+        rc = fn(comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, out_ptr, status_ptr, st)
+    _lib.check(rc, "svx_bgzf_inflate (%s)" % variant)
 
 
 INFLATE_BAD_CRC = 9                 # SVX_INFLATE_BAD_CRC: the block inflated, but not to the bytes its footer's CRC32 was taken of
@@ -427,16 +442,11 @@ def bgzf_inflate(d_comp, src_off, src_len, isize, wave=None, crc=None):
         d_src = torch.from_numpy(np.ascontiguousarray(src_off, np.uint64).view(np.int64)).to(dev)
         d_len = torch.from_numpy(np.ascontiguousarray(src_len, np.uint32).view(np.int32)).to(dev)
         d_dst = torch.from_numpy(dst.view(np.int64)).to(dev)
-        # the implementations of one contract: wave None picks the fastest for this launch size, True / False the wave- / the
-        # lane-per-block kernel, "lds" / "private" one version of the latter by name
-        if wave is None:
-            fn = inflate_kernel_for(lib, n)
-        elif isinstance(wave, str):
-            fn = {"lds": lib.svx_bgzf_inflate_lds, "private": lib.svx_bgzf_inflate_private, "wave": lib.svx_bgzf_inflate_wave}[wave]
-        else:
-            fn = lib.svx_bgzf_inflate_wave if wave else lib.svx_bgzf_inflate
-        rc = fn(d_comp.data_ptr(), d_src.data_ptr(), d_len.data_ptr(), d_dst.data_ptr(), n, d_out.data_ptr(), d_status.data_ptr(), _stream_ptr(dev))
-        _lib.check(rc, "svx_bgzf_inflate")
+        # the implementations of one contract: wave None = the default for this launch size, True / False the wave- / the
+        # lane-per-block kernel, a string one implementation by name ("lds", "private", "wave", "lane", "fast")
+        variant = inflate_variant_for(n) if wave is None else wave if isinstance(wave, str) else ("wave" if wave else "lane")
+        launch_inflate(lib, variant, d_comp.data_ptr(), d_src.data_ptr(), d_len.data_ptr(), d_dst.data_ptr(), n, d_out.data_ptr(),
+                       d_status.data_ptr(), total, dev)
         if bgzf_crc_wanted() if crc is None else crc:
             # the blocks' footers (CRC32 of the inflated bytes) checked on the device: status 9 where one differs
             rc = lib.svx_bgzf_crc32(d_out.data_ptr(), d_dst.data_ptr(), d_comp.data_ptr(), d_src.data_ptr(), d_len.data_ptr(), n,

@@ -42,7 +42,7 @@ def _inflate_on_device(raw, wave=False):
     return out.cpu().numpy().tobytes(), status.cpu().numpy()
 
 
-@pytest.mark.parametrize("wave", ["lds", "private", "wave"])
+@pytest.mark.parametrize("wave", ["lds", "private", "wave", "fast"])
 def test_every_block_type_and_match_shape(wave):
     rng = np.random.default_rng(3)
     text = (b"ACGTTGCA" * 40 + bytes(rng.integers(0, 256, 300, dtype=np.uint8))) * 20
@@ -64,7 +64,7 @@ def test_every_block_type_and_match_shape(wave):
     assert got == b"".join(want)
 
 
-@pytest.mark.parametrize("wave", ["lds", "private", "wave"])
+@pytest.mark.parametrize("wave", ["lds", "private", "wave", "fast"])
 def test_golden_and_synthetic_bams_inflate_like_zlib(tmp_path, wave):
     from svision_amd import synth
     paths = [os.path.join(helpers.GOLDEN, n) for n in ("collect_small.bam", "ont_small.bam", "hash_collect.bam")]
@@ -79,7 +79,7 @@ def test_golden_and_synthetic_bams_inflate_like_zlib(tmp_path, wave):
         assert got == bam.bgzf_decompress(raw), path
 
 
-@pytest.mark.parametrize("wave", ["lds", "private", "wave"])
+@pytest.mark.parametrize("wave", ["lds", "private", "wave", "fast"])
 def test_damaged_blocks_are_flagged(wave):
     rng = np.random.default_rng(5)
     good = _block(bytes(rng.integers(65, 70, 50000, dtype=np.uint8)))
@@ -92,7 +92,7 @@ def test_damaged_blocks_are_flagged(wave):
     assert status[0] == 0 and status[3] == 0 and status[1] != 0 and status[2] != 0
 
 
-@pytest.mark.parametrize("wave", ["lds", "private", "wave"])
+@pytest.mark.parametrize("wave", ["lds", "private", "wave", "fast"])
 def test_a_damaged_payload_that_keeps_isize_is_caught_by_the_crc(wave):
     """a flipped bit that leaves the DEFLATE stream decodable and ISIZE right (here: inside a stored block)
     went through both engines silently; htslib checks the footer's CRC32 on every block, and so does svx_bgzf_crc32."""
@@ -112,6 +112,23 @@ def test_a_damaged_payload_that_keeps_isize_is_caught_by_the_crc(wave):
     padded[:r.size] = r
     _out, status = kernels.bgzf_inflate(torch.from_numpy(padded).cuda(), src_off, src_len, isize, wave=wave, crc=False)
     assert not status.cpu().numpy().any()
+
+
+def test_fast_inflate_leaves_streams_of_tiny_deflate_blocks_to_the_wave_kernel():
+    """svx_bgzf_inflate_fast transcodes a block into an LZ sequence stream of at most 1.5 x ISIZE + 1 KB; a BGZF block made of
+    hundreds of one-byte DEFLATE blocks (a full flush behind every byte) needs more: the entry point hands exactly those
+    blocks to the wave-per-block kernel, and the result is still zlib's."""
+    rng = np.random.default_rng(8)
+    data = bytes(rng.integers(65, 91, 3000, dtype=np.uint8))
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    cdata = b"".join(co.compress(data[i:i + 1]) + co.flush(zlib.Z_FULL_FLUSH) for i in range(len(data))) + co.flush()
+    assert zlib.decompress(cdata, -15) == data and len(cdata) > 5 * len(data)
+    tiny = (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(cdata) + 25) + cdata
+            + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+    normal = _block(bytes(rng.integers(65, 70, 40000, dtype=np.uint8)))
+    got, status = _inflate_on_device(normal + tiny + normal, "fast")
+    assert not status.any()
+    assert got == bam.bgzf_decompress(normal + tiny + normal + bam._BGZF_EOF)
 
 
 def _same_table(a, b):

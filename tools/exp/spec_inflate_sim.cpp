@@ -106,6 +106,24 @@ static Tok token(const Stream& in, const Tables& t, int64_t p) {
     return k;
 }
 
+static bool g_seq = false;
+static std::vector<uint8_t> g_stream;           // the block's LZ sequence stream (kernel A's output, kernel B's input)
+
+// kernel B: one lane, the block's sequences in order
+static int lz_replay(const std::vector<uint8_t>& s, uint8_t* out, size_t cap, size_t* produced, long* steps) {
+    size_t p = 0, w = 0;
+    while (p < s.size()) {
+        uint32_t h; memcpy(&h, &s[p], 4); p += 4;
+        uint32_t lit = h & 255, mlen = (h >> 8) & 511, dist = (h >> 17) + 1;
+        if (w + lit + mlen > cap || p + lit > s.size()) return 95;
+        for (uint32_t k = 0; k < lit; k += 8) ++*steps;
+        memcpy(out + w, &s[p], lit); p += lit; w += lit;
+        if (mlen) { if (dist > w) return 8; for (uint32_t k = 0; k < mlen; ++k) { out[w] = out[w - dist]; ++w; } for (uint32_t k = 0; k < mlen; k += 8) ++*steps; }
+        ++*steps;
+    }
+    *produced = w; return 0;
+}
+
 struct Stats { long chunks = 0, s1_turns = 0, s2_turns = 0, s2_rounds = 0, s3_turns = 0, tokens = 0, stall = 0, headers = 0; };
 
 // -> 0 ok, else error code; out must have room for `cap` bytes (+8 slack)
@@ -123,7 +141,9 @@ static int spec_inflate(const uint8_t* src, size_t n, uint8_t* out, size_t cap, 
             if ((len ^ nlen) != 0xffff) return 2;
             if (W + len > cap) return 5;
             if (P + 8ll * len > in.nbits) return 6;
-            memcpy(out + W, src + (P >> 3), len); W += len; P += 8ll * len;
+            if (g_seq) { for (uint32_t k = 0; k < len; k += 255) { uint32_t n2 = len - k < 255 ? len - k : 255; uint32_t h2 = n2; size_t q2 = g_stream.size(); g_stream.resize(q2 + 4 + n2); memcpy(&g_stream[q2], &h2, 4); memcpy(&g_stream[q2 + 4], src + (P >> 3) + k, n2); } }
+            else memcpy(out + W, src + (P >> 3), len);
+            W += len; P += 8ll * len;
             if (last) break; else continue;
         }
         uint8_t lens[320] = {0};
@@ -189,6 +209,36 @@ static int spec_inflate(const uint8_t* src, size_t n, uint8_t* out, size_t cap, 
             }
             int first = LANES; for (int i = 0; i < LANES; ++i) if (flag[i]) { first = i; break; }
             if (first < LANES && flag[first] == 2) return 4;
+            if (g_seq) {
+                // S3': every lane re-decodes its segment and appends LZ sequences -- u32 header [litlen:8 | matchlen:9 | dist-1:15]
+                // followed by litlen literal bytes -- to ITS part of the block's stream; sizes first (what S2 would also count)
+                size_t enc[LANES + 1]; enc[0] = g_stream.size();
+                size_t o2[LANES + 1]; o2[0] = W;
+                for (int i = 0; i < LANES; ++i) {
+                    size_t bytes = 0; uint32_t lit = 0; int64_t p = start[i];
+                    if (i <= first) while (p < f[i]) { Tok k = token(in, t, p); p += k.used;
+                        if (k.kind == K_LIT) { if (lit == 255) { bytes += 4 + 255; lit = 0; } ++lit; }
+                        else if (k.kind == K_LEN) { bytes += 4 + lit; lit = 0; }
+                        else break; }
+                    if (lit) bytes += 4 + lit;
+                    enc[i + 1] = enc[i] + bytes; o2[i + 1] = o2[i] + (i <= first ? olen[i] : 0);
+                }
+                if (o2[LANES] > cap) return 5;
+                g_stream.resize(enc[LANES]);
+                for (int i = 0; i <= first && i < LANES; ++i) {
+                    size_t q2 = enc[i]; uint8_t lits[256]; uint32_t lit = 0; int64_t p = start[i]; size_t w = o2[i];
+                    auto flush = [&](uint32_t mlen, uint32_t dist) { uint32_t h = lit | mlen << 8 | (dist ? dist - 1 : 0) << 17; memcpy(&g_stream[q2], &h, 4); memcpy(&g_stream[q2 + 4], lits, lit); q2 += 4 + lit; lit = 0; };
+                    while (p < f[i]) { Tok k = token(in, t, p); p += k.used; st.tokens++;
+                        if (k.kind == K_LIT) { if (lit == 255) flush(0, 0); lits[lit++] = (uint8_t)k.val; w += 1; }
+                        else if (k.kind == K_LEN) { if (k.dist > w) return 8; flush(k.len, k.dist); w += k.len; }
+                        else break; }
+                    if (lit) flush(0, 0);
+                    if (q2 != enc[i + 1] || w != o2[i + 1]) return 94;
+                }
+                W = o2[LANES];
+                if (first < LANES) { eob = true; P = f[first]; } else P = f[LANES - 1];
+                continue;
+            }
             // S3: offsets
             size_t o[LANES + 1]; o[0] = W; for (int i = 0; i < LANES; ++i) o[i + 1] = o[i] + (i <= first ? olen[i] : 0);
             if (o[LANES] > cap) return 5;
@@ -246,7 +296,8 @@ int main(int argc, char** argv) {
     int S = argc > 2 ? atoi(argv[2]) : 512; long maxb = argc > 3 ? atol(argv[3]) : 1 << 30;
     FILE* fp = fopen(argv[1], "rb"); if (!fp) { perror("open"); return 1; }
     std::vector<uint8_t> raw; { uint8_t buf[1 << 16]; size_t k; while ((k = fread(buf, 1, sizeof buf, fp)) > 0) raw.insert(raw.end(), buf, buf + k); } fclose(fp);
-    size_t p = 0; long nb = 0, bad = 0; Stats st; double bytes = 0;
+    size_t p = 0; long nb = 0, bad = 0; Stats st; double bytes = 0; long lz_steps = 0; double stream_bytes = 0;
+    g_seq = getenv("SEQ") != nullptr;
     std::vector<uint8_t> out(65536 + 64), want(65536 + 64);
     while (p + 18 <= raw.size() && nb < maxb) {
         int xlen = raw[p + 10] | raw[p + 11] << 8; int bsize = -1;
@@ -256,11 +307,14 @@ int main(int argc, char** argv) {
         uint32_t isize = raw[end - 4] | raw[end - 3] << 8 | raw[end - 2] << 16 | (uint32_t)raw[end - 1] << 24;
         z_stream z; memset(&z, 0, sizeof z); inflateInit2(&z, -15); z.next_in = &raw[s0]; z.avail_in = sl; z.next_out = want.data(); z.avail_out = 65536; int zr = inflate(&z, Z_FINISH); inflateEnd(&z);
         size_t got = 0; memset(out.data(), 0xAA, out.size());
+        g_stream.clear();
         int rc = spec_inflate(&raw[s0], sl, out.data(), isize, &got, S, st);
+        if (g_seq && !rc) { size_t got2 = 0; rc = lz_replay(g_stream, out.data(), isize, &got2, &lz_steps); if (!rc && got2 != got) rc = 96; stream_bytes += g_stream.size(); }
         if (rc || got != isize || zr != Z_STREAM_END || memcmp(out.data(), want.data(), isize)) { if (bad < 5) fprintf(stderr, "block %ld: rc %d got %zu isize %u zlib %d\n", nb, rc, got, isize, zr); ++bad; }
         bytes += isize; ++nb; p = end;
     }
     printf("S=%d: %ld blocks, %ld differ; per block: %.1f headers, %.1f chunks, turns S1 %.0f S2 %.0f (%.2f rounds/chunk) S3 %.0f (stalled lane-turns %.0f), tokens %.0f; bytes %.0f\n", S, nb, bad,
            (double)st.headers / nb, (double)st.chunks / nb, (double)st.s1_turns / nb, (double)st.s2_turns / nb, (double)st.s2_rounds / st.chunks, (double)st.s3_turns / nb, (double)st.stall / nb, (double)st.tokens / nb, bytes / nb);
+    if (g_seq) printf("  sequence stream: %.0f bytes per block (%.2f x the output), kernel-B steps per block %.0f\n", stream_bytes / nb, stream_bytes / bytes, (double)lz_steps / nb);
     return bad != 0;
 }
