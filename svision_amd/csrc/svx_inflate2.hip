@@ -17,8 +17,9 @@
 //      the block's stream (offsets by wave prefix sums).  No LZ77 copy happens here: nothing in this kernel waits for a
 //      store.
 //   B. bgzf_lz_kernel -- one LANE per block walks its sequence stream: literal runs and matches are copied in steps of up
-//      to eight bytes.  No tables, no LDS, ~40 VGPRs: every block of a launch is resident at once and a turn costs ~50
-//      instructions instead of ~300; 22 k steps per 64 KB block instead of 36 k turns.
+//      to eight bytes through a ring of the lane's last 256 output bytes in LDS (near matches are read from it, output leaves
+//      in whole aligned 16-byte chunks; svx_lz_core.hpp).  No tables: every block of a launch is resident at once and a turn
+//      costs ~100 instructions instead of ~300; ~10 k turns per 64 KB block instead of 36 k.
 //
 // Byte-identical to zlib by construction (tests/test_gpu_inflate.py runs this pair through every case the other kernels
 // pass).  Blocks whose sequence stream would not fit its slot (1.5 x ISIZE + 1 KB: only pathological streams -- hundreds of
@@ -27,6 +28,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "../../include/svx.h"
+#include "svx_lz_core.hpp"
 
 namespace {
 
@@ -437,72 +439,21 @@ void bgzf_tokens_kernel(const uint8_t* __restrict__ comp, const uint64_t* __rest
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// B: one lane per block copies its sequences, every lane in its own state.  A turn is one dependent memory round trip, so a
-// turn does as much as the data allows: up to eight literal bytes (stream -> output) AND, when they are the run's last and
-// the match's source lies clear of them, the match's first eight bytes (output -> output) -- both loads leave together, both
-// stores follow; the header of the NEXT sequence is requested when a header is parsed and is there when it is needed.
-__global__ __launch_bounds__(256)
+// B: one lane per block copies its sequences (svx_lz_core.hpp: the loop itself, shared with the CPU model).  Every lane keeps the
+// last 256 bytes of its output in LDS -- near matches never touch memory, output leaves in whole aligned 16-byte chunks.
+constexpr int LZ_LANES = 64, RING_STRIDE = svx_lz::RING + 16;      // (+ 16: lanes at the same ring offset fall into different banks)
+
+__global__ __launch_bounds__(LZ_LANES)
 void bgzf_lz_kernel(const uint8_t* __restrict__ streams, const uint32_t* __restrict__ stream_len, const uint64_t* __restrict__ dst_off,
                     uint32_t n_blocks, uint8_t* out, uint32_t* __restrict__ status)
 {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ __attribute__((aligned(16))) uint8_t rings[LZ_LANES * RING_STRIDE];
+    const uint32_t b = blockIdx.x * LZ_LANES + threadIdx.x;
     if (b >= n_blocks) return;
     if (status[b] != 0) return;
-    const uint8_t* p = streams + stream_base(dst_off, b);
-    const uint8_t* const p_end = p + stream_len[b];
-    const uint64_t lo = dst_off[b], hi = dst_off[b + 1];
-    uint64_t w = lo;
-    uint32_t lit = 0, mlen = 0, dist = 0, hn;
-    __builtin_memcpy(&hn, p, 4);                     // (behind the stream's end: the next slot or the workspace's slack)
-    int err = INF_OK;
-    for (;;) {
-        if (lit == 0 && mlen == 0) {                 // next sequence
-            if (p >= p_end) break;
-            const uint32_t h = hn;
-            p += 4;
-            lit = h & 255u; mlen = (h >> 8) & 511u; dist = (h >> 17) + 1u;
-            if (w + lit + mlen > hi || p + lit > p_end) { err = INF_OUT_OVERRUN; break; }
-            if (mlen && dist > w + lit - lo) { err = INF_BAD_DIST; break; }
-            __builtin_memcpy(&hn, p + lit, 4);       // the header behind this sequence's literals
-        }
-        const uint32_t nl = lit < 8u ? lit : 8u;
-        const uint32_t nm = (mlen && lit <= 8u) ? (mlen < 8u ? mlen : 8u) : 0u;       // the literals end in this turn (or there are none)
-        if (nl) {
-            // the match rides along when its eight source bytes lie clear of the eight bytes the literal store writes
-            const bool merged = nm && dist >= nl + 8u && w + nl + 8 <= hi;
-            if (w + 8 <= hi) {                       // wide: the (up to seven) bytes of garbage behind the literals land in this block's
-                uint64_t vl, vm = 0;                 // own not yet written output
-                __builtin_memcpy(&vl, p, 8);
-                if (merged) __builtin_memcpy(&vm, out + w + nl - dist, 8);
-                __builtin_memcpy(out + w, &vl, 8);
-                if (merged) __builtin_memcpy(out + w + nl, &vm, 8);
-            } else {
-                for (uint32_t i = 0; i < nl; ++i) out[w + i] = p[i];
-            }
-            p += nl; w += nl; lit -= nl;
-            if (merged) { w += nm; mlen -= nm; }
-        } else if (nm) {                             // a step of the match alone
-            if (w + 8 <= hi) {
-                uint64_t v;
-                __builtin_memcpy(&v, out + w - dist, 8);
-                if (dist < 8u) {                     // the period of `dist` bytes, repeated
-                    const uint32_t sh = 8u * dist;
-                    uint64_t q = v & ((1ull << sh) - 1ull);
-                    q |= q << sh;
-                    if (2u * sh < 64u) q |= q << (2u * sh);
-                    if (4u * sh < 64u) q |= q << (4u * sh);
-                    v = q;
-                    dist *= (0x2222348u >> (4u * (dist - 1u))) & 15u;      // smallest multiple of the period >= 8: 8 8 9 8 10 12 14
-                }
-                __builtin_memcpy(out + w, &v, 8);
-            } else {
-                for (uint32_t i = 0; i < nm; ++i) out[w + i] = out[w + i - dist];
-            }
-            w += nm; mlen -= nm;
-        }
-    }
-    if (err == INF_OK && w != hi) err = INF_SHORT;
-    if (err != INF_OK) status[b] = (uint32_t)err;
+    const int err = svx_lz::decode_block(streams + stream_base(dst_off, b), stream_len[b], out, dst_off[b], dst_off[b + 1],
+                                         rings + threadIdx.x * RING_STRIDE);
+    if (err != svx_lz::LZ_OK) status[b] = (uint32_t)err;
 }
 
 }  // namespace
@@ -530,7 +481,7 @@ extern "C" int svx_bgzf_inflate_fast(const uint8_t* d_comp, const uint64_t* d_sr
     hipLaunchKernelGGL(bgzf_tokens_kernel, dim3(n_blocks), dim3(LANES), 0, st, d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, streams, stream_len, d_status);
     static const bool only_a = getenv("SVX_INFLATE2_ONLY_A") != nullptr;     // measurements: kernel A alone (the output stays unwritten)
     if (only_a) return SVX_OK;
-    hipLaunchKernelGGL(bgzf_lz_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, st, streams, stream_len, d_dst_off, n_blocks, d_out, d_status);
+    hipLaunchKernelGGL(bgzf_lz_kernel, dim3((n_blocks + LZ_LANES - 1) / LZ_LANES), dim3(LZ_LANES), 0, st, streams, stream_len, d_dst_off, n_blocks, d_out, d_status);
     if (hipGetLastError() != hipSuccess) return SVX_ELAUNCH;
     // the (pathological) blocks whose sequence stream did not fit its slot: the wave-per-block kernel, those blocks only
     return svx_bgzf_inflate_wave_only(d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, d_out, d_status, INF_TOKENS_OVERFLOW, stream);

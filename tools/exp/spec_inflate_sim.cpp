@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include "../../svision_amd/csrc/svx_lz_core.hpp"
 
 static const int LANES = 64, LB = 10, DB = 8;
 enum { K_BAD = 0, K_LIT = 1, K_LEN = 2, K_EOB = 3, K_SUB = 4, K_DIST = 2 };
@@ -309,6 +310,15 @@ int main(int argc, char** argv) {
         size_t got = 0; memset(out.data(), 0xAA, out.size());
         g_stream.clear();
         int rc = spec_inflate(&raw[s0], sl, out.data(), isize, &got, S, st);
+        if (g_seq && !rc && getenv("LZCORE")) {          // the device's own LZ loop (svx_lz_core.hpp), the block placed at an odd offset of a larger buffer
+            static std::vector<uint8_t> big(1 << 17); static uint8_t ring[svx_lz::RING];
+            const uint64_t lo = 16 * 100 + (nb % 16), hi = lo + isize;
+            memset(big.data(), 0xCC, big.size());
+            std::vector<uint8_t> st2(g_stream); st2.resize(st2.size() + 32, 0x5A);
+            rc = svx_lz::decode_block(st2.data(), (uint32_t)g_stream.size(), big.data(), lo, hi, ring);
+            if (!rc) { memcpy(out.data(), big.data() + lo, isize); if (big[lo - 1] != 0xCC || big[hi] != 0xCC) rc = 97; }   // nothing written outside [lo, hi)
+            stream_bytes += g_stream.size();
+        } else
         if (g_seq && !rc) { size_t got2 = 0; rc = lz_replay(g_stream, out.data(), isize, &got2, &lz_steps); if (!rc && got2 != got) rc = 96; stream_bytes += g_stream.size(); }
         if (rc || got != isize || zr != Z_STREAM_END || memcmp(out.data(), want.data(), isize)) { if (bad < 5) fprintf(stderr, "block %ld: rc %d got %zu isize %u zlib %d\n", nb, rc, got, isize, zr); ++bad; }
         bytes += isize; ++nb; p = end;
