@@ -45,13 +45,15 @@ SVX_HD void ring_put(uint8_t* ring, uint64_t w, uint64_t v, uint32_t n)
         if (i < n) ring[(uint32_t)(w + i) & (RING - 1)] = (uint8_t)(v >> (8 * i));
 }
 
-// eight bytes of the ring from output position s (bytes behind the newest one are whatever the ring holds)
+// eight bytes of the ring from output position s (bytes behind the newest one are whatever the ring holds): three aligned
+// dwords and a funnel shift (eight byte reads + seven shift-ors before)
 SVX_HD uint64_t ring_get8(const uint8_t* ring, uint64_t s)
 {
-    uint64_t v = 0;
-#pragma unroll
-    for (uint32_t i = 0; i < 8; ++i) v |= (uint64_t)ring[(uint32_t)(s + i) & (RING - 1)] << (8 * i);
-    return v;
+    const uint32_t* r32 = reinterpret_cast<const uint32_t*>(__builtin_assume_aligned(ring, 16));
+    const uint32_t o = (uint32_t)s & (RING - 1), d = o >> 2, sh = (o & 3u) * 8u;
+    const uint32_t a = r32[d], b = r32[(d + 1) & (RING / 4 - 1)], c = r32[(d + 2) & (RING / 4 - 1)];
+    const uint64_t lo = ((uint64_t)b << 32 | a) >> sh;
+    return sh ? lo | (uint64_t)c << (64 - sh) : lo;
 }
 
 // the 16-byte chunk that ends at the boundary `upto` (a multiple of 16 in the address space of `out`) leaves the ring
