@@ -304,7 +304,10 @@ def main():
         # gets a HIP call through meanwhile); one block of the size the legs' buffers add up to is allocated here and stays in
         # the caching allocator, which cuts the legs' buffers out of it.
         # (compressed bytes x 2.4 inflated x 1.5 for the two-kernel inflate's sequence streams + packed arrays, several groups in flight)
-        torch.empty(min(24 << 30, 6 * int(e2e["bytes"])), dtype=torch.uint8, device=dev)
+        # (peak of the 20-window job: compressed 3.9 GB + inflated 9.3 GB + the two-kernel inflate's sequence streams of the groups
+        # in flight 13 GB + packed arrays: ~27 GB.  The block serves allocations made on the default stream: the decoder takes its
+        # large buffers there, ingest_gpu.launch)
+        torch.empty(min(48 << 30, 8 * int(e2e["bytes"])), dtype=torch.uint8, device=dev)
     net = AlexNet(random_weights(0), device=dev)
     net.executed = torch.zeros(5, dtype=torch.int64, device=dev)     # executed conv pixels per layer + images, summed on the device
     hot = PooledHotPath(sample, opts, net, device=dev, n_streams=args.streams, max_inflight=args.inflight, launch_batches=args.launch_batches, pool=pool)

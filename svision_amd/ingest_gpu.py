@@ -338,17 +338,27 @@ class DeviceDecoder:
         def launch(item, stream):
             nb = item["nb"]
             self._mark("launch %s: start" % item["group"][:2])
+            # The group's large buffers -- the inflated bytes, the inflate's workspace -- are taken on THIS thread's (default)
+            # stream and handed to the group's stream with record_stream: the caching allocator keeps its free blocks per
+            # stream, so buffers allocated on the ingest streams (new ones every run) never met a cached block and were
+            # hipMalloc'ed fresh -- 0.2 ms per GB on most boxes, 15 ms per GB on some: a 0.24 s stall in front of the
+            # largest group's launch (two of nine bench runs).
+            variant = kernels.inflate_variant_for(nb)
+            d_raw = torch.empty(max(item["total"], 16), dtype=torch.uint8, device=dev)
+            d_ws = kernels.inflate_workspace(lib, variant, item["total"], nb, dev)
             with torch.cuda.stream(stream):
                 stream.wait_event(item["copied"])              # the last slot of the group's compressed bytes is on the device
                 d_comp = item["d_comp"]
                 d_comp.record_stream(stream)
+                d_raw.record_stream(stream)
+                if d_ws is not None:
+                    d_ws.record_stream(stream)
                 d_tab = item["tab"].to(dev, non_blocking=True)
-                d_raw = torch.empty(max(item["total"], 16), dtype=torch.uint8, device=dev)
                 d_status = torch.zeros(nb, dtype=torch.int32, device=dev)
                 d_len = d_tab[nb:2 * nb].to(torch.int32)
                 st = kernels._stream_ptr(dev)
-                kernels.launch_inflate(lib, kernels.inflate_variant_for(nb), d_comp.data_ptr(), d_tab.data_ptr(), d_len.data_ptr(), d_tab[2 * nb:].data_ptr(), nb,
-                                       d_raw.data_ptr(), d_status.data_ptr(), item["total"], dev)
+                kernels.launch_inflate(lib, variant, d_comp.data_ptr(), d_tab.data_ptr(), d_len.data_ptr(), d_tab[2 * nb:].data_ptr(), nb,
+                                       d_raw.data_ptr(), d_status.data_ptr(), item["total"], dev, ws=d_ws)
                 if kernels.bgzf_crc_wanted():                  # the footers' CRC32 (htslib checks it on every block): status 9 where one differs
                     _lib.check(lib.svx_bgzf_crc32(d_raw.data_ptr(), d_tab[2 * nb:].data_ptr(), d_comp.data_ptr(), d_tab.data_ptr(), d_len.data_ptr(), nb,
                                                   d_status.data_ptr(), st), "svx_bgzf_crc32")
@@ -404,11 +414,13 @@ class DeviceDecoder:
             for at, n_starts, r0, *_rest in plan:
                 if n_starts > 1:
                     base_all.numpy()[r0 + 1:r0 + n_starts] = np.cumsum(counts[r0:r0 + n_starts - 1, :3], axis=0)
+            d_pack_all = torch.empty(max(pack_at, 256), dtype=torch.uint8, device=dev)        # (default stream: see launch())
+            d_cigar_all = torch.empty(max(word_at, 64), dtype=torch.int32, device=dev)
             with torch.cuda.stream(stream):
                 st = kernels._stream_ptr(dev)
+                d_pack_all.record_stream(stream)
+                d_cigar_all.record_stream(stream)
                 d_base_all = base_all.to(dev, non_blocking=True)
-                d_pack_all = torch.empty(max(pack_at, 256), dtype=torch.uint8, device=dev)
-                d_cigar_all = torch.empty(max(word_at, 64), dtype=torch.int32, device=dev)
                 h_pack_all = torch.empty(max(pack_at, 256), dtype=torch.uint8, pin_memory=True)
                 for at, n_starts, r0, n, words, name_bytes, offs, p0, size, w0 in plan:
                     d_pack = d_pack_all[p0:p0 + size]

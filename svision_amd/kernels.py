@@ -398,13 +398,20 @@ def inflate_variant_for(n_blocks):
     return variant
 
 
-def launch_inflate(lib, variant, comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, out_ptr, status_ptr, inflated_bytes, device):
-    """Enqueue one inflate launch on the current stream of ``device`` (the "fast" form takes its workspace from the caching
-    allocator: stream-ordered, so it may die with this call)."""
+def inflate_workspace(lib, variant, inflated_bytes, n_blocks, device):
+    """The workspace tensor a launch of ``variant`` needs (None: none), allocated on the caller's current stream."""
+    if variant != "fast":
+        return None
+    return torch.empty(int(lib.svx_bgzf_inflate_fast_ws_bytes(int(inflated_bytes), int(n_blocks))), dtype=torch.uint8, device=device)
+
+
+def launch_inflate(lib, variant, comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, out_ptr, status_ptr, inflated_bytes, device, ws=None):
+    """Enqueue one inflate launch on the current stream of ``device``.  ``ws``: the "fast" form's workspace
+    (:func:`inflate_workspace`); None: taken from the caching allocator here -- stream-ordered, so it may die with this call."""
     st = _stream_ptr(device)
     if variant == "fast":
-        ws_bytes = int(lib.svx_bgzf_inflate_fast_ws_bytes(int(inflated_bytes), int(n_blocks)))
-        d_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+        d_ws = ws if ws is not None else inflate_workspace(lib, variant, inflated_bytes, n_blocks, device)
+        ws_bytes = int(d_ws.numel())
         rc = lib.svx_bgzf_inflate_fast(comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, out_ptr, status_ptr, d_ws.data_ptr(), ws_bytes, st)
     else:
         fn = {"lds": lib.svx_bgzf_inflate_lds, "private": lib.svx_bgzf_inflate_private, "wave": lib.svx_bgzf_inflate_wave,
