@@ -158,14 +158,20 @@ __device__ int build_tables(const uint8_t* lens, int n, int root, uint32_t* tab,
     const int nroot = 1 << root;
     for (int i = lane; i < nroot; i += LANES) { tab[i] = 0; tmp[i] = 0; }
     lds_fence();
-    // sub-table bits per root prefix: the longest code below it
-    for (int s = 0; s < n; ++s) {
-        const int l = uni((int)lens[s]);
-        if (l <= root) continue;
-        const uint32_t r = __brev((uint32_t)uni((int)code_of[s])) >> (32 - l);
-        const int pre = (int)(r & (uint32_t)(nroot - 1));
-        if (lane == 0 && (int)tmp[pre] < l - root) tmp[pre] = (uint8_t)(l - root);
-        lds_fence();
+    // sub-table bits per root prefix: the longest code below it.  (The symbols' lengths and codes are read 64 at a time into
+    // a register and handed round with v_readlane: one LDS round trip per 64 symbols instead of two per symbol.)
+    for (int s0 = 0; s0 < n; s0 += LANES) {
+        const int lv = s0 + lane < n ? (int)lens[s0 + lane] : 0, cv = s0 + lane < n ? (int)code_of[s0 + lane] : 0;
+        unsigned long long longs = __ballot(lv > root);
+        while (longs) {
+            const int j = __ffsll((long long)longs) - 1;
+            longs &= longs - 1;
+            const int l = __builtin_amdgcn_readlane(lv, j);
+            const uint32_t r = __brev((uint32_t)__builtin_amdgcn_readlane(cv, j)) >> (32 - l);
+            const int pre = (int)(r & (uint32_t)(nroot - 1));
+            if (lane == 0 && (int)tmp[pre] < l - root) tmp[pre] = (uint8_t)(l - root);
+            lds_fence();
+        }
     }
     // allocate: exclusive prefix of 2^bits over the root entries (each lane owns nroot / 64 consecutive entries)
     int top = nroot;
@@ -187,19 +193,24 @@ __device__ int build_tables(const uint8_t* lens, int n, int root, uint32_t* tab,
         top = nroot + total;
     }
     lds_fence();
-    // entries: symbol after symbol, the wave fills a symbol's replicas
-    for (int s = 0; s < n; ++s) {
-        const int l = uni((int)lens[s]);
-        if (l == 0) continue;
-        const uint32_t r = __brev((uint32_t)uni((int)code_of[s])) >> (32 - l);
-        if (l <= root) {
-            const uint32_t e = payload(s) | (uint32_t)l;
-            for (uint32_t i = r + ((uint32_t)lane << l); i < (uint32_t)nroot; i += (uint32_t)LANES << l) tab[i] = e;
-        } else {
-            const uint32_t p = tab[r & (uint32_t)(nroot - 1)];
-            const uint32_t start = (p >> 8) & 0xfffu, sb = (p >> 20) & 15u;
-            const uint32_t e = payload(s) | (uint32_t)(l - root);
-            for (uint32_t i = (r >> root) + ((uint32_t)lane << (l - root)); i < (1u << sb); i += (uint32_t)LANES << (l - root)) tab[start + i] = e;
+    // entries: symbol after symbol (the used ones), the wave fills a symbol's replicas
+    for (int s0 = 0; s0 < n; s0 += LANES) {
+        const int lv = s0 + lane < n ? (int)lens[s0 + lane] : 0, cv = s0 + lane < n ? (int)code_of[s0 + lane] : 0;
+        unsigned long long used = __ballot(lv != 0);
+        while (used) {
+            const int j = __ffsll((long long)used) - 1;
+            used &= used - 1;
+            const int s = s0 + j, l = __builtin_amdgcn_readlane(lv, j);
+            const uint32_t r = __brev((uint32_t)__builtin_amdgcn_readlane(cv, j)) >> (32 - l);
+            if (l <= root) {
+                const uint32_t e = payload(s) | (uint32_t)l;
+                for (uint32_t i = r + ((uint32_t)lane << l); i < (uint32_t)nroot; i += (uint32_t)LANES << l) tab[i] = e;
+            } else {
+                const uint32_t p = tab[r & (uint32_t)(nroot - 1)];
+                const uint32_t start = (p >> 8) & 0xfffu, sb = (p >> 20) & 15u;
+                const uint32_t e = payload(s) | (uint32_t)(l - root);
+                for (uint32_t i = (r >> root) + ((uint32_t)lane << (l - root)); i < (1u << sb); i += (uint32_t)LANES << (l - root)) tab[start + i] = e;
+            }
         }
     }
     lds_fence();

@@ -461,6 +461,7 @@ class DeviceDecoder:
         # high priority: the ingest kernels and the CNN share the device and do not overlap; whatever the order, the device
         # does the same work, but chromosomes that arrive early give the pipeline behind a backlog (and the per-chromosome
         # kernels here are small: behind queued graph replays they would wait for tens of ms)
+        depth = int(os.environ.get("SVX_INGEST_DEPTH", depth))          # (experiments)
         streams = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(depth)]
         inflight = collections.deque()
         state = {"done": False, "k": 0, "finished": 0, "hold_until": float("inf")}
