@@ -11,9 +11,9 @@
 //   * literals and matches are written to the ring (byte stores: no alignment cases);
 //   * a match whose source lies within the ring (distance <= NEAR) is read from it -- a few LDS round trips instead of a
 //     store acknowledgement + a load from HBM; overlapping matches (distance < length) replicate the period in a register;
-//   * a farther match reads global memory: everything below the last 16-byte boundary has been stored;
-//   * output leaves as whole, 16-byte aligned chunks, read back from the ring when a chunk completes (the block's first
-//     and last partial chunk byte-wise: their neighbours belong to other lanes);
+//   * a farther match reads global memory: everything below the last 64-byte boundary has been stored;
+//   * output leaves as whole 64-byte lines (four aligned 16-byte stores), read back from the ring when a line completes (the
+//     block's first and last partial line byte-wise: their neighbours belong to other lanes);
 //   * the next sequence's header and its first 12 literal bytes are one 16-byte load issued when the current header is parsed
 //     (pulling the stream towards the L2 hundreds of bytes ahead of its use was measured: no gain -- what a turn waits for are
 //     its ~200 dependent instructions, the LDS round trips and the far matches' loads).
@@ -30,7 +30,8 @@
 namespace svx_lz {
 
 constexpr uint32_t RING = 256;                       // bytes of recent output per lane (a power of two, a multiple of 16)
-constexpr uint32_t NEAR = RING - 16;                 // matches up to this distance read the ring
+constexpr uint32_t NEAR = RING - 16;                 // matches up to this distance read the ring (farther ones read memory: everything
+                                                     // below the last 64-byte boundary has been stored, i.e. everything more than 63 bytes back)
 enum { LZ_OK = 0, LZ_OUT_OVERRUN = 5, LZ_SHORT = 7, LZ_BAD_DIST = 8 };
 
 struct Seq16 { uint32_t w[4]; };                     // a header and the 12 bytes behind it
@@ -56,16 +57,19 @@ SVX_HD uint64_t ring_get8(const uint8_t* ring, uint64_t s)
     return sh ? lo | (uint64_t)c << (64 - sh) : lo;
 }
 
-// the 16-byte chunk that ends at the boundary `upto` (a multiple of 16 in the address space of `out`) leaves the ring
-SVX_HD void flush_chunk(const uint8_t* ring, uint8_t* out, uint64_t upto, uint64_t lo)
+// the 64-byte line that ends at the boundary `upto` (a multiple of LINE in the address space of `out`) leaves the ring: four
+// aligned 16-byte stores back to back -- a whole line of the memory system (16-byte chunks, one at a time, still cost 2.5 x the
+// output's bytes in write traffic: PMC WRITE_SIZE)
+constexpr uint32_t LINE = 64;
+SVX_HD void flush_line(const uint8_t* ring, uint8_t* out, uint64_t upto, uint64_t lo)
 {
-    const uint64_t from = upto - 16;
-    const uint32_t r = (uint32_t)from & (RING - 1);  // 16-byte aligned in the ring as well (ring offsets = positions mod RING,
+    const uint64_t from = upto - LINE;
+    const uint32_t r = (uint32_t)from & (RING - 1);  // LINE-aligned in the ring as well (ring offsets = positions mod RING,
     if (from >= lo) {                                // the ring itself is 16-byte aligned)
-        uint32_t c[4];
-        memcpy(c, static_cast<const uint8_t*>(__builtin_assume_aligned(ring, 16)) + r, 16);
-        memcpy(out + from, c, 16);
-    } else {                                         // the block's first chunk: the bytes in front of lo are another block's
+        uint32_t c[LINE / 4];
+        memcpy(c, static_cast<const uint8_t*>(__builtin_assume_aligned(ring, 16)) + r, LINE);
+        memcpy(out + from, c, LINE);
+    } else {                                         // the block's first line: the bytes in front of lo are another block's
         for (uint64_t a = lo; a < upto; ++a) out[a] = ring[(uint32_t)a & (RING - 1)];
     }
 }
@@ -98,8 +102,8 @@ SVX_HD int decode_block(const uint8_t* stream, uint32_t stream_len, uint8_t* out
             p += lit;
             near = dist <= NEAR;
             // a far match's first eight source bytes are requested now if they are in memory already: everything below the last
-            // 16-byte boundary in front of w is (the literals of this sequence are not)
-            pre = mlen != 0 && !near && dist >= lit + 24u;
+            // 64-byte boundary in front of w is (the literals of this sequence are not)
+            pre = mlen != 0 && !near && dist >= lit + 8u + 64u;
             if (pre) memcpy(&fv, out + (w + lit - dist), 8);
             load16(nx, p);                           // the next header + its first literals
         }
@@ -111,7 +115,7 @@ SVX_HD int decode_block(const uint8_t* stream, uint32_t stream_len, uint8_t* out
             else { v = 0; memcpy(&v, lp + done, 8); }
             ring_put(ring, w, v, n);
             const uint64_t w2 = w + n;
-            if ((w2 & ~15ull) != (w & ~15ull)) flush_chunk(ring, out, w2 & ~15ull, lo);
+            if ((w2 & ~63ull) != (w & ~63ull)) flush_line(ring, out, w2 & ~63ull, lo);
             w = w2; done += n; lit -= n;
         }
         if (lit == 0 && mlen) {                      // a step of the match
@@ -131,12 +135,12 @@ SVX_HD int decode_block(const uint8_t* stream, uint32_t stream_len, uint8_t* out
             else memcpy(&v, out + (w - dist), 8);
             ring_put(ring, w, v, n);
             const uint64_t w2 = w + n;
-            if ((w2 & ~15ull) != (w & ~15ull)) flush_chunk(ring, out, w2 & ~15ull, lo);
+            if ((w2 & ~63ull) != (w & ~63ull)) flush_line(ring, out, w2 & ~63ull, lo);
             w = w2; mlen -= n;
         }
     }
     if (w != hi) return LZ_SHORT;
-    for (uint64_t a = (w & ~15ull) > lo ? (w & ~15ull) : lo; a < hi; ++a) out[a] = ring[(uint32_t)a & (RING - 1)];     // the last, partial chunk
+    for (uint64_t a = (w & ~63ull) > lo ? (w & ~63ull) : lo; a < hi; ++a) out[a] = ring[(uint32_t)a & (RING - 1)];     // the last, partial line
     return LZ_OK;
 }
 
