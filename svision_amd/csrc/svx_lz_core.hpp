@@ -18,6 +18,9 @@
 //     (pulling the stream towards the L2 hundreds of bytes ahead of its use was measured: no gain -- what a turn waits for are
 //     its ~200 dependent instructions, the LDS round trips and the far matches' loads).
 #pragma once
+#ifndef SVX_LZ_DBG
+#define SVX_LZ_DBG 0                 // measurements only: bit 0 = far sources are not loaded, bit 1 = lines are not stored (wrong output)
+#endif
 #include <stdint.h>
 #include <string.h>
 
@@ -68,7 +71,7 @@ SVX_HD void flush_line(const uint8_t* ring, uint8_t* out, uint64_t upto, uint64_
     if (from >= lo) {                                // the ring itself is 16-byte aligned)
         uint32_t c[LINE / 4];
         memcpy(c, static_cast<const uint8_t*>(__builtin_assume_aligned(ring, 16)) + r, LINE);
-        memcpy(out + from, c, LINE);
+        if (!(SVX_LZ_DBG & 2)) memcpy(out + from, c, LINE);
     } else {                                         // the block's first line: the bytes in front of lo are another block's
         for (uint64_t a = lo; a < upto; ++a) out[a] = ring[(uint32_t)a & (RING - 1)];
     }
@@ -104,7 +107,7 @@ SVX_HD int decode_block(const uint8_t* stream, uint32_t stream_len, uint8_t* out
             // a far match's first eight source bytes are requested now if they are in memory already: everything below the last
             // 64-byte boundary in front of w is (the literals of this sequence are not)
             pre = mlen != 0 && !near && dist >= lit + 8u + 64u;
-            if (pre) memcpy(&fv, out + (w + lit - dist), 8);
+            if (pre && !(SVX_LZ_DBG & 1)) memcpy(&fv, out + (w + lit - dist), 8);
             load16(nx, p);                           // the next header + its first literals
         }
         if (lit) {                                   // a step of the literal run
@@ -132,7 +135,8 @@ SVX_HD int decode_block(const uint8_t* stream, uint32_t stream_len, uint8_t* out
                     v = q;
                 }
             } else if (pre) { v = fv; pre = false; }
-            else memcpy(&v, out + (w - dist), 8);
+            else if (!(SVX_LZ_DBG & 1)) memcpy(&v, out + (w - dist), 8);
+            else v = 0;
             ring_put(ring, w, v, n);
             const uint64_t w2 = w + n;
             if ((w2 & ~63ull) != (w & ~63ull)) flush_line(ring, out, w2 & ~63ull, lo);
