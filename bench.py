@@ -423,7 +423,7 @@ def main():
                         os.environ[k] = v
             dd = leg["rank0_feed"].get("device_decoder", {})
             sweep.append({"env": env, "seconds": leg["seconds"], "read_s": dd.get("read_s"), "pread_s": dd.get("pread_s"), "slot_wait_s": dd.get("slot_wait_s"),
-                          "last_ready_s": leg["rank0_feed"].get("last_ready_s"), "device_busy_frac": leg["device_busy_frac"]})
+                          "last_ready_s": leg["rank0_feed"].get("last_ready_s"), "device_busy_frac": leg["device_busy_frac"], "trace": dd.get("trace")})
             if rank == 0:
                 print("e2e sweep %s: %.3f s (read %s, pread %s, slot wait %s, last chromosome ready %s)" % (
                     spec or "(default)", leg["seconds"], dd.get("read_s"), dd.get("pread_s"), dd.get("slot_wait_s"), leg["rank0_feed"].get("last_ready_s")), file=sys.stderr)

@@ -134,20 +134,38 @@ __device__ unsigned long long svx_enc_prof[8];
 constexpr int ENC_ROWS = SVX_ENC_ROWS;
 static_assert(P1 % ENC_ROWS == 0 && ENC_ROWS * WAVE <= ENC_BLOCK, "rows per workgroup: a divisor of 27, one wave each for the masks");
 
+struct EncLds {
+    unsigned bits[2 * svx_raster::PLANE_WORDS];       // plane 0 (all segments) and the reverse-segment plane; plane 1 = plane 0 & colmask
+    unsigned colcnt[svx_raster::IMG];
+    unsigned colmask[svx_raster::ROW_WORDS + 1];      // (+1: window_mask may look one word past a row)
+    unsigned pooled_bits[ENC_ROWS][P1 * C1P];         // [row][ox][k] pooled activations as float bit patterns (padded: no bank conflicts)
+    unsigned rowany[ENC_ROWS][3][svx_raster::ROW_WORDS];
+    int has_empty[ENC_ROWS][P1];                      // per conv row of a strip: OR of its 11 image rows x 3 planes
+    unsigned short queue[ENC_ROWS * P1 * 9];
+    int n_queue;
+};
+
 __global__ __launch_bounds__(ENC_BLOCK)
 void encode_conv1_kernel(const int32_t* __restrict__ records, const float* __restrict__ w1, const float* __restrict__ base,
                          float* __restrict__ y, int lrn, int radius, float alpha, float beta, float kk,
                          uint32_t* __restrict__ touched)
 {
     using namespace svx_raster;
-    __shared__ unsigned bits[2 * PLANE_WORDS];        // plane 0 (all segments) and the reverse-segment plane; plane 1 = plane 0 & colmask
-    __shared__ unsigned colcnt[IMG];
-    __shared__ unsigned colmask[ROW_WORDS + 1];       // (+1: window_mask may look one word past a row)
-    __shared__ unsigned pooled_bits[ENC_ROWS][P1 * C1P];  // [row][ox][k] pooled activations as float bit patterns (padded: no bank conflicts)
-    __shared__ unsigned rowany[ENC_ROWS][3][ROW_WORDS];
-    __shared__ int has_empty[ENC_ROWS][P1];   // per conv row of a strip: OR of its 11 image rows x 3 planes
-    __shared__ unsigned short queue[ENC_ROWS * P1 * 9];
-    __shared__ int n_queue;
+    // The LDS is taken as DYNAMIC shared memory although its size is a constant: for a kernel whose occupancy its static LDS
+    // limits, the compiler raises the VGPR allocation in the kernel descriptor to the most that occupancy leaves room for
+    // (AMDGPUAsmPrinter: getMinNumVGPRs(max waves per EU)) -- 73 instead of the 38 this kernel uses, 129 instead of 66 for
+    // bgzf_lz_kernel -- and registers a wave does not use are registers the waves of OTHER kernels (the convolutions of the
+    // next stream's launch, which fill this one's tail) cannot have.
+    extern __shared__ __attribute__((aligned(16))) unsigned char enc_lds_raw[];
+    EncLds& L = *reinterpret_cast<EncLds*>(enc_lds_raw);
+    unsigned (&bits)[2 * PLANE_WORDS] = L.bits;
+    unsigned (&colcnt)[IMG] = L.colcnt;
+    unsigned (&colmask)[ROW_WORDS + 1] = L.colmask;
+    unsigned (&pooled_bits)[ENC_ROWS][P1 * C1P] = L.pooled_bits;
+    unsigned (&rowany)[ENC_ROWS][3][ROW_WORDS] = L.rowany;
+    int (&has_empty)[ENC_ROWS][P1] = L.has_empty;
+    unsigned short (&queue)[ENC_ROWS * P1 * 9] = L.queue;
+    int& n_queue = L.n_queue;
 
     constexpr int STRIPS = P1 / ENC_ROWS;
     const int img = blockIdx.x / STRIPS;
@@ -284,7 +302,7 @@ extern "C" int svx_encode_conv1(const int32_t* d_records, uint32_t n, const floa
     if (n == 0) return SVX_OK;
     if (!d_records || !d_w1 || !d_base || !d_y) return SVX_EINVAL;
     if ((reinterpret_cast<uintptr_t>(d_w1) & 15u) || (reinterpret_cast<uintptr_t>(d_base) & 15u)) return SVX_EINVAL;
-    hipLaunchKernelGGL(encode_conv1_kernel, dim3(n * (P1 / ENC_ROWS)), dim3(ENC_BLOCK), 0, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(encode_conv1_kernel, dim3(n * (P1 / ENC_ROWS)), dim3(ENC_BLOCK), sizeof(EncLds), static_cast<hipStream_t>(stream),
                        d_records, d_w1, d_base, d_y, lrn, (int)radius, alpha, beta, k, d_touched);
     return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
 }

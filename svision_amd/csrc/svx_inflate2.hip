@@ -458,7 +458,10 @@ __global__ __launch_bounds__(LZ_LANES)
 void bgzf_lz_kernel(const uint8_t* __restrict__ streams, const uint32_t* __restrict__ stream_len, const uint64_t* __restrict__ dst_off,
                     uint32_t n_blocks, uint8_t* out, uint32_t* __restrict__ status)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t rings[LZ_LANES * RING_STRIDE];
+    // (dynamic although constant: with static LDS the compiler raises the kernel's VGPR allocation to what its LDS-limited
+    // occupancy leaves room for -- 129 registers instead of the 66 in use -- and the convolutions this kernel runs next to
+    // cannot have them: svx_cnn.hip, encode_conv1_kernel)
+    extern __shared__ __attribute__((aligned(16))) uint8_t rings[];
     const uint32_t b = blockIdx.x * LZ_LANES + threadIdx.x;
     if (b >= n_blocks) return;
     if (status[b] != 0) return;
@@ -489,10 +492,12 @@ extern "C" int svx_bgzf_inflate_fast(const uint8_t* d_comp, const uint64_t* d_sr
     uint32_t* stream_len = static_cast<uint32_t*>(d_ws);
     uint8_t* streams = static_cast<uint8_t*>(d_ws) + (((size_t)4 * n_blocks + 255) & ~(size_t)255);
     (void)ws_bytes;
-    hipLaunchKernelGGL(bgzf_tokens_kernel, dim3(n_blocks), dim3(LANES), 0, st, d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, streams, stream_len, d_status);
-    static const bool only_a = getenv("SVX_INFLATE2_ONLY_A") != nullptr;     // measurements: kernel A alone (the output stays unwritten)
-    if (only_a) return SVX_OK;
-    hipLaunchKernelGGL(bgzf_lz_kernel, dim3((n_blocks + LZ_LANES - 1) / LZ_LANES), dim3(LZ_LANES), 0, st, streams, stream_len, d_dst_off, n_blocks, d_out, d_status);
+    const char* only = getenv("SVX_INFLATE2_ONLY");                          // measurements: "A" = kernel A alone (the output stays unwritten),
+    if (!only && getenv("SVX_INFLATE2_ONLY_A")) only = "A";                  // "B" = kernel B alone on the streams an earlier call left in the same workspace
+    if (!only || only[0] != 'B')
+        hipLaunchKernelGGL(bgzf_tokens_kernel, dim3(n_blocks), dim3(LANES), 0, st, d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, streams, stream_len, d_status);
+    if (only && only[0] == 'A') return SVX_OK;
+    hipLaunchKernelGGL(bgzf_lz_kernel, dim3((n_blocks + LZ_LANES - 1) / LZ_LANES), dim3(LZ_LANES), LZ_LANES * RING_STRIDE, st, streams, stream_len, d_dst_off, n_blocks, d_out, d_status);
     if (hipGetLastError() != hipSuccess) return SVX_ELAUNCH;
     // the (pathological) blocks whose sequence stream did not fit its slot: the wave-per-block kernel, those blocks only
     return svx_bgzf_inflate_wave_only(d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, d_out, d_status, INF_TOKENS_OVERFLOW, stream);

@@ -23,6 +23,7 @@ import time
 import numpy as np
 
 from .io.bam import AlignmentTable, BamStream
+from . import streams
 from .sample import Sample
 
 
@@ -193,7 +194,7 @@ class ChromosomeFeed:
             self.stats["engine"] = engine
             stage_a = threading.Thread(target=self._decode, args=(engine, tids, decoded), name="svx-decode", daemon=True)
             stage_a.start()
-            scan_stream = torch.cuda.Stream(device=self.device, priority=-1)
+            scan_stream = streams.get("scan", self.device)      # (a hardware queue of its own: svision_amd/streams.py)
             spill = queue.Queue()
             threading.Thread(target=self._spill, args=(spill,), name="svx-spill", daemon=True).start()
             while not self._stop:
@@ -210,6 +211,12 @@ class ChromosomeFeed:
                     raise item
                 table, arrays = item
                 t0 = time.perf_counter()
+                dec = getattr(self, "decoder", None)
+                if dec is not None:
+                    dec._mark("consumer: got a part")
+                    if os.environ.get("SVX_TIMING"):
+                        from . import sample as _sample_mod
+                        _sample_mod._MARK = dec._mark
                 if callable(table):                            # device engine: the QNAME ids are still to be computed
                     table = table()
                 tid = int(table.tid[0])
@@ -224,6 +231,8 @@ class ChromosomeFeed:
                     else:
                         sample = Sample.from_device(table, self.fasta, self.options.min_sv_size, *arrays)
                 alloc = table._alloc
+                if dec is not None:
+                    dec._mark("consumer: scanned")
                 for name, arr in (("gaps", sample.gaps), ("gap_off", sample.gap_off), ("stats", sample.stats)):
                     alloc.put(name, arr)
                 self.stats["upload_scan_s"] += time.perf_counter() - t0
@@ -244,7 +253,7 @@ class ChromosomeFeed:
                 self._emit_empty(want.pop(0))
             if getattr(self, "decoder", None) is not None:
                 self.stats["device_decoder"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in self.decoder.stats.items()}
-                self.stats["device_decoder"]["trace"] = ["%.3f %s" % (t + (self.decoder._t0 - self._t0), w) for t, w in self.decoder.trace[:120]]
+                self.stats["device_decoder"]["trace"] = ["%.3f %s" % (t + (self.decoder._t0 - self._t0), w) for t, w in self.decoder.trace[:400]]
         except BaseException as exc:                           # noqa: BLE001 -- surfaces in the owner thread (poll / get)
             self.error = exc
             self._stop = True
@@ -264,7 +273,7 @@ class ChromosomeFeed:
         """Stage C: host copies of the device-decoded CIGAR words (ingest_gpu.spill_cigar), after the hand-over."""
         import torch
         from .ingest_gpu import spill_cigar
-        stream = torch.cuda.Stream(device=self.device, priority=-1)
+        stream = streams.get("spill", self.device)
         while True:
             job = jobs.get()
             if job is None:

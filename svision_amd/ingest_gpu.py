@@ -16,14 +16,15 @@ import os
 import numpy as np
 import torch
 
-from . import _lib, kernels
+from . import _lib, kernels, streams
 from .io.bam import AlignmentTable, read_bai_linear
 
 FIRST_GROUP_BYTES = 192 << 20            # the first launch is small (~7 k blocks: the wave-per-block kernel): the pipeline starts after ~0.1 s
 STAGE_BYTES = 64 << 20                   # a pinned staging slot of the pipelined reader (ring of four)
-PIPE_GROUP_BYTES = 768 << 20             # parts_pipelined, second group: ~30 k blocks
-LARGE_GROUP_BYTES = 2560 << 20           # parts_pipelined, from the third group on ...
-LARGE_GROUP_BLOCKS = 94_000              # ... but not more blocks than one round of the lane-per-block kernel holds (98,304)
+PIPE_GROUP_BYTES = 600 << 20             # parts_pipelined, the groups behind the first: ~21 k blocks.  (Round 3 / early round 4: 768 MB, then 2.5 GB
+LARGE_GROUP_BYTES = 600 << 20            # -- a launch of the lane-per-block kernel cost 60-90 ms whatever it held.  The two-kernel inflate is
+LARGE_GROUP_BLOCKS = 94_000              # proportional to the launch, and once the read-backs no longer blocked each other (launch(), streams.py)
+                                         # a steady flow of small groups beat the large ones: the CNN behind never runs out of chromosomes.)
 GROUP_BYTES = 24 << 30                   # serial form (groups / decode_group): later groups as large as they come
 
 
@@ -129,7 +130,7 @@ class DeviceDecoder:
 
     def _mark(self, what):
         import time
-        if len(self.trace) < 120:
+        if len(self.trace) < 400:
             self.trace.append((round(time.perf_counter() - self._t0, 4), what))
 
     def usable(self, tids):
@@ -213,7 +214,10 @@ class DeviceDecoder:
         self._mark("groups cut: %s" % [len(g) for g in groups])
         q = queue.Queue(maxsize=1)
         stop = threading.Event()
-        # Staging: a ring of four pinned 64 MB slots.  A group's compressed bytes go to the device slot by slot -- read (8
+        # Staging: a ring of eight pinned 64 MB slots (four, until round 4: a slot's "copy done" event sits in a hardware queue its
+        # stream shares with long kernels and completes tens of ms after the copy itself -- with four slots the reader waited 0.15 s
+        # of a 0.5 s job for slots whose copies had long finished, with eight 0.02 s; a stream with a hardware queue of its own
+        # -- one of the low priority class, which nothing else of the process uses -- changed nothing).  A group's compressed bytes go to the device slot by slot -- read (8
         # pread threads), index the BGZF blocks the slot holds, copy them to their place in the group's device buffer on a
         # copy stream, reuse the slot once its copy is done.  (First version: one pinned buffer per group in flight --
         # 3.7 GB of hipHostMalloc at 0.1 s per GB inside the run, during which every other HIP call of the process waited.)
@@ -222,11 +226,9 @@ class DeviceDecoder:
         for r in ring:
             r[1] = None
         ring_at = [0]
-        # high priority like the ingest kernels' streams: where the runtime copies with a kernel of its own, that kernel must
-        # not queue up behind the CNN's launches (the ring then waits for its slots and the "reads" crawl at 10 GB/s while
-        # pread alone delivers 50: tools/exp/read_rate.py)
-        copy_stream = torch.cuda.Stream(device=dev, priority=-1)
-        n_slots = max(2, int(os.environ.get("SVX_STAGE_SLOTS", "4")))
+        # (low class: the copies run on the DMA engines, and nothing else of the process uses that class's hardware queues: streams.py)
+        copy_stream = streams.get("copy", dev)
+        n_slots = max(2, int(os.environ.get("SVX_STAGE_SLOTS", "8")))
 
         def slot():
             if ring_at[0] < n_slots and len(ring) < n_slots:
@@ -369,11 +371,13 @@ class DeviceDecoder:
                     _lib.check(lib.svx_bam_walk_count(d_raw.data_ptr(), d_tab[at:].data_ptr(), n, d_counts[row:].data_ptr(), st), "svx_bam_walk_count")
                     row += n
                 d_counts[total_starts, 0] = d_status.max()
-                h_counts = torch.empty((total_starts + 1, 4), dtype=torch.int64, pin_memory=True)
-                h_counts.copy_(d_counts, non_blocking=True)
+                # NO read-back is enqueued here.  A device-to-host copy goes to a DMA engine's queue at once, with a wait for
+                # the kernels in front of it -- and the engine serves its queue in order: the counts' copy sat there for the
+                # whole inflate (40-120 ms) and every other read-back of the process (the previous group's packed arrays,
+                # the scans' results, the CNN's predictions) waited behind it.  finish_group() copies once the event is through.
                 ev = torch.cuda.Event()
                 ev.record()
-            item.update(d_raw=d_raw, d_tab=d_tab, h_counts=h_counts, event=ev, stream=stream)
+            item.update(d_raw=d_raw, d_tab=d_tab, d_counts=d_counts, event=ev, stream=stream)
             self._mark("launched %s" % item["group"][:2])
             return item
 
@@ -383,7 +387,14 @@ class DeviceDecoder:
             self._mark("inflate + count done %s" % item["group"][:2])
             item["d_comp"] = None
             self.stats["h2d_inflate_s"] += time.perf_counter() - t0
-            counts = item["h_counts"].numpy()
+            d_counts = item.pop("d_counts")
+            h_counts = torch.empty(tuple(d_counts.shape), dtype=torch.int64, pin_memory=True)
+            with torch.cuda.stream(item["stream"]):
+                h_counts.copy_(d_counts, non_blocking=True)
+                ev_c = torch.cuda.Event()
+                ev_c.record()
+            ev_c.synchronize()
+            counts = h_counts.numpy()
             if int(counts[-1, 0]) != 0:
                 raise DeviceIngestError("corrupt BGZF blocks in references %s" % item["group"], item["group"])
             d_raw, d_tab, stream = item["d_raw"], item["d_tab"], item["stream"]
@@ -462,7 +473,8 @@ class DeviceDecoder:
         # does the same work, but chromosomes that arrive early give the pipeline behind a backlog (and the per-chromosome
         # kernels here are small: behind queued graph replays they would wait for tens of ms)
         depth = int(os.environ.get("SVX_INGEST_DEPTH", depth))          # (experiments)
-        streams = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(depth)]
+        depth = max(1, min(depth, 3))
+        group_streams = [streams.get("ingest%d" % i, dev) for i in range(depth)]
         inflight = collections.deque()
         state = {"done": False, "k": 0, "finished": 0, "hold_until": float("inf")}
 
@@ -490,7 +502,7 @@ class DeviceDecoder:
                     # consumer's count of finished chromosomes points at the failing group and nothing decoded is thrown away
                     state["error"], state["done"] = item, True
                     return
-                inflight.append(launch(item, streams[state["k"] % depth]))
+                inflight.append(launch(item, group_streams[state["k"] % depth]))
                 state["k"] += 1
                 if state["k"] == 1:
                     state["hold_until"] = time.perf_counter() + 0.15

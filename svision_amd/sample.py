@@ -11,6 +11,16 @@ import numpy as np
 from .io.bam import Fasta, read_bam
 
 _CACHE = {}
+_MARK = None                                                 # (SVX_TIMING: ingest._run points this at the decoder's trace)
+_PINNED = []                                                 # pinned int32 scratch buffers of the scans' read-backs (grow-only, reused)
+
+
+def _pinned_scratch(words):
+    import torch
+    for i, buf in enumerate(_PINNED):
+        if buf.numel() >= words:
+            return _PINNED.pop(i)
+    return torch.empty(max(int(words), 1 << 20), dtype=torch.int32, pin_memory=True)
 
 
 class Sample:
@@ -51,8 +61,34 @@ class Sample:
         # stream's back when they are freed
         for t in (d_cigar, d_off, d_pos):
             t.record_stream(torch.cuda.current_stream(t.device))
-        res = kernels.cigar_scan(d_cigar, d_off, d_pos, min_sv)
-        gaps, gap_off, stats = res.to_host()
+        # The result comes back through PINNED memory, copies and event on the caller's (high-priority) stream.  A read-back
+        # into pageable memory (.item(), .cpu()) is staged by the runtime through a copy kernel on an internal queue of
+        # normal priority: behind the CNN's queued launches and a tokens launch that owns every CU it took 40-90 ms instead
+        # of 1-3, several times per job -- the hand-over of a whole group of chromosomes waited for another group's inflate.
+        n = int(d_pos.numel())
+        cap = max(1024, n // 2)
+        while True:
+            res = kernels.cigar_scan(d_cigar, d_off, d_pos, min_sv, gaps_cap=cap)
+            if _MARK: _MARK("from_device: scan enqueued")
+            need = (n + 1) + cap * 6 + n * 4
+            host = _pinned_scratch(need)
+            host[:n + 1].copy_(res.gap_off, non_blocking=True)
+            host[n + 1:n + 1 + cap * 6].copy_(res.gaps[:cap * 6], non_blocking=True)
+            host[n + 1 + cap * 6:need].copy_(res.stats.view(-1), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            if _MARK: _MARK("from_device: copies enqueued")
+            ev.synchronize()
+            if _MARK: _MARK("from_device: event done")
+            h = host.numpy()
+            total = int(h[:n + 1].view(np.uint32)[n])
+            if total <= cap:
+                break
+            cap = total                                      # gap_off[n] holds the full count: once more with the exact capacity
+        gap_off = h[:n + 1].view(np.uint32).copy()
+        gaps = h[n + 1:n + 1 + total * 6].copy().view(kernels.GAP_DTYPE) if total else np.empty(0, kernels.GAP_DTYPE)
+        stats = h[n + 1 + cap * 6:need].reshape(n, 4).copy()
+        _PINNED.append(host)
         from .segmentplot import run_hash_lineplot
         run_hash_lineplot.DEVICE = d_cigar.device
         return cls(table, fasta, gaps, gap_off, stats, min_sv, device_buffers=(d_cigar, d_off, d_pos, res))
@@ -96,7 +132,8 @@ class Sample:
         cap = int(self.gap_off[hi] - self.gap_off[lo])
         capd = max(cap, 16)
         if getattr(self, "_scan_stream", None) is None:
-            self._scan_stream = torch.cuda.Stream(device=d_cigar.device, priority=-1)
+            from . import streams
+            self._scan_stream = streams.get("scan", d_cigar.device)   # ONE high-priority scan stream per process (streams.py)
             self._scan_pinned = []
         need = (n + 1) + capd * 6 + n * 4
         host = None
