@@ -423,7 +423,8 @@ def main():
                         os.environ[k] = v
             dd = leg["rank0_feed"].get("device_decoder", {})
             sweep.append({"env": env, "seconds": leg["seconds"], "read_s": dd.get("read_s"), "pread_s": dd.get("pread_s"), "slot_wait_s": dd.get("slot_wait_s"),
-                          "last_ready_s": leg["rank0_feed"].get("last_ready_s"), "device_busy_frac": leg["device_busy_frac"], "trace": dd.get("trace")})
+                          "last_ready_s": leg["rank0_feed"].get("last_ready_s"), "device_busy_frac": leg["device_busy_frac"], "trace": dd.get("trace"),
+                          "cnn_span_ms": leg.get("cnn_span_ms_rank0"), "cnn_gaps_ms": leg.get("cnn_gaps_ms_rank0")})
             if rank == 0:
                 print("e2e sweep %s: %.3f s (read %s, pread %s, slot wait %s, last chromosome ready %s)" % (
                     spec or "(default)", leg["seconds"], dd.get("read_s"), dd.get("pread_s"), dd.get("slot_wait_s"), leg["rank0_feed"].get("last_ready_s")), file=sys.stderr)
@@ -582,6 +583,16 @@ def run_from_file(args, e2e, hot, run, fasta, opts, dev, sync_all, cores, world,
         if not keep:
             shutil.rmtree(e2e["dir"], ignore_errors=True)
     dev_ms = hot.device_busy_ms()
+    cnn_gaps, cnn_span = [], None
+    if getattr(hot, "batch_events", None):                      # where the CNN stood still: gaps of more than 3 ms between two launches
+        ref = hot._t_ref
+        iv = sorted((ref.elapsed_time(ev[0]), ref.elapsed_time(ev[1])) for ev in hot.batch_events)
+        hi = iv[0][1]
+        for lo_, hi_ in iv[1:]:
+            if lo_ - hi > 3.0:
+                cnn_gaps.append([round(hi, 1), round(lo_ - hi, 1)])
+            hi = max(hi, hi_)
+        cnn_span = round(hi - iv[0][0], 1)
     tot = torch.tensor([sites, images, len(e2e["windows"]), e2e["bytes"], e2e["inflated"], dev_ms], dtype=torch.float64, device=dev)
     if grouped:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -593,6 +604,7 @@ def run_from_file(args, e2e, hot, run, fasta, opts, dev, sync_all, cores, world,
     return {"ingest_engine": st.get("engine"), "value": float(tot[0]) / dt, "unit": "sites/s", "seconds": dt, "windows": int(tot[2]), "sites": int(tot[0]), "images": int(tot[1]),
             "bam_bytes": int(tot[3]), "inflated_bytes": int(tot[4]), "compressed_GB_per_s": float(tot[3]) / dt / 1e9,
             "inflated_GB_per_s": float(tot[4]) / dt / 1e9, "inflate_threads_per_rank": threads, "device_busy_frac": float(tot[5]) * 1e-3 / world / dt,
+            "cnn_span_ms_rank0": cnn_span, "cnn_gaps_ms_rank0": cnn_gaps,        # from the first launch's upload: [start of the gap, length] of every pause > 3 ms
             "rank0_feed": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in st.items()},
             "owner_profile_rank0": {k: round(v, 4) for k, v in getattr(hot, "owner_profile", {}).items()},
             "note": "timed from opening the BAM (random bases, 7-bin qualities: ~0.4 compressed bytes per base, like a HiFi BAM) to the end of "

@@ -30,6 +30,10 @@
 #include "../../include/svx.h"
 #include "svx_lz_core.hpp"
 
+#ifndef SVX_TOK_DBG
+#define SVX_TOK_DBG 0                // measurements only (wrong output): 1 = the Huffman tables are built twice, 2 = no transcode pass, 4 = no S1 pass
+#endif
+
 namespace {
 
 constexpr int LANES = 64;
@@ -351,6 +355,10 @@ void bgzf_tokens_kernel(const uint8_t* __restrict__ comp, const uint64_t* __rest
             if (uni((int)t.lens[256]) == 0) { err = INF_BAD_TABLE; break; }
         }
         P += hr.fed;
+#if SVX_TOK_DBG & 1
+        build_tables(t.lens, nlen, LB, t.lit, LIT_CAP, t.code, reinterpret_cast<uint8_t*>(t.dist), LitPayload{});
+        build_tables(t.lens + 288, ndist, DB, t.dist, DIST_CAP, t.code, reinterpret_cast<uint8_t*>(t.chunk), DistPayload{});
+#endif
         if (!build_tables(t.lens, nlen, LB, t.lit, LIT_CAP, t.code, reinterpret_cast<uint8_t*>(t.dist), LitPayload{}) ||
             !build_tables(t.lens + 288, ndist, DB, t.dist, DIST_CAP, t.code, reinterpret_cast<uint8_t*>(t.chunk), DistPayload{})) { err = INF_BAD_TABLE; break; }
         // ---- the block's tokens, chunk by chunk
@@ -369,6 +377,9 @@ void bgzf_tokens_kernel(const uint8_t* __restrict__ comp, const uint64_t* __rest
             const uint32_t q0 = P + (uint32_t)lane * SEG_BITS, q1 = q0 + SEG_BITS;   // this lane's segment
             // S1: from the segment's first bit
             uint32_t p = q0;
+#if SVX_TOK_DBG & 4
+            p = q1;
+#endif
             while (__any(p < q1 && p < nbits)) {
                 if (p < q1 && p < nbits) { const Tok k = token(t, p - bit0); p += k.kind == K_BAD ? 1u : k.used; }
             }
@@ -413,6 +424,9 @@ void bgzf_tokens_kernel(const uint8_t* __restrict__ comp, const uint64_t* __rest
             if (W + tot_o > isize) { err = INF_OUT_OVERRUN; break; }
             if (Q + tot_e > cap) { err = INF_TOKENS_OVERFLOW; break; }
             // S3: transcode
+#if SVX_TOK_DBG & 2
+            if (false)
+#endif
             {
                 uint8_t* hdr = stream + qoff;
                 uint32_t w = o, nl = 0;
@@ -482,23 +496,45 @@ extern "C" size_t svx_bgzf_inflate_fast_ws_bytes(uint64_t inflated_bytes, uint32
 extern "C" __attribute__((visibility("hidden"))) int svx_bgzf_inflate_wave_only(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len, const uint64_t* d_dst_off,
                                           uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, uint32_t only, void* stream);
 
-extern "C" int svx_bgzf_inflate_fast(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len, const uint64_t* d_dst_off,
-                                     uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, void* d_ws, uint64_t ws_bytes, void* stream)
+extern "C" int svx_bgzf_inflate_fast_on(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len, const uint64_t* d_dst_off,
+                                        uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, void* d_ws, uint64_t ws_bytes, void* stream_tokens,
+                                        void* stream_lz)
 {
     if (n_blocks == 0) return SVX_OK;
     if (!d_comp || !d_src_off || !d_src_len || !d_dst_off || !d_out || !d_status || !d_ws) return SVX_EINVAL;
     if (reinterpret_cast<uintptr_t>(d_ws) & 15u) return SVX_EINVAL;
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipStream_t sa = static_cast<hipStream_t>(stream_tokens), sb = static_cast<hipStream_t>(stream_lz);
     uint32_t* stream_len = static_cast<uint32_t*>(d_ws);
     uint8_t* streams = static_cast<uint8_t*>(d_ws) + (((size_t)4 * n_blocks + 255) & ~(size_t)255);
     (void)ws_bytes;
     const char* only = getenv("SVX_INFLATE2_ONLY");                          // measurements: "A" = kernel A alone (the output stays unwritten),
     if (!only && getenv("SVX_INFLATE2_ONLY_A")) only = "A";                  // "B" = kernel B alone on the streams an earlier call left in the same workspace
-    if (!only || only[0] != 'B')
-        hipLaunchKernelGGL(bgzf_tokens_kernel, dim3(n_blocks), dim3(LANES), 0, st, d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, streams, stream_len, d_status);
+    if (!only || only[0] != 'B') {
+        if (sa != sb) {                                                      // A reads what the caller's stream (stream_lz) has prepared: the tables, d_status
+            hipEvent_t ready;
+            if (hipEventCreateWithFlags(&ready, hipEventDisableTiming) != hipSuccess) return SVX_ELAUNCH;
+            hipEventRecord(ready, sb);
+            hipStreamWaitEvent(sa, ready, 0);
+            hipEventDestroy(ready);
+        }
+        hipLaunchKernelGGL(bgzf_tokens_kernel, dim3(n_blocks), dim3(LANES), 0, sa, d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, streams, stream_len, d_status);
+        if (sa != sb) {
+            hipEvent_t done;
+            if (hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) return SVX_ELAUNCH;
+            hipEventRecord(done, sa);
+            hipStreamWaitEvent(sb, done, 0);
+            hipEventDestroy(done);
+        }
+    }
     if (only && only[0] == 'A') return SVX_OK;
-    hipLaunchKernelGGL(bgzf_lz_kernel, dim3((n_blocks + LZ_LANES - 1) / LZ_LANES), dim3(LZ_LANES), LZ_LANES * RING_STRIDE, st, streams, stream_len, d_dst_off, n_blocks, d_out, d_status);
+    hipLaunchKernelGGL(bgzf_lz_kernel, dim3((n_blocks + LZ_LANES - 1) / LZ_LANES), dim3(LZ_LANES), LZ_LANES * RING_STRIDE, sb, streams, stream_len, d_dst_off, n_blocks, d_out, d_status);
     if (hipGetLastError() != hipSuccess) return SVX_ELAUNCH;
     // the (pathological) blocks whose sequence stream did not fit its slot: the wave-per-block kernel, those blocks only
-    return svx_bgzf_inflate_wave_only(d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, d_out, d_status, INF_TOKENS_OVERFLOW, stream);
+    return svx_bgzf_inflate_wave_only(d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, d_out, d_status, INF_TOKENS_OVERFLOW, stream_lz);
+}
+
+extern "C" int svx_bgzf_inflate_fast(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len, const uint64_t* d_dst_off,
+                                     uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, void* d_ws, uint64_t ws_bytes, void* stream)
+{
+    return svx_bgzf_inflate_fast_on(d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, d_out, d_status, d_ws, ws_bytes, stream, stream);
 }

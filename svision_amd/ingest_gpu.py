@@ -359,8 +359,15 @@ class DeviceDecoder:
                 d_status = torch.zeros(nb, dtype=torch.int32, device=dev)
                 d_len = d_tab[nb:2 * nb].to(torch.int32)
                 st = kernels._stream_ptr(dev)
+                # every group's tokens kernel on ONE stream, in launch order (include/svx.h, svx_bgzf_inflate_fast_on): two of them
+                # side by side share the chip and finish together -- late; in a row, the first group's chromosomes are out a
+                # whole tokens launch earlier and its LZ copies (latency-bound) run next to the second group's tokens
+                if tokens_stream is not None and variant == "fast":
+                    for t_ in (d_comp, d_ws, d_tab, d_len, d_status):
+                        t_.record_stream(tokens_stream)
                 kernels.launch_inflate(lib, variant, d_comp.data_ptr(), d_tab.data_ptr(), d_len.data_ptr(), d_tab[2 * nb:].data_ptr(), nb,
-                                       d_raw.data_ptr(), d_status.data_ptr(), item["total"], dev, ws=d_ws)
+                                       d_raw.data_ptr(), d_status.data_ptr(), item["total"], dev, ws=d_ws,
+                                       tokens_stream=tokens_stream if variant == "fast" else None)
                 if kernels.bgzf_crc_wanted():                  # the footers' CRC32 (htslib checks it on every block): status 9 where one differs
                     _lib.check(lib.svx_bgzf_crc32(d_raw.data_ptr(), d_tab[2 * nb:].data_ptr(), d_comp.data_ptr(), d_tab.data_ptr(), d_len.data_ptr(), nb,
                                                   d_status.data_ptr(), st), "svx_bgzf_crc32")
@@ -473,7 +480,8 @@ class DeviceDecoder:
         # does the same work, but chromosomes that arrive early give the pipeline behind a backlog (and the per-chromosome
         # kernels here are small: behind queued graph replays they would wait for tens of ms)
         depth = int(os.environ.get("SVX_INGEST_DEPTH", depth))          # (experiments)
-        depth = max(1, min(depth, 3))
+        depth = max(1, min(depth, 2))                              # (the high class has four hardware queues: tokens, two groups, scans)
+        tokens_stream = streams.get("tokens", dev) if os.environ.get("SVX_TOKENS_STREAM", "1") != "0" else None
         group_streams = [streams.get("ingest%d" % i, dev) for i in range(depth)]
         inflight = collections.deque()
         state = {"done": False, "k": 0, "finished": 0, "hold_until": float("inf")}

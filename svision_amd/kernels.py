@@ -405,14 +405,19 @@ def inflate_workspace(lib, variant, inflated_bytes, n_blocks, device):
     return torch.empty(int(lib.svx_bgzf_inflate_fast_ws_bytes(int(inflated_bytes), int(n_blocks))), dtype=torch.uint8, device=device)
 
 
-def launch_inflate(lib, variant, comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, out_ptr, status_ptr, inflated_bytes, device, ws=None):
+def launch_inflate(lib, variant, comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, out_ptr, status_ptr, inflated_bytes, device, ws=None, tokens_stream=None):
     """Enqueue one inflate launch on the current stream of ``device``.  ``ws``: the "fast" form's workspace
-    (:func:`inflate_workspace`); None: taken from the caching allocator here -- stream-ordered, so it may die with this call."""
+    (:func:`inflate_workspace`); None: taken from the caching allocator here -- stream-ordered, so it may die with this call.
+    ``tokens_stream``: the "fast" form's first kernel goes there (svx_bgzf_inflate_fast_on), the rest stays on the current stream."""
     st = _stream_ptr(device)
     if variant == "fast":
         d_ws = ws if ws is not None else inflate_workspace(lib, variant, inflated_bytes, n_blocks, device)
         ws_bytes = int(d_ws.numel())
-        rc = lib.svx_bgzf_inflate_fast(comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, out_ptr, status_ptr, d_ws.data_ptr(), ws_bytes, st)
+        if tokens_stream is not None:
+            rc = lib.svx_bgzf_inflate_fast_on(comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, out_ptr, status_ptr, d_ws.data_ptr(), ws_bytes,
+                                              ctypes.c_void_p(tokens_stream.cuda_stream), st)
+        else:
+            rc = lib.svx_bgzf_inflate_fast(comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, out_ptr, status_ptr, d_ws.data_ptr(), ws_bytes, st)
     else:
         fn = {"lds": lib.svx_bgzf_inflate_lds, "private": lib.svx_bgzf_inflate_private, "wave": lib.svx_bgzf_inflate_wave,
               "lane": lib.svx_bgzf_inflate}[variant]

@@ -9,7 +9,8 @@ each time it happened, several times per job (the decoder's trace: "inflate + co
 "scanned" 38-50 ms) -- and the pipeline behind waited with them.  Next to a long kernel on ANOTHER hardware queue the same small
 kernel takes 0.04 ms at any priority (``tools/exp/prio_probe.py``).
 
-So: the high class carries exactly four streams -- three for the ingest groups in flight and one for the scans -- and nothing
+So: the high class carries exactly four streams -- one for every group's tokens kernel (one after the other:
+svx_bgzf_inflate_fast_on), two for the rest of the ingest groups in flight and one for the scans -- and nothing
 else of the process asks for a high-priority stream; the copies (staging H2D, CIGAR spill D2H: DMA engines, no workgroups) go to
 the LOW class, which nothing else uses either; the CNN's streams stay torch's normal-priority ones.
 """
@@ -20,7 +21,7 @@ import torch
 
 _LOCK = threading.Lock()
 _STREAMS = {}
-_HIGH = ("ingest0", "ingest1", "ingest2", "scan")
+_HIGH = ("tokens", "ingest0", "ingest1", "scan")
 _LOW = ("copy", "spill")
 
 
@@ -33,7 +34,7 @@ def _create(hip, priority):
 
 
 def get(name, device):
-    """-> the process-wide stream ``name`` ("ingest0".."ingest2", "scan": high priority; "copy", "spill": low) of ``device``."""
+    """-> the process-wide stream ``name`` ("tokens", "ingest0", "ingest1", "scan": high priority; "copy", "spill": low) of ``device``."""
     dev = torch.device(device)
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     with _LOCK:
