@@ -75,13 +75,15 @@ size_t svx_cigar_scan_ws_bytes(uint32_t n_aln);
  *   d_ref_start [n_aln] 0-based reference start of each alignment
  *   min_sv      options.min_sv_size
  *   d_gaps      [gaps_cap] out: long gaps sorted by (aln, op)
- *   d_gap_off   [n_aln + 1] out: CSR offsets into d_gaps per alignment
+ *   d_gap_off   [n_aln + 1] out, 16-byte aligned: CSR offsets into d_gaps per alignment
  *               (d_gap_off[n_aln] = total number of long gaps, even when it
  *               exceeds gaps_cap; gaps beyond gaps_cap are not written)
  *   d_stats     [n_aln][4] out, may be NULL: ref_span (M,D,N,=,X),
  *               lead_clip (leading S/H), trail_clip (trailing S/H),
  *               query_len (M,I,S,H,=,X)
  *   d_ws        scratch of svx_cigar_scan_ws_bytes(n_aln) bytes, 8-byte aligned, contents ignored
+ *   n_aln       < 2^30
+ * Three launches (count -> offsets, its prefix over the tiles by a decoupled look-back -> emit), no atomics on results.
  * H is treated as S (the reference rewrites H to S, collect_signatures.py:91);
  * N advances the read position only (analyze_reads.py:831-832). */
 int svx_cigar_scan(const uint32_t* d_cigar, const uint64_t* d_cig_off,

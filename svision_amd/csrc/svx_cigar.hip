@@ -7,20 +7,17 @@
 //
 // HBM-read bound: 4 B per CIGAR op, 16 B per alignment of CSR/start data,
 // 24 B written per long gap (rare).  No atomics on results, output deterministic and
-// sorted by (alignment, op) without a sort:
-//   1. count_kernel  : eight lanes per alignment (eight alignments in flight per wave)
-//                      stream the CIGAR once in 16-byte quads and reduce the per-alignment
-//                      spans, clip runs and the number of long gaps; every workgroup also
-//                      stores its gap and owner totals.  An alignment of more than 512 words
-//                      (ONT) is only started here and put on a list;
-//   1b. count_long_kernel + retotal_kernel: one wave per listed alignment streams the rest of it
-//                      with eight 16-byte loads in flight per lane and adds its (integer) sums;
-//                      the totals of the count workgroups concerned are recomputed from the counts;
-//   2. scan_kernel   : exclusive prefix of the totals per tile of 256 alignments (one workgroup);
-//   3. offsets_kernel: a workgroup per tile scans its counts into the CSR offsets d_gap_off
-//                      and writes the alignments that own a gap (a few % of HiFi reads, most
+// sorted by (alignment, op) without a sort.  Round 4: THREE kernels (six until then -- count, count_long, retotal, scan,
+// offsets, emit: at HiFi sizes a third of a scan's time was the launches' own latency):
+//   1. count_kernel  : eight lanes per alignment (eight alignments in flight per wave) stream the CIGAR once in
+//                      16-byte quads and reduce the per-alignment spans, clip runs and the number of long gaps.  An
+//                      alignment of more than 512 words (ONT) is only started by its eight lanes; its wave finishes it at
+//                      the end of the kernel with eight 16-byte loads in flight per lane;
+//   2. offsets_kernel: a workgroup per tile of 1024 alignments turns the counts into the CSR offsets d_gap_off -- the
+//                      prefix over the tiles by a decoupled look-back in the same launch (one packed 64-bit descriptor per
+//                      tile, 64 of them per step) -- and writes the alignments that own a gap (a few % of HiFi reads, most
 //                      ONT reads) into a work list, in alignment order;
-//   4. emit_kernel   : resident waves walk the work list, one wave per alignment, 256
+//   3. emit_kernel   : resident waves walk the work list, one wave per alignment, 256
 //                      CIGAR words per step requested two steps ahead: wave prefix sums of
 //                      read/ref advance give readPos/refPos at every op, ballot-ranked stores
 //                      keep op order.
@@ -48,8 +45,6 @@ __device__ inline unsigned wave_sum_u(unsigned v)
     return v;
 }
 
-constexpr int TILE_SHIFT = 8;
-constexpr int TILE = 1 << TILE_SHIFT;               // alignments per workgroup of the count / offsets passes
 #ifndef SVX_CGROUP
 #define SVX_CGROUP 8
 #define SVX_CQUADS 2
@@ -57,7 +52,6 @@ constexpr int TILE = 1 << TILE_SHIFT;               // alignments per workgroup 
 constexpr int CGROUP = SVX_CGROUP;                  // lanes per alignment in the count pass
 constexpr int CQUADS = SVX_CQUADS;                  // 16-byte loads in flight per lane
 constexpr int ALN_PER_CBLOCK = BLOCK / CGROUP;      // alignments per workgroup of the count pass
-constexpr int CBLOCKS_PER_TILE = TILE / ALN_PER_CBLOCK;
 constexpr int LONG_Q = 128;                         // quads (512 words) of an alignment the eight-lane count pass handles itself
 
 __device__ inline unsigned cgroup_sum(unsigned v)
@@ -86,38 +80,36 @@ __device__ inline void tally(uint32_t w, int32_t min_sv, unsigned& ref_span, uns
 // over the first / last eight words (longer runs loop).  All loads of an alignment are requested up front.
 // The gap count of an alignment goes to gap_off[a] (turned into an offset by the offsets pass); the tile's
 // workgroup's totals (gaps, alignments owning one) are plain stores: no atomics anywhere.
+// descriptor of a count workgroup for the look-back: [flag:2 | owners:30 | gaps:32]
+constexpr unsigned long long D_AGG = 1ull << 62, D_INC = 2ull << 62, D_FLAG = 3ull << 62;
+__device__ inline unsigned long long d_pack(uint32_t gaps, uint32_t owners) { return (unsigned long long)(owners & 0x3fffffffu) << 32 | gaps; }
+constexpr int LQUADS = 8;                            // 16-byte loads in flight per lane while a wave finishes a long alignment
+
 __global__ __launch_bounds__(BLOCK)
 void count_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict__ cig_off,
                   uint32_t n_aln, int32_t min_sv, uint32_t* __restrict__ gap_off, int32_t* __restrict__ stats,
-                  uint2* __restrict__ block_tot, uint32_t* __restrict__ long_list, uint32_t* __restrict__ long_count)
+                  unsigned long long* __restrict__ desc, uint32_t n_tiles)
 {
-    __shared__ uint32_t s_tot[3];                        // gaps, owners, waves done
-    if (threadIdx.x < 3) s_tot[threadIdx.x] = 0u;
-    __syncthreads();                                     // the only barrier: before the waves drift apart
+    // (the look-back descriptors of the offsets pass behind this kernel start out empty: zeroed here instead of by a memset
+    // launch of its own -- 5 us of a 70 us scan; there are more count workgroups than tiles)
+    if (threadIdx.x == 0 && blockIdx.x < n_tiles) desc[blockIdx.x] = 0ull;
     const int sub = threadIdx.x & (CGROUP - 1);
-    const int gshift = (threadIdx.x & (WAVE - 1)) & ~(CGROUP - 1);
+    const int wl = threadIdx.x & (WAVE - 1);
+    const int gshift = wl & ~(CGROUP - 1);
     const uint32_t a = blockIdx.x * ALN_PER_CBLOCK + (threadIdx.x / CGROUP);
     const bool live = a < n_aln;
     const uint64_t full = cig_off[n_aln] >> 2;           // quads that lie entirely inside the array
     const uint64_t b = live ? cig_off[a] : 0, e = live ? cig_off[a + 1] : 0;
     const long long n = (long long)(e - b);
     const uint64_t q0 = b >> 2, q_end = min((e + 3) >> 2, full);
-    // an alignment of more than LONG_Q quads (ONT: 10^3-10^5 ops) leaves everything behind its first LONG_Q quads to
-    // count_long_kernel (a wave of its own, deep load pipeline): for its eight lanes here it would be a chain of
-    // hundreds of memory round trips that the whole launch waits for.  All sums are modular and additive, so the
-    // corrections below (computed from q_end) and the partial sums of the two kernels simply add up.
+    // an alignment of more than LONG_Q quads (ONT: 10^3-10^5 ops) is only STARTED by its eight lanes -- for them it would be
+    // a chain of hundreds of memory round trips that the whole launch waits for -- and finished by the whole wave at the END
+    // of this kernel, when everything else is stored and few registers are live (in the middle of it the deep load
+    // pipeline's registers cost every HiFi launch a third of its occupancy: 163 instead of 74; until round 4 a list + a
+    // kernel of its own).  All sums are modular and additive: the corrections (computed from q_end) and the two partial
+    // sums simply add up.
     const bool is_long = q_end - q0 > (uint64_t)LONG_Q;
     const uint64_t q1 = is_long ? q0 + LONG_Q : q_end;
-    {                                                    // one atomic per wave: the (up to eight) group leaders share a reservation
-        const unsigned long long m = __ballot(is_long && sub == 0);
-        if (m) {
-            const int wl = threadIdx.x & (WAVE - 1), first = __ffsll((long long)m) - 1;
-            uint32_t base = 0;
-            if (wl == first) base = atomicAdd(long_count, (uint32_t)__popcll(m));
-            base = __shfl(base, first, WAVE);
-            if (is_long && sub == 0) long_list[base + (uint32_t)__popcll(m & ((1ull << wl) - 1ull))] = a;
-        }
-    }
     // the words at either end for the clip runs, the neighbours' words inside the first / last quad (lanes 0-2
     // look before b and from e on), the alignment's words beyond the last whole quad of the array (at most 3,
     // last alignments only), then the quads
@@ -149,15 +141,10 @@ void count_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict
         ref_span -= fr; qlen -= fq; ngap -= fn;
     }
     ngap = cgroup_sum(ngap);
-    if (live && sub == 0) gap_off[a] = ngap;
-    // workgroup totals without a closing barrier and off the waves' critical path: the (few) owners add to LDS,
-    // fire and forget; the last wave to arrive stores the totals (LDS operations of a wave stay in order)
-    if (sub == 0 && ngap != 0u) { atomicAdd(&s_tot[0], ngap); atomicAdd(&s_tot[1], 1u); }
-    if ((threadIdx.x & (WAVE - 1)) == 0 && atomicAdd(&s_tot[2], 1u) == BLOCK / WAVE - 1)
-        block_tot[blockIdx.x] = make_uint2(atomicAdd(&s_tot[0], 0u), atomicAdd(&s_tot[1], 0u));
+    ref_span = cgroup_sum(ref_span);
+    qlen = cgroup_sum(qlen);
+    if (live && sub == 0) gap_off[a] = ngap;             // (turned into an offset by the offsets pass)
     if (stats) {
-        ref_span = cgroup_sum(ref_span);
-        qlen = cgroup_sum(qlen);
         unsigned lead = 0, trail = 0;
         long long n_lead = 0;                                  // words in the leading clip run
         {
@@ -194,141 +181,116 @@ void count_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict
             reinterpret_cast<int4*>(stats)[a] = s4;
         }
     }
-}
-
-// Long alignments (listed by count_kernel, any order): one wave each, everything behind the first LONG_Q quads,
-// LQUADS 16-byte loads in flight per lane (2048 words per step).  Adds its sums to what count_kernel stored
-// (retotal_kernel then refreshes the totals of the count workgroups concerned).
-constexpr int LQUADS = 8;
-
-__global__ __launch_bounds__(BLOCK)
-void count_long_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict__ cig_off, uint32_t n_aln, int32_t min_sv,
-                       uint32_t* __restrict__ gap_off, int32_t* __restrict__ stats,
-                       const uint32_t* __restrict__ long_list, const uint32_t* __restrict__ long_count)
-{
-    const int lane = threadIdx.x & (WAVE - 1);
-    const uint32_t n_long = *long_count, n_waves = gridDim.x * (BLOCK / WAVE);
-    const uint64_t full = cig_off[n_aln] >> 2;
-    const uint4* __restrict__ quads = reinterpret_cast<const uint4*>(cigar);
-    for (uint32_t k = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6); k < n_long; k += n_waves) {
-        const uint32_t a = long_list[k];
-        const uint64_t b = cig_off[a], e = cig_off[a + 1];
-        const uint64_t q0 = (b >> 2) + LONG_Q, q1 = min((e + 3) >> 2, full);
-        unsigned ref_span = 0, qlen = 0, ngap = 0;
-        for (uint64_t q = q0 + lane; q < q1; q += (uint64_t)LQUADS * WAVE) {
+    // ---- the long alignments of this wave, one after the other: everything behind their first LONG_Q quads, 64 lanes with
+    // LQUADS 16-byte loads in flight each (2048 words per step); the sums are added to what the leaders have just stored
+    unsigned long long lm = __ballot(is_long && sub == 0);
+    while (lm) {
+        const int src = __ffsll((long long)lm) - 1;
+        lm &= lm - 1;
+        const uint64_t qa = __shfl(q0, src, WAVE) + LONG_Q, qb = __shfl(q_end, src, WAVE);
+        const uint32_t al = __shfl(a, src, WAVE);
+        unsigned r2 = 0, l2 = 0, g2 = 0;
+#pragma clang loop unroll(disable)
+        for (uint64_t q = qa + wl; q < qb; q += (uint64_t)LQUADS * WAVE) {
             uint4 w[LQUADS];
 #pragma unroll
-            for (int u = 0; u < LQUADS; ++u) w[u] = quads[min(q + (uint64_t)u * WAVE, q1 - 1)];
+            for (int u = 0; u < LQUADS; ++u) w[u] = quads[min(q + (uint64_t)u * WAVE, qb - 1)];
 #pragma unroll
             for (int u = 0; u < LQUADS; ++u) {
-                const bool in = q + (uint64_t)u * WAVE < q1;
-                tally(in ? w[u].x : 0u, min_sv, ref_span, qlen, ngap); tally(in ? w[u].y : 0u, min_sv, ref_span, qlen, ngap);
-                tally(in ? w[u].z : 0u, min_sv, ref_span, qlen, ngap); tally(in ? w[u].w : 0u, min_sv, ref_span, qlen, ngap);
+                const bool in = q + (uint64_t)u * WAVE < qb;
+                tally(in ? w[u].x : 0u, min_sv, r2, l2, g2); tally(in ? w[u].y : 0u, min_sv, r2, l2, g2);
+                tally(in ? w[u].z : 0u, min_sv, r2, l2, g2); tally(in ? w[u].w : 0u, min_sv, r2, l2, g2);
+                __builtin_amdgcn_sched_barrier(0);           // quad after quad: left alone the scheduler spreads the 32 tallies over 160 registers
             }
         }
-        ref_span = wave_sum_u(ref_span); qlen = wave_sum_u(qlen); ngap = wave_sum_u(ngap);
-        if (lane == 0) {
-            if (stats) { stats[4 * (size_t)a] += (int)ref_span; stats[4 * (size_t)a + 3] += (int)qlen; }
-            if (ngap) gap_off[a] += ngap;
+        r2 = wave_sum_u(r2); l2 = wave_sum_u(l2); g2 = wave_sum_u(g2);
+        if (wl == 0) {                                   // (atomics: performed in the L2, behind this wave's own stores to the same words)
+            if (stats) { atomicAdd(reinterpret_cast<unsigned*>(stats) + 4 * (size_t)al, r2); atomicAdd(reinterpret_cast<unsigned*>(stats) + 4 * (size_t)al + 3, l2); }
+            if (g2) atomicAdd(&gap_off[al], g2);
         }
     }
 }
 
-// Totals of the count workgroups that hold a long alignment, recomputed from the final per-alignment counts (the
-// count pass stored them before count_long_kernel added its share): one wave per listed alignment rewrites the totals
-// of that alignment's group of ALN_PER_CBLOCK alignments -- idempotent, so several long alignments of one group are harmless.
+// Offsets pass with a decoupled look-back, one workgroup per tile of 1024 alignments (four per thread): the tile's counts ->
+// its totals (gaps, owners), published as one packed 64-bit descriptor; the workgroup's first wave looks back over the
+// tiles in front of it (64 descriptors per step) for the exclusive prefix; a workgroup scan on top of it turns the counts
+// into the CSR offsets d_gap_off, and the (few) alignments that own a long gap go to the work list (alignment, first slot),
+// in alignment order.  (Until round 4 a one-workgroup scan kernel over per-workgroup totals sat between the count pass and
+// this one -- plus two launches for the long alignments: six dependent launches per scan.  The look-back inside the COUNT
+// pass -- one launch less still -- was measured and is slower: 62 k count workgroups each end in a wave that waits.)
+constexpr int OTILE = 4 * BLOCK;
+
 __global__ __launch_bounds__(BLOCK)
-void retotal_kernel(const uint32_t* __restrict__ gap_off, uint32_t n_aln, uint2* __restrict__ block_tot,
-                    const uint32_t* __restrict__ long_list, const uint32_t* __restrict__ long_count)
+void offsets_kernel(uint32_t n_aln, uint32_t* __restrict__ gap_off, unsigned long long* __restrict__ desc, uint2* __restrict__ totals,
+                    uint2* __restrict__ work)
 {
-    static_assert(ALN_PER_CBLOCK <= WAVE, "one lane per alignment of a count workgroup");
-    const int lane = threadIdx.x & (WAVE - 1);
-    const uint32_t n_long = *long_count, n_waves = gridDim.x * (BLOCK / WAVE);
-    for (uint32_t k = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6); k < n_long; k += n_waves) {
-        const uint32_t blk = long_list[k] / ALN_PER_CBLOCK, a = blk * ALN_PER_CBLOCK + lane;
-        const uint32_t c = (lane < ALN_PER_CBLOCK && a < n_aln) ? gap_off[a] : 0u;
-        const unsigned gaps = wave_sum_u(c), owners = (unsigned)__popcll(__ballot(c != 0u));
-        if (lane == 0) block_tot[blk] = make_uint2(gaps, owners);
-    }
-}
-
-// Exclusive prefix over the tiles of 256 alignments (a tile = CBLOCKS_PER_TILE consecutive count workgroups);
-// tile_pre[n_tiles] receives the grand totals.  One workgroup of 1024 threads; per step the totals of 1024 tiles
-// are read with coalesced loads (all requested at once), folded per tile with lane shuffles and scanned.
-constexpr int SBLOCK = 1024;
-
-__global__ __launch_bounds__(SBLOCK)
-void scan_kernel(const uint2* __restrict__ block_tot, uint32_t n_blocks, uint2* __restrict__ tile_pre, uint32_t n_tiles)
-{
-    __shared__ uint2 s_tile[SBLOCK];
-    __shared__ uint2 s_wave[SBLOCK / WAVE];
-    const int t = threadIdx.x, lane = t & (WAVE - 1), wv = t >> 6;
-    uint2 carry = make_uint2(0u, 0u);                      // kept by every thread
-    for (uint32_t base = 0; base < n_tiles; base += SBLOCK) {
-        uint2 x[CBLOCKS_PER_TILE];
-#pragma unroll
-        for (int r = 0; r < CBLOCKS_PER_TILE; ++r) {
-            const uint32_t blk = base * CBLOCKS_PER_TILE + r * SBLOCK + t;
-            x[r] = block_tot[min(blk, n_blocks - 1)];
-            if (blk >= n_blocks) x[r] = make_uint2(0u, 0u);
-        }
-#pragma unroll
-        for (int r = 0; r < CBLOCKS_PER_TILE; ++r) {
-#pragma unroll
-            for (int o = 1; o < CBLOCKS_PER_TILE; o <<= 1) { x[r].x += __shfl_xor(x[r].x, o, WAVE); x[r].y += __shfl_xor(x[r].y, o, WAVE); }
-            if ((t & (CBLOCKS_PER_TILE - 1)) == 0) s_tile[(r * SBLOCK + t) / CBLOCKS_PER_TILE] = x[r];
-        }
-        __syncthreads();
-        const uint2 v = s_tile[t];
-        uint2 inc = v;
-#pragma unroll
-        for (int o = 1; o < WAVE; o <<= 1) {
-            const uint32_t ux = __shfl_up(inc.x, o, WAVE), uy = __shfl_up(inc.y, o, WAVE);
-            if (lane >= o) { inc.x += ux; inc.y += uy; }
-        }
-        if (lane == WAVE - 1) s_wave[wv] = inc;
-        __syncthreads();
-        uint2 pre = carry, all = carry;
-#pragma unroll
-        for (int w = 0; w < SBLOCK / WAVE; ++w) {
-            const uint2 y = s_wave[w];
-            if (w < wv) { pre.x += y.x; pre.y += y.y; }
-            all.x += y.x; all.y += y.y;
-        }
-        if (base + t < n_tiles) tile_pre[base + t] = make_uint2(pre.x + inc.x - v.x, pre.y + inc.y - v.y);
-        carry = all;
-        __syncthreads();
-    }
-    if (t == 0) tile_pre[n_tiles] = carry;
-}
-
-// Offsets pass, one workgroup per tile of 256 alignments: a workgroup scan on top of the tile's prefix turns
-// the 256 counts into CSR offsets; the (few) alignments that own a long gap go to the work list (alignment,
-// first slot) at the position given by the prefix of the owner counts, i.e. in alignment order.
-__global__ __launch_bounds__(BLOCK)
-void offsets_kernel(uint32_t n_aln, uint32_t* __restrict__ gap_off, const uint2* __restrict__ tile_pre, uint2* __restrict__ work)
-{
-    __shared__ uint32_t s_wave[2 * BLOCK / WAVE];
     constexpr int NW = BLOCK / WAVE;
-    const int t = threadIdx.x, lane = t & (WAVE - 1), wv = t >> 6;
-    const uint32_t tile = blockIdx.x;
-    const uint32_t a = (tile << TILE_SHIFT) + t;
-    const uint32_t c = a < n_aln ? gap_off[a] : 0u;
-    const uint2 before = tile_pre[tile];
-    uint32_t inc = c;
+    __shared__ uint32_t s_wave[2 * NW];
+    __shared__ uint32_t s_ex[2];
+    const int t = threadIdx.x, wl = t & (WAVE - 1), wv = t >> 6;
+    const uint32_t v = blockIdx.x;
+    const uint32_t a0 = v * OTILE + 4u * (uint32_t)t;
+    uint32_t c[4];
+    if (a0 + 3 < n_aln) { const uint4 q = *reinterpret_cast<const uint4*>(gap_off + a0); c[0] = q.x; c[1] = q.y; c[2] = q.z; c[3] = q.w; }
+    else {
 #pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) { const uint32_t u = __shfl_up(inc, o, WAVE); if (lane >= o) inc += u; }
-    const unsigned long long owners = __ballot(c != 0u);
-    if (lane == WAVE - 1) { s_wave[wv] = inc; s_wave[NW + wv] = (uint32_t)__popcll(owners); }
+        for (int u = 0; u < 4; ++u) c[u] = a0 + u < n_aln ? gap_off[a0 + u] : 0u;
+    }
+    const uint32_t mine_g = c[0] + c[1] + c[2] + c[3];
+    const uint32_t mine_o = (uint32_t)(c[0] != 0u) + (uint32_t)(c[1] != 0u) + (uint32_t)(c[2] != 0u) + (uint32_t)(c[3] != 0u);
+    uint32_t inc_g = mine_g, inc_o = mine_o;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const uint32_t ug = __shfl_up(inc_g, o, WAVE), uo = __shfl_up(inc_o, o, WAVE);
+        if (wl >= o) { inc_g += ug; inc_o += uo; }
+    }
+    if (wl == WAVE - 1) { s_wave[wv] = inc_g; s_wave[NW + wv] = inc_o; }
     __syncthreads();
-    uint32_t off = before.x + inc - c, rank = before.y + (uint32_t)__popcll(owners & ((1ull << lane) - 1ull));
+    uint32_t pre_g = 0, pre_o = 0, tot_g = 0, tot_o = 0;
 #pragma unroll
-    for (int w = 0; w < NW; ++w)
-        if (w < wv) { off += s_wave[w]; rank += s_wave[NW + w]; }
-    if (a < n_aln) {
-        gap_off[a] = off;
-        if (a == n_aln - 1) gap_off[n_aln] = off + c;
-        if (c) work[rank] = make_uint2(a, off);
+    for (int w = 0; w < NW; ++w) {
+        if (w < wv) { pre_g += s_wave[w]; pre_o += s_wave[NW + w]; }
+        tot_g += s_wave[w]; tot_o += s_wave[NW + w];
+    }
+    if (wv == 0) {
+        uint32_t ex_g = 0, ex_o = 0;                     // totals of the tiles in front
+        if (v > 0) {
+            if (wl == 0) __hip_atomic_store(&desc[v], D_AGG | d_pack(tot_g, tot_o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // Workgroups are dispatched in the order of their index (every XCD takes its share in order), so the ones in
+            // front have at least started and none of them waits for this one: the spin ends.  (Bounded all the same: a
+            // descriptor that never arrives would otherwise hang the device.)
+            long long j = (long long)v - 1;
+            for (;;) {
+                const long long i = j - wl;
+                unsigned long long d = D_INC;            // in front of the first tile: an inclusive prefix of nothing
+                if (i >= 0) {
+                    int spins = 0;
+                    do { d = __hip_atomic_load(&desc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((d & D_FLAG) == 0 && ++spins < (1 << 20));
+                }
+                const unsigned long long incl = __ballot((d & D_FLAG) == D_INC);
+                const int stop = incl ? __ffsll((long long)incl) - 1 : WAVE - 1;      // the nearest tile whose inclusive prefix is known
+                const uint32_t g = wl <= stop ? (uint32_t)d : 0u, o = wl <= stop ? (uint32_t)(d >> 32) & 0x3fffffffu : 0u;
+                ex_g += wave_sum_u(g); ex_o += wave_sum_u(o);
+                if (incl) break;
+                j -= WAVE;
+            }
+        }
+        if (wl == 0) {
+            __hip_atomic_store(&desc[v], D_INC | d_pack(ex_g + tot_g, ex_o + tot_o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_ex[0] = ex_g; s_ex[1] = ex_o;
+        }
+    }
+    __syncthreads();
+    uint32_t off = s_ex[0] + pre_g + inc_g - mine_g, rank = s_ex[1] + pre_o + inc_o - mine_o;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t a = a0 + u;
+        if (a < n_aln) {
+            gap_off[a] = off;
+            if (c[u]) work[rank++] = make_uint2(a, off);
+            off += c[u];
+            if (a == n_aln - 1) { gap_off[n_aln] = off; *totals = make_uint2(off, rank); }
+        }
     }
 }
 
@@ -422,17 +384,15 @@ void emit_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict_
     }
 }
 
-// workspace: [block_tot: uint2 {gaps, owners} per count workgroup][tile_pre: uint2 per 256 alignments, + 1 for the
-// totals] | [work: uint2 per alignment]
-inline size_t ws_tile_offset(uint32_t n_aln)
+// workspace: [desc: one 64-bit descriptor per tile of the offsets pass (zeroed by the count pass)][totals: uint2] | [work: uint2 per alignment]
+inline size_t ws_totals_offset(uint32_t n_aln)
 {
-    const size_t blocks = ((size_t)n_aln + ALN_PER_CBLOCK - 1) / ALN_PER_CBLOCK;
-    return (blocks * sizeof(uint2) + 255) & ~(size_t)255;
+    const size_t tiles = ((size_t)n_aln + OTILE - 1) / OTILE;
+    return tiles * sizeof(unsigned long long);
 }
 inline size_t ws_work_offset(uint32_t n_aln)
 {
-    const size_t tiles = (((size_t)n_aln + TILE - 1) >> TILE_SHIFT) + 1;
-    return ws_tile_offset(n_aln) + ((tiles * sizeof(uint2) + 255) & ~(size_t)255);
+    return (ws_totals_offset(n_aln) + sizeof(uint2) + 255) & ~(size_t)255;
 }
 
 }  // namespace
@@ -454,26 +414,18 @@ extern "C" int svx_cigar_scan(const uint32_t* d_cigar, const uint64_t* d_cig_off
     }
     if (!d_cigar || !d_cig_off || !d_ref_start || !d_ws || (!d_gaps && gaps_cap)) return SVX_EINVAL;
     if (d_stats && (reinterpret_cast<uintptr_t>(d_stats) & 15u)) return SVX_EINVAL;
-    if ((reinterpret_cast<uintptr_t>(d_ws) & 7u) || (reinterpret_cast<uintptr_t>(d_cigar) & 15u)) return SVX_EINVAL;
-    const uint32_t tiles = (n_aln + TILE - 1) >> TILE_SHIFT, count_blocks = (n_aln + ALN_PER_CBLOCK - 1) / ALN_PER_CBLOCK;
-    uint2* block_tot = static_cast<uint2*>(d_ws);
-    uint2* tile_pre = reinterpret_cast<uint2*>(static_cast<char*>(d_ws) + ws_tile_offset(n_aln));
+    if ((reinterpret_cast<uintptr_t>(d_ws) & 7u) || (reinterpret_cast<uintptr_t>(d_cigar) & 15u) || (reinterpret_cast<uintptr_t>(d_gap_off) & 15u)) return SVX_EINVAL;
+    if (n_aln >= (1u << 30)) return SVX_EINVAL;            // (the look-back descriptors keep the owner count in 30 bits)
+    const uint32_t count_blocks = (n_aln + ALN_PER_CBLOCK - 1) / ALN_PER_CBLOCK;
+    unsigned long long* desc = static_cast<unsigned long long*>(d_ws);
+    uint2* totals = reinterpret_cast<uint2*>(static_cast<char*>(d_ws) + ws_totals_offset(n_aln));
     uint2* work = reinterpret_cast<uint2*>(static_cast<char*>(d_ws) + ws_work_offset(n_aln));
-    // list of the long alignments: built by the count pass in the (not yet used) work area, its counter in the area's last word
-    uint32_t* long_list = reinterpret_cast<uint32_t*>(work);
-    uint32_t* long_count = reinterpret_cast<uint32_t*>(work + n_aln) - 1;
-    if (hipMemsetAsync(long_count, 0, sizeof(uint32_t), st) != hipSuccess) return SVX_ELAUNCH;
-    hipLaunchKernelGGL(count_kernel, dim3(count_blocks), dim3(BLOCK), 0, st, d_cigar, d_cig_off, n_aln, min_sv, d_gap_off, d_stats, block_tot,
-                       long_list, long_count);
-    const uint32_t long_blocks = min(2048u, (n_aln + 3u) / 4u);
-    hipLaunchKernelGGL(count_long_kernel, dim3(long_blocks), dim3(BLOCK), 0, st, d_cigar, d_cig_off, n_aln, min_sv,
-                       d_gap_off, d_stats, long_list, long_count);
-    hipLaunchKernelGGL(retotal_kernel, dim3(long_blocks), dim3(BLOCK), 0, st, d_gap_off, n_aln, block_tot, long_list, long_count);
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(SBLOCK), 0, st, block_tot, count_blocks, tile_pre, tiles);
-    hipLaunchKernelGGL(offsets_kernel, dim3(tiles), dim3(BLOCK), 0, st, n_aln, d_gap_off, tile_pre, work);
+    const uint32_t n_tiles = (n_aln + OTILE - 1) / OTILE;
+    hipLaunchKernelGGL(count_kernel, dim3(count_blocks), dim3(BLOCK), 0, st, d_cigar, d_cig_off, n_aln, min_sv, d_gap_off, d_stats, desc, n_tiles);
+    hipLaunchKernelGGL(offsets_kernel, dim3(n_tiles), dim3(BLOCK), 0, st, n_aln, d_gap_off, desc, totals, work);
     // resident waves (8 workgroups per CU at most); small inputs get one wave per 4 alignments
     const uint32_t emit_blocks = min(2048u, (n_aln + 15u) / 16u);
     hipLaunchKernelGGL(emit_kernel, dim3(emit_blocks), dim3(BLOCK), 0, st, d_cigar, d_cig_off, d_ref_start, min_sv, d_gaps, gaps_cap,
-                       tile_pre + tiles, work);
+                       totals, work);
     return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
 }

@@ -11,7 +11,7 @@ from tests import datagen
 dev = torch.device("cuda:0")
 reps = int(os.environ.get("REPS", "20"))
 out = {}
-SIZES = ((2_000_000, 150), (100_000, 150), (50_000, 6000), (35_000, -5000))      # negative: log-normal op counts (sigma 0.7) around the median
+SIZES = ((2_000_000, 150), (100_000, 150), (50_000, 6000), (35_000, -5000), (416_000, 145))      # negative: log-normal op counts (sigma 0.7) around the median
 if os.environ.get("ONLY"):
     SIZES = (SIZES[int(os.environ["ONLY"])],)
 for na, mean_ops in SIZES:
