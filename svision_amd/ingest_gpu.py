@@ -209,8 +209,12 @@ class DeviceDecoder:
             cur_bytes += size_of(t)
         if cur:
             groups.append(cur)
-        if groups and len(groups[-1]) > 1 and sum(size_of(t) for t in groups[-1]) > FIRST_GROUP_BYTES + size_of(groups[-1][-1]):
-            groups[-1:] = [groups[-1][:-1], groups[-1][-1:]]
+        # A small remainder joins the group in front of it: launched on its own it is the last launch of the job, its LZ copies
+        # -- latency-bound -- run next to a CNN that has its full backlog by then (3-4 x slower than alone: 100 ms for 7 k blocks)
+        # and everything waits for that one chromosome.  (The lane-per-block era cut the last chromosome OFF instead: a launch
+        # cost 60-90 ms whatever it held.)
+        if len(groups) > 2 and os.environ.get("SVX_MERGE_LAST", "1") != "0" and sum(size_of(t) for t in groups[-1]) * 2 <= large:
+            groups[-2:] = [groups[-2] + groups[-1]]
         self._mark("groups cut: %s" % [len(g) for g in groups])
         q = queue.Queue(maxsize=1)
         stop = threading.Event()
