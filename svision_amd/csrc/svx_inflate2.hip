@@ -513,17 +513,17 @@ extern "C" int svx_bgzf_inflate_fast_on(const uint8_t* d_comp, const uint64_t* d
         if (sa != sb) {                                                      // A reads what the caller's stream (stream_lz) has prepared: the tables, d_status
             hipEvent_t ready;
             if (hipEventCreateWithFlags(&ready, hipEventDisableTiming) != hipSuccess) return SVX_ELAUNCH;
-            hipEventRecord(ready, sb);
-            hipStreamWaitEvent(sa, ready, 0);
-            hipEventDestroy(ready);
+            (void)hipEventRecord(ready, sb);
+            (void)hipStreamWaitEvent(sa, ready, 0);
+            (void)hipEventDestroy(ready);
         }
         hipLaunchKernelGGL(bgzf_tokens_kernel, dim3(n_blocks), dim3(LANES), 0, sa, d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, streams, stream_len, d_status);
         if (sa != sb) {
             hipEvent_t done;
             if (hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) return SVX_ELAUNCH;
-            hipEventRecord(done, sa);
-            hipStreamWaitEvent(sb, done, 0);
-            hipEventDestroy(done);
+            (void)hipEventRecord(done, sa);
+            (void)hipStreamWaitEvent(sb, done, 0);
+            (void)hipEventDestroy(done);
         }
     }
     if (only && only[0] == 'A') return SVX_OK;

@@ -112,6 +112,30 @@ def spill_cigar(table):
             pass
 
 
+def cut_groups(tids, size_of, first_limits, limit, merge_last=True):
+    """Chromosomes in file order -> the groups whose blocks are inflated in one launch: the first groups of at most
+    ``first_limits`` compressed bytes (the very first is small: the pipeline behind starts after one short launch), the others of at
+    most ``limit``; a chromosome larger than its limit is a group of its own.  The two-kernel inflate is proportional to the launch
+    and the read-backs of the groups no longer block each other, so a steady flow of small groups keeps the CNN behind supplied
+    (the lane-per-block era made them as large as the chip: a launch cost 60-90 ms whatever it held).  ``merge_last``: a remainder
+    of at most half a group joins the group in front of it -- launched on its own it is the last launch of the job, its LZ copies
+    (latency-bound) run next to a CNN that has its full backlog by then (3-4 x slower than alone: 100 ms for 7 k blocks), and
+    everything waits for that one chromosome."""
+    groups, cur, cur_bytes = [], [], 0
+    for t in tids:
+        lim = first_limits[len(groups)] if len(groups) < len(first_limits) else limit
+        if cur and cur_bytes + size_of(t) > lim:
+            groups.append(cur)
+            cur, cur_bytes = [], 0
+        cur.append(t)
+        cur_bytes += size_of(t)
+    if cur:
+        groups.append(cur)
+    if merge_last and len(groups) > 2 and sum(size_of(t) for t in groups[-1]) * 2 <= limit:
+        groups[-2:] = [groups[-2] + groups[-1]]
+    return groups
+
+
 class DeviceDecoder:
     def __init__(self, path, index, references, lengths, header_text, device, threads=8, alloc_for=None):
         import time
@@ -187,34 +211,15 @@ class DeviceDecoder:
         import time
         lib, dev = self.lib, self.device
         have = sorted((self.spans[t][0], t) for t in tids if t < len(self.spans) and self.spans[t] is not None)
-        # Group sizes: small, medium, then large.  A launch of the lane-per-block kernel takes 60-90 ms whether it holds 28 k
-        # or 98 k blocks (the blocks a chip holds at once), so once the pipeline behind has chromosomes to work on the launches
-        # are made as large as the chip; the first chromosomes and the last one travel in small groups (the wave-per-block
-        # kernel: ~3.5 ms per 1,000 blocks), the first to start the pipeline early, the last because everything waits for it.
         def size_of(t):
             return (self.spans[t][1] >> 16) - (self.spans[t][0] >> 16) + 65536
         def mb(name, default):                                 # (experiments: SVX_FIRST_GROUP_MB / SVX_PIPE_GROUP_MB / SVX_LARGE_GROUP_MB)
             v = os.environ.get(name)
             return int(v) << 20 if v else default
-        limits = [mb("SVX_FIRST_GROUP_MB", FIRST_GROUP_BYTES), mb("SVX_PIPE_GROUP_MB", PIPE_GROUP_BYTES)]
         large = mb("SVX_LARGE_GROUP_MB", LARGE_GROUP_BYTES)
         large = min(large, int(LARGE_GROUP_BLOCKS * self._block_bytes(have[0][1]))) if have else large
-        groups, cur, cur_bytes = [], [], 0
-        for _v, t in have:
-            limit = limits[len(groups)] if len(groups) < len(limits) else large
-            if cur and cur_bytes + size_of(t) > limit:
-                groups.append(cur)
-                cur, cur_bytes = [], 0
-            cur.append(t)
-            cur_bytes += size_of(t)
-        if cur:
-            groups.append(cur)
-        # A small remainder joins the group in front of it: launched on its own it is the last launch of the job, its LZ copies
-        # -- latency-bound -- run next to a CNN that has its full backlog by then (3-4 x slower than alone: 100 ms for 7 k blocks)
-        # and everything waits for that one chromosome.  (The lane-per-block era cut the last chromosome OFF instead: a launch
-        # cost 60-90 ms whatever it held.)
-        if len(groups) > 2 and os.environ.get("SVX_MERGE_LAST", "1") != "0" and sum(size_of(t) for t in groups[-1]) * 2 <= large:
-            groups[-2:] = [groups[-2] + groups[-1]]
+        groups = cut_groups([t for _v, t in have], size_of, [mb("SVX_FIRST_GROUP_MB", FIRST_GROUP_BYTES), mb("SVX_PIPE_GROUP_MB", PIPE_GROUP_BYTES)], large,
+                            merge_last=os.environ.get("SVX_MERGE_LAST", "1") != "0")
         self._mark("groups cut: %s" % [len(g) for g in groups])
         q = queue.Queue(maxsize=1)
         stop = threading.Event()

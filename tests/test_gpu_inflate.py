@@ -131,6 +131,41 @@ def test_fast_inflate_leaves_streams_of_tiny_deflate_blocks_to_the_wave_kernel()
     assert got == bam.bgzf_decompress(normal + tiny + normal + bam._BGZF_EOF)
 
 
+def test_fast_inflate_with_its_tokens_kernel_on_a_stream_of_its_own():
+    """svx_bgzf_inflate_fast_on: kernel A on one stream, kernel B (and what the caller enqueues behind it) on another -- three
+    launches in flight at once, the tokens kernels in a row on the process's "tokens" stream, each launch's tables uploaded on
+    its own stream right in front of it: every output is zlib's, and the streams of svision_amd.streams are what they say."""
+    from svision_amd import _lib, streams
+    rng = np.random.default_rng(11)
+    dev = torch.device("cuda:0")
+    tok = streams.get("tokens", dev)
+    assert streams.get("tokens", dev) is tok and streams.get("scan", dev).priority <= streams.get("copy", dev).priority
+    lib = _lib.load()
+    jobs = []
+    for k, s in enumerate((streams.get("ingest0", dev), streams.get("ingest1", dev), torch.cuda.Stream())):
+        payloads = [bytes(rng.integers(65, 69 + k, int(rng.integers(1, 65280)), dtype=np.uint8)) for _ in range(200)]
+        raw = np.frombuffer(b"".join(_block(p, level=(1, 6, 9)[k]) for p in payloads), np.uint8)
+        src_off, src_len, isize, _blk = kernels.bgzf_block_table(raw)
+        padded = np.zeros((raw.size + 31) // 16 * 16, np.uint8)
+        padded[:raw.size] = raw
+        dst = np.zeros(len(isize) + 1, np.uint64)
+        dst[1:] = np.cumsum(isize.astype(np.uint64))
+        with torch.cuda.stream(s):
+            d_comp = torch.from_numpy(padded).to(dev, non_blocking=True)
+            d_src, d_len = torch.from_numpy(src_off.view(np.int64)).to(dev), torch.from_numpy(src_len.view(np.int32)).to(dev)
+            d_dst = torch.from_numpy(dst.view(np.int64)).to(dev)
+            d_out = torch.empty(int(dst[-1]), dtype=torch.uint8, device=dev)
+            d_status = torch.zeros(len(isize), dtype=torch.int32, device=dev)
+            ws = kernels.inflate_workspace(lib, "fast", int(dst[-1]), len(isize), dev)
+            kernels.launch_inflate(lib, "fast", d_comp.data_ptr(), d_src.data_ptr(), d_len.data_ptr(), d_dst.data_ptr(), len(isize), d_out.data_ptr(),
+                                   d_status.data_ptr(), int(dst[-1]), dev, ws=ws, tokens_stream=tok)
+        jobs.append((s, d_out, d_status, b"".join(payloads), (d_comp, d_src, d_len, d_dst, ws)))
+    for s, d_out, d_status, want, _keep in jobs:
+        s.synchronize()
+        assert not d_status.cpu().numpy().any()
+        assert d_out.cpu().numpy().tobytes() == want
+
+
 def _same_table(a, b):
     for f in ("tid", "pos", "flag", "mapq", "l_seq", "name_id", "cigar", "cig_off"):
         assert np.array_equal(getattr(a, f), getattr(b, f)), f
