@@ -68,6 +68,26 @@ def test_cigar_scan_matches_oracle(oracle_lib, n_aln, mean_ops, rate):
     assert gaps.tobytes() == o_gaps.tobytes()
 
 
+def test_sample_from_device_reads_the_scan_back_through_pinned_memory_and_grows_its_capacity(oracle_lib):
+    """Sample.from_device (device ingest): the scan's result comes back through a pinned scratch buffer on the caller's
+    stream; more long gaps than the first guess of the capacity (n / 2, at least 1024) -> one more scan with the exact one.
+    Same arrays as the C oracle's, both ways."""
+    from oracle import cbind
+    from svision_amd.io.bam import AlignmentTable
+    from svision_amd.sample import Sample
+    for n_aln, mean_ops, rate in ((40, 4000, 0.05), (3000, 100, 0.001)):       # ~8,000 gaps for a capacity of 1,024; and a few
+        cigar, off, ref_start = datagen.random_cigars(n_aln, seed=7 + n_aln, mean_ops=mean_ops, long_gap_rate=rate)
+        o_gaps, o_off, o_stats = cbind.cigar_scan(cigar, off, ref_start, 50)
+        table = AlignmentTable(["c"], [10 ** 9], np.zeros(n_aln, np.int32), ref_start, np.zeros(n_aln, np.uint16), np.full(n_aln, 60, np.uint8),
+                               np.zeros(n_aln, np.int32), np.arange(n_aln, dtype=np.int32), ["r%d" % i for i in range(n_aln)], cigar, off.astype(np.int64), "")
+        with torch.cuda.stream(torch.cuda.Stream()):
+            sample = Sample.from_device(table, None, 50, _dev(cigar.view(np.int32)), _dev(off.astype(np.int64)), _dev(ref_start))
+        assert (n_aln == 40) == (int(o_off[-1]) > 1024)
+        assert np.array_equal(sample.gap_off, o_off.astype(np.int64))
+        assert np.array_equal(sample.stats, o_stats)
+        assert sample.gaps.tobytes() == o_gaps.tobytes()
+
+
 def test_cigar_scan_full_size(oracle_lib):
     """A whole-chromosome-sized batch (1.5 M alignments: several scan steps of 1024 tiles, a last partial tile, a work list
     of tens of thousands of alignments) against the C oracle, plus the size-independent properties of the output."""
