@@ -60,6 +60,8 @@ const char* svx_strerror(int code);
  * Saver().restore verifies them inside TensorFlow) */
 uint32_t    svx_crc32c(const void* data, size_t n);
 
+#define SVX_SCAN_FAILED   0xFFFFFFFFu
+
 /* Bytes of device scratch svx_cigar_scan needs for n_aln alignments. */
 size_t svx_cigar_scan_ws_bytes(uint32_t n_aln);
 
@@ -77,7 +79,10 @@ size_t svx_cigar_scan_ws_bytes(uint32_t n_aln);
  *   d_gaps      [gaps_cap] out: long gaps sorted by (aln, op)
  *   d_gap_off   [n_aln + 1] out, 16-byte aligned: CSR offsets into d_gaps per alignment
  *               (d_gap_off[n_aln] = total number of long gaps, even when it
- *               exceeds gaps_cap; gaps beyond gaps_cap are not written)
+ *               exceeds gaps_cap; gaps beyond gaps_cap are not written;
+ *               SVX_SCAN_FAILED = the offsets pass gave up waiting for a tile in front of it
+ *               -- workgroups are dispatched in index order on this hardware, so this is a
+ *               bug or a different dispatcher, never data --: the other outputs are invalid)
  *   d_stats     [n_aln][4] out, may be NULL: ref_span (M,D,N,=,X),
  *               lead_clip (leading S/H), trail_clip (trailing S/H),
  *               query_len (M,I,S,H,=,X)

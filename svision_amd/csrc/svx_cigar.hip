@@ -93,6 +93,7 @@ void count_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict
     // (the look-back descriptors of the offsets pass behind this kernel start out empty: zeroed here instead of by a memset
     // launch of its own -- 5 us of a 70 us scan; there are more count workgroups than tiles)
     if (threadIdx.x == 0 && blockIdx.x < n_tiles) desc[blockIdx.x] = 0ull;
+    if (threadIdx.x == 0 && blockIdx.x == 0) gap_off[n_aln] = 0u;        // (the total: written with atomicMax by the offsets pass, see there)
     const int sub = threadIdx.x & (CGROUP - 1);
     const int wl = threadIdx.x & (WAVE - 1);
     const int gshift = wl & ~(CGROUP - 1);
@@ -184,6 +185,7 @@ void count_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict
     // ---- the long alignments of this wave, one after the other: everything behind their first LONG_Q quads, 64 lanes with
     // LQUADS 16-byte loads in flight each (2048 words per step); the sums are added to what the leaders have just stored
     unsigned long long lm = __ballot(is_long && sub == 0);
+    if (lm) __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): the leaders' stores above are acknowledged by the L2 before the atomics below go there
     while (lm) {
         const int src = __ffsll((long long)lm) - 1;
         lm &= lm - 1;
@@ -266,6 +268,7 @@ void offsets_kernel(uint32_t n_aln, uint32_t* __restrict__ gap_off, unsigned lon
                 if (i >= 0) {
                     int spins = 0;
                     do { d = __hip_atomic_load(&desc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((d & D_FLAG) == 0 && ++spins < (1 << 20));
+                    if ((d & D_FLAG) == 0) atomicMax(&gap_off[n_aln], SVX_SCAN_FAILED);      // never seen on this hardware; loud if it ever is
                 }
                 const unsigned long long incl = __ballot((d & D_FLAG) == D_INC);
                 const int stop = incl ? __ffsll((long long)incl) - 1 : WAVE - 1;      // the nearest tile whose inclusive prefix is known
@@ -289,7 +292,7 @@ void offsets_kernel(uint32_t n_aln, uint32_t* __restrict__ gap_off, unsigned lon
             gap_off[a] = off;
             if (c[u]) work[rank++] = make_uint2(a, off);
             off += c[u];
-            if (a == n_aln - 1) { gap_off[n_aln] = off; *totals = make_uint2(off, rank); }
+            if (a == n_aln - 1) { atomicMax(&gap_off[n_aln], off); *totals = make_uint2(off, rank); }
         }
     }
 }

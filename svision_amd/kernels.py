@@ -71,6 +71,15 @@ def rasterize(records, layout="NCHW", mean=MEAN, out=None):
     return out
 
 
+SCAN_FAILED = 0xFFFFFFFF            # SVX_SCAN_FAILED (include/svx.h): d_gap_off[n_aln] when the offsets pass timed out
+
+
+def check_scan_total(total):
+    if total == SCAN_FAILED:
+        raise _lib.SvxError("svx_cigar_scan: the offsets pass gave up waiting for a tile in front of it (SVX_SCAN_FAILED)")
+    return total
+
+
 class CigarScanResult:
     """Device-side result of :func:`cigar_scan`."""
 
@@ -78,12 +87,12 @@ class CigarScanResult:
         self.gaps, self.gap_off, self.stats, self.n_aln, self.cap = gaps, gap_off, stats, n_aln, cap
 
     def total(self):
-        return int(self.gap_off[self.n_aln].item())
+        return check_scan_total(int(self.gap_off[self.n_aln].item()) & 0xFFFFFFFF)
 
     def to_host(self):
         """(gaps structured array sorted by (aln, op), gap_off uint32[n+1], stats int32[n,4])."""
         off = self.gap_off.cpu().numpy().view(np.uint32)
-        total = int(off[self.n_aln])
+        total = check_scan_total(int(off[self.n_aln]))
         if total > self.cap:
             raise _lib.SvxError(f"cigar_scan: {total} long gaps exceed the capacity {self.cap}")
         raw = self.gaps[: total * 6].cpu().numpy()

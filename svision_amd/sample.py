@@ -81,7 +81,7 @@ class Sample:
             ev.synchronize()
             if _MARK: _MARK("from_device: event done")
             h = host.numpy()
-            total = int(h[:n + 1].view(np.uint32)[n])
+            total = kernels.check_scan_total(int(h[:n + 1].view(np.uint32)[n]))
             if total <= cap:
                 break
             cap = total                                      # gap_off[n] holds the full count: once more with the exact capacity
