@@ -1,13 +1,15 @@
 """Device-side BAM ingestion (the default engine, svision_amd.ingest.ChromosomeFeed): the compressed file goes to the GPU as
-it is -- through a ring of pinned 64 MB slots --, the BGZF blocks are inflated there (svx_bgzf_inflate: one lane per block,
-svx_bgzf_inflate_wave: one wave per block; kernels.inflate_kernel_for picks by launch size), the records are located through
+it is -- through a ring of pinned 64 MB slots --, the BGZF blocks are inflated there (svx_bgzf_inflate_fast_on: parallel Huffman
+decoding per block, then the LZ copies; the round-3 kernels by name: SVX_INFLATE_VARIANT), the CRC32 of every block is checked,
+the records are located through
 the .bai linear index and their fixed fields, QNAMEs and CIGAR words are packed on the device (svx_bam_walk_*).  The packed
 CIGARs -- the input of svx_cigar_scan -- never leave HBM; the host receives the small per-record arrays its collection step
 needs and hands them to the helper processes by WRITING them to shared-memory files (it never maps them: DESIGN.md section 5).
 
 Why: DEFLATE decoding is the cost of ingestion (a HiFi BAM inflates to ~22 KB per read, ~0.6 GB/s per host core), and the
 GPU boxes this was built on give a container the CPU time of 16 cores (svision_amd.ingest.effective_cpus): ~10 GB/s of
-inflated data, a quarter of what the device pipeline consumes.  The same data inflates at 75-90 GB/s on the MI355X.
+inflated data, a quarter of what the device pipeline consumes.  The same data inflates at 75 GB/s on the MI355X (two kernels,
+136 and 170 GB/s).
 Replaces pysam's AlignmentFile.fetch (run_collection.py:23-26) like the host reader (io.bam.BamStream), which stays the
 engine for files without a linear index, for --hash / --graph (read bases wanted) and for SVX_INGEST=cpu.
 """
@@ -20,7 +22,7 @@ from . import _lib, kernels, streams
 from .io.bam import AlignmentTable, read_bai_linear
 
 FIRST_GROUP_BYTES = 192 << 20            # the first launch is small (~7 k blocks: the wave-per-block kernel): the pipeline starts after ~0.1 s
-STAGE_BYTES = 64 << 20                   # a pinned staging slot of the pipelined reader (ring of four)
+STAGE_BYTES = 64 << 20                   # a pinned staging slot of the pipelined reader (ring of eight)
 PIPE_GROUP_BYTES = 600 << 20             # parts_pipelined, the groups behind the first: ~21 k blocks.  (Round 3 / early round 4: 768 MB, then 2.5 GB
 LARGE_GROUP_BYTES = 600 << 20            # -- a launch of the lane-per-block kernel cost 60-90 ms whatever it held.  The two-kernel inflate is
 LARGE_GROUP_BLOCKS = 94_000              # proportional to the launch, and once the read-backs no longer blocked each other (launch(), streams.py)
@@ -199,12 +201,13 @@ class DeviceDecoder:
         return self.pinned
 
     # ---- pipelined form: a reader thread, up to `depth` groups in flight on streams of their own ------------------------
-    def parts_pipelined(self, tids, depth=3):
+    def parts_pipelined(self, tids, depth=2):
         """Generator like :meth:`decode_group` over ALL chromosomes of ``tids``, with the steps overlapped: a reader thread
-        fills pinned buffers a few groups ahead; every group is uploaded, inflated and counted on one of ``depth`` streams
-        without a host synchronisation (a lane needs ~0.1 s for its block whatever the launch size, so launches of ~30 k
-        blocks are staggered rather than made large: the first chromosomes arrive after one such latency, the later ones
-        at the rate the device decodes); per group ONE read-back (block status + walk counts), per chromosome ONE."""
+        fills the device buffers of the groups ahead (through the staging ring); every group (cut_groups: ~600 MB of file) is
+        inflated and counted without a host synchronisation -- its tokens kernel on the process's "tokens" stream, one group
+        after the other, the rest on one of ``depth`` group streams (svision_amd/streams.py: hardware queues of their own) --;
+        per group ONE read-back (block status + walk counts: issued when the inflate is through, never queued behind it), per
+        chromosome ONE (the packed arrays)."""
         import collections
         import queue
         import threading
