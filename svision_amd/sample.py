@@ -38,29 +38,48 @@ class Sample:
     # -- construction -----------------------------------------------------------------
     @classmethod
     def from_table(cls, table, fasta, min_sv, device="cuda"):
-        """Upload the packed CIGARs and run the device scan (the product path)."""
+        """Upload the packed CIGARs and run the device scan (the product path of a host-decoded table).  The upload goes
+        through pinned memory on the caller's current stream, like the read-back (:meth:`_scan_resident`): a copy from or to
+        pageable memory is staged by the runtime on an internal queue of normal priority, where it waits behind the CNN's
+        queued launches (tens of ms per chromosome in a file-driven run)."""
         import torch
-        from . import kernels
         dev = torch.device(device)
-        d_cigar = torch.from_numpy(table.cigar.view(np.int32)).to(dev)
-        d_off = torch.from_numpy(table.cig_off).to(dev)
-        d_pos = torch.from_numpy(table.pos).to(dev)
-        res = kernels.cigar_scan(d_cigar, d_off, d_pos, min_sv)
-        gaps, gap_off, stats = res.to_host()
-        from .segmentplot import run_hash_lineplot
-        run_hash_lineplot.DEVICE = dev                       # this process owns a GPU: --hash re-alignment seeds on the device
-        return cls(table, fasta, gaps, gap_off, stats, min_sv, device_buffers=(d_cigar, d_off, d_pos, res))
+        cigar = np.ascontiguousarray(table.cigar).view(np.int32).reshape(-1)
+        cig_off = np.ascontiguousarray(table.cig_off, np.int64)
+        pos = np.ascontiguousarray(table.pos, np.int32)
+        n, words = int(pos.size), int(cigar.size)
+        pad = (-words) % 4                                       # (svx_cigar_scan reads 16-byte quads)
+        stage = _pinned_scratch(words + pad + 2 * (n + 1) + 2 + n)
+        h = stage.numpy()
+        h[:words] = cigar
+        h[words:words + pad] = 0
+        at_off = (words + pad + 1) // 2 * 2                     # int64 view: an even word index
+        h[at_off:at_off + 2 * (n + 1)].view(np.int64)[:] = cig_off
+        at_pos = at_off + 2 * (n + 1)
+        h[at_pos:at_pos + n] = pos
+        d_all = stage[:at_pos + n].to(dev, non_blocking=True)
+        d_cigar = d_all[:max(words, 1)] if words else torch.zeros(4, dtype=torch.int32, device=dev)
+        d_off = d_all[at_off:at_off + 2 * (n + 1)].view(torch.int64)
+        d_pos = d_all[at_pos:at_pos + n]
+        out = cls._scan_resident(table, fasta, min_sv, d_cigar, d_off, d_pos)
+        _PINNED.append(stage)                                    # (the scan's event is through: the upload has been consumed)
+        return out
 
     @classmethod
     def from_device(cls, table, fasta, min_sv, d_cigar, d_off, d_pos):
         """The packed arrays are already in HBM (device-side ingestion, svision_amd/ingest_gpu.py): scan them in place."""
         import torch
-        from . import kernels
         # the arrays were produced (and allocated) on the decoder's stream, whose event the caller has waited for; they are
         # used on the caller's current stream from here on: the caching allocator must not hand their blocks out behind that
         # stream's back when they are freed
         for t in (d_cigar, d_off, d_pos):
             t.record_stream(torch.cuda.current_stream(t.device))
+        return cls._scan_resident(table, fasta, min_sv, d_cigar, d_off, d_pos)
+
+    @classmethod
+    def _scan_resident(cls, table, fasta, min_sv, d_cigar, d_off, d_pos):
+        import torch
+        from . import kernels
         # The result comes back through PINNED memory, copies and event on the caller's (high-priority) stream.  A read-back
         # into pageable memory (.item(), .cpu()) is staged by the runtime through a copy kernel on an internal queue of
         # normal priority: behind the CNN's queued launches and a tokens launch that owns every CU it took 40-90 ms instead
@@ -84,13 +103,14 @@ class Sample:
             total = kernels.check_scan_total(int(h[:n + 1].view(np.uint32)[n]))
             if total <= cap:
                 break
+            _PINNED.append(host)
             cap = total                                      # gap_off[n] holds the full count: once more with the exact capacity
         gap_off = h[:n + 1].view(np.uint32).copy()
         gaps = h[n + 1:n + 1 + total * 6].copy().view(kernels.GAP_DTYPE) if total else np.empty(0, kernels.GAP_DTYPE)
         stats = h[n + 1 + cap * 6:need].reshape(n, 4).copy()
         _PINNED.append(host)
         from .segmentplot import run_hash_lineplot
-        run_hash_lineplot.DEVICE = d_cigar.device
+        run_hash_lineplot.DEVICE = d_cigar.device            # this process owns a GPU: --hash re-alignment seeds on the device
         return cls(table, fasta, gaps, gap_off, stats, min_sv, device_buffers=(d_cigar, d_off, d_pos, res))
 
     @classmethod
