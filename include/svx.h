@@ -320,7 +320,8 @@ int            svx_bgzf_inflate_wave(const uint8_t* d_comp, const uint64_t* d_sr
  *                         record.  A CIGAR of more than 65,535 operations is read from the record's CG:B,I tag
  *                         (SAMv1 4.2.2), by both passes
  *   svx_bam_walk_extract  d_base [n_starts][3] = exclusive prefix sums of the first three counts; fills tid / pos / flag /
- *                         mapq / l_seq [records], cig_off / name_off [records] (offsets of each record's words / name),
+ *                         mapq / l_seq [records], cig_off / name_off [records + 1] (offsets of each record's words / name;
+ *                         the closing entry = the totals: ABI 370, the caller appended it before),
  *                         cigar [words], names [bytes] ('\n' behind every name) */
 int            svx_bam_walk_count(const uint8_t* d_raw, const uint64_t* d_starts, uint32_t n_starts, uint64_t* d_counts, void* stream);
 int            svx_bam_walk_extract(const uint8_t* d_raw, const uint64_t* d_starts, uint32_t n_starts, const uint64_t* d_base,

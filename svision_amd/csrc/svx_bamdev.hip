@@ -149,6 +149,9 @@ void bam_walk_extract_kernel(const uint8_t* __restrict__ raw, const uint64_t* __
         ++k;
         p += 4ull + bs;
     }
+    // the closing entries of the two CSR arrays (the totals), by the last interval's wave: the caller needed two fill launches
+    // per chromosome for them, each a few hundred microseconds of waiting for room next to the inflate and the CNN
+    if (i == n_starts - 1 && lane == 0) { cig_off[k] = (int64_t)w; name_off[k] = (int64_t)nb; }
 }
 
 }  // namespace
@@ -164,7 +167,7 @@ extern "C" int svx_bam_walk_count(const uint8_t* d_raw, const uint64_t* d_starts
 }
 
 // pass 2: d_base [n_starts][3] = exclusive prefix sums of the first three counts; the output arrays are sized by their
-// totals (d_cig_off / d_name_off get one entry per record; the caller appends the totals)
+// totals (d_cig_off / d_name_off: one entry per record + the closing entry = the totals, written by the last interval's wave)
 extern "C" int svx_bam_walk_extract(const uint8_t* d_raw, const uint64_t* d_starts, uint32_t n_starts, const uint64_t* d_base,
                                     int32_t* d_tid, int32_t* d_pos, uint16_t* d_flag, uint8_t* d_mapq, int32_t* d_l_seq,
                                     int64_t* d_cig_off, uint32_t* d_cigar, int64_t* d_name_off, uint8_t* d_names, void* stream)

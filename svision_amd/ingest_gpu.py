@@ -465,17 +465,16 @@ class DeviceDecoder:
                     _lib.check(lib.svx_bam_walk_extract(d_raw.data_ptr(), d_tab[at:].data_ptr(), n_starts, d_base.data_ptr(), d_tid.data_ptr(),
                                                         d_pos.data_ptr(), d_flag.data_ptr(), d_mapq.data_ptr(), d_lseq.data_ptr(), d_cig_off.data_ptr(),
                                                         d_cigar.data_ptr(), d_name_off.data_ptr(), d_names.data_ptr(), st), "svx_bam_walk_extract")
-                    d_cig_off[n:].fill_(words)
-                    d_name_off[n:].fill_(name_bytes)
                     h_pack = h_pack_all[p0:p0 + size]
                     h_pack.copy_(d_pack, non_blocking=True)
-                    # device copies svx_cigar_scan keeps: own tensors (the pack goes away with this group's read-backs), made IN
-                    # FRONT of the event the consumer synchronises on: it scans on another stream and orders itself behind
-                    # this one through that event only
-                    keep_off, keep_pos = d_cig_off.clone(), d_pos.clone()
+                    # svx_cigar_scan reads the offsets and positions where they are: views of the group's pack buffer, which
+                    # lives as long as one of them does (until round 4: two clones and two fills of the CSR arrays' closing
+                    # entries per chromosome -- four tiny launches, each a few hundred microseconds of waiting for room on a
+                    # chip that is full of inflate and CNN waves; the extract kernel writes the closing entries itself now).
+                    # The consumer scans on another stream and orders itself behind this one through the event only.
                     ev = torch.cuda.Event()
                     ev.record()
-                    pending.append((ev, h_pack, offs, n, words, name_bytes, d_cigar, keep_off, keep_pos, base_all, d_pack))
+                    pending.append((ev, h_pack, offs, n, words, name_bytes, d_cigar, d_cig_off, d_pos, base_all, d_pack))
             self.stats["walk_s"] += time.perf_counter() - t0
             yield None                                          # every chromosome's extraction is enqueued: the caller may launch the next group
             for ev, h_pack, offs, n, words, name_bytes, d_cigar, d_cig_off, d_pos, _base, _d_pack in pending:
@@ -741,8 +740,6 @@ class DeviceDecoder:
         _lib.check(lib.svx_bam_walk_extract(d_raw.data_ptr(), d_starts.data_ptr(), n_starts, d_base.data_ptr(), d_tid.data_ptr(), d_pos.data_ptr(),
                                             d_flag.data_ptr(), d_mapq.data_ptr(), d_lseq.data_ptr(), d_cig_off.data_ptr(), d_cigar.data_ptr(),
                                             d_name_off.data_ptr(), d_names.data_ptr(), st), "svx_bam_walk_extract")
-        d_cig_off[n] = words
-        d_name_off[n] = name_bytes
         t1 = time.perf_counter()
         alloc = self.alloc_for() if self.alloc_for is not None else (lambda _name, dtype, k: np.empty(k, dtype))
 
