@@ -25,6 +25,22 @@ _HIGH = ("tokens", "ingest0", "ingest1", "scan")
 _LOW = ("copy", "spill")
 
 
+def _hip_runtime():
+    """The HIP runtime torch itself has loaded (its path from /proc/self/maps): a second copy of the library, found by name
+    somewhere else on the search path, would hand out streams the first knows nothing about."""
+    import torch  # noqa: F401 -- (loads it)
+    path = None
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    path = line.split()[-1]
+                    break
+    except OSError:
+        pass
+    return ctypes.CDLL(path or "libamdhip64.so")
+
+
 def _create(hip, priority):
     handle = ctypes.c_void_p()
     rc = hip.hipStreamCreateWithPriority(ctypes.byref(handle), ctypes.c_uint(1), ctypes.c_int(priority))      # hipStreamNonBlocking
@@ -39,7 +55,7 @@ def get(name, device):
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     with _LOCK:
         if key not in _STREAMS:
-            hip = ctypes.CDLL("libamdhip64.so")
+            hip = _hip_runtime()
             least, greatest = ctypes.c_int(), ctypes.c_int()
             with torch.cuda.device(key):
                 hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest))
