@@ -2,7 +2,8 @@
 """The file-inclusive leg of `bench.py --no-other-engine --no-cpu-baseline --no-calibration` in a rocprofv3 --kernel-trace CSV:
 which kernels the device ran, class by class (union of their intervals = time with at least one kernel of the class in flight;
 sum = kernel time), when nothing ran, and how long the ingest kernels ran next to the CNN.  The leg is found by its tokens
-launches: the last cluster of bgzf_tokens_kernel launches of the trace (the warm-up pass from the file comes before it)."""
+launches: the last cluster of bgzf_tokens_kernel launches of the trace (the warm-up pass from the file comes before it), or the
+last argv[2] of them."""
 import csv, glob, os, sys
 path = sys.argv[1]
 if os.path.isdir(path):
@@ -10,11 +11,14 @@ if os.path.isdir(path):
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(path))]
 rows.sort()
 tok = [r for r in rows if "bgzf_tokens_kernel" in r[2]]
-cluster = [tok[-1]]
-for r in reversed(tok[:-1]):
-    if cluster[0][0] - r[1] > 150e6:
-        break
-    cluster.insert(0, r)
+if len(sys.argv) > 2:                                           # argv[2]: the leg's number of inflate launches (7 for the 20-window job)
+    cluster = tok[-int(sys.argv[2]):]
+else:
+    cluster = [tok[-1]]
+    for r in reversed(tok[:-1]):
+        if cluster[0][0] - r[1] > 100e6:
+            break
+        cluster.insert(0, r)
 lz = [r for r in rows if "bgzf_lz_kernel" in r[2] and r[0] >= cluster[0][0]]
 t_start = cluster[0][0] - 20e6                               # read + index of the first group in front of its launch
 cnn = ("conv_wave", "fc_splitk", "fc_reduce", "encode_conv1", "bias_relu_pool", "active_", "fc8_softmax")

@@ -32,7 +32,7 @@ pmc write_prof_cnn "WRITE_SIZE" python $REPO/tools/prof_cnn.py 4
 python $REPO/tools/kstats.py $OUT/stage_kernel_stats.csv > $OUT/stage_kernel_stats.txt
 # 5. the file-inclusive leg kernel by kernel (profiles/r04_e2e_timeline.md, third part)
 run e2e_trace rocprofv3 --kernel-trace --output-format csv -d /tmp/rp_e2e_trace -- python $REPO/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-calibration --no-other-engine
-python $REPO/tools/e2e_kernel_timeline.py /tmp/rp_e2e_trace > $OUT/e2e_kernel_timeline.txt
+python $REPO/tools/e2e_kernel_timeline.py /tmp/rp_e2e_trace 7 > $OUT/e2e_kernel_timeline.txt
 # 6. the scan alone and the experiments behind section 5 of DESIGN.md ("Round 4, second half")
 timeout 300 python $REPO/tools/bench_cigar.py > $OUT/bench_cigar.json 2> /dev/null
 for p in -1 0 1; do timeout 200 python $REPO/tools/exp/queue_map.py $p 6; done > $OUT/queue_map.txt 2>&1
