@@ -496,6 +496,11 @@ class DeviceDecoder:
         group_streams = [streams.get("ingest%d" % i, dev) for i in range(depth)]
         inflight = collections.deque()
         state = {"done": False, "k": 0, "finished": 0, "hold_until": float("inf")}
+        # (SVX_FIRST_HOLD=1: the round-3 rule -- nothing is launched behind the first group until its chromosome is through.
+        # It protected that chromosome's small kernels from waiting behind the second group's inflate in a shared hardware
+        # queue; with queues of their own (streams.py) it only kept the second group's tokens kernel out of the start-up, when
+        # the device has nothing else to do: without it the second group's chromosomes arrive 20-30 ms earlier, 0.41 -> 0.40 s.)
+        hold_first = os.environ.get("SVX_FIRST_HOLD", "0") == "1"
 
         def pump(block):
             """Launch what the reader has ready, up to `depth` groups in flight; block only when nothing is in flight."""
@@ -503,7 +508,7 @@ class DeviceDecoder:
                 # Nothing is launched behind the very first group until its chromosome is through (extracted here, scanned by the
                 # consumer; at most 0.15 s): kernels do not pre-empt each other, these steps are a few small kernels, and behind the
                 # second group's inflate launch they would wait 60-90 ms -- while the pipeline waits for exactly that chromosome.
-                if state["k"] == 1 and not (state["finished"] and self.first_handover.is_set()) and time.perf_counter() < state["hold_until"]:
+                if hold_first and state["k"] == 1 and not (state["finished"] and self.first_handover.is_set()) and time.perf_counter() < state["hold_until"]:
                     if inflight or not block:
                         return                                  # (the caller goes on to finish the group in flight)
                     time.sleep(0.0005)
