@@ -61,12 +61,25 @@ __device__ inline unsigned cgroup_sum(unsigned v)
     return v;
 }
 
-// one CIGAR word into the three per-alignment sums (32-bit modular; "0M" is inert)
+// one CIGAR word into the three per-alignment sums (32-bit modular; "0M" is inert).  The count pass is bound by the vector
+// ALU, not by memory (PMC, profiles/r04_pmc_cigar.txt: 605 VALU instructions per wave of eight alignments, the SIMD's vector
+// port busy for the whole launch), so the instruction count per word is its speed: a signed one-bit field extract turns "is this
+// op in the set" into an AND mask in one instruction (v_bfe_i32: 0 or -1), where shift / and / compare / select took three.
 __device__ inline void tally(uint32_t w, int32_t min_sv, unsigned& ref_span, unsigned& qlen, unsigned& ngap)
 {
     const uint32_t op = w & 15u, len = w >> 4;
-    ref_span += len & (0u - ((0x18Du >> op) & 1u));                 // M D N = X (reference_end)
-    qlen += len & (0u - ((0x1B3u >> op) & 1u));                     // M I S H = X
+    ref_span += len & (uint32_t)__builtin_amdgcn_sbfe(0x18D, op, 1u);      // M D N = X (reference_end)
+    qlen += len & (uint32_t)__builtin_amdgcn_sbfe(0x1B3, op, 1u);          // M I S H = X
+    ngap -= (uint32_t)((int32_t)len >= min_sv ? __builtin_amdgcn_sbfe(0x6, op, 1u) : 0);      // I, D of at least min_sv bases
+}
+
+// (the same in the form the long-alignment loop at the end of the count pass keeps: there a wave streams ONE alignment, bound by
+// the round trips of its loads, and the select-based form schedules 4 % better between them)
+__device__ inline void tally_long(uint32_t w, int32_t min_sv, unsigned& ref_span, unsigned& qlen, unsigned& ngap)
+{
+    const uint32_t op = w & 15u, len = w >> 4;
+    ref_span += len & (0u - ((0x18Du >> op) & 1u));
+    qlen += len & (0u - ((0x1B3u >> op) & 1u));
     ngap += (uint32_t)((op - 1u) < 2u) & (uint32_t)((int32_t)len >= min_sv);
 }
 
@@ -200,8 +213,8 @@ void count_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict
 #pragma unroll
             for (int u = 0; u < LQUADS; ++u) {
                 const bool in = q + (uint64_t)u * WAVE < qb;
-                tally(in ? w[u].x : 0u, min_sv, r2, l2, g2); tally(in ? w[u].y : 0u, min_sv, r2, l2, g2);
-                tally(in ? w[u].z : 0u, min_sv, r2, l2, g2); tally(in ? w[u].w : 0u, min_sv, r2, l2, g2);
+                tally_long(in ? w[u].x : 0u, min_sv, r2, l2, g2); tally_long(in ? w[u].y : 0u, min_sv, r2, l2, g2);
+                tally_long(in ? w[u].z : 0u, min_sv, r2, l2, g2); tally_long(in ? w[u].w : 0u, min_sv, r2, l2, g2);
                 __builtin_amdgcn_sched_barrier(0);           // quad after quad: left alone the scheduler spreads the 32 tallies over 160 registers
             }
         }
