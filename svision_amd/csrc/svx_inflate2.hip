@@ -221,40 +221,46 @@ __device__ int build_tables(const uint8_t* lens, int n, int root, uint32_t* tab,
     return top;
 }
 
-// >= 57 bits of the chunk from bit `rel` of the staged words (rel < 32 * (CHUNK_WORDS - 2))
-__device__ __forceinline__ uint64_t peek(const uint32_t* chunk, uint32_t rel)
+// 64 bits of the chunk from bit `rel` of the staged words (rel < 32 * (CHUNK_WORDS - 2)) as two dwords: two funnel shifts
+// (v_alignbit_b32, full rate).  A token is at most 15 + 5 code and extra bits of the literal / length alphabet -- all inside the
+// first dword -- and 15 + 13 of the distance alphabet, which start at bit <= 20: one more funnel shift brings them into one
+// dword as well.  (Round 4, first version: one 64-bit value and 64-bit shifts throughout -- fourteen of them per token, at
+// half the rate of the 32-bit ones: the tokens kernel is bound by the vector ALU, profiles/r04_pmc_sq_inflate.txt.)
+struct Bits { uint32_t lo, hi; };
+__device__ __forceinline__ Bits peek(const uint32_t* chunk, uint32_t rel)
 {
     const uint32_t w = rel >> 5, sh = rel & 31u;
     const uint32_t d0 = chunk[w], d1 = chunk[w + 1], d2 = chunk[w + 2];
-    const uint64_t lo = ((uint64_t)d1 << 32 | d0) >> sh;
-    return sh ? lo | (uint64_t)d2 << (64 - sh) : lo;
+    return Bits{__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh)};
 }
 
 struct Tok { uint32_t kind, used, val, len, dist; };
 
 __device__ __forceinline__ Tok token(const Lds& t, uint32_t rel)
 {
-    const uint64_t bits = peek(t.chunk, rel);
-    uint32_t e = t.lit[(uint32_t)bits & ((1u << LB) - 1u)];
+    const Bits b = peek(t.chunk, rel);
+    uint32_t e = t.lit[b.lo & ((1u << LB) - 1u)];
     uint32_t used;
     if (((e >> 4) & 15u) == K_SUB) {
-        e = t.lit[((e >> 8) & 0xfffu) + ((uint32_t)(bits >> LB) & ((1u << ((e >> 20) & 15u)) - 1u))];
+        e = t.lit[((e >> 8) & 0xfffu) + ((b.lo >> LB) & ((1u << ((e >> 20) & 15u)) - 1u))];
         used = LB + (e & 15u);
     } else used = e & 15u;
     Tok k{(e >> 4) & 15u, used, (e >> 8) & 255u, 0u, 0u};
     if (k.kind != K_LEN) return k;
     const uint32_t xb = (e >> 17) & 7u;
-    k.len = ((e >> 8) & 511u) + ((uint32_t)(bits >> used) & ((1u << xb) - 1u));
+    k.len = ((e >> 8) & 511u) + ((b.lo >> used) & ((1u << xb) - 1u));          // used + xb <= 20
     used += xb;
-    uint32_t d = t.dist[(uint32_t)(bits >> used) & ((1u << DB) - 1u)];
+    const uint32_t db32 = __builtin_amdgcn_alignbit(b.hi, b.lo, used);          // the 32 bits from bit `used` (<= 20) on
+    uint32_t d = t.dist[db32 & ((1u << DB) - 1u)];
+    uint32_t dused;
     if (((d >> 4) & 15u) == K_SUB) {
-        d = t.dist[((d >> 8) & 0xfffu) + ((uint32_t)(bits >> (used + DB)) & ((1u << ((d >> 20) & 15u)) - 1u))];
-        used += DB + (d & 15u);
-    } else used += d & 15u;
-    if (((d >> 4) & 15u) != K_LEN) { k.kind = K_BAD; k.used = used; return k; }
-    const uint32_t db = (d >> 23) & 15u;
-    k.dist = ((d >> 8) & 0x7fffu) + ((uint32_t)(bits >> used) & ((1u << db) - 1u));
-    k.used = used + db;
+        d = t.dist[((d >> 8) & 0xfffu) + ((db32 >> DB) & ((1u << ((d >> 20) & 15u)) - 1u))];
+        dused = DB + (d & 15u);
+    } else dused = d & 15u;
+    if (((d >> 4) & 15u) != K_LEN) { k.kind = K_BAD; k.used = used + dused; return k; }
+    const uint32_t nb = (d >> 23) & 15u;
+    k.dist = ((d >> 8) & 0x7fffu) + ((db32 >> dused) & ((1u << nb) - 1u));      // dused + nb <= 28
+    k.used = used + dused + nb;
     return k;
 }
 
@@ -393,20 +399,24 @@ void bgzf_tokens_kernel(const uint8_t* __restrict__ comp, const uint64_t* __rest
                 bool run = dirty;
                 if (dirty) { p = start; olen = 0; enc = 0; lit = 0; flag = 0; }
                 while (__any(run)) {
-                    if (run) {
-                        if (p >= q1) { run = false; f = p; }
-                        else if (p >= nbits) { flag = 2; run = false; f = p; }
-                        else {
-                            const Tok k = token(t, p - bit0);
-                            if (k.kind == K_BAD) { flag = 2; run = false; f = p; }
-                            else {
-                                p += k.used;
-                                if (k.kind == K_EOB) { flag = 1; run = false; f = p; }
-                                else if (k.kind == K_LIT) { if (lit == 255u) { enc += 259u; lit = 0; } ++lit; ++olen; }
-                                else { enc += 4u + lit; lit = 0; olen += k.len; }
-                            }
-                        }
-                    }
+                    // (one branch around the decode, the bookkeeping behind it with selects: written as the nest of ifs it is,
+                    // every path back into the loop carried half a dozen register moves -- a third of the loop's vector
+                    // instructions, in a kernel the vector ALU bounds)
+                    const bool go = run && p < q1 && p < nbits;
+                    Tok k{K_BAD, 0u, 0u, 0u, 0u};
+                    if (go) k = token(t, p - bit0);
+                    const bool bad = run && p < q1 && (p >= nbits || k.kind == K_BAD);
+                    const bool adv = go && k.kind != K_BAD;
+                    const bool eob = adv && k.kind == K_EOB, isl = adv && k.kind == K_LIT, ism = adv && k.kind == K_LEN;
+                    p += adv ? k.used : 0u;
+                    const bool full = isl && lit == 255u;
+                    enc += ism ? 4u + lit : full ? 259u : 0u;
+                    lit = isl ? (full ? 1u : lit + 1u) : ism ? 0u : lit;
+                    olen += ism ? k.len : isl ? 1u : 0u;
+                    flag = bad ? 2u : eob ? 1u : flag;
+                    const bool stop = run && (!go || bad || eob);        // (!go: the segment's end, or the stream's)
+                    f = stop ? p : f;
+                    run = run && !stop;
                 }
                 const unsigned long long fm = __ballot(flag != 0);
                 first = fm ? __ffsll((long long)fm) - 1 : LANES;
@@ -433,23 +443,24 @@ void bgzf_tokens_kernel(const uint8_t* __restrict__ comp, const uint64_t* __rest
                 bool bad_dist = false;
                 p = start;
                 bool run = valid;
-                while (__any(run)) {
-                    if (run) {
-                        if (p >= f) run = false;
-                        else {
-                            const Tok k = token(t, p - bit0);
-                            p += k.used;
-                            if (k.kind == K_LIT) {
-                                if (nl == 255u) { put32(hdr, 255u); hdr += 259; nl = 0; }
-                                hdr[4 + nl] = (uint8_t)k.val;
-                                ++nl; ++w;
-                            } else if (k.kind == K_LEN) {
-                                if (k.dist > w) { bad_dist = true; run = false; }
-                                put32(hdr, nl | k.len << 8 | (k.dist - 1u) << 17);
-                                hdr += 4 + nl; nl = 0; w += k.len;
-                            } else run = false;              // the end-of-block code
-                        }
-                    }
+                while (__any(run)) {                           // (flattened like S2: the stores are the only branches)
+                    const bool go = run && p < f;
+                    Tok k{K_EOB, 0u, 0u, 0u, 0u};
+                    if (go) k = token(t, p - bit0);
+                    p += k.used;
+                    const bool isl = go && k.kind == K_LIT, ism = go && k.kind == K_LEN;
+                    const bool full = isl && nl == 255u;
+                    if (full) put32(hdr, 255u);
+                    hdr += full ? 259 : 0;
+                    nl = full ? 0u : nl;
+                    if (isl) hdr[4 + nl] = (uint8_t)k.val;
+                    if (ism) put32(hdr, nl | k.len << 8 | (k.dist - 1u) << 17);
+                    const bool far = ism && k.dist > w;          // a distance beyond the start of the output
+                    bad_dist = bad_dist || far;
+                    hdr += ism ? 4 + nl : 0;
+                    nl = ism ? 0u : nl + (isl ? 1u : 0u);
+                    w += ism ? k.len : isl ? 1u : 0u;
+                    run = (isl || ism) && !far;                  // (not: the segment's end, the end-of-block code, a bad distance)
                 }
                 if (valid && nl) put32(hdr, nl);
                 if (__any(bad_dist)) { err = INF_BAD_DIST; break; }
