@@ -231,6 +231,18 @@ def resolve_defaults(args):
     return args
 
 
+def rank_command(n_ranks, port, argv):
+    """The launcher line of `python bench.py --gpus N` without a launcher: N ranks of this script on one node, rendezvous on
+    127.0.0.1 (the container's host name may not resolve), the caller's own arguments passed through."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def rank_environment(environ):
+    """dmabuf IPC between the ranks' HIP contexts (the host driver supports nothing else: RCCL fails with hipIpcGetMemHandle otherwise)."""
+    return dict(environ, HSA_ENABLE_IPC_MODE_LEGACY=environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: run the N ranks under torch.distributed.run and pass rank 0's
     JSON line through."""
@@ -238,10 +250,21 @@ def spawn_ranks(args):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    return subprocess.call(cmd, env=env)
+    return subprocess.call(rank_command(args.gpus, port, sys.argv[1:]), env=rank_environment(os.environ))
+
+
+def first_contact(world, grouped, backend, rank_mb, rank_file_bytes, identities):
+    """What an N-GPU run says about its own layout before any rate is believed (the line's `config.first_contact`; rank 0 also
+    prints it to stderr): the size of the RCCL world, the device every rank resolved to, the LPT loads and their imbalance --
+    chromosomes are not divisible, so max / mean of the loads bounds the strong-scaling speed-up at N / imbalance before
+    any other loss (the 24 GRCh38 chromosomes on 8 ranks: 1.036 -> at most 7.72 x of 8) -- and the bytes of BAM every rank reads."""
+    imbalance = (max(rank_mb) / (sum(rank_mb) / len(rank_mb))) if rank_mb else None
+    dup = sdist.duplicate_devices(identities)
+    return {"rccl_world": world if grouped and backend == "nccl" else 0, "world": world, "backend": backend if grouped else None,
+            "devices": ["%s %s" % tuple(i) for i in identities], "ranks_sharing_a_device": sorted(r for v in dup.values() for r in v),
+            "rank_mb": [round(v, 1) for v in rank_mb] if rank_mb else None, "imbalance": imbalance,
+            "strong_scaling_cap": (world / imbalance) if imbalance else None,
+            "rank_bam_bytes": [int(v) for v in rank_file_bytes] if rank_file_bytes else None}
 
 
 def main():
@@ -271,6 +294,7 @@ def main():
                          "= a 19 GB file); 0 = no file leg (`value` is then the resident leg)")
     ap.add_argument("--decode-threads", type=int, default=0, help="inflate threads of the e2e leg per rank (default: cores / ranks - helpers - 2, at most 128)")
     ap.add_argument("--bam-dir", default=None, help="where the synthetic BAM of the e2e leg is written (default: the temp directory)")
+    ap.add_argument("--no-cold-leg", action="store_true", help="skip the file-inclusive leg with the BAM's pages dropped from the page cache first (`e2e_cold_cache`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-calibration", action="store_true", help="skip the per-kernel timings outside the timed region")
     args = ap.parse_args()
@@ -330,7 +354,7 @@ def main():
         scores = []
         hot.reset_timing()
         done = {}
-        sample = lambda chrom: hot.feed.get(chrom, block=True)[1]     # noqa: E731  (the resident Sample, or the chromosome's own)
+        sample = lambda chrom, start: hot.feed.get(chrom, block=True, start=start)[1]     # noqa: E731  (the resident Sample, or the one that served the window)
         for res in hot.run_windows(seq, rescan=rescan):
             images += res.n_images
             done[res.wid] = res
@@ -428,6 +452,11 @@ def main():
             if rank == 0:
                 print("e2e sweep %s: %.3f s (read %s, pread %s, slot wait %s, last chromosome ready %s)" % (
                     spec or "(default)", leg["seconds"], dd.get("read_s"), dd.get("pread_s"), dd.get("slot_wait_s"), leg["rank0_feed"].get("last_ready_s")), file=sys.stderr)
+    e2e_cold = None
+    if e2e is not None and not args.resident and not args.no_cold_leg:
+        # the same leg on a cold file: the BAM's pages are written back and dropped from the page cache first ("BAM on
+        # local NVMe"; `value` reads it from the page cache it was written through).  Reported beside `value`, never as `value`.
+        e2e_cold = run_from_file(args, e2e, hot, run, fasta, opts, dev, sync_all, cores, world, workers, grouped, engine=os.environ.get("SVX_INGEST", "auto"), keep=True, cold=True)
     if e2e is not None and not args.no_other_engine:
         # the file-inclusive leg with the other ingest engine, reported beside it (default engine: BGZF inflate + record packing
         # on the device; the other: libdeflate on the host's threads)
@@ -438,6 +467,15 @@ def main():
         import shutil
         shutil.rmtree(e2e["dir"], ignore_errors=True)
 
+    # the N-GPU first-contact checklist (every rank takes part in the two small gathers)
+    file_bytes = [int(e2e["bytes"]) if e2e is not None else 0]
+    if grouped:
+        gathered = [None] * world
+        tdist.all_gather_object(gathered, file_bytes[0])
+        file_bytes = gathered
+    contact = first_contact(world, grouped, tdist.get_backend() if grouped else None, getattr(args, "rank_mb", None), file_bytes, sdist.gather_identities())
+    if rank == 0 and world > 1:
+        print("first contact: %s" % json.dumps(contact), file=sys.stderr)
     B = args.batch
     headline_e2e = e2e_block is not None
     stage = e2e_block["stage"] if headline_e2e else res_stage       # the device stage over the timed region of `value`
@@ -486,6 +524,11 @@ def main():
                                     "binned qualities) -- read, BGZF inflate + record packing (ingest engine: %s), device scan, collection, encode + "
                                     "CNN, vote -- to the end of the cross-rank exchange" % (e2e_block["bam_bytes"], e2e_block["ingest_engine"]))
                                    if headline_e2e else "resident: alignments decoded and in HBM before the timed region (--resident, or a workload without a file leg)",
+                   "warm_state": ("`value` is measured in a process that has run --warmup windows through both paths before: the caching allocator holds one block "
+                                  "of min(48 GB, 8 x the file) allocated during set-up, the pinned staging ring and the kernels' code objects exist, and the BAM "
+                                  "sits in the page cache it was written through.  e2e_cold_cache is the same leg with the file's pages dropped first; a first "
+                                  "command-line run of a fresh process additionally pays the first hipMalloc / hipHostMalloc calls (0.15-0.35 s, measured: "
+                                  "tools/e2e_cli_timing.py)") if headline_e2e else None,
                    "step": ("one chromosome" if args.workload == "contig" else "one 10 Mb collection window") +
                            " through [file -> inflate -> records ->] scan -> collection -> encode + CNN (batches of %d candidate images, fp32) -> vote" % B,
                    "batch": B, "alignments_rank0": len(table), "cigar_ops_rank0": int(table.cigar.size),
@@ -494,7 +537,8 @@ def main():
                    "resident_sites_per_s": res_sites / dt, "resident_seconds": dt, "resident_steps": steps_job,
                    "resident_ms_per_step": dt / max(steps_job, 1) * 1e3,
                    "file_inclusive_over_resident": (job_sites / job_s) / max(res_sites / dt, 1e-9) if headline_e2e else None,
-                   "rccl_world": world if grouped else 0, "dist_backend": (tdist.get_backend() if grouped else None),
+                   "rccl_world": world if grouped and tdist.get_backend() == "nccl" else 0, "dist_backend": (tdist.get_backend() if grouped else None),
+                   "first_contact": contact,
                    "rank_mb": [round(v, 1) for v in getattr(args, "rank_mb", [])] or None,
                    "imbalance": (max(args.rank_mb) / (sum(args.rank_mb) / len(args.rank_mb)) if getattr(args, "rank_mb", None) else None),
                    "host_workers_per_rank": workers, "host_modules_compiled": not build_host.compiled_state()[1], "host_cores": cores, "host_cpus_visible": visible_cpus, "streams": args.streams, "batches_per_launch": args.launch_batches,
@@ -541,6 +585,12 @@ def main():
         e2e_block["resident_sites_per_s"] = res_sites / dt
         e2e_block["ratio_to_resident"] = e2e_block["value"] / max(res_sites / dt, 1e-9)
         line["e2e"] = e2e_block
+    if e2e_cold is not None:
+        e2e_cold["ratio_to_resident"] = e2e_cold["value"] / max(res_sites / dt, 1e-9)
+        e2e_cold["note"] = ("the file-inclusive leg once more with the BAM (and its index) dropped from the page cache first (fsync + posix_fadvise DONTNEED; "
+                            "page_cache.after_drop = the fraction of its pages still cached when the leg started, .filesystem = where it lies): the reads come "
+                            "from the box's disk.  Allocator, staging ring and code objects are as warm as in `value`.")
+        line["e2e_cold_cache"] = e2e_cold
     if e2e_other is not None:
         e2e_other["ratio_to_resident"] = e2e_other["value"] / max(res_sites / dt, 1e-9)
         line["e2e_host_ingest" if e2e_other["ingest_engine"] == "cpu" else "e2e_device_ingest"] = e2e_other
@@ -557,7 +607,67 @@ def main():
         tdist.destroy_process_group()
 
 
-def run_from_file(args, e2e, hot, run, fasta, opts, dev, sync_all, cores, world, workers, grouped, engine="cpu", keep=False):
+def cached_fraction(path):
+    """Fraction of a file's pages that sit in the page cache (mincore over a mapping of it); None where that cannot be asked."""
+    import ctypes
+    import mmap
+    try:
+        size = os.path.getsize(path)
+        if size == 0:
+            return 0.0
+        with open(path, "rb") as f:
+            m = mmap.mmap(f.fileno(), size, prot=mmap.PROT_READ)
+        try:
+            page = mmap.PAGESIZE
+            n = (size + page - 1) // page
+            vec = (ctypes.c_ubyte * n)()
+            libc = ctypes.CDLL(None, use_errno=True)
+            # mmap objects opened read-only do not export a writable buffer: take the address through a NumPy view
+            arr = np.frombuffer(m, dtype=np.uint8)
+            rc = libc.mincore(ctypes.c_void_p(arr.ctypes.data), ctypes.c_size_t(size), vec)
+            del arr
+            if rc != 0:
+                return None
+            return float(sum(v & 1 for v in vec)) / n
+        finally:
+            m.close()
+    except Exception:                                          # noqa: BLE001 -- a report, never a failure
+        return None
+
+
+def drop_file_cache(paths):
+    """Write the files back and ask the kernel to drop their pages (posix_fadvise DONTNEED) -> {path: cached fraction afterwards}:
+    what a first run on a file that nobody has read yet finds.  (A file on tmpfs stays where it is: its pages ARE the file.)"""
+    out = {}
+    for path in paths:
+        try:
+            fd = os.open(path, os.O_RDONLY)
+            try:
+                os.fsync(fd)
+                os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+            finally:
+                os.close(fd)
+        except OSError:
+            pass
+        out[os.path.basename(path)] = cached_fraction(path)
+    return out
+
+
+def filesystem_of(path):
+    best = ("", "?")
+    try:
+        real = os.path.realpath(path)
+        with open("/proc/mounts") as f:
+            for line in f:
+                _dev, mnt, fstype = line.split()[:3]
+                if (real == mnt or real.startswith(mnt.rstrip("/") + "/")) and len(mnt) > len(best[0]):
+                    best = (mnt, fstype)
+    except OSError:
+        pass
+    return best[1]
+
+
+def run_from_file(args, e2e, hot, run, fasta, opts, dev, sync_all, cores, world, workers, grouped, engine="cpu", keep=False, cold=False):
     """The file-inclusive leg (wall of Step 1 + Step 2 with the BAM on local disk): a timed region of its
     own that starts with nothing but the file -- svx_bam_stream_* reads and inflates it on host threads chromosome by
     chromosome, every chromosome is uploaded and scanned on the device when it arrives and handed to the helpers through
@@ -571,9 +681,15 @@ def run_from_file(args, e2e, hot, run, fasta, opts, dev, sync_all, cores, world,
     from svision_amd.ingest import decode_threads
     threads = args.decode_threads or decode_threads(world, workers)
     resident = hot.feed
+    cache = None
+    if cold:                                                   # the leg beside `value` that reads the file from the disk, not from the page cache
+        cache = {"after_drop": drop_file_cache([e2e["path"], e2e["path"] + ".bai"]), "filesystem": filesystem_of(e2e["path"])}
     sync_all()
     t0 = time.perf_counter()
-    feed = ChromosomeFeed(e2e["path"], fasta, opts, refs, header_refs, lens, device=dev, index=e2e["path"] + ".bai", threads=threads, engine=engine)
+    tasks = {}
+    for c, a, b in e2e["windows"]:
+        tasks.setdefault(c, []).append((a, b))
+    feed = ChromosomeFeed(e2e["path"], fasta, opts, refs, header_refs, lens, device=dev, index=e2e["path"] + ".bai", threads=threads, engine=engine, tasks=tasks)
     hot.feed = feed
     try:
         sites, images, records, scores = run(e2e["windows"], rescan=False)
@@ -607,7 +723,10 @@ def run_from_file(args, e2e, hot, run, fasta, opts, dev, sync_all, cores, world,
         dt = float(tmax.item())
     tot = tot.cpu().numpy()
     st = feed.stats
-    return {"ingest_engine": st.get("engine"), "value": float(tot[0]) / dt, "unit": "sites/s", "seconds": dt, "windows": int(tot[2]), "sites": int(tot[0]), "images": int(tot[1]),
+    if cache is not None:
+        cache["after_leg"] = {os.path.basename(e2e["path"]): cached_fraction(e2e["path"])}
+    return {"page_cache": cache if cache is not None else "warm (the file was written during set-up and read by the warm-up pass)",
+            "ingest_engine": st.get("engine"), "value": float(tot[0]) / dt, "unit": "sites/s", "seconds": dt, "windows": int(tot[2]), "sites": int(tot[0]), "images": int(tot[1]),
             "bam_bytes": int(tot[3]), "inflated_bytes": int(tot[4]), "compressed_GB_per_s": float(tot[3]) / dt / 1e9,
             "inflated_GB_per_s": float(tot[4]) / dt / 1e9, "inflate_threads_per_rank": threads, "device_busy_frac": float(tot[5]) * 1e-3 / world / dt,
             "cnn_span_ms_rank0": cnn_span, "cnn_gaps_ms_rank0": cnn_gaps,        # from the first launch's upload: [start of the gap, length] of every pause > 3 ms

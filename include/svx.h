@@ -21,7 +21,8 @@
 extern "C" {
 #endif
 
-#define SVX_VERSION 370            /* 0.3.0: + svx_bgzf_crc32, svx_bgzf_inflate_fast (360); + svx_bgzf_inflate_fast_on: the two kernels on two streams (370) */
+#define SVX_VERSION 380            /* 0.3.0: + svx_bgzf_crc32, svx_bgzf_inflate_fast (360); + svx_bgzf_inflate_fast_on: the two kernels on two streams (370);
+                                    * svx_bgzf_inflate_fast / _on take the inflated byte count and refuse a workspace that is too small (380) */
 
 #define SVX_OK            0
 #define SVX_EINVAL       (-1)      /* bad argument (null pointer, bad layout...) */
@@ -285,21 +286,22 @@ int            svx_bgzf_inflate_private(const uint8_t* d_comp, const uint64_t* d
 /* The same contract in two kernels (svx_inflate2.hip): (A) one WAVE per block decodes the Huffman code in parallel -- 64
  * segments of the compressed bits per step, every lane from its segment's first bit, re-synchronised with its predecessor --
  * and transcodes the tokens into a byte-aligned LZ sequence stream; (B) one LANE per block copies literals and matches
- * from that stream.  d_ws: svx_bgzf_inflate_fast_ws_bytes(d_dst_off[n] - d_dst_off[0], n) bytes (16-byte aligned) for the
+ * from that stream.  inflated_bytes: d_dst_off[n] - d_dst_off[0] (the caller summed the ISIZE fields on the host).  d_ws: at least
+ * svx_bgzf_inflate_fast_ws_bytes(inflated_bytes, n) bytes (16-byte aligned; SVX_EINVAL if ws_bytes is less) for the
  * sequence streams.  Same statuses; blocks whose stream would not fit its slot (pathological: hundreds of tiny DEFLATE
  * blocks) are decoded by the wave-per-block kernel inside the call. */
 size_t         svx_bgzf_inflate_fast_ws_bytes(uint64_t inflated_bytes, uint32_t n_blocks);
 int            svx_bgzf_inflate_fast(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len,
-                                     const uint64_t* d_dst_off, uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status,
-                                     void* d_ws, uint64_t ws_bytes, void* stream);
+                                     const uint64_t* d_dst_off, uint32_t n_blocks, uint64_t inflated_bytes, uint8_t* d_out,
+                                     uint32_t* d_status, void* d_ws, uint64_t ws_bytes, void* stream);
 /* The same with kernel A on stream_tokens and kernel B (and whatever follows in the caller's order: the CRC, the record walk)
  * on stream_lz, which waits for A through an event.  A caller with several launches in flight puts every A on ONE stream:
  * the tokens kernels own the chip while they run, so two of them launched side by side on two streams finish together --
  * late --, while one after the other the first launch's blocks go on to their LZ copies (latency-bound, next to the second
  * launch's A) a whole A earlier.  stream_tokens == stream_lz: svx_bgzf_inflate_fast. */
 int            svx_bgzf_inflate_fast_on(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len,
-                                        const uint64_t* d_dst_off, uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status,
-                                        void* d_ws, uint64_t ws_bytes, void* stream_tokens, void* stream_lz);
+                                        const uint64_t* d_dst_off, uint32_t n_blocks, uint64_t inflated_bytes, uint8_t* d_out,
+                                        uint32_t* d_status, void* d_ws, uint64_t ws_bytes, void* stream_tokens, void* stream_lz);
 /* CRC32 of every inflated block against the block's footer -- the four bytes behind its DEFLATE payload in d_comp (RFC 1952
  * 2.3.1) -- what htslib checks on every block behind pysam's fetch (/root/reference/src/collection/run_collection.py:23-26).
  * d_out / d_dst_off / d_comp / d_src_off / d_src_len: as svx_bgzf_inflate took and wrote them.  d_status [n]: left alone where

@@ -52,8 +52,8 @@ SYMBOLS = {
     "svx_bgzf_inflate_lds": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
     "svx_bgzf_inflate_private": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
     "svx_bgzf_inflate_fast_ws_bytes": (_sz, [_u64, _u32]),
-    "svx_bgzf_inflate_fast": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _u64, _vp]),
-    "svx_bgzf_inflate_fast_on": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _u64, _vp, _vp]),
+    "svx_bgzf_inflate_fast": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _u64, _vp, _vp, _vp, _u64, _vp]),
+    "svx_bgzf_inflate_fast_on": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _u64, _vp, _vp, _vp, _u64, _vp, _vp]),
     "svx_bgzf_crc32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp]),
     "svx_bam_walk_count": (ctypes.c_int, [_vp, _vp, _u32, _vp, _vp]),
     "svx_bam_walk_extract": (ctypes.c_int, [_vp, _vp, _u32, _vp] + [_vp] * 9 + [_vp]),
@@ -77,7 +77,7 @@ class SvxMissing(SvxError):
 _lib = None
 
 
-ABI_VERSION = 370                     # SVX_VERSION of include/svx.h this binding was written against
+ABI_VERSION = 380                     # SVX_VERSION of include/svx.h this binding was written against
 
 
 def load():

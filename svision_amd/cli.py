@@ -208,7 +208,8 @@ def run(options, sample=None, classifier=None):
             from .ingest import decode_threads
             threads = decode_threads(int(os.environ.get("LOCAL_WORLD_SIZE", ws)), options.thread_num)      # inflate threads of this rank
             feed = ChromosomeFeed(options.bam_path, fasta, options, [c for c in mine if c in references], references, lengths,
-                                  device=torch.device("cuda", torch.cuda.current_device()), index=find_index(options.bam_path), threads=threads)
+                                  device=torch.device("cuda", torch.cuda.current_device()), index=find_index(options.bam_path), threads=threads,
+                                  tasks={c: tasks[c] for c in mine if c in tasks})
             logging.info("rank %d/%d: %s streamed from %s with %d decode threads", rank, ws, ",".join(mine) or "-", options.bam_path, threads)
         else:
             feed = StaticFeed(sample)
@@ -337,26 +338,28 @@ def _run_streaming(options, feed, tasks, chroms, seg_dir, pred_dir):
     hot = HotPath(None, options, net, n_streams=3)
     _t1 = _time.time()
     for chrom in chroms:
-        _key, sample = feed.get(chrom, block=True)                # waits for the chromosome's records (decoded ahead)
-        hot.sample = sample
         prefix = os.path.join(pred_dir, "%s.predict.s%s" % (chrom, options.min_support))
         with open(prefix + ".score.txt", "w") as score_out, open(prefix + ".vcf", "w") as vcf_out, \
                 open(os.path.join(seg_dir, chrom + ".segments.all.bed"), "w") as all_bed:
-            voter = SiteVoter(Predict(chrom, None), vcf_out, score_out, options, sample)
+            voter = SiteVoter(Predict(chrom, None), vcf_out, score_out, options, None)
             logging.info("Predicting " + chrom)
 
             def feed_votes(res):
                 classes, probs = hot.fetch_predictions(res)
+                voter.next_sample = res.sample                    # a site is written on the records of the window that opened it
                 voter.feed_batch([ln.label() for ln in res.lines], classes, probs)
 
             prev = None
             for part, (start, end) in enumerate(tasks[chrom]):
+                # waits for the window's records (decoded ahead; the device engine hands a chromosome over in slices of windows)
+                _key, hot.sample = feed.get(chrom, block=True, start=start)
                 try:
                     cur = hot.collect(chrom, start, end, rescan=False)
                 except Exception:                                 # run_collection.py:44-47: the window yields nothing
                     _t, value, trace = sys.exc_info()
                     logging.error("%s:%s-%s [ERROR]: %s. Locate At: %s", chrom, start, end, value, traceback.extract_tb(trace))
                     cur = hot.empty(chrom, start, end)
+                cur.sample = hot.sample
                 text = "".join(ln.text() for ln in cur.lines)
                 with open(os.path.join(seg_dir, "%s.segments.%d.bed" % (chrom, part)), "w") as f:
                     f.write(text)
@@ -394,8 +397,8 @@ def _run_pooled(options, feed, tasks, chroms, seg_dir, pred_dir, pool=None):
 
     def write_chromosome(chrom):
         wids = range(first[chrom], first[chrom] + len(tasks[chrom]))
-        _key, sample = feed.get(chrom, block=True)
-        texts = stitch_windows([done[w] for w in wids], options, sample)      # per-chromosome vote: edge sites written once
+        texts = stitch_windows([done[w] for w in wids], options,               # per-chromosome vote: edge sites written once
+                               lambda c, start: feed.get(c, block=True, start=start)[1])
         vcf_text, score_text = texts.get(chrom, ("", ""))
         prefix = os.path.join(pred_dir, "%s.predict.s%s" % (chrom, options.min_support))
         logging.info("Predicting " + chrom)

@@ -38,11 +38,13 @@ struct Tables {
     uint32_t tail[LANES];                                    // x^(32 (64 - l)) mod P
 };
 
-// built once per process on the host (2 M shift steps), kept in device memory
+// built once per process on the host (2 M shift steps), one copy in the memory of every device that asks for it
 const Tables* device_tables()
 {
-    static const Tables* d_tab = nullptr;
+    static Tables* host = nullptr;
     static std::once_flag once;
+    static std::mutex lock;
+    static const Tables* d_tab[64] = {};
     std::call_once(once, [] {
         Tables* h = new Tables;
         for (int k = 0; k < 4; ++k)
@@ -51,12 +53,17 @@ const Tables* device_tables()
                 h->stride[k][b] = times_x((uint32_t)b << (8 * k), 2048);
             }
         for (int l = 0; l < LANES; ++l) h->tail[l] = times_x(0x80000000u, 32 * (LANES - l));
-        void* d = nullptr;
-        if (hipMalloc(&d, sizeof(Tables)) == hipSuccess && hipMemcpy(d, h, sizeof(Tables), hipMemcpyHostToDevice) == hipSuccess)
-            d_tab = static_cast<const Tables*>(d);
-        delete h;
+        host = h;
     });
-    return d_tab;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> g(lock);
+    if (!d_tab[dev]) {
+        void* d = nullptr;
+        if (hipMalloc(&d, sizeof(Tables)) == hipSuccess && hipMemcpy(d, host, sizeof(Tables), hipMemcpyHostToDevice) == hipSuccess)
+            d_tab[dev] = static_cast<const Tables*>(d);
+    }
+    return d_tab[dev];
 }
 
 // a * b mod P (32 shift-and-add steps)

@@ -499,7 +499,9 @@ void bgzf_lz_kernel(const uint8_t* __restrict__ streams, const uint32_t* __restr
 
 extern "C" size_t svx_bgzf_inflate_fast_ws_bytes(uint64_t inflated_bytes, uint32_t n_blocks)
 {
-    return (size_t)(inflated_bytes + (inflated_bytes >> 1) + 1024ull * n_blocks + 4ull * n_blocks + 256);
+    // [stream lengths: 4 n, rounded up to 256][the blocks' slots: 1.5 x ISIZE + 1 KB each][64 bytes: svx_lz::decode_block reads a
+    // header and the 12 bytes behind it with one 16-byte load, also at the end of the last slot]
+    return (size_t)((((size_t)4 * n_blocks + 255) & ~(size_t)255) + inflated_bytes + (inflated_bytes >> 1) + 1024ull * n_blocks + 64);
 }
 
 // The contract of svx_bgzf_inflate with a workspace (svx_bgzf_inflate_fast_ws_bytes(d_dst_off[n] - d_dst_off[0], n) bytes, 16-byte
@@ -508,16 +510,18 @@ extern "C" __attribute__((visibility("hidden"))) int svx_bgzf_inflate_wave_only(
                                           uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, uint32_t only, void* stream);
 
 extern "C" int svx_bgzf_inflate_fast_on(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len, const uint64_t* d_dst_off,
-                                        uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, void* d_ws, uint64_t ws_bytes, void* stream_tokens,
-                                        void* stream_lz)
+                                        uint32_t n_blocks, uint64_t inflated_bytes, uint8_t* d_out, uint32_t* d_status, void* d_ws, uint64_t ws_bytes,
+                                        void* stream_tokens, void* stream_lz)
 {
     if (n_blocks == 0) return SVX_OK;
     if (!d_comp || !d_src_off || !d_src_len || !d_dst_off || !d_out || !d_status || !d_ws) return SVX_EINVAL;
     if (reinterpret_cast<uintptr_t>(d_ws) & 15u) return SVX_EINVAL;
+    // inflated_bytes = d_dst_off[n] - d_dst_off[0], which the caller summed on the host (the array itself is device memory):
+    // the slots of the sequence streams are laid out by it, so a smaller workspace would be overrun by the tokens kernel
+    if (ws_bytes < svx_bgzf_inflate_fast_ws_bytes(inflated_bytes, n_blocks)) return SVX_EINVAL;
     hipStream_t sa = static_cast<hipStream_t>(stream_tokens), sb = static_cast<hipStream_t>(stream_lz);
     uint32_t* stream_len = static_cast<uint32_t*>(d_ws);
     uint8_t* streams = static_cast<uint8_t*>(d_ws) + (((size_t)4 * n_blocks + 255) & ~(size_t)255);
-    (void)ws_bytes;
     const char* only = getenv("SVX_INFLATE2_ONLY");                          // measurements: "A" = kernel A alone (the output stays unwritten),
     if (!only && getenv("SVX_INFLATE2_ONLY_A")) only = "A";                  // "B" = kernel B alone on the streams an earlier call left in the same workspace
     if (!only || only[0] != 'B') {
@@ -545,7 +549,8 @@ extern "C" int svx_bgzf_inflate_fast_on(const uint8_t* d_comp, const uint64_t* d
 }
 
 extern "C" int svx_bgzf_inflate_fast(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len, const uint64_t* d_dst_off,
-                                     uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, void* d_ws, uint64_t ws_bytes, void* stream)
+                                     uint32_t n_blocks, uint64_t inflated_bytes, uint8_t* d_out, uint32_t* d_status, void* d_ws, uint64_t ws_bytes,
+                                     void* stream)
 {
-    return svx_bgzf_inflate_fast_on(d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, d_out, d_status, d_ws, ws_bytes, stream, stream);
+    return svx_bgzf_inflate_fast_on(d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, inflated_bytes, d_out, d_status, d_ws, ws_bytes, stream, stream);
 }

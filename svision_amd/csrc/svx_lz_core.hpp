@@ -24,7 +24,7 @@
 #include <stdint.h>
 #include <string.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define SVX_HD __host__ __device__ __forceinline__
 #else
 #define SVX_HD inline

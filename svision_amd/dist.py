@@ -51,9 +51,56 @@ def init_from_env(timeout_hours=24.0):
         import datetime
         kw = {}
         if backend == "nccl":                  # bind the communicator to this rank's GPU (otherwise guessed from the global rank)
+            # one process per GPU: more local ranks than visible devices would put two ranks on one device, which RCCL answers
+            # with a hang or an obscure "duplicate GPU" error minutes later.  Said here, at once, on every rank.
+            local_ws, n_dev = int(os.environ.get("LOCAL_WORLD_SIZE", ws)), torch.cuda.device_count()
+            if local_ws > n_dev:
+                raise RuntimeError("%d ranks on this node but %d visible GPU(s): rank %s would share cuda:%d with another rank under RCCL "
+                                   "(one process per GPU; SVX_DIST_BACKEND=gloo runs several ranks on one device for rehearsals)"
+                                   % (local_ws, n_dev, os.environ.get("RANK", "?"), local_device_index()))
             kw["device_id"] = torch.device("cuda", local_device_index())
         dist.init_process_group(backend, timeout=datetime.timedelta(hours=timeout_hours), **kw)
+        if backend == "nccl":
+            assert_one_device_per_rank()
     return world()
+
+
+def device_identity():
+    """(host name, physical identity of this rank's GPU): the device's UUID where the runtime reports one, else its PCI bus id."""
+    import socket
+    if not torch.cuda.is_available():
+        return socket.gethostname(), "cpu"
+    i = torch.cuda.current_device()
+    props = torch.cuda.get_device_properties(i)
+    ident = str(getattr(props, "uuid", "")) or ""
+    if not ident or set(ident) <= set("0-"):
+        ident = "pci:%s:%s:%s" % (getattr(props, "pci_domain_id", "?"), getattr(props, "pci_bus_id", i), getattr(props, "pci_device_id", "?"))
+    return socket.gethostname(), ident
+
+
+def duplicate_devices(identities):
+    """[(host, device identity) per rank] -> {(host, identity): [ranks]} of the devices that more than one rank resolved to."""
+    seen = {}
+    for r, ident in enumerate(identities):
+        seen.setdefault(tuple(ident), []).append(r)
+    return {k: v for k, v in seen.items() if len(v) > 1}
+
+
+def gather_identities():
+    """Every rank's :func:`device_identity`, on every rank (one small all_gather_object; [own] without a group)."""
+    if not world_initialized():
+        return [device_identity()]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, device_identity())
+    return [tuple(x) for x in out]
+
+
+def assert_one_device_per_rank():
+    """Under RCCL every rank must own a GPU of its own (HIP_VISIBLE_DEVICES masks, a launcher that sets LOCAL_RANK wrongly):
+    checked once, right after the group is up, and fatal on every rank."""
+    dup = duplicate_devices(gather_identities())
+    if dup:
+        raise RuntimeError("ranks share a GPU under the nccl (RCCL) backend: %s" % "; ".join("%s %s <- ranks %s" % (h, d, r) for (h, d), r in sorted(dup.items())))
 
 
 def _comm_device():

@@ -13,6 +13,7 @@ Two feeds, one interface (``poll`` / ``get`` / ``release``):
   StaticFeed      a Sample that is already complete (tests, ``bench.py`` with the alignments resident in HBM)
   ChromosomeFeed  the file-driven one (the command line, ``bench.py --from-bam``)
 """
+import itertools
 import os
 import queue
 import shutil
@@ -25,6 +26,8 @@ import numpy as np
 from .io.bam import AlignmentTable, BamStream
 from . import streams
 from .sample import Sample
+
+_KEYS = itertools.count()                                    # keys of the parts announced to the helper processes (pipeline.PooledHotPath)
 
 
 def effective_cpus():
@@ -78,11 +81,11 @@ class StaticFeed:
     def take_fresh(self):
         return []
 
-    def get(self, chrom, block=True):
+    def get(self, chrom, block=True, start=None):
         return None, self.sample
 
-    def key_of(self, chrom):
-        return None
+    def keys_of(self, chrom):
+        return []
 
     def release(self, chrom):
         pass
@@ -97,8 +100,13 @@ class ChromosomeFeed:
     scanning, and blocked on a full hand-over queue; bytes of packed CIGAR uploaded."""
 
     def __init__(self, bam_path, fasta, options, chroms, references, lengths, device="cuda", index=None, threads=0, depth=2,
-                 engine=None, header_text=""):
+                 engine=None, header_text="", tasks=None):
         self.bam_path, self.fasta, self.options = bam_path, fasta, options
+        # tasks: {chromosome: [[start, end], ...]} -- the job's collection windows (cli.build_tasks).  With them the device engine
+        # hands a chromosome over in SLICES of whole windows (ingest_gpu.DeviceDecoder.plan_units) instead of in one piece: the
+        # first window of a 3 GB chromosome starts after its first ~200 MB, as the reference's window-by-window fetch does
+        # (run_collection.py:23-26).  None: whole chromosomes.
+        self.tasks = None if tasks is None else {c: [(int(a), int(b)) for a, b in w] for c, w in tasks.items()}
         self.header_text = header_text
         # where the BGZF blocks are inflated: "gpu" = on the device (ingest_gpu.DeviceDecoder), "cpu" = libdeflate on host
         # threads (io.bam.BamStream), "auto" (the default; SVX_INGEST overrides) = the device whenever it can: the file has a
@@ -114,12 +122,13 @@ class ChromosomeFeed:
         shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
         self.root = tempfile.mkdtemp(prefix="svx_feed_", dir=shm)
         self.handover = queue.Queue(maxsize=depth)           # feeder thread -> owner thread
-        self.samples = {}                                      # chrom -> (key, Sample, meta) once the owner has seen it
+        self.samples = {}                                      # chrom -> [[lo, hi, key, Sample, meta], ...] (ascending; a whole chromosome: one entry) once the owner has seen them
         self.fresh = []                                        # (key, meta) not yet announced to the helpers
         self.error = None
         self.finished = False
         self.stats = {"engine": None, "decode_wait_s": 0.0, "upload_scan_s": 0.0, "handover_wait_s": 0.0, "cigar_bytes": 0, "records": 0,
-                      "first_ready_s": None, "last_ready_s": None}
+                      "first_ready_s": None, "last_ready_s": None, "slices": 0, "replans": 0}
+        self._epoch, self._replan, self._acked = 0, None, (0, 0)   # slices cut again with a larger margin (_run -> _decode)
         self._t0 = time.perf_counter()
         self._stop = False
         self._slot_lock, self._free_slots, self._n_slots = threading.Lock(), [], 0
@@ -177,13 +186,15 @@ class ChromosomeFeed:
             self._free_slots.append(d)
 
     def _run(self):
-        """Stage B of the feeder (this thread): QNAME ids, upload (host engine) + device scan, hand-over.  Stage A (a thread
-        of its own, :meth:`_decode`) reads / inflates / packs the next chromosome meanwhile."""
+        """Stage B of the feeder (this thread): QNAME ids, upload (host engine) + device scan, the check that a slice holds
+        every record its windows can touch, hand-over.  Stage A (a thread of its own, :meth:`_decode`) reads / inflates /
+        packs the next chromosomes / slices meanwhile."""
         import torch
         decoded = queue.Queue(maxsize=2)
         try:
             tids = [self.references.index(c) for c in self.chroms]
-            want = list(tids)
+            want = list(tids)                                  # chromosomes not completely handed over yet, in task order
+            covered = {}                                       # tid -> the coordinate up to which its windows have been handed over
             if not torch.cuda.is_available():
                 raise RuntimeError("ChromosomeFeed needs the GPU (svx_cigar_scan); there is no CPU fallback")
             engine = self.engine
@@ -197,6 +208,7 @@ class ChromosomeFeed:
             scan_stream = streams.get("scan", self.device)      # (a hardware queue of its own: svision_amd/streams.py)
             spill = queue.Queue()
             threading.Thread(target=self._spill, args=(spill,), name="svx-spill", daemon=True).start()
+            inf = float("inf")
             while not self._stop:
                 t0 = time.perf_counter()
                 try:
@@ -209,7 +221,9 @@ class ChromosomeFeed:
                     break
                 if isinstance(item, BaseException):
                     raise item
-                table, arrays = item
+                epoch, unit, table, arrays = item
+                if epoch != self._epoch:                       # decoded before the slices were cut again (a margin that was too small)
+                    continue
                 t0 = time.perf_counter()
                 dec = getattr(self, "decoder", None)
                 if dec is not None:
@@ -219,12 +233,23 @@ class ChromosomeFeed:
                         _sample_mod._MARK = dec._mark
                 if callable(table):                            # device engine: the QNAME ids are still to be computed
                     table = table()
-                tid = int(table.tid[0])
-                while want and want[0] != tid:                 # chromosomes of this rank without a record in the file
-                    self._emit_empty(want.pop(0))
+                tid = unit.tid if unit is not None else int(table.tid[0])
+                while want and want[0] != tid:                 # chromosomes of this rank without a record in the file (or without one in the rest of it)
+                    t_ = want.pop(0)
+                    self._emit_empty(t_, covered.get(t_, 0))
                 if not want:
                     break
-                want.pop(0)
+                # what the part serves: a whole chromosome from the host engine = everything of it not handed over yet
+                lo = covered.get(tid, 0) if unit is None else max(unit.lo, covered.get(tid, 0))
+                last = unit is None or unit.last
+                hi = inf if last else unit.hi
+                if table is None:                              # a slice without a record
+                    self._emit_empty(tid, lo, hi)
+                    self._acked = (epoch, self._acked[1] + 1 if self._acked[0] == epoch else 1)
+                    covered[tid] = hi
+                    if last:
+                        want.pop(0)
+                    continue
                 with torch.cuda.stream(scan_stream):
                     if arrays is None:
                         sample = Sample.from_table(table, self.fasta, self.options.min_sv_size, self.device)
@@ -233,11 +258,24 @@ class ChromosomeFeed:
                 alloc = table._alloc
                 if dec is not None:
                     dec._mark("consumer: scanned")
+                if unit is not None and not self._slice_complete(unit, sample):
+                    # the records of this slice reach farther than the margin it was cut with: it may miss records its windows'
+                    # clusters count or genotype with.  Nothing of it is handed over; stage A cuts the rest of the file again.
+                    self.stats["replans"] += 1
+                    if dec is not None:
+                        dec._mark("slice %r rejected: reach %d" % (unit, sample.reach()))
+                    self._replan = (epoch, tid, lo, sample.reach())
+                    self._epoch = epoch + 1
+                    sample.device_buffers = None
+                    if getattr(alloc, "dir", None) is not None:
+                        self._slot_free(alloc.dir)
+                    continue
                 for name, arr in (("gaps", sample.gaps), ("gap_off", sample.gap_off), ("stats", sample.stats)):
                     alloc.put(name, arr)
                 self.stats["upload_scan_s"] += time.perf_counter() - t0
                 self.stats["cigar_bytes"] += int(table.cigar.nbytes)
                 self.stats["records"] += len(table)
+                self.stats["slices"] += 1
                 meta = {"dir": alloc.dir, "arrays": dict(alloc.arrays), "references": self.references, "lengths": self.lengths,
                         "min_sv": self.options.min_sv_size, "n": len(table), "with_seq": self.with_seq, "header_text": table.header_text,
                         "stats_shape": list(np.shape(sample.stats))}
@@ -245,12 +283,17 @@ class ChromosomeFeed:
                     meta["lazy_cigar"] = int(table.cigar.size)
                     meta["spilled"] = threading.Event()
                     spill.put((table, meta["spilled"]))
-                if getattr(self, "decoder", None) is not None:
-                    self.decoder._mark("handed over %s (scan + slot writes)" % self.references[tid])
-                    self.decoder.first_handover.set()           # (the decoder holds its second launch back for this, ingest_gpu.py)
-                self._put((self.references[tid], sample, meta))
+                if dec is not None:
+                    dec._mark("handed over %s [%s, %s) (scan + slot writes)" % (self.references[tid], lo, hi))
+                    dec.first_handover.set()                    # (the decoder holds its second launch back for this, ingest_gpu.py)
+                covered[tid] = hi
+                if last:
+                    want.pop(0)
+                self._put((self.references[tid], lo, hi, sample, meta))
+                self._acked = (epoch, self._acked[1] + 1 if self._acked[0] == epoch else 1)
             while want and not self._stop:
-                self._emit_empty(want.pop(0))
+                t_ = want.pop(0)
+                self._emit_empty(t_, covered.get(t_, 0))
             if getattr(self, "decoder", None) is not None:
                 self.stats["device_decoder"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in self.decoder.stats.items()}
                 self.stats["device_decoder"]["trace"] = ["%.3f %s" % (t + (self.decoder._t0 - self._t0), w) for t, w in self.decoder.trace[:400]]
@@ -268,6 +311,19 @@ class ChromosomeFeed:
             except NameError:
                 pass
             self.handover.put(None)
+
+    @staticmethod
+    def _slice_complete(unit, sample):
+        """Does the slice hold every record its windows can touch?  Everything a window [a, b) of it does -- collection,
+        cluster coverage (classes.py:165-170), genotyping (genotype.py:22-26: +-1000 bp) -- stays within ``reach`` =
+        Sample.reach() of [a, b): on the left the slice starts at the linear-index entry of ``left_edge`` (every record
+        reaching beyond that coordinate lies behind it), on the right it ends in front of a record that starts at or behind
+        its last one (the file is sorted)."""
+        reach = sample.reach()
+        table = sample.table
+        left = unit.left_edge is None or unit.left_edge <= unit.lo - reach
+        right = unit.to_end or (len(table) > 0 and int(table.pos[-1]) >= unit.hi + reach)
+        return left and right
 
     def _spill(self, jobs):
         """Stage C: host copies of the device-decoded CIGAR words (ingest_gpu.spill_cigar), after the hand-over."""
@@ -289,8 +345,9 @@ class ChromosomeFeed:
                 done.set()
 
     def _decode(self, engine, tids, decoded):
-        """Stage A: chromosome after chromosome as (table or a callable finishing it, device arrays or None) into ``decoded``."""
-        import torch
+        """Stage A: the rank's chromosomes -- whole, or in slices of collection windows (device engine with ``tasks``) -- as
+        (epoch, unit or None, table or a callable finishing it, device arrays or None) into ``decoded``."""
+        import logging
 
         def put(item):
             while not self._stop:
@@ -301,24 +358,38 @@ class ChromosomeFeed:
                     continue
             return False
 
-        def host_parts(which):                                 # BGZF inflate on host threads (libdeflate)
-            state = {"alloc": None, "used": True, "arrays": {}}
+        state = {"epoch": 0, "put": 0}
+
+        def host_parts(which):                                 # BGZF inflate on host threads (libdeflate): whole chromosomes
+            slot = {"alloc": None, "used": True, "arrays": {}}
 
             def alloc(name, dtype, n):                         # one slot per part: "tid" is the first array of a part (io.bam._table_from_handle)
-                if name == "tid" and state["used"]:           # (a part the stream skipped leaves its slot to the next one)
-                    state["alloc"], state["used"], state["arrays"] = self._slot_alloc(), False, {}
-                arr = state["arrays"][name] = np.empty(int(n), dtype)      # the decoder fills this process's own memory ...
+                if name == "tid" and slot["used"]:            # (a part the stream skipped leaves its slot to the next one)
+                    slot["alloc"], slot["used"], slot["arrays"] = self._slot_alloc(), False, {}
+                arr = slot["arrays"][name] = np.empty(int(n), dtype)       # the decoder fills this process's own memory ...
                 return arr
             stream = BamStream(self.bam_path, with_seq=self.with_seq, threads=self.threads, tids=which, index=self.index, alloc=alloc)
             try:
                 for table in stream:
-                    for name, arr in state["arrays"].items():  # ... and the slot's files are written from it (no mapping in this process: _slot_alloc.put)
-                        state["alloc"].put(name, arr)
-                    table._alloc, state["used"] = state["alloc"], True
-                    if not put((table, None)):
-                        return
+                    for name, arr in slot["arrays"].items():   # ... and the slot's files are written from it (no mapping in this process: _slot_alloc.put)
+                        slot["alloc"].put(name, arr)
+                    table._alloc, slot["used"] = slot["alloc"], True
+                    if not put((state["epoch"], None, table, None)):
+                        return False
+                    state["put"] += 1
             finally:
                 stream.close()
+            return True
+
+        def replan_wanted():
+            rp = self._replan
+            return rp if rp is not None and rp[0] == state["epoch"] else None
+
+        def settle():
+            """Wait until stage B has looked at everything put in this epoch: the LAST slice may be the one it rejects."""
+            while not self._stop and replan_wanted() is None and self._acked != (state["epoch"], state["put"]) and state["put"]:
+                time.sleep(0.0005)
+            return replan_wanted()
 
         try:
             if engine == "gpu":                                # BGZF inflate + record packing on the device
@@ -330,42 +401,69 @@ class ChromosomeFeed:
                 if not dec.usable(tids):
                     host_parts(tids)
                 else:
-                    order = [t for _v, t in sorted((dec.spans[t][0], t) for t in tids if t < len(dec.spans) and dec.spans[t] is not None)]
-                    import logging
+                    windows_of = None
+                    if self.tasks is not None and not getattr(self.options, "contig", False):
+                        def windows_of(t):
+                            return self.tasks.get(self.references[t])
+                    # (SVX_SLICE_MARGIN: tests -- a margin that is too small must be noticed and the slices cut again)
+                    margin = (int(os.environ.get("SVX_SLICE_MARGIN", "0")) or dec.estimate_reach(tids)) if windows_of is not None else 0
+                    units = dec.plan_units(tids, windows_of, margin)
                     refusals = 0
-                    while order:
-                        done = 0
+                    while units and not self._stop:
+                        done, outcome, exc_ = 0, "end", None
                         try:
-                            for part in dec.parts_pipelined(order):
-                                if not put(part):
+                            for part in dec.units_pipelined(units):
+                                if replan_wanted() is not None:
+                                    outcome = "replan"
+                                    break
+                                if not put((state["epoch"],) + tuple(part)):
                                     return
+                                state["put"] += 1
                                 done += 1
-                            break
                         except DeviceIngestError as exc:
-                            # an index that does not fit, a corrupt block: the host reader takes that reference
-                            # and the device engine goes on behind it -- three times; then the host reader takes the rest
-                            refusals += 1
-                            # the references the error names (a group-wide failure: the whole group; a walk error: the one
-                            # chromosome) and whatever lies in front of them and has not been yielded; unnamed: the reference
-                            # the consumer waits for.  Parts must arrive in order (the feeder emits skipped references as empty).
-                            named = [order.index(t) for t in (getattr(exc, "tids", None) or []) if t in order[done:]]
-                            hi = max(named) + 1 if named else done + 1
-                            rest = order[done:] if refusals >= 3 else order[done:hi]
-                            logging.warning("device ingestion failed at reference %s (%s): decoding %s on the host",
-                                            ", ".join(self.references[t] for t in order[done:hi][-max(1, len(named)):]), exc,
-                                            "the rest of the file" if refusals >= 3 else "%d reference(s)" % len(rest))
-                            host_parts(rest)
-                            order = order[done + len(rest):]
+                            outcome, exc_ = "error", exc
+                        if outcome != "replan" and settle() is not None:
+                            outcome = "replan"                   # (an error behind a rejected slice: cut again first, the error will come back)
+                        if outcome == "replan":
+                            # a slice's records reach farther than the margin guessed from the file's first reads (ONT: a log-normal
+                            # tail): everything from that slice on is cut again with twice what it needed
+                            _ep, tid_, coord, needed = replan_wanted()
+                            margin = (max(2 * needed, 2 * margin) + 16383) >> 14 << 14
+                            state["epoch"], state["put"] = state["epoch"] + 1, 0
+                            logging.info("device ingestion: slices of %s cut again from %d on with a margin of %d bases", self.references[tid_], coord, margin)
+                            units = dec.plan_units(tids, windows_of, margin, resume=(tid_, coord))
+                            continue
+                        if outcome == "end":
+                            break
+                        # an index that does not fit, a corrupt block: the host reader takes those references -- whole; what the
+                        # device has handed over of them stays, the host's table serves the rest -- and the device engine goes on
+                        # behind them -- three times; then the host reader takes the rest of the file
+                        refusals += 1
+                        rest = units[done:]
+                        named = [i for i, u in enumerate(rest) if u.tid in (getattr(exc_, "tids", None) or [])]
+                        hi = (max(named) + 1) if named else 1
+                        bad = []
+                        for u in (rest if refusals >= 3 else rest[:hi]):
+                            if u.tid not in bad:
+                                bad.append(u.tid)
+                        logging.warning("device ingestion failed at reference %s (%s): decoding %s on the host",
+                                        ", ".join(self.references[t] for t in bad[-max(1, len({rest[i].tid for i in named})):]), exc_,
+                                        "the rest of the file" if refusals >= 3 else "%d reference(s)" % len(bad))
+                        if not host_parts(bad):
+                            return
+                        units = [u for u in rest if u.tid not in bad]
+                    settle()
             else:
                 host_parts(tids)
             put(None)
         except BaseException as exc:                           # noqa: BLE001
             put(exc)
 
-    def _emit_empty(self, tid):
+    def _emit_empty(self, tid, lo=0, hi=float("inf")):
+        """Windows [lo, hi) of a chromosome without records there: they still exist as tasks (SVision:172-201) and yield nothing."""
         meta = {"dir": None, "references": self.references, "lengths": self.lengths, "min_sv": self.options.min_sv_size, "n": 0,
                 "with_seq": self.with_seq, "header_text": ""}
-        self._put((self.references[tid], empty_sample(self.references, self.lengths, self.fasta, self.options.min_sv_size), meta))
+        self._put((self.references[tid], lo, hi, empty_sample(self.references, self.lengths, self.fasta, self.options.min_sv_size), meta))
 
     def _put(self, item):
         t0 = time.perf_counter()
@@ -374,8 +472,8 @@ class ChromosomeFeed:
 
     # ---- owner thread ----------------------------------------------------------------------------------------------
     def poll(self, block=False):
-        """Move the chromosomes the feeder has finished into ``samples`` (and onto the ``fresh`` list of what the helpers
-        have not been told yet); ``block``: wait until at least one arrives or the stream ends.  -> whether any arrived."""
+        """Move the chromosomes / slices the feeder has finished into ``samples`` (and onto the ``fresh`` list of what the
+        helpers have not been told yet); ``block``: wait until at least one arrives or the stream ends.  -> whether any arrived."""
         got = False
         while not self.finished:
             try:
@@ -389,48 +487,57 @@ class ChromosomeFeed:
                 if self.error is not None:
                     raise self.error
                 break
-            chrom, sample, meta = item
-            key = len(self.samples)
+            chrom, lo, hi, sample, meta = item
+            key = next(_KEYS)                                  # unique in the process: a helper may still hold a key of an earlier feed
             now = time.perf_counter() - self._t0
             if self.stats["first_ready_s"] is None:
                 self.stats["first_ready_s"] = now
             self.stats["last_ready_s"] = now
-            self.samples[chrom] = (key, sample, meta)
+            self.samples.setdefault(chrom, []).append([lo, hi, key, sample, meta])
             self.fresh.append((key, chrom, meta))
             got = True
         return got
 
-    def get(self, chrom, block=True):
-        """-> (key, Sample) of a chromosome, or (None, None) when it is not ready and ``block`` is False."""
-        while chrom not in self.samples:
-            if self.finished:
-                raise KeyError("chromosome %s is not part of this feed" % chrom)
-            self.poll(block=block)
-            if not block and chrom not in self.samples:
-                return None, None
-        key, sample, _meta = self.samples[chrom]
-        return key, sample
+    def _find(self, chrom, start):
+        for ent in self.samples.get(chrom, ()):
+            if start is None or ent[0] <= start < ent[1]:
+                return ent
+        return None
 
-    def key_of(self, chrom):
-        return self.samples[chrom][0]
+    def get(self, chrom, block=True, start=None):
+        """-> (key, Sample) of the part of a chromosome that serves the collection window starting at ``start`` (None: its
+        first part -- a whole chromosome is one part), or (None, None) when it is not ready and ``block`` is False."""
+        while True:
+            ent = self._find(chrom, start)
+            if ent is not None:
+                return ent[2], ent[3]
+            if self.finished:
+                raise KeyError("chromosome %s%s is not part of this feed" % (chrom, "" if start is None else " at %s" % start))
+            self.poll(block=block)
+            if not block and self._find(chrom, start) is None:
+                return None, None
+
+    def keys_of(self, chrom):
+        return [ent[2] for ent in self.samples[chrom]]
 
     def take_fresh(self):
-        """(key, chrom, meta) of the chromosomes that arrived since the last call: what the helpers must be sent."""
+        """(key, chrom, meta) of the parts that arrived since the last call: what the helpers must be sent."""
         out, self.fresh = self.fresh, []
         # (the meta of a chromosome goes through a pipe: without the owner-side event)
         return [(k, c, None if m is None else {a: b for a, b in m.items() if a != "spilled"}) for k, c, m in out]
 
     def release(self, chrom):
         """The chromosome is done (its windows voted and stitched): free its device buffers and shared memory."""
-        key, sample, meta = self.samples[chrom]
-        if sample is None:
-            return
-        sample.device_buffers = None
-        self.samples[chrom] = (key, None, None)
-        if meta is not None and meta["dir"] is not None:
-            if meta.get("spilled") is not None:
-                meta["spilled"].wait(timeout=120)              # the slot must not be reused under a running spill
-            self._slot_free(meta["dir"])
+        for ent in self.samples.get(chrom, ()):
+            _lo, _hi, _key, sample, meta = ent
+            if sample is None:
+                continue
+            sample.device_buffers = None
+            ent[3], ent[4] = None, None
+            if meta is not None and meta["dir"] is not None:
+                if meta.get("spilled") is not None:
+                    meta["spilled"].wait(timeout=120)          # the slot must not be reused under a running spill
+                self._slot_free(meta["dir"])
 
     def close(self):
         self._stop = True

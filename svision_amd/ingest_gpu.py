@@ -28,6 +28,8 @@ LARGE_GROUP_BYTES = 600 << 20            # -- a launch of the lane-per-block ker
 LARGE_GROUP_BLOCKS = 94_000              # proportional to the launch, and once the read-backs no longer blocked each other (launch(), streams.py)
                                          # a steady flow of small groups beat the large ones: the CNN behind never runs out of chromosomes.)
 GROUP_BYTES = 24 << 30                   # serial form (groups / decode_group): later groups as large as they come
+SLICE_BYTES = 256 << 20                  # a chromosome is handed over in slices of whole collection windows of about this many compressed bytes
+MIN_MARGIN = 128 << 10                   # reference bases a slice's records reach beyond its windows on either side, at least (plan_units)
 
 
 # The pinned staging slots outlive a decoder: a process that reads a second file (a service, a bench's warm-up pass) finds them
@@ -114,6 +116,49 @@ def spill_cigar(table):
             pass
 
 
+class Unit:
+    """What the decoder hands over in one piece: the records of reference ``tid`` that the collection windows [lo, hi) of the
+    job can touch -- every record overlapping [lo - reach, hi + reach), reach = the longest alignment's span + the longest
+    read + 1000 (sample.Sample.reach: cluster extents, the coverage count and the genotyper's +-1000 bp stay inside) -- as
+    the file range [vlo, vhi) of virtual offsets, both ends at linear-index entries (or the ends of the reference's records).
+    A whole chromosome is one unit with lo = 0, hi = its length.  ``left_edge``: every record that reaches beyond this
+    coordinate lies at or behind ``vlo`` (None: vlo is the reference's first record)."""
+    __slots__ = ("tid", "lo", "hi", "vlo", "vhi", "left_edge", "to_end", "first", "last")
+
+    def __init__(self, tid, lo, hi, vlo, vhi, left_edge=None, to_end=True, first=True, last=True):
+        self.tid, self.lo, self.hi, self.vlo, self.vhi = int(tid), int(lo), int(hi), int(vlo), int(vhi)
+        self.left_edge, self.to_end, self.first, self.last = left_edge, bool(to_end), bool(first), bool(last)
+
+    def __repr__(self):
+        return "Unit(tid %d, [%d, %d)%s%s)" % (self.tid, self.lo, self.hi, "" if self.left_edge is None else ", records from %d" % self.left_edge,
+                                                 "" if self.to_end else ", cut")
+
+
+class MarginError(RuntimeError):
+    """A slice turned out not to hold every record its windows can touch: ``needed`` = the reach its own records have."""
+
+    def __init__(self, unit, needed):
+        super().__init__("%r: its records reach %d bases, more than the margin it was cut with" % (unit, needed))
+        self.unit, self.needed = unit, int(needed)
+
+
+def voff_at(span, coord):
+    """Linear-index look-up: the virtual offset of the first record of the reference overlapping the 16 kb bin of ``coord`` or
+    a later one (SAMv1 5.1.3) -- every record that reaches beyond the start of that bin lies at or behind it --, clamped to
+    the reference's records [lo, hi).  Entries of 0 (bins a writer left unfilled) are skipped."""
+    lo, hi, linear = span
+    if coord <= 0:
+        return int(lo)
+    b = int(coord) >> 14
+    if b >= linear.size:
+        return int(hi)
+    tail = linear[b:]
+    nz = tail[tail != 0]
+    if nz.size == 0:
+        return int(hi)
+    return int(min(max(int(nz[0]), int(lo)), int(hi)))
+
+
 def cut_groups(tids, size_of, first_limits, limit, merge_last=True):
     """Chromosomes in file order -> the groups whose blocks are inflated in one launch: the first groups of at most
     ``first_limits`` compressed bytes (the very first is small: the pipeline behind starts after one short launch), the others of at
@@ -178,6 +223,94 @@ class DeviceDecoder:
             out.append(cur)
         return out
 
+    def whole_units(self, tids):
+        """One unit per reference that has records, in file order: whole chromosomes."""
+        have = sorted((self.spans[t][0], t) for t in tids if t < len(self.spans) and self.spans[t] is not None)
+        return [Unit(t, 0, self.lengths[t] if t < len(self.lengths) else 1 << 62, self.spans[t][0], self.spans[t][1]) for _v, t in have]
+
+    def plan_units(self, tids, windows_of=None, margin=None, slice_bytes=None, resume=None):
+        """The references of ``tids`` that have records, in file order, each cut into slices of whole collection windows:
+        ``windows_of(tid)`` -> its windows [(start, end), ...] ascending (None / a single window: the whole reference is one
+        unit).  A slice is a run of windows of about ``slice_bytes`` compressed bytes (at least one window) and reads the
+        records from the linear-index entry of ``start - margin`` to that of ``end + margin``: a real 30x chromosome is 3 GB
+        of file, and its first window should not wait for all of it (the reference fetches window by window,
+        run_collection.py:23-26).  ``margin`` is a guess (:meth:`estimate_reach`); the consumer checks every slice against the
+        reach of its own records (ingest.ChromosomeFeed: MarginError -> planned again with a larger one).  ``resume`` = (tid,
+        coordinate): leave out that reference's windows in front of the coordinate and every reference in front of it."""
+        margin = int(margin if margin is not None else self.estimate_reach(tids))
+        slice_bytes = int(slice_bytes or int(os.environ.get("SVX_SLICE_BYTES", "0")) or SLICE_BYTES)      # (the variable: experiments, tests)
+        have = sorted((self.spans[t][0], t) for t in tids if t < len(self.spans) and self.spans[t] is not None)
+        units, skipping = [], resume is not None
+        for _v, t in have:
+            span = self.spans[t]
+            wins = sorted((int(a), int(b)) for a, b in windows_of(t)) if windows_of is not None else None
+            if skipping:
+                if t != resume[0]:
+                    continue
+                skipping = False
+                if wins is not None:
+                    wins = [w for w in wins if w[1] > resume[1]]
+                    if not wins:
+                        continue
+            if wins is None or os.environ.get("SVX_SLICES", "1") == "0":
+                units.append(Unit(t, 0, self.lengths[t], span[0], span[1]))        # the whole chromosome (a resumed one: what is left of it is served by it)
+                continue
+            i = 0
+            while i < len(wins):
+                j = i + 1
+                v0 = voff_at(span, wins[i][0])
+                while j < len(wins) and ((voff_at(span, wins[j][1]) >> 16) - (v0 >> 16)) <= slice_bytes:
+                    j += 1
+                lo, hi = wins[i][0], wins[j - 1][1]
+                vlo, vhi = voff_at(span, lo - margin), (span[1] if j == len(wins) and hi >= self.lengths[t] else voff_at(span, hi + margin))
+                vhi = max(vhi, vlo)
+                units.append(Unit(t, lo, hi, vlo, vhi, left_edge=None if vlo == span[0] else max(0, (lo - margin) >> 14 << 14), to_end=vhi == span[1],
+                                  first=i == 0, last=j == len(wins)))
+                i = j
+        return units
+
+    def estimate_reach(self, tids=None, sample=1 << 20, blocks=6):
+        """A first guess of how far a slice must reach beyond its windows (:meth:`plan_units`): the first few BGZF blocks of the
+        first reference that has records are inflated on the host (zlib: some hundred KB) and their records walked -- four
+        times the largest (reference span + read length) seen, at least MIN_MARGIN, a multiple of 16 kb.  Only a guess: reads
+        are not of one length; every slice is checked against its own records afterwards."""
+        if getattr(self, "_reach", None) is not None:
+            return self._reach
+        import struct
+        import zlib
+        reach = 0
+        try:
+            tid = min((s[0], t) for t, s in enumerate(self.spans) if s is not None and (tids is None or t in tids))[1]
+            v0 = self.spans[tid][0]
+            start = v0 >> 16
+            n = int(min(sample, self.size - start))
+            buf = np.empty(n, np.uint8)
+            if n > 0 and self.lib.svx_read_range(self.path.encode(), start, n, buf.ctypes.data, 1) == 0:
+                raw, at, data = buf.tobytes(), 0, b""
+                for _ in range(blocks):
+                    if at + 18 > n or raw[at:at + 4] != b"\x1f\x8b\x08\x04":
+                        break
+                    xlen = struct.unpack_from("<H", raw, at + 10)[0]
+                    bsize = struct.unpack_from("<H", raw, at + 16)[0] + 1          # (htslib writes BC as the only extra subfield)
+                    if at + bsize > n:
+                        break
+                    data += zlib.decompress(raw[at + 12 + xlen:at + bsize - 8], -15)
+                    at += bsize
+                p = v0 & 0xFFFF
+                while p + 36 <= len(data):
+                    size, _ref, _pos, l_name, _mq, _bin, n_cig, _flag, l_seq = struct.unpack_from("<iiiBBHHHi", data, p)
+                    if size < 32 or p + 4 + size > len(data):
+                        break
+                    words = np.frombuffer(data, "<u4", n_cig, p + 36 + l_name)
+                    span = int(((words >> 4).astype(np.int64) * np.asarray([1, 0, 1, 1, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0], np.int64)[words & 15]).sum())
+                    reach = max(reach, span + max(l_seq, 0))
+                    p += 4 + size
+        except Exception:                                       # noqa: BLE001 -- a guess: the default stands
+            reach = 0
+        self._reach = max(MIN_MARGIN, (4 * reach + 1000 + 16383) >> 14 << 14)
+        self._mark("reach guessed from the first blocks: %d" % self._reach)
+        return self._reach
+
     def _block_bytes(self, tid, sample=1 << 20):
         """Mean size of a BGZF block in the file (a megabyte sampled at the start of reference ``tid``): the large groups are
         cut to the number of blocks one round of the lane-per-block kernel holds, whatever the file's compression ratio."""
@@ -202,26 +335,37 @@ class DeviceDecoder:
 
     # ---- pipelined form: a reader thread, up to `depth` groups in flight on streams of their own ------------------------
     def parts_pipelined(self, tids, depth=2):
-        """Generator like :meth:`decode_group` over ALL chromosomes of ``tids``, with the steps overlapped: a reader thread
-        fills the device buffers of the groups ahead (through the staging ring); every group (cut_groups: ~600 MB of file) is
-        inflated and counted without a host synchronisation -- its tokens kernel on the process's "tokens" stream, one group
-        after the other, the rest on one of ``depth`` group streams (svision_amd/streams.py: hardware queues of their own) --;
-        per group ONE read-back (block status + walk counts: issued when the inflate is through, never queued behind it), per
-        chromosome ONE (the packed arrays)."""
+        """:meth:`units_pipelined` over whole chromosomes: yields (finish, device arrays) per reference that has records."""
+        for _unit, finish, arrays in self.units_pipelined(self.whole_units(tids), depth):
+            yield finish, arrays
+
+    def units_pipelined(self, units, depth=2):
+        """Generator over the units (:meth:`plan_units` / :meth:`whole_units`: whole chromosomes or slices of them, in file
+        order): (unit, finish, (d_cigar int32, d_cig_off int64 [n+1], d_pos int32)) where ``finish()`` -> AlignmentTable on the
+        host (the QNAME ids are computed there: host work the caller can overlap with the next unit's device work); (unit, None,
+        None) for a unit without a record.  The steps are overlapped: a reader thread fills the device buffers of the groups
+        ahead (through the staging ring); every group (cut_groups: ~600 MB of file) is inflated and counted without a host
+        synchronisation -- its tokens kernel on the process's "tokens" stream, one group after the other, the rest on one of
+        ``depth`` group streams (svision_amd/streams.py: hardware queues of their own) --; per group ONE read-back (block
+        status + walk counts: issued when the inflate is through, never queued behind it), per unit ONE (the packed arrays).
+        Consecutive slices of one chromosome overlap by their margins: inside a group the overlap is inflated once (the
+        group's bytes are one range of the file), across a group boundary twice (~2 % of a group)."""
         import collections
         import queue
         import threading
         import time
         lib, dev = self.lib, self.device
-        have = sorted((self.spans[t][0], t) for t in tids if t < len(self.spans) and self.spans[t] is not None)
-        def size_of(t):
-            return (self.spans[t][1] >> 16) - (self.spans[t][0] >> 16) + 65536
+        units = list(units)
+
+        def size_of(u):
+            return (u.vhi >> 16) - (u.vlo >> 16) + 65536
+
         def mb(name, default):                                 # (experiments: SVX_FIRST_GROUP_MB / SVX_PIPE_GROUP_MB / SVX_LARGE_GROUP_MB)
             v = os.environ.get(name)
             return int(v) << 20 if v else default
         large = mb("SVX_LARGE_GROUP_MB", LARGE_GROUP_BYTES)
-        large = min(large, int(LARGE_GROUP_BLOCKS * self._block_bytes(have[0][1]))) if have else large
-        groups = cut_groups([t for _v, t in have], size_of, [mb("SVX_FIRST_GROUP_MB", FIRST_GROUP_BYTES), mb("SVX_PIPE_GROUP_MB", PIPE_GROUP_BYTES)], large,
+        large = min(large, int(LARGE_GROUP_BLOCKS * self._block_bytes(units[0].tid))) if units else large
+        groups = cut_groups(units, size_of, [mb("SVX_FIRST_GROUP_MB", FIRST_GROUP_BYTES), mb("SVX_PIPE_GROUP_MB", PIPE_GROUP_BYTES)], large,
                             merge_last=os.environ.get("SVX_MERGE_LAST", "1") != "0")
         self._mark("groups cut: %s" % [len(g) for g in groups])
         q = queue.Queue(maxsize=1)
@@ -256,7 +400,8 @@ class DeviceDecoder:
             return s_
 
         def read_group(group):
-            spans = [self.spans[t] for t in group]
+            spans = [(u.vlo, u.vhi, self.spans[u.tid][2]) for u in group]
+            tids_of = sorted({u.tid for u in group})
             c0 = min(s[0] >> 16 for s in spans)
             c1 = min(self.size, max(s[1] >> 16 for s in spans) + 65536 + 64)
             nbytes = c1 - c0
@@ -270,7 +415,7 @@ class DeviceDecoder:
                 pin = st_[0]
                 t_p = time.perf_counter()
                 if lib.svx_read_range(self.path.encode(), c0 + off, want, pin.data_ptr(), self.threads) != 0:
-                    raise DeviceIngestError(lib.svx_bam_error().decode(), group)
+                    raise DeviceIngestError(lib.svx_bam_error().decode(), tids_of)
                 self.stats["pread_s"] = self.stats.get("pread_s", 0.0) + (time.perf_counter() - t_p)
                 cap = want // 28 + 16
                 so, co = np.empty(cap, np.uint64), np.empty(cap, np.uint64)
@@ -279,7 +424,7 @@ class DeviceDecoder:
                 k = int(lib.svx_bgzf_index(pin.data_ptr(), want, c0 + off, cap, so.ctypes.data, sl.ctypes.data, isz.ctypes.data, co.ctypes.data,
                                            used.ctypes.data))
                 if k < 0 or (k == 0 and off == 0):
-                    raise DeviceIngestError("no BGZF block at file offset %d" % (c0 + off), group)
+                    raise DeviceIngestError("no BGZF block at file offset %d" % (c0 + off), tids_of)
                 if k == 0:
                     break                                      # what is left of the range is the head of a block that ends behind it
                 u = int(used[0])
@@ -305,13 +450,13 @@ class DeviceDecoder:
                     raise DeviceIngestError("the index points between two BGZF blocks")
                 return np.where(at_end, dst[nb], dst[idx] + (voffs & np.uint64(0xFFFF)))
             starts = []
-            for t_, (lo, hi, linear) in zip(group, spans):
+            for u_, (lo, hi, linear) in zip(group, spans):
                 seeds = linear[(linear >= np.uint64(lo)) & (linear < np.uint64(hi))]
                 voffs = np.unique(np.concatenate([np.asarray([lo], np.uint64), seeds, np.asarray([hi], np.uint64)]))
                 try:
                     starts.append(np.unique(inflated_offset(voffs)))
                 except DeviceIngestError as exc:
-                    raise DeviceIngestError(str(exc), [t_]) from None
+                    raise DeviceIngestError(str(exc), [u_.tid]) from None
             # one pinned block of small tables: payload offsets, payload sizes, inflated offsets, then every chromosome's starts
             n_starts = [int(a.size) - 1 for a in starts]
             words = 3 * nb + 1 + sum(a.size for a in starts) + 8
@@ -334,20 +479,21 @@ class DeviceDecoder:
                     "n_starts": n_starts}
 
         def reader():
+            def hand(item):                                     # stop-aware, the end marker and an exception included: an abandoned run
+                while not stop.is_set():                        # (a failed group, a plan that is cut again) leaves nobody to take them,
+                    try:                                        # and a reader blocked for ever keeps the process-wide staging ring busy
+                        q.put(item, timeout=0.2)
+                        return True
+                    except queue.Full:
+                        continue
+                return False
             try:
                 for g in groups:
-                    item = read_group(g)
-                    while not stop.is_set():
-                        try:
-                            q.put(item, timeout=0.2)
-                            break
-                        except queue.Full:
-                            continue
-                    if stop.is_set():
+                    if not hand(read_group(g)):
                         return
-                q.put(None)
+                hand(None)
             except BaseException as exc:                         # noqa: BLE001
-                q.put(exc)
+                hand(exc)
 
         def launch(item, stream):
             nb = item["nb"]
@@ -360,7 +506,14 @@ class DeviceDecoder:
             variant = kernels.inflate_variant_for(nb)
             d_raw = torch.empty(max(item["total"], 16), dtype=torch.uint8, device=dev)
             d_ws = kernels.inflate_workspace(lib, variant, item["total"], nb, dev)
+            # (the allocator may hand out a block that default-stream work freed and is still using: the group's streams
+            # order themselves behind whatever the default stream holds at this point -- normally nothing)
+            allocated = torch.cuda.Event()
+            allocated.record(torch.cuda.default_stream(dev))
+            if tokens_stream is not None:
+                tokens_stream.wait_event(allocated)
             with torch.cuda.stream(stream):
+                stream.wait_event(allocated)
                 stream.wait_event(item["copied"])              # the last slot of the group's compressed bytes is on the device
                 d_comp = item["d_comp"]
                 d_comp.record_stream(stream)
@@ -415,7 +568,7 @@ class DeviceDecoder:
             ev_c.synchronize()
             counts = h_counts.numpy()
             if int(counts[-1, 0]) != 0:
-                raise DeviceIngestError("corrupt BGZF blocks in references %s" % item["group"], item["group"])
+                raise DeviceIngestError("corrupt BGZF blocks in %s" % item["group"], sorted({u.tid for u in item["group"]}))
             d_raw, d_tab, stream = item["d_raw"], item["d_tab"], item["stream"]
             pending, row = [], 0
             t0 = time.perf_counter()
@@ -424,19 +577,19 @@ class DeviceDecoder:
             # milliseconds during which the other threads' HIP calls -- and their page faults -- wait; per chromosome that
             # was six of them.
             plan, pack_at, word_at = [], 0, 0
-            for tid_, at, n_starts in zip(item["group"], item["start_at"], item["n_starts"]):
+            for unit_, at, n_starts in zip(item["group"], item["start_at"], item["n_starts"]):
                 c = counts[row:row + n_starts]
                 bad = c[:, 3] != 0
                 if bad.any():
                     code = int(c[bad, 3][0])
-                    raise DeviceIngestError({1: "the linear index does not match the records", 2: "malformed BAM record"}.get(code, "walk error %d" % code), [tid_])
-                n, words, name_bytes = (int(v) for v in c[:, :3].sum(axis=0))
+                    raise DeviceIngestError({1: "the linear index does not match the records", 2: "malformed BAM record"}.get(code, "walk error %d" % code), [unit_.tid])
+                n, words, name_bytes = (int(v) for v in c[:, :3].sum(axis=0)) if n_starts else (0, 0, 0)
                 # [cig_off n+1][name_off n+1][tid n][pos n][l_seq n][flag n][mapq n][names]: everything the host wants
                 sect = [8 * (n + 1), 8 * (n + 1), 4 * n, 4 * n, 4 * n, 2 * n, n, name_bytes]
                 offs = np.zeros(len(sect) + 1, np.int64)
                 offs[1:] = np.cumsum([(v + 15) // 16 * 16 for v in sect])
                 size = (int(offs[-1]) + 16 + 255) // 256 * 256
-                plan.append((at, n_starts, row, n, words, name_bytes, offs, pack_at, size, word_at))
+                plan.append((at, n_starts, row, n, words, name_bytes, offs, pack_at, size, word_at, unit_))
                 pack_at += size
                 word_at += (max(words, 1) + 63) // 64 * 64       # (svx_cigar_scan reads 16-byte quads: every chromosome starts aligned)
                 row += n_starts
@@ -446,13 +599,19 @@ class DeviceDecoder:
                     base_all.numpy()[r0 + 1:r0 + n_starts] = np.cumsum(counts[r0:r0 + n_starts - 1, :3], axis=0)
             d_pack_all = torch.empty(max(pack_at, 256), dtype=torch.uint8, device=dev)        # (default stream: see launch())
             d_cigar_all = torch.empty(max(word_at, 64), dtype=torch.int32, device=dev)
+            allocated = torch.cuda.Event()
+            allocated.record(torch.cuda.default_stream(dev))
             with torch.cuda.stream(stream):
+                stream.wait_event(allocated)
                 st = kernels._stream_ptr(dev)
                 d_pack_all.record_stream(stream)
                 d_cigar_all.record_stream(stream)
                 d_base_all = base_all.to(dev, non_blocking=True)
                 h_pack_all = torch.empty(max(pack_at, 256), dtype=torch.uint8, pin_memory=True)
-                for at, n_starts, r0, n, words, name_bytes, offs, p0, size, w0 in plan:
+                for at, n_starts, r0, n, words, name_bytes, offs, p0, size, w0, unit_ in plan:
+                    if n == 0:                                   # a slice (or a reference) without a record: nothing to extract
+                        pending.append((None, None, offs, 0, 0, 0, None, None, None, base_all, None, unit_))
+                        continue
                     d_pack = d_pack_all[p0:p0 + size]
                     d_base = d_base_all[r0:r0 + n_starts]
 
@@ -474,15 +633,18 @@ class DeviceDecoder:
                     # The consumer scans on another stream and orders itself behind this one through the event only.
                     ev = torch.cuda.Event()
                     ev.record()
-                    pending.append((ev, h_pack, offs, n, words, name_bytes, d_cigar, d_cig_off, d_pos, base_all, d_pack))
+                    pending.append((ev, h_pack, offs, n, words, name_bytes, d_cigar, d_cig_off, d_pos, base_all, d_pack, unit_))
             self.stats["walk_s"] += time.perf_counter() - t0
             yield None                                          # every chromosome's extraction is enqueued: the caller may launch the next group
-            for ev, h_pack, offs, n, words, name_bytes, d_cigar, d_cig_off, d_pos, _base, _d_pack in pending:
+            for ev, h_pack, offs, n, words, name_bytes, d_cigar, d_cig_off, d_pos, _base, _d_pack, unit_ in pending:
+                if ev is None:
+                    yield unit_, None, None
+                    continue
                 t0 = time.perf_counter()
                 ev.synchronize()
                 self.stats["d2h_s"] += time.perf_counter() - t0
                 self._mark("packed read-back done")
-                yield self._make_finish(h_pack.numpy(), offs, n, words, name_bytes, d_cigar), (d_cigar, d_cig_off, d_pos)
+                yield unit_, self._make_finish(h_pack.numpy(), offs, n, words, name_bytes, d_cigar), (d_cigar, d_cig_off, d_pos)
             item["d_raw"] = item["d_tab"] = None
 
         th = threading.Thread(target=reader, name="svx-read", daemon=True)
@@ -576,7 +738,7 @@ class DeviceDecoder:
             other HIP call of the process returns -- and the large groups' buffers are better allocated when their turn comes,
             next to device work that is already queued."""
             for g in groups[:2]:                               # in the order they will be asked for: compressed bytes, inflated bytes
-                nbytes = sum(size_of(t) for t in g)
+                nbytes = sum(size_of(u) for u in g)
                 if stop.is_set():
                     break
                 for n in (nbytes + (1 << 20), 3 * nbytes + (1 << 20)):

@@ -423,10 +423,10 @@ def launch_inflate(lib, variant, comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, 
         d_ws = ws if ws is not None else inflate_workspace(lib, variant, inflated_bytes, n_blocks, device)
         ws_bytes = int(d_ws.numel())
         if tokens_stream is not None:
-            rc = lib.svx_bgzf_inflate_fast_on(comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, out_ptr, status_ptr, d_ws.data_ptr(), ws_bytes,
+            rc = lib.svx_bgzf_inflate_fast_on(comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, int(inflated_bytes), out_ptr, status_ptr, d_ws.data_ptr(), ws_bytes,
                                               ctypes.c_void_p(tokens_stream.cuda_stream), st)
         else:
-            rc = lib.svx_bgzf_inflate_fast(comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, out_ptr, status_ptr, d_ws.data_ptr(), ws_bytes, st)
+            rc = lib.svx_bgzf_inflate_fast(comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, int(inflated_bytes), out_ptr, status_ptr, d_ws.data_ptr(), ws_bytes, st)
     else:
         fn = {"lds": lib.svx_bgzf_inflate_lds, "private": lib.svx_bgzf_inflate_private, "wave": lib.svx_bgzf_inflate_wave,
               "lane": lib.svx_bgzf_inflate}[variant]

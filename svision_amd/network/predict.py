@@ -115,6 +115,10 @@ class SiteVoter:
         # first site when its start is <= lo, the last one when its end is >= hi (pipeline._vote derives both from the
         # longest alignment of the sample); any other edge site is written at once like an interior one
         self.hold_range = hold_range
+        # file-driven runs hand a chromosome over in slices (svision_amd/ingest.py): ``next_sample`` = the Sample of the window
+        # whose lines are being fed.  A site is written on the records of the window that reported its FIRST line (a site that
+        # continues into the next window lies within reach of both, Sample.reach()).
+        self.next_sample = None
 
     def feed_batch(self, labels, classes, probs):
         classes = np.asarray(classes)
@@ -136,6 +140,8 @@ class SiteVoter:
             if region != site.region:
                 if site.region != "":
                     self._flush(site)
+                if self.next_sample is not None:
+                    self.sample = self.next_sample
                 site = self.site = _SiteState(region)
             if self.hold_edges:
                 site.items.append((label, cls, score))
@@ -199,7 +205,11 @@ class ChromosomeVote:
         self.vcf_out, self.score_out = vcf_out, score_out
         self.voter = SiteVoter(Predict(chrom, None), vcf_out, score_out, options, sample)
 
-    def add(self, head, vcf_text, score_text, tail):
+    def add(self, head, vcf_text, score_text, tail, sample=None):
+        """``sample``: the Sample that served this window (a slice of the chromosome in a file-driven run): a site opened by this
+        window's head or tail is written on its records; a site that the previous window's tail opened and this window's head
+        continues stays with the previous window's (it lies within reach of both)."""
+        self.voter.next_sample = sample
         if head:
             self.voter.feed_items(head)
         if vcf_text or score_text or tail:

@@ -36,7 +36,7 @@ _PAD_REC = parse_data_fields(PAD_DATA.split("_"))
 
 class WindowResult:
     __slots__ = ("chrom", "start", "end", "lines", "n_images", "packed", "vcf", "scores", "n_sites", "n_records",
-                 "records", "done_event", "t_device", "wid", "tsv", "head", "tail", "edges")
+                 "records", "done_event", "t_device", "wid", "tsv", "head", "tail", "edges", "sample")
 
 
 def _collect_lines(sample, options, chrom, start, end):
@@ -75,11 +75,7 @@ def edge_margin(sample):
     """A site farther than this from a window boundary cannot be collected by the neighbouring window as well: a
     cluster reported by a window is built from records that overlap that window, and a signature's coordinates stay
     within the reference span of its records plus one read length (inserted / re-placed pieces)."""
-    m = getattr(sample, "_edge_margin", None)
-    if m is None:
-        t = sample.table
-        m = sample._edge_margin = (int(t.ref_span.max()) + int(t.l_seq.max()) + 1000) if len(t) else 0
-    return m
+    return sample.reach()
 
 
 class WindowVote:
@@ -150,19 +146,22 @@ def distinct_sites(results):
 def stitch_windows(results, options, sample):
     """WindowResults of any number of chromosomes in task order -> {chrom: (VCF body text, score text)}: the
     per-chromosome vote over the windows' held-back edge sites and their interior texts.  ``sample``: the Sample, or a
-    callable chromosome -> Sample (file-driven runs hold one Sample per chromosome in flight, svision_amd/ingest.py)."""
+    callable (chromosome, window start) -> the Sample that served that window (file-driven runs hold one Sample per
+    chromosome -- or per slice of it -- in flight, svision_amd/ingest.py): an edge site is genotyped on the records of the
+    window that reported it."""
     from .network.predict import ChromosomeVote
     out, cur, bufs = {}, None, None
     for res in results:
+        smp = sample(res.chrom, res.start) if callable(sample) else sample
         if res.chrom not in out:
             if cur is not None:
                 cur.finish()
             bufs = (io.StringIO(), io.StringIO())
             out[res.chrom] = bufs
-            cur = ChromosomeVote(res.chrom, bufs[0], bufs[1], options, sample(res.chrom) if callable(sample) else sample)
+            cur = ChromosomeVote(res.chrom, bufs[0], bufs[1], options, smp)
         elif out[res.chrom] is not bufs:
             raise ValueError("windows of %s are not contiguous in task order" % res.chrom)
-        cur.add(res.head, res.vcf, res.scores, res.tail)
+        cur.add(res.head, res.vcf, res.scores, res.tail, sample=smp)
     if cur is not None:
         cur.finish()
     return {c: (v.getvalue(), sc.getvalue()) for c, (v, sc) in out.items()}
@@ -421,13 +420,15 @@ def _worker_main(conn):
         if msg[0] == "stop":
             return
         if msg[0] == "chrom":
+            meta = msg[2]
+            if "references" in meta:                          # the header's dictionary travels with a helper's first part of a file only
+                header_dict = (meta["references"], meta["lengths"])
+            elif header_dict is None:
+                raise RuntimeError("helper: part %r announced without the header's sequence dictionary" % (msg[1],))
+            else:
+                meta = dict(meta, references=header_dict[0], lengths=header_dict[1])
             if msg[1] not in samples:
                 from .ingest import load_shared_sample
-                meta = msg[2]
-                if "references" in meta:                      # the header's dictionary travels with a helper's first chromosome only
-                    header_dict = (meta["references"], meta["lengths"])
-                else:
-                    meta = dict(meta, references=header_dict[0], lengths=header_dict[1])
                 samples[msg[1]] = load_shared_sample(meta, sample.fasta if sample is not None else _POOL_STATE.get("fasta"))
             continue
         if msg[0] == "drop":
@@ -578,18 +579,39 @@ class PooledHotPath(HotPath):
         self.conns, self.procs = self.pool.conns, self.pool.procs
         self.max_inflight = max_inflight
         from .ingest import StaticFeed
-        self.feed = feed if feed is not None else StaticFeed(sample)   # where a chromosome's Sample comes from
-        self._chrom_meta = {}                                          # key -> meta of the chromosomes of a file-driven run that are alive
+        self._chrom_meta = {}                                          # key -> meta of the parts of a file-driven run that are alive
         self._helper_keys = [set() for _ in self.conns]                # per helper: the keys it has been told about
         self._helper_has_dict = [False] * len(self.conns)              # per helper: has it received the header's sequence dictionary
+        self._feed = None
+        self.feed = feed if feed is not None else StaticFeed(sample)   # where a chromosome's Sample comes from
+
+    @property
+    def feed(self):
+        return self._feed
+
+    @feed.setter
+    def feed(self, feed):
+        """Another feed (bench.py: the file-driven legs and the resident one take turns; a service: the next file): whatever the
+        helpers still hold of the previous one is dropped, and the next part every helper is told about carries the header's
+        sequence dictionary again -- it belongs to the file, not to the pool.  (Keys are unique in the process,
+        ingest._KEYS, so a part of the old feed can never be taken for one of the new.)"""
+        if feed is self._feed:
+            return
+        for ci, c in enumerate(self.conns):
+            for key in sorted(self._helper_keys[ci]):
+                c.send(("drop", key))
+            self._helper_keys[ci].clear()
+        self._chrom_meta = {}
+        self._helper_has_dict = [False] * len(self.conns)
+        self._feed = feed
 
     def release(self, chrom):
-        """A chromosome of a file-driven run is finished (voted, stitched): the helpers unmap it, the feed frees it."""
+        """A chromosome of a file-driven run is finished (voted, stitched): the helpers unmap its parts, the feed frees them."""
         try:
-            key = self.feed.key_of(chrom)
+            keys = self.feed.keys_of(chrom)
         except KeyError:
             return
-        if key is not None:
+        for key in keys:
             self._chrom_meta.pop(key, None)
             for ci, c in enumerate(self.conns):               # only the helpers that were told about it (see _announce)
                 if key in self._helper_keys[ci]:
@@ -686,7 +708,7 @@ class PooledHotPath(HotPath):
             t = clock()
             while idle and nxt < len(windows):
                 chrom, start, end = windows[nxt]
-                key, smp = self.feed.get(chrom, block=False)          # file-driven runs: is the chromosome decoded + scanned yet?
+                key, smp = self.feed.get(chrom, block=False, start=start)     # file-driven runs: is the window's part of the chromosome decoded + scanned yet?
                 for k, _c, meta in self.feed.take_fresh():            # where it lies in shared memory: told to a helper with its first window of it
                     self._chrom_meta[k] = meta
                 if smp is None:

@@ -204,6 +204,17 @@ class Sample:
             table._ref_end = None                               # reference ends (and their sorted copies) are derived from ref_span
             table._max_span = None
 
+    def reach(self):
+        """How far anything a collection window does can lie outside the window: a cluster reported by a window is built from
+        records that overlap it, its signatures' coordinates stay within the reference span of those records plus one read
+        length (inserted / re-placed pieces), and the genotyper looks 1000 bases farther (genotype.py:22-26).  The longest
+        span + the longest read + 1000 of the whole table: an upper bound for every window of it."""
+        m = getattr(self, "_reach", None)
+        if m is None:
+            t = self.table
+            m = self._reach = (int(t.ref_span.max()) + int(t.l_seq.max()) + 1000) if len(t) else 0
+        return m
+
     # -- accessors used by the collection step ----------------------------------------
     def gaps_of(self, aln):
         return self.gaps[self.gap_off[aln]:self.gap_off[aln + 1]]

@@ -122,3 +122,44 @@ def test_defaults_make_the_file_inclusive_job_the_timed_one():
     assert a.e2e_windows == 5
     a = ns(e2e_windows=0)
     assert a.e2e_windows == 0
+
+
+def test_rank_launcher_line_and_the_first_contact_block():
+    """`python bench.py --gpus 8 --workload wg` without a launcher: the line it starts its ranks with, their environment, and
+    the layout block every N-GPU line carries (rccl_world, per-rank loads and bytes, the imbalance and what
+    it caps strong scaling at, ranks that share a device)."""
+    b = _bench()
+    from svision_amd import dist as sdist
+    cmd = b.rank_command(8, 29517, ["--gpus", "8", "--workload", "wg", "--steps", "40"])
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29517" and cmd[-6:] == ["--gpus", "8", "--workload", "wg", "--steps", "40"]
+    assert cmd[cmd.index("29517") + 1].endswith("bench.py")
+    assert b.rank_environment({})["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and b.rank_environment({"HSA_ENABLE_IPC_MODE_LEGACY": "1"})["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"
+    # the whole genome on 8 ranks: LPT loads, max / mean = 1.036 -> at most 7.72 x of 8
+    shards = sdist.shard_chromosomes([n for n, _l in b.GRCH38], [l for _n, l in b.GRCH38], 8)
+    rank_mb = [sum(dict(b.GRCH38)[c] for c in sh) / 1e6 for sh in shards]
+    ids = [("node0", "GPU-%02d" % r) for r in range(8)]
+    fc = b.first_contact(8, True, "nccl", rank_mb, [10 ** 9] * 8, ids)
+    assert fc["rccl_world"] == 8 and fc["ranks_sharing_a_device"] == [] and len(fc["devices"]) == 8
+    assert abs(fc["imbalance"] - 1.036) < 5e-4 and abs(fc["strong_scaling_cap"] - 7.72) < 6e-3 and len(fc["rank_mb"]) == 8
+    assert fc["rank_bam_bytes"] == [10 ** 9] * 8
+    # two ranks that resolved to one device are named (under nccl dist.init_from_env refuses them outright)
+    ids[5] = ids[2]
+    assert b.first_contact(8, True, "gloo", rank_mb, None, ids)["ranks_sharing_a_device"] == [2, 5]
+    assert b.first_contact(8, True, "gloo", rank_mb, None, ids)["rccl_world"] == 0
+    assert sdist.duplicate_devices(ids) == {("node0", "GPU-02"): [2, 5]}
+
+
+def test_more_ranks_than_devices_is_refused_under_nccl(monkeypatch):
+    import pytest
+    import torch
+    from svision_amd import dist as sdist
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    monkeypatch.setenv("RANK", "3")
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    monkeypatch.setenv("SVX_DIST_BACKEND", "nccl")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    with pytest.raises(RuntimeError, match="8 ranks on this node but 2 visible GPU"):
+        sdist.init_from_env()

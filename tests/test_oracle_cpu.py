@@ -64,3 +64,19 @@ def test_cigar_text_roundtrip():
     assert cigar_ref.inside_align(ops, 100, 10000, 15200, 50) == [
         [100, 2100, 10000, 11999], [2401, 3901, 12000, 13500], [3901, 5401, 13700, 15200]]
     assert cigar_ref.inside_align(cigar_ref.parse_cigar("5000M"), 0, 0, 5000, 50) is None
+
+
+def test_line_walk_was_compared_with_two_independent_rasterisers():
+    """tools/pin_line_rasterisers.py (run under /opt/conda python3.9 in the build container; its result is committed): on every
+    line without a Bresenham tie -- fixture end points and 100,000 random ones -- the oracle's OpenCV LineIterator restatement
+    equals skimage.draw.line and Pillow's ImageDraw.line pixel for pixel.  (OpenCV's tie rule itself stays pinned to its
+    published text only: DESIGN.md section 3.)"""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "line_pin.json")) as f:
+        pin = json.load(f)
+    for name, st in pin["sets"].items():
+        assert st["no_tie"]["n"] > 500 and st["no_tie"]["skimage_equal"] == st["no_tie"]["pillow_equal"] == st["no_tie"]["n"], name
+        assert st["same_pixel_count_always"] and st["endpoints_always_drawn"], name
+        assert st["tie"]["n"] > 0
+    assert pin["sets"]["random_100000_seed5"]["pairs"] == 100000

@@ -1,0 +1,155 @@
+"""Slices of a chromosome (svision_amd/ingest_gpu.py: Unit, plan_units; ingest.ChromosomeFeed._slice_complete) without a GPU.
+
+The device engine hands a chromosome over in slices of whole collection windows: the records between the linear-index entries
+of `first window's start - margin` and `last window's end + margin`.  Here the same file ranges are decoded by the HOST
+decoder (svx_bam_open_range takes virtual offsets), scanned by the oracle, and every window is collected, voted and stitched
+on its slice: the results must be those of the whole chromosome, byte for byte -- the reference fetches window by window from
+the whole file (run_collection.py:23-26), so a slice must never change what a window sees."""
+import io
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from svision_amd import _lib, synth
+from svision_amd.collection.output_clusters import collect_pair_lines
+from svision_amd.collection.run_collection import detect_window
+from svision_amd.ingest import ChromosomeFeed
+from svision_amd.ingest_gpu import DeviceDecoder, Unit, voff_at
+from svision_amd.io import bam
+from svision_amd.pipeline import WindowResult, _vote, stitch_windows
+from svision_amd.sample import Sample
+from tests import helpers
+
+LENGTH, WINDOW = 1_200_000, 100_000
+
+
+@pytest.fixture(scope="module")
+def sliced(tmp_path_factory):
+    d = tmp_path_factory.mktemp("slices")
+    cfg = synth.SimConfig(contigs=[("chrA", LENGTH), ("chrB", 300_000)], coverage=14, read_len_mean=8000, read_len_sd=1500, err_rate=0.004,
+                          sv_spacing=9_000, sv_min_gap=6_000, sv_max=3000, inline_max=1200, seed=77)
+    table, genome, _svs = synth.simulate(cfg)
+    path = str(d / "s.bam")
+    bam.write_bam(path, table, level=1, index=True)
+    head = bam.read_bam_header(path)
+    dec = DeviceDecoder(path, path + ".bai", head.references, head.lengths, head.header_text, "cpu")
+    return path, table, bam.Fasta(sequences=genome), dec
+
+
+def _windows(length):
+    return [(a, min(length, a + WINDOW)) for a in range(0, length, WINDOW)]
+
+
+def _range_table(dec, unit):
+    lib = _lib.load()
+    h = lib.svx_bam_open_range(dec.path.encode(), 2, 0, unit.vlo, unit.vhi)
+    assert h, lib.svx_bam_error().decode()
+    return bam._table_from_handle(lib, h, False)
+
+
+def test_plan_cuts_whole_windows_in_file_order(sliced):
+    _path, _table, _fasta, dec = sliced
+    units = dec.plan_units([0, 1], lambda t: _windows(dec.lengths[t]), margin=64 << 10, slice_bytes=1)
+    a = [u for u in units if u.tid == 0]
+    assert [(u.lo, u.hi) for u in a] == _windows(LENGTH)                        # slice_bytes below one window: a slice per window
+    assert a[0].left_edge is None and a[0].vlo == dec.spans[0][0] and a[-1].to_end and a[-1].vhi == dec.spans[0][1]
+    assert all(u.vlo <= v.vlo and u.vhi <= v.vhi and u.vlo < u.vhi for u, v in zip(a, a[1:]))
+    assert all(v.vlo < u.vhi for u, v in zip(a, a[1:]))                         # neighbours overlap by their margins
+    assert [u.tid for u in units] == [0] * len(a) + [1] * (len(units) - len(a))
+    # larger slices: runs of windows; every window in exactly one slice
+    big = dec.plan_units([0], lambda t: _windows(LENGTH), margin=64 << 10, slice_bytes=((dec.spans[0][1] >> 16) - (dec.spans[0][0] >> 16)) // 3)
+    assert 3 <= len(big) < 12 and big[0].lo == 0 and big[-1].hi == LENGTH
+    assert all(u.hi == v.lo for u, v in zip(big, big[1:]))
+    # no windows known / one window: the whole chromosome
+    whole = dec.plan_units([0, 1], None, margin=0)
+    assert [(u.tid, u.lo, u.hi, u.vlo, u.vhi) for u in whole] == [(t, 0, dec.lengths[t], dec.spans[t][0], dec.spans[t][1]) for t in (0, 1)]
+    one = dec.plan_units([1], lambda t: [(0, dec.lengths[1])], margin=64 << 10)
+    assert len(one) == 1 and one[0].left_edge is None and one[0].to_end
+    # resumed behind a rejected slice
+    rest = dec.plan_units([0, 1], lambda t: _windows(dec.lengths[t]), margin=128 << 10, slice_bytes=1, resume=(0, 500_000))
+    assert rest[0].tid == 0 and rest[0].lo == 500_000 and rest[0].left_edge == (500_000 - (128 << 10)) >> 14 << 14
+    assert {u.tid for u in rest} == {0, 1}
+
+
+def test_linear_index_lookup(sliced):
+    _path, table, _fasta, dec = sliced
+    span = dec.spans[0]
+    assert voff_at(span, -5) == span[0] and voff_at(span, 0) == span[0] and voff_at(span, 10 * LENGTH) == span[1]
+    # the entry of a bin = the first record overlapping it: everything in front of it ends at or before the bin's start
+    rows = np.flatnonzero(table.tid == 0)
+    scan = helpers.oracle_scan(table, 50)
+    ref_end = table.pos[rows].astype(np.int64) + np.maximum(scan[2][rows, 0], 1)
+    for coord in (16384 * 7, 300_000, 777_777):
+        u = Unit(0, 0, LENGTH, voff_at(span, coord), span[1])
+        t = _range_table(dec, u)
+        n_front = rows.size - len(t)
+        assert n_front > 0 and (ref_end[:n_front] <= coord >> 14 << 14).all()
+        assert np.array_equal(t.pos, table.pos[rows][n_front:])
+
+
+def test_guessed_reach_covers_the_reads(sliced):
+    _path, table, _fasta, dec = sliced
+    scan = helpers.oracle_scan(table, 50)
+    smp = Sample.with_scan(table, None, 50, scan)
+    assert dec.estimate_reach([0, 1]) >= smp.reach() and dec.estimate_reach([0, 1]) % 16384 == 0
+
+
+def _votes(sample_of, opts, chrom, windows):
+    results, texts = [], []
+    for part, (start, end) in enumerate(windows):
+        smp = sample_of(start)
+        _s, clusters = detect_window(opts, smp, chrom, start, end, part)
+        lines = collect_pair_lines(clusters, opts)
+        texts.append("".join(ln.text() for ln in lines))
+        h = np.array([zlib.crc32(ln.text().encode()) for ln in lines], np.int64)
+        cls = h % 5
+        prob = np.full((len(lines), 5), 0.05, np.float32)
+        prob[np.arange(len(lines)), cls] = (0.5 + (h % 50) / 100.0).astype(np.float32)
+        res = WindowResult()
+        res.chrom, res.start, res.end = chrom, start, end
+        res.vcf, res.scores, res.n_sites, res.head, res.tail = _vote(smp, opts, chrom, lines, cls, prob, start, end)
+        results.append(res)
+    return results, texts
+
+
+@pytest.mark.parametrize("slice_windows", [1, 3])
+def test_windows_on_their_slices_equal_windows_on_the_whole_chromosome(sliced, slice_windows):
+    _path, table, fasta, dec = sliced
+    opts = helpers.default_options(min_support=3, batch_size=64, window_size=WINDOW, qname=True)
+    windows = _windows(LENGTH)
+    whole = Sample.with_scan(table, fasta, 50, helpers.oracle_scan(table, 50))
+    want_results, want_tsv = _votes(lambda _s: whole, opts, "chrA", windows)
+    want = stitch_windows(want_results, opts, whole)["chrA"]
+    assert want[0].count("\n") > 40 and sum(bool(r.head) + bool(r.tail) for r in want_results) > 4
+
+    per_window = ((dec.spans[0][1] >> 16) - (dec.spans[0][0] >> 16)) // len(windows)
+    units = dec.plan_units([0], lambda t: windows, margin=dec.estimate_reach([0]), slice_bytes=per_window * slice_windows + per_window // 2)
+    assert len(units) >= len(windows) // slice_windows - 1 and len(units) > 2
+    samples = []
+    for u in units:
+        t = _range_table(dec, u)
+        assert len(t) < 0.6 * int((table.tid == 0).sum())                      # a slice, not the chromosome
+        smp = Sample.with_scan(t, fasta, 50, helpers.oracle_scan(t, 50))
+        assert ChromosomeFeed._slice_complete(u, smp)
+        samples.append((u, smp))
+
+    def sample_of(start):
+        return next(s for u, s in samples if u.lo <= start < u.hi)
+    got_results, got_tsv = _votes(sample_of, opts, "chrA", windows)
+    assert got_tsv == want_tsv                                                  # region strings carry the coverage counts
+    got = stitch_windows(got_results, opts, lambda _c, start: sample_of(start))["chrA"]
+    assert got == want                                                          # GT:DR:DV from the genotyper's +-1000 bp, edge sites once
+
+
+def test_a_margin_that_is_too_small_is_noticed(sliced):
+    _path, table, fasta, dec = sliced
+    windows = _windows(LENGTH)
+    units = dec.plan_units([0], lambda t: windows, margin=1, slice_bytes=1)
+    bad = 0
+    for u in units[1:-1]:
+        t = _range_table(dec, u)
+        smp = Sample.with_scan(t, fasta, 50, helpers.oracle_scan(t, 50))
+        bad += not ChromosomeFeed._slice_complete(u, smp)
+    assert bad == len(units) - 2
