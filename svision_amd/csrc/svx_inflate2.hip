@@ -279,9 +279,14 @@ __host__ __device__ inline uint64_t stream_base(const uint64_t* dst_off, uint32_
 
 __device__ __forceinline__ void put32(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
 
+// SPLIT: the stream format of bgzf_lz_wave_kernel -- the sequences' u32 headers as an array that grows upwards from the slot's
+// first 4-byte boundary, their literal bytes downwards from the slot's end (literal j of the block at end[-1 - j]): 64 headers are
+// one coalesced load, the positions of 64 sequences' outputs and literals two wave prefix sums.  stream_cnt[b] = (sequences,
+// literal bytes).  Not SPLIT: headers and literals interleaved (bgzf_lz_kernel walks them), stream_cnt[b].x = the stream's bytes.
+template <bool SPLIT>
 __global__ __launch_bounds__(LANES)
 void bgzf_tokens_kernel(const uint8_t* __restrict__ comp, const uint64_t* __restrict__ src_off, const uint32_t* __restrict__ src_len,
-                        const uint64_t* __restrict__ dst_off, uint32_t n_blocks, uint8_t* __restrict__ streams, uint32_t* __restrict__ stream_len,
+                        const uint64_t* __restrict__ dst_off, uint32_t n_blocks, uint8_t* __restrict__ streams, uint2* __restrict__ stream_cnt,
                         uint32_t* __restrict__ status)
 {
     __shared__ Lds t;
@@ -292,7 +297,11 @@ void bgzf_tokens_kernel(const uint8_t* __restrict__ comp, const uint64_t* __rest
     const uint32_t isize = (uint32_t)(dst_off[b + 1] - dst_off[b]);
     uint8_t* stream = streams + stream_base(dst_off, b);
     const uint32_t cap = (uint32_t)(stream_base(dst_off, b + 1) - stream_base(dst_off, b));
-    uint32_t P = 0, W = 0, Q = 0;                    // (uniform) bit position, bytes decoded, stream bytes written
+    const uint32_t pad = SPLIT ? (uint32_t)(-(intptr_t)reinterpret_cast<uintptr_t>(stream)) & 3u : 0u;
+    uint8_t* const hdr0 = stream + pad;              // (SPLIT) the header array; the literals end at stream + cap
+    uint8_t* const lit_end = stream + cap;
+    uint32_t P = 0, W = 0, Q = pad;                  // (uniform) bit position, bytes decoded, stream bytes written
+    uint32_t H = 0, Lc = 0;                          // (SPLIT, uniform) sequences and literal bytes written
     int err = INF_OK;
     bool last = isize == 0;                          // an empty block (the EOF marker): nothing to decode
     HeadReader hr;
@@ -312,11 +321,17 @@ void bgzf_tokens_kernel(const uint8_t* __restrict__ comp, const uint64_t* __rest
             const uint8_t* from = src + (P >> 3);
             for (uint32_t s = lane; s < nseq; s += LANES) {
                 const uint32_t n = min(255u, len - 255u * s);
-                uint8_t* q = stream + Q + 259u * s;
-                put32(q, n);
-                for (uint32_t i = 0; i < n; ++i) q[4 + i] = from[255u * s + i];
+                if (SPLIT) {
+                    put32(hdr0 + 4u * (H + s), n);
+                    uint8_t* q = lit_end - 1 - (Lc + 255u * s);
+                    for (uint32_t i = 0; i < n; ++i) q[-(int)i] = from[255u * s + i];
+                } else {
+                    uint8_t* q = stream + Q + 259u * s;
+                    put32(q, n);
+                    for (uint32_t i = 0; i < n; ++i) q[4 + i] = from[255u * s + i];
+                }
             }
-            Q += len + 4u * nseq; W += len; P += 8u * len;
+            Q += len + 4u * nseq; W += len; P += 8u * len; H += nseq; Lc += len;
             continue;
         }
         if (type == 3) { err = INF_BAD_TYPE; break; }
@@ -392,12 +407,12 @@ void bgzf_tokens_kernel(const uint8_t* __restrict__ comp, const uint64_t* __rest
             // S2: from the predecessor's end; again for the lanes whose start moved
             uint32_t start = (uint32_t)__shfl_up((int)p, 1, LANES);
             if (lane == 0) start = P;
-            uint32_t f = 0, olen = 0, enc = 0, lit = 0, flag = 0;
+            uint32_t f = 0, olen = 0, enc = 0, lit = 0, flag = 0, nsq = 0;
             bool dirty = true;
             int first = LANES;
             for (;;) {
                 bool run = dirty;
-                if (dirty) { p = start; olen = 0; enc = 0; lit = 0; flag = 0; }
+                if (dirty) { p = start; olen = 0; enc = 0; lit = 0; flag = 0; nsq = 0; }
                 while (__any(run)) {
                     // (one branch around the decode, the bookkeeping behind it with selects: written as the nest of ifs it is,
                     // every path back into the loop carried half a dozen register moves -- a third of the loop's vector
@@ -411,6 +426,7 @@ void bgzf_tokens_kernel(const uint8_t* __restrict__ comp, const uint64_t* __rest
                     p += adv ? k.used : 0u;
                     const bool full = isl && lit == 255u;
                     enc += ism ? 4u + lit : full ? 259u : 0u;
+                    if (SPLIT) nsq += (ism || full) ? 1u : 0u;
                     lit = isl ? (full ? 1u : lit + 1u) : ism ? 0u : lit;
                     olen += ism ? k.len : isl ? 1u : 0u;
                     flag = bad ? 2u : eob ? 1u : flag;
@@ -427,10 +443,12 @@ void bgzf_tokens_kernel(const uint8_t* __restrict__ comp, const uint64_t* __rest
             }
             if (first < LANES && uni((int)__shfl((int)flag, first, LANES)) == 2) { err = INF_BAD_CODE; break; }
             const bool valid = lane <= first;
-            if (lit) enc += 4u + lit;
-            uint32_t tot_o, tot_e;
+            if (lit) { enc += 4u + lit; nsq += 1u; }
+            uint32_t tot_o, tot_e, tot_h = 0;
             const uint32_t o = W + wave_excl_sum(valid ? olen : 0u, &tot_o);
             const uint32_t qoff = Q + wave_excl_sum(valid ? enc : 0u, &tot_e);
+            const uint32_t hoff = SPLIT ? H + wave_excl_sum(valid ? nsq : 0u, &tot_h) : 0u;      // this lane's first sequence / first literal
+            const uint32_t loff = SPLIT ? Lc + (qoff - Q) - 4u * (hoff - H) : 0u;
             if (W + tot_o > isize) { err = INF_OUT_OVERRUN; break; }
             if (Q + tot_e > cap) { err = INF_TOKENS_OVERFLOW; break; }
             // S3: transcode
@@ -438,7 +456,8 @@ void bgzf_tokens_kernel(const uint8_t* __restrict__ comp, const uint64_t* __rest
             if (false)
 #endif
             {
-                uint8_t* hdr = stream + qoff;
+                uint8_t* hdr = SPLIT ? hdr0 + 4u * hoff : stream + qoff;
+                uint8_t* lp = lit_end - loff;                    // (SPLIT) one behind the next literal's place
                 uint32_t w = o, nl = 0;
                 bool bad_dist = false;
                 p = start;
@@ -451,13 +470,14 @@ void bgzf_tokens_kernel(const uint8_t* __restrict__ comp, const uint64_t* __rest
                     const bool isl = go && k.kind == K_LIT, ism = go && k.kind == K_LEN;
                     const bool full = isl && nl == 255u;
                     if (full) put32(hdr, 255u);
-                    hdr += full ? 259 : 0;
+                    hdr += full ? (SPLIT ? 4 : 259) : 0;
                     nl = full ? 0u : nl;
-                    if (isl) hdr[4 + nl] = (uint8_t)k.val;
+                    if (SPLIT) { lp -= isl ? 1 : 0; if (isl) *lp = (uint8_t)k.val; }
+                    else if (isl) hdr[4 + nl] = (uint8_t)k.val;
                     if (ism) put32(hdr, nl | k.len << 8 | (k.dist - 1u) << 17);
                     const bool far = ism && k.dist > w;          // a distance beyond the start of the output
                     bad_dist = bad_dist || far;
-                    hdr += ism ? 4 + nl : 0;
+                    hdr += ism ? (SPLIT ? 4 : 4 + nl) : 0;
                     nl = ism ? 0u : nl + (isl ? 1u : 0u);
                     w += ism ? k.len : isl ? 1u : 0u;
                     run = (isl || ism) && !far;                  // (not: the segment's end, the end-of-block code, a bad distance)
@@ -466,12 +486,13 @@ void bgzf_tokens_kernel(const uint8_t* __restrict__ comp, const uint64_t* __rest
                 if (__any(bad_dist)) { err = INF_BAD_DIST; break; }
             }
             W += tot_o; Q += tot_e;
+            if (SPLIT) { Lc += tot_e - 4u * tot_h; H += tot_h; }
             if (first < LANES) { eob = true; P = (uint32_t)__shfl((int)f, first, LANES); }
             else P = (uint32_t)__shfl((int)f, LANES - 1, LANES);
         }
     }
     if (err == INF_OK && W != isize) err = INF_SHORT;
-    if (lane == 0) { status[b] = (uint32_t)err; stream_len[b] = Q; }
+    if (lane == 0) { status[b] = (uint32_t)err; stream_cnt[b] = SPLIT ? make_uint2(H, Lc) : make_uint2(Q, 0u); }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -480,7 +501,7 @@ void bgzf_tokens_kernel(const uint8_t* __restrict__ comp, const uint64_t* __rest
 constexpr int LZ_LANES = 64, RING_STRIDE = svx_lz::RING + 16;      // (+ 16: lanes at the same ring offset fall into different banks)
 
 __global__ __launch_bounds__(LZ_LANES)
-void bgzf_lz_kernel(const uint8_t* __restrict__ streams, const uint32_t* __restrict__ stream_len, const uint64_t* __restrict__ dst_off,
+void bgzf_lz_kernel(const uint8_t* __restrict__ streams, const uint2* __restrict__ stream_cnt, const uint64_t* __restrict__ dst_off,
                     uint32_t n_blocks, uint8_t* out, uint32_t* __restrict__ status)
 {
     // (dynamic although constant: with static LDS the compiler raises the kernel's VGPR allocation to what its LDS-limited
@@ -490,18 +511,181 @@ void bgzf_lz_kernel(const uint8_t* __restrict__ streams, const uint32_t* __restr
     const uint32_t b = blockIdx.x * LZ_LANES + threadIdx.x;
     if (b >= n_blocks) return;
     if (status[b] != 0) return;
-    const int err = svx_lz::decode_block(streams + stream_base(dst_off, b), stream_len[b], out, dst_off[b], dst_off[b + 1],
+    const int err = svx_lz::decode_block(streams + stream_base(dst_off, b), stream_cnt[b].x, out, dst_off[b], dst_off[b + 1],
                                          rings + threadIdx.x * RING_STRIDE);
     if (err != svx_lz::LZ_OK) status[b] = (uint32_t)err;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// B', round 5: one WAVE per block.  The lane-per-block kernel above needs ~25 ms for a block whatever the launch holds (one lane
+// walks the block's ~9,500 sequences, each a chain of dependent steps), so every group of chromosomes -- the first one of a job
+// above all: the pipeline behind waits for it -- pays that latency, and its dribbling 16-byte stores and far-match loads move
+// five times the output through the fabric.  Here the wave keeps the block's last 32 KB of output -- DEFLATE's whole window --
+// in LDS, indexed by the output's own address, so that a match never reads memory; 64 headers are one coalesced load and two
+// wave prefix sums give every sequence its output and literal positions; the sequences are then executed in order, all lanes
+// on one -- literal bytes from a staged window of the literal stream (filled 1 KB at a time, a load ahead), match bytes from the
+// ring (an overlapping match reads its period: source = start + i mod distance, all of it written before) --, and the output
+// leaves in whole aligned 16-byte chunks, 4 KB at a time, read back from the ring: every byte of the stream is fetched once and
+// every byte of the output written once.  ~0.5-1 ms per block: a launch of n blocks takes n / 1024 rounds of that (36 KB of LDS
+// per wave: four waves per CU), where the lane kernel takes its 25 ms + 0.1 ms per 1,000 blocks -- the entry point picks.
+constexpr int WAVE_LZ_BELOW = 12000;
+constexpr uint32_t WRING = 32768, WMASK = WRING - 1, WSTAGE = 4096, WFLUSH = 4096;
+
+__global__ __launch_bounds__(LANES)
+void bgzf_lz_wave_kernel(const uint8_t* __restrict__ streams, const uint2* __restrict__ stream_cnt, const uint64_t* __restrict__ dst_off,
+                         uint32_t n_blocks, uint8_t* out, uint32_t* __restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t wlds[];   // [ring: WRING][literal window: WSTAGE][the batch's sequences: 1 KB]
+    uint8_t* const ring = wlds;
+    uint8_t* const stage = wlds + WRING;
+    const uint32_t b = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    if (status[b] != 0) return;
+    const uint64_t lo = dst_off[b], hi = dst_off[b + 1];
+    if (hi == lo) return;
+    const uint32_t nseq = stream_cnt[b].x, nlit = stream_cnt[b].y;
+    const uint8_t* slot = streams + stream_base(dst_off, b);
+    const uint32_t cap = (uint32_t)(stream_base(dst_off, b + 1) - stream_base(dst_off, b));
+    const uint32_t* hdr = reinterpret_cast<const uint32_t*>(slot + ((uint32_t)(-(intptr_t)reinterpret_cast<uintptr_t>(slot)) & 3u));
+    // literal j lies at lit_end[-1 - j]; in 16-byte chunks counted downwards from the chunk that holds lit_end - 1 ... : with
+    // t = j + 16 - r (r = lit_end mod 16; r = 0: the chunk above is never needed), chunk t >> 4 is the 16 bytes at a16 - 16 (t >> 4)
+    // and the byte is its 15 - (t & 15)-th -- staged at (chunk * 16) mod WSTAGE, literal j is the window's byte (t ^ 15) mod WSTAGE
+    const uint8_t* lit_end = slot + cap;
+    const uint32_t r = (uint32_t)reinterpret_cast<uintptr_t>(lit_end) & 15u;
+    const uint8_t* a16 = lit_end - r;
+    auto chunk_ptr = [&](uint32_t c) {
+        const uint8_t* q = a16 - 16ull * c;
+        return reinterpret_cast<const uint4*>(q < streams ? streams : q);          // (the first block's window may start below its slot: never used)
+    };
+    uint32_t staged = 0;                                 // chunks in the window
+    uint4 pend = *chunk_ptr(lane);                       // chunks [staged, staged + 64) on their way
+    auto need_chunk = [&](uint32_t cmax) {               // the window holds chunk cmax afterwards
+        while (cmax >= staged) {
+            *reinterpret_cast<uint4*>(stage + ((16u * (staged + lane)) & (WSTAGE - 1))) = pend;
+            staged += LANES;
+            pend = *chunk_ptr(staged + lane);
+        }
+    };
+    uint64_t W = lo, flushed = lo;                       // (uniform) next output byte, everything below is in memory
+    uint32_t L = 0;                                      // literals consumed
+    int err = svx_lz::LZ_OK;
+    auto flush_to = [&](uint64_t upto) {                 // [flushed, upto) leaves the ring; upto: a multiple of 16, or hi
+        if (flushed < upto && (flushed & 15ull)) {       // the block's first bytes, up to the first boundary: another block's lie in front
+            const uint64_t e = min(upto, (flushed + 15ull) & ~15ull);
+            if (flushed + lane < e) out[flushed + lane] = ring[(uint32_t)(flushed + lane) & WMASK];
+            flushed = e;
+        }
+        for (uint64_t a = flushed + 16ull * lane; a + 16 <= upto; a += 16ull * LANES)
+            *reinterpret_cast<uint4*>(out + a) = *reinterpret_cast<const uint4*>(ring + ((uint32_t)a & WMASK));
+        const uint64_t whole = flushed + ((upto - flushed) & ~15ull);
+        if (whole + lane < upto) out[whole + lane] = ring[(uint32_t)(whole + lane) & WMASK];     // (upto == hi: the last, partial chunk)
+        flushed = upto;
+    };
+    // one sequence, all lanes on it (long literal runs, long or overlapping matches, whatever a step below cannot take)
+    auto careful = [&](uint32_t hk, uint64_t w, uint32_t l0) {
+        const uint32_t knl = hk & 255u, kml = (hk >> 8) & 511u, kd = (hk >> 17) + 1u;
+        if (knl) {
+            const uint32_t t0 = l0 + 16u - r;
+            need_chunk((t0 + knl - 1u) >> 4);
+            for (uint32_t i = lane; i < knl; i += LANES)
+                ring[(uint32_t)(w + i) & WMASK] = stage[((t0 + i) ^ 15u) & (WSTAGE - 1)];
+        }
+        if (kml) {
+            const uint64_t wm = w + knl;
+            if (kd > wm - lo) { err = svx_lz::LZ_BAD_DIST; return; }
+            const uint32_t from = (uint32_t)(wm - kd);
+            if (kd >= kml) {
+                for (uint32_t i = lane; i < kml; i += LANES) ring[(uint32_t)(wm + i) & WMASK] = ring[(from + i) & WMASK];
+            } else {                                     // the match overlaps its own output: its period, as often as it takes
+                const float inv = 1.0f / (float)kd;
+                for (uint32_t i = lane; i < kml; i += LANES) {
+                    const uint32_t q = (uint32_t)((float)i * inv);
+                    int32_t rem = (int32_t)(i - q * kd);
+                    if (rem < 0) rem += (int32_t)kd;
+                    if (rem >= (int32_t)kd) rem -= (int32_t)kd;
+                    ring[(uint32_t)(wm + i) & WMASK] = ring[(from + (uint32_t)rem) & WMASK];
+                }
+            }
+        }
+    };
+    uint4* const meta = reinterpret_cast<uint4*>(wlds + WRING + WSTAGE);      // [64] (header, output offset, literal offset) of the batch's sequences
+    constexpr uint32_t SEQ_LANES = 8, STEP_SEQS = LANES / SEQ_LANES;     // lanes per sequence, sequences per step
+    const uint32_t q8 = lane / SEQ_LANES, i8 = lane & (SEQ_LANES - 1u);
+    uint32_t hnext = lane < nseq ? hdr[lane] : 0u;
+    for (uint32_t s0 = 0; s0 < nseq && err == svx_lz::LZ_OK; s0 += LANES) {
+        const uint32_t h = hnext;
+        hnext = s0 + LANES + lane < nseq ? hdr[s0 + LANES + lane] : 0u;
+        uint32_t T, Lt;
+        {
+            const uint32_t nl = h & 255u, ml = (h >> 8) & 511u;
+            const uint32_t wofs = wave_excl_sum(nl + ml, &T), lofs = wave_excl_sum(nl, &Lt);
+            meta[lane] = make_uint4(h, wofs, lofs, 0u);
+        }
+        if (W + T > hi || L + Lt > nlit) { err = svx_lz::LZ_OUT_OVERRUN; break; }
+        const uint32_t nb = min((uint32_t)LANES, nseq - s0);
+        // the literals of a batch are normally ~100 bytes: staged here, once; a batch of long runs stages sequence by sequence
+        const bool bulk = Lt <= 1024u;
+        if (bulk && Lt) need_chunk((L + Lt + 15u - r) >> 4);
+        const uint32_t base32 = (uint32_t)W, rel0 = (uint32_t)(W - lo);
+        // A STEP takes the next (up to) eight sequences, eight lanes each (four of sixteen, which take 97 % of the sequences instead
+        // of 89 %, were measured: 10 % slower -- the steps are cut short by dependent matches, not by long ones): lane (q, i) copies literal byte i and match byte i of
+        // sequence k0 + q.  Literals first, then the matches' reads, then their writes -- in order in the LDS --, so a step may
+        // hold every sequence whose match reads nothing a match of the SAME step writes (conservatively: nothing at or behind
+        // the step's first output byte; the step's first sequence is exempt: what it reads is older, or its own literals) and
+        // that has at most eight literal and eight match bytes (89 % on HiFi-like data).  The first sequence that does not fit
+        // ends the step; if it is the step's first, all lanes take it alone.
+        uint32_t k0 = 0;
+        uint4 mnext = meta[min(q8, nb - 1u)];
+        while (k0 < nb) {
+            const uint32_t k = k0 + q8;
+            const bool valid = k < nb;
+            const uint4 m = mnext;
+            const uint32_t nl = m.x & 255u, ml = (m.x >> 8) & 511u, d = (m.x >> 17) + 1u;
+            const int32_t step0 = __builtin_amdgcn_readfirstlane((int32_t)m.y);
+            if ((uint32_t)(base32 + (uint32_t)step0 - (uint32_t)flushed) >= WFLUSH + 16u) flush_to((W + (uint32_t)step0) & ~15ull);
+            uint32_t imod = i8;
+            if (d < ml) imod = i8 - d * (uint32_t)((float)i8 * __builtin_amdgcn_rcpf((float)d) + 1e-3f);
+            const int32_t srel = (int32_t)(m.y + nl - d + imod);
+            const bool rd = valid && i8 < ml;
+            // (a distance of nearly the whole window: the ring slot the match reads is the slot of a byte up to 64 positions AHEAD --
+            // a literal of a later sequence of the step, written before the matches read, would be in it: such a match goes alone)
+            const bool bad = valid && (nl > 8u || ml > 8u || !bulk || d > WRING - 512u || (rd && q8 > 0 && srel >= step0));
+            const unsigned long long bm = __ballot(bad);
+            const uint32_t n_ok = bm ? (uint32_t)(__ffsll((long long)bm) - 1) / SEQ_LANES : min(STEP_SEQS, nb - k0);
+            // the next step's sequences are known now: their descriptors are on their way while this step's bytes move
+            const uint32_t k1 = k0 + (n_ok ? n_ok : 1u);
+            mnext = meta[min(k1 + q8, nb - 1u)];
+            if (n_ok) {
+                const bool act = valid && q8 < n_ok;
+                if (__any(act && rd && d > rel0 + m.y + nl)) { err = svx_lz::LZ_BAD_DIST; break; }
+                const uint32_t w32 = base32 + m.y;
+                if (__any(act && i8 < nl)) {
+                    if (act && i8 < nl) ring[(w32 + i8) & WMASK] = stage[((L + m.z + 16u - r + i8) ^ 15u) & (WSTAGE - 1)];
+                }
+                if (act && rd) ring[(w32 + nl + i8) & WMASK] = ring[(base32 + (uint32_t)srel) & WMASK];
+                k0 += n_ok;
+            } else {
+                careful((uint32_t)__builtin_amdgcn_readfirstlane((int32_t)m.x), W + (uint32_t)step0, L + (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)m.z));
+                if (err != svx_lz::LZ_OK) break;
+                k0 += 1;
+            }
+        }
+        W += T; L += Lt;
+        if ((uint32_t)((uint32_t)W - (uint32_t)flushed) >= WFLUSH + 16u) flush_to(W & ~15ull);
+    }
+    if (err == svx_lz::LZ_OK && W != hi) err = svx_lz::LZ_SHORT;
+    if (err == svx_lz::LZ_OK) flush_to(hi);
+    else if (lane == 0) status[b] = (uint32_t)err;
 }
 
 }  // namespace
 
 extern "C" size_t svx_bgzf_inflate_fast_ws_bytes(uint64_t inflated_bytes, uint32_t n_blocks)
 {
-    // [stream lengths: 4 n, rounded up to 256][the blocks' slots: 1.5 x ISIZE + 1 KB each][64 bytes: svx_lz::decode_block reads a
+    // [per block (sequences, literal bytes) -- or the stream's bytes --: 8 n, rounded up to 256][the blocks' slots: 1.5 x ISIZE + 1 KB each][64 bytes: svx_lz::decode_block reads a
     // header and the 12 bytes behind it with one 16-byte load, also at the end of the last slot]
-    return (size_t)((((size_t)4 * n_blocks + 255) & ~(size_t)255) + inflated_bytes + (inflated_bytes >> 1) + 1024ull * n_blocks + 64);
+    return (size_t)((((size_t)8 * n_blocks + 255) & ~(size_t)255) + inflated_bytes + (inflated_bytes >> 1) + 1024ull * n_blocks + 64);
 }
 
 // The contract of svx_bgzf_inflate with a workspace (svx_bgzf_inflate_fast_ws_bytes(d_dst_off[n] - d_dst_off[0], n) bytes, 16-byte
@@ -520,8 +704,13 @@ extern "C" int svx_bgzf_inflate_fast_on(const uint8_t* d_comp, const uint64_t* d
     // the slots of the sequence streams are laid out by it, so a smaller workspace would be overrun by the tokens kernel
     if (ws_bytes < svx_bgzf_inflate_fast_ws_bytes(inflated_bytes, n_blocks)) return SVX_EINVAL;
     hipStream_t sa = static_cast<hipStream_t>(stream_tokens), sb = static_cast<hipStream_t>(stream_lz);
-    uint32_t* stream_len = static_cast<uint32_t*>(d_ws);
-    uint8_t* streams = static_cast<uint8_t*>(d_ws) + (((size_t)4 * n_blocks + 255) & ~(size_t)255);
+    uint2* stream_cnt = static_cast<uint2*>(d_ws);
+    uint8_t* streams = static_cast<uint8_t*>(d_ws) + (((size_t)8 * n_blocks + 255) & ~(size_t)255);
+    // which LZ kernel: one wave per block (B': ~1 ms per block, 1,024 blocks at once) below WAVE_LZ_BELOW blocks, one lane per
+    // block (B: ~25 ms whatever the launch holds + 0.1 ms per 1,000 blocks) above.  SVX_LZ=wave|lane: by name (measurements).
+    const char* lz = getenv("SVX_LZ");
+    const char* below = getenv("SVX_WAVE_LZ_BELOW");
+    const bool wave_lz = lz ? lz[0] == 'w' : n_blocks < (below ? (uint32_t)atoi(below) : (uint32_t)WAVE_LZ_BELOW);
     const char* only = getenv("SVX_INFLATE2_ONLY");                          // measurements: "A" = kernel A alone (the output stays unwritten),
     if (!only && getenv("SVX_INFLATE2_ONLY_A")) only = "A";                  // "B" = kernel B alone on the streams an earlier call left in the same workspace
     if (!only || only[0] != 'B') {
@@ -532,7 +721,8 @@ extern "C" int svx_bgzf_inflate_fast_on(const uint8_t* d_comp, const uint64_t* d
             (void)hipStreamWaitEvent(sa, ready, 0);
             (void)hipEventDestroy(ready);
         }
-        hipLaunchKernelGGL(bgzf_tokens_kernel, dim3(n_blocks), dim3(LANES), 0, sa, d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, streams, stream_len, d_status);
+        if (wave_lz) hipLaunchKernelGGL(bgzf_tokens_kernel<true>, dim3(n_blocks), dim3(LANES), 0, sa, d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, streams, stream_cnt, d_status);
+        else hipLaunchKernelGGL(bgzf_tokens_kernel<false>, dim3(n_blocks), dim3(LANES), 0, sa, d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, streams, stream_cnt, d_status);
         if (sa != sb) {
             hipEvent_t done;
             if (hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) return SVX_ELAUNCH;
@@ -542,7 +732,8 @@ extern "C" int svx_bgzf_inflate_fast_on(const uint8_t* d_comp, const uint64_t* d
         }
     }
     if (only && only[0] == 'A') return SVX_OK;
-    hipLaunchKernelGGL(bgzf_lz_kernel, dim3((n_blocks + LZ_LANES - 1) / LZ_LANES), dim3(LZ_LANES), LZ_LANES * RING_STRIDE, sb, streams, stream_len, d_dst_off, n_blocks, d_out, d_status);
+    if (wave_lz) hipLaunchKernelGGL(bgzf_lz_wave_kernel, dim3(n_blocks), dim3(LANES), WRING + WSTAGE + 1024, sb, streams, stream_cnt, d_dst_off, n_blocks, d_out, d_status);
+    else hipLaunchKernelGGL(bgzf_lz_kernel, dim3((n_blocks + LZ_LANES - 1) / LZ_LANES), dim3(LZ_LANES), LZ_LANES * RING_STRIDE, sb, streams, stream_cnt, d_dst_off, n_blocks, d_out, d_status);
     if (hipGetLastError() != hipSuccess) return SVX_ELAUNCH;
     // the (pathological) blocks whose sequence stream did not fit its slot: the wave-per-block kernel, those blocks only
     return svx_bgzf_inflate_wave_only(d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, d_out, d_status, INF_TOKENS_OVERFLOW, stream_lz);

@@ -263,8 +263,8 @@ class ChromosomeFeed:
                     # clusters count or genotype with.  Nothing of it is handed over; stage A cuts the rest of the file again.
                     self.stats["replans"] += 1
                     if dec is not None:
-                        dec._mark("slice %r rejected: reach %d" % (unit, sample.reach()))
-                    self._replan = (epoch, tid, lo, sample.reach())
+                        dec._mark("slice %r rejected: its windows need %d bases beyond them" % (unit, self._slice_needs(unit, sample)))
+                    self._replan = (epoch, tid, lo, self._slice_needs(unit, sample))
                     self._epoch = epoch + 1
                     sample.device_buffers = None
                     if getattr(alloc, "dir", None) is not None:
@@ -314,16 +314,46 @@ class ChromosomeFeed:
 
     @staticmethod
     def _slice_complete(unit, sample):
-        """Does the slice hold every record its windows can touch?  Everything a window [a, b) of it does -- collection,
-        cluster coverage (classes.py:165-170), genotyping (genotype.py:22-26: +-1000 bp) -- stays within ``reach`` =
-        Sample.reach() of [a, b): on the left the slice starts at the linear-index entry of ``left_edge`` (every record
-        reaching beyond that coordinate lies behind it), on the right it ends in front of a record that starts at or behind
-        its last one (the file is sorted)."""
-        reach = sample.reach()
+        """Does the slice hold every record its windows can touch?  A window [a, b) collects on the records that overlap it; the
+        coordinates of their signatures -- and so the extents of the clusters the window reports -- stay within those records'
+        [pos - read length, end + read length] (inserted / re-placed pieces), the cluster coverage (classes.py:165-170) counts the
+        records overlapping those extents and the genotyper looks 1000 bases farther (genotype.py:22-26).  So the window needs every
+        record overlapping [min(pos - l_seq) - 1000, max(end + l_seq) + 1000) of ITS records.  On the left the slice starts at the
+        linear-index entry of ``left_edge`` (every record reaching beyond that coordinate lies behind it), on the right it ends in
+        front of a record that starts at or behind its last one (the file is sorted)."""
         table = sample.table
-        left = unit.left_edge is None or unit.left_edge <= unit.lo - reach
-        right = unit.to_end or (len(table) > 0 and int(table.pos[-1]) >= unit.hi + reach)
-        return left and right
+        if len(table) == 0:
+            return unit.left_edge is None and unit.to_end
+        tid = int(table.tid[0])
+        ref_end = table.ref_end()
+        last_pos = int(table.pos[-1])
+        for a, b in unit.windows:
+            rows = table.fetch(tid, a, b)
+            if rows.size == 0:
+                lo_need, hi_need = a - 1000, b + 1000
+            else:
+                l_seq = table.l_seq[rows].astype(np.int64)
+                lo_need = min(a, int((table.pos[rows].astype(np.int64) - l_seq).min())) - 1000
+                hi_need = max(b, int((ref_end[rows] + l_seq).max())) + 1000
+            if unit.left_edge is not None and unit.left_edge > lo_need:
+                return False
+            if not unit.to_end and last_pos < hi_need:
+                return False
+        return True
+
+    @staticmethod
+    def _slice_needs(unit, sample):
+        """The margin (bases beyond its windows) the slice turned out to need: what it is cut again with, doubled."""
+        table = sample.table
+        if len(table) == 0:
+            return 0
+        tid, ref_end, need = int(table.tid[0]), table.ref_end(), 0
+        for a, b in unit.windows:
+            rows = table.fetch(tid, a, b)
+            if rows.size:
+                l_seq = table.l_seq[rows].astype(np.int64)
+                need = max(need, a - int((table.pos[rows].astype(np.int64) - l_seq).min()), int((ref_end[rows] + l_seq).max()) - b)
+        return need + 1000
 
     def _spill(self, jobs):
         """Stage C: host copies of the device-decoded CIGAR words (ingest_gpu.spill_cigar), after the hand-over."""

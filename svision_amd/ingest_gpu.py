@@ -123,11 +123,12 @@ class Unit:
     the file range [vlo, vhi) of virtual offsets, both ends at linear-index entries (or the ends of the reference's records).
     A whole chromosome is one unit with lo = 0, hi = its length.  ``left_edge``: every record that reaches beyond this
     coordinate lies at or behind ``vlo`` (None: vlo is the reference's first record)."""
-    __slots__ = ("tid", "lo", "hi", "vlo", "vhi", "left_edge", "to_end", "first", "last")
+    __slots__ = ("tid", "lo", "hi", "vlo", "vhi", "left_edge", "to_end", "first", "last", "windows")
 
-    def __init__(self, tid, lo, hi, vlo, vhi, left_edge=None, to_end=True, first=True, last=True):
+    def __init__(self, tid, lo, hi, vlo, vhi, left_edge=None, to_end=True, first=True, last=True, windows=None):
         self.tid, self.lo, self.hi, self.vlo, self.vhi = int(tid), int(lo), int(hi), int(vlo), int(vhi)
         self.left_edge, self.to_end, self.first, self.last = left_edge, bool(to_end), bool(first), bool(last)
+        self.windows = list(windows) if windows is not None else [(self.lo, self.hi)]
 
     def __repr__(self):
         return "Unit(tid %d, [%d, %d)%s%s)" % (self.tid, self.lo, self.hi, "" if self.left_edge is None else ", records from %d" % self.left_edge,
@@ -228,7 +229,7 @@ class DeviceDecoder:
         have = sorted((self.spans[t][0], t) for t in tids if t < len(self.spans) and self.spans[t] is not None)
         return [Unit(t, 0, self.lengths[t] if t < len(self.lengths) else 1 << 62, self.spans[t][0], self.spans[t][1]) for _v, t in have]
 
-    def plan_units(self, tids, windows_of=None, margin=None, slice_bytes=None, resume=None):
+    def plan_units(self, tids, windows_of=None, margin=None, slice_bytes=None, resume=None, min_span_margins=None):
         """The references of ``tids`` that have records, in file order, each cut into slices of whole collection windows:
         ``windows_of(tid)`` -> its windows [(start, end), ...] ascending (None / a single window: the whole reference is one
         unit).  A slice is a run of windows of about ``slice_bytes`` compressed bytes (at least one window) and reads the
@@ -239,6 +240,7 @@ class DeviceDecoder:
         coordinate): leave out that reference's windows in front of the coordinate and every reference in front of it."""
         margin = int(margin if margin is not None else self.estimate_reach(tids))
         slice_bytes = int(slice_bytes or int(os.environ.get("SVX_SLICE_BYTES", "0")) or SLICE_BYTES)      # (the variable: experiments, tests)
+        min_span = int(os.environ.get("SVX_SLICE_MIN_MARGINS", "13") if min_span_margins is None else min_span_margins) * margin
         have = sorted((self.spans[t][0], t) for t in tids if t < len(self.spans) and self.spans[t] is not None)
         units, skipping = [], resume is not None
         for _v, t in have:
@@ -255,38 +257,48 @@ class DeviceDecoder:
             if wins is None or os.environ.get("SVX_SLICES", "1") == "0":
                 units.append(Unit(t, 0, self.lengths[t], span[0], span[1]))        # the whole chromosome (a resumed one: what is left of it is served by it)
                 continue
+            # a slice reads its margins twice (once with each neighbour): behind the reference's first slice -- one window, whatever
+            # it costs: the pipeline waits for it -- a slice spans at least ~13 margins' worth of reference, so that long reads (ONT: a
+            # margin of a megabase) do not turn a fifth of the file into overlap
             i = 0
             while i < len(wins):
                 j = i + 1
                 v0 = voff_at(span, wins[i][0])
-                while j < len(wins) and ((voff_at(span, wins[j][1]) >> 16) - (v0 >> 16)) <= slice_bytes:
+                while j < len(wins) and (((voff_at(span, wins[j][1]) >> 16) - (v0 >> 16)) <= slice_bytes
+                                         or (i > 0 and wins[j - 1][1] - wins[i][0] < min_span)):
                     j += 1
                 lo, hi = wins[i][0], wins[j - 1][1]
-                vlo, vhi = voff_at(span, lo - margin), (span[1] if j == len(wins) and hi >= self.lengths[t] else voff_at(span, hi + margin))
+                # (on the right TWICE the margin: the entry of a bin is the first record that overlaps it, which may start a whole read
+                # length in front of it -- and the slice holds the records in front of THAT one)
+                vlo, vhi = voff_at(span, lo - margin), (span[1] if j == len(wins) and hi >= self.lengths[t] else voff_at(span, hi + 2 * margin))
                 vhi = max(vhi, vlo)
                 units.append(Unit(t, lo, hi, vlo, vhi, left_edge=None if vlo == span[0] else max(0, (lo - margin) >> 14 << 14), to_end=vhi == span[1],
-                                  first=i == 0, last=j == len(wins)))
+                                  first=i == 0, last=j == len(wins), windows=wins[i:j]))
                 i = j
         return units
 
-    def estimate_reach(self, tids=None, sample=1 << 20, blocks=6):
-        """A first guess of how far a slice must reach beyond its windows (:meth:`plan_units`): the first few BGZF blocks of the
-        first reference that has records are inflated on the host (zlib: some hundred KB) and their records walked -- four
-        times the largest (reference span + read length) seen, at least MIN_MARGIN, a multiple of 16 kb.  Only a guess: reads
-        are not of one length; every slice is checked against its own records afterwards."""
+    def estimate_reach(self, tids=None, sample=1 << 20, blocks=12):
+        """A first guess of how far a slice must reach beyond its windows (:meth:`plan_units`): the records of a few 16 kb bins in
+        the middle of the first reference are inflated on the host (zlib, a dozen blocks: ~9 ms) and walked -> the
+        largest (reference span + read length) a log-normal fit of the sample expects among the reads crossing a window edge; at
+        least MIN_MARGIN, a multiple of 16 kb.  Only a guess: reads are not of one length; every slice is checked against its own
+        records afterwards."""
         if getattr(self, "_reach", None) is not None:
             return self._reach
         import struct
         import zlib
-        reach = 0
+        reach, logs = 0, []
         try:
             tid = min((s[0], t) for t, s in enumerate(self.spans) if s is not None and (tids is None or t in tids))[1]
-            v0 = self.spans[tid][0]
+            # (from the middle of the reference: the reads at its start are cut to it -- all of them short)
+            v0 = voff_at(self.spans[tid], self.lengths[tid] // 2) if tid < len(self.lengths) else self.spans[tid][0]
+            if v0 >= self.spans[tid][1]:
+                v0 = self.spans[tid][0]
             start = v0 >> 16
             n = int(min(sample, self.size - start))
             buf = np.empty(n, np.uint8)
             if n > 0 and self.lib.svx_read_range(self.path.encode(), start, n, buf.ctypes.data, 1) == 0:
-                raw, at, data = buf.tobytes(), 0, b""
+                raw, at, parts = buf.tobytes(), 0, []
                 for _ in range(blocks):
                     if at + 18 > n or raw[at:at + 4] != b"\x1f\x8b\x08\x04":
                         break
@@ -294,20 +306,32 @@ class DeviceDecoder:
                     bsize = struct.unpack_from("<H", raw, at + 16)[0] + 1          # (htslib writes BC as the only extra subfield)
                     if at + bsize > n:
                         break
-                    data += zlib.decompress(raw[at + 12 + xlen:at + bsize - 8], -15)
+                    parts.append(zlib.decompress(raw[at + 12 + xlen:at + bsize - 8], -15))
                     at += bsize
+                data = b"".join(parts)
+                span_of = np.asarray([1, 0, 1, 1, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0], np.int64)
                 p = v0 & 0xFFFF
                 while p + 36 <= len(data):
                     size, _ref, _pos, l_name, _mq, _bin, n_cig, _flag, l_seq = struct.unpack_from("<iiiBBHHHi", data, p)
-                    if size < 32 or p + 4 + size > len(data):
+                    if size < 32:
                         break
-                    words = np.frombuffer(data, "<u4", n_cig, p + 36 + l_name)
-                    span = int(((words >> 4).astype(np.int64) * np.asarray([1, 0, 1, 1, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0], np.int64)[words & 15]).sum())
-                    reach = max(reach, span + max(l_seq, 0))
+                    if p + 36 + l_name + 4 * n_cig <= len(data):         # (the CIGAR is in hand although the record's bases may not be)
+                        words = np.frombuffer(data, "<u4", n_cig, p + 36 + l_name)
+                        each = int(((words >> 4).astype(np.int64) * span_of[words & 15]).sum()) + max(l_seq, 0)
+                        reach = max(reach, each)
+                        logs.append(np.log(max(each, 1)))
                     p += 4 + size
         except Exception:                                       # noqa: BLE001 -- a guess: the default stands
-            reach = 0
-        self._reach = max(MIN_MARGIN, (4 * reach + 1000 + 16383) >> 14 << 14)
+            reach, logs = 0, []
+        # what a window needs beyond its edges is set by the longest of the reads that cross an edge -- a few dozen at 30 x, drawn
+        # with a bias towards the long ones.  A log-normal fit of (reference span + read length) over the sample -- mu, sigma of the
+        # logs -- puts the largest of ~60 length-biased draws near exp(mu + sigma^2 + 2.7 sigma): 1.4 x the median for reads of one
+        # length (HiFi, sigma ~0.13), ~11 x for an ONT-like tail (sigma 0.7); never less than 1.25 x the largest seen.
+        guess = 1.25 * reach
+        if len(logs) > 3:
+            mu, sg = float(np.mean(logs)), float(np.std(logs))
+            guess = min(max(guess, float(np.exp(mu + sg * sg + 2.7 * sg))), 2.0 * reach)      # (a few dozen reads: the fit is kept within 1.25-2 x the largest)
+        self._reach = max(MIN_MARGIN, (int(guess) + 1000 + 16383) >> 14 << 14)
         self._mark("reach guessed from the first blocks: %d" % self._reach)
         return self._reach
 

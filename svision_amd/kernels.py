@@ -409,7 +409,7 @@ def inflate_variant_for(n_blocks):
 
 def inflate_workspace(lib, variant, inflated_bytes, n_blocks, device):
     """The workspace tensor a launch of ``variant`` needs (None: none), allocated on the caller's current stream."""
-    if variant != "fast":
+    if not variant.startswith("fast"):
         return None
     return torch.empty(int(lib.svx_bgzf_inflate_fast_ws_bytes(int(inflated_bytes), int(n_blocks))), dtype=torch.uint8, device=device)
 
@@ -419,19 +419,34 @@ def launch_inflate(lib, variant, comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, 
     (:func:`inflate_workspace`); None: taken from the caching allocator here -- stream-ordered, so it may die with this call.
     ``tokens_stream``: the "fast" form's first kernel goes there (svx_bgzf_inflate_fast_on), the rest stays on the current stream."""
     st = _stream_ptr(device)
+    lz = None
+    if variant in ("fast-lane", "fast-wave"):                 # the "fast" form with its LZ kernel by name (tests, measurements): SVX_LZ
+        lz, variant = variant[5:], "fast"
     if variant == "fast":
         d_ws = ws if ws is not None else inflate_workspace(lib, variant, inflated_bytes, n_blocks, device)
         ws_bytes = int(d_ws.numel())
-        if tokens_stream is not None:
-            rc = lib.svx_bgzf_inflate_fast_on(comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, int(inflated_bytes), out_ptr, status_ptr, d_ws.data_ptr(), ws_bytes,
-                                              ctypes.c_void_p(tokens_stream.cuda_stream), st)
-        else:
-            rc = lib.svx_bgzf_inflate_fast(comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, int(inflated_bytes), out_ptr, status_ptr, d_ws.data_ptr(), ws_bytes, st)
-    else:
-        fn = {"lds": lib.svx_bgzf_inflate_lds, "private": lib.svx_bgzf_inflate_private, "wave": lib.svx_bgzf_inflate_wave,
-              "lane": lib.svx_bgzf_inflate}[variant]
-        rc = fn(comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, out_ptr, status_ptr, st)
+        import os
+        saved = os.environ.get("SVX_LZ")
+        if lz is not None:
+            os.environ["SVX_LZ"] = lz
+        try:
+            rc = _launch_fast(lib, comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, inflated_bytes, out_ptr, status_ptr, d_ws, ws_bytes, tokens_stream, st)
+        finally:
+            if lz is not None:
+                os.environ.pop("SVX_LZ", None) if saved is None else os.environ.__setitem__("SVX_LZ", saved)
+        _lib.check(rc, "svx_bgzf_inflate (%s)" % variant)
+        return
+    fn = {"lds": lib.svx_bgzf_inflate_lds, "private": lib.svx_bgzf_inflate_private, "wave": lib.svx_bgzf_inflate_wave,
+          "lane": lib.svx_bgzf_inflate}[variant]
+    rc = fn(comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, out_ptr, status_ptr, st)
     _lib.check(rc, "svx_bgzf_inflate (%s)" % variant)
+
+
+def _launch_fast(lib, comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, inflated_bytes, out_ptr, status_ptr, d_ws, ws_bytes, tokens_stream, st):
+    if tokens_stream is not None:
+        return lib.svx_bgzf_inflate_fast_on(comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, int(inflated_bytes), out_ptr, status_ptr, d_ws.data_ptr(), ws_bytes,
+                                            ctypes.c_void_p(tokens_stream.cuda_stream), st)
+    return lib.svx_bgzf_inflate_fast(comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, int(inflated_bytes), out_ptr, status_ptr, d_ws.data_ptr(), ws_bytes, st)
 
 
 INFLATE_BAD_CRC = 9                 # SVX_INFLATE_BAD_CRC: the block inflated, but not to the bytes its footer's CRC32 was taken of

@@ -51,7 +51,7 @@ def _range_table(dec, unit):
 
 def test_plan_cuts_whole_windows_in_file_order(sliced):
     _path, _table, _fasta, dec = sliced
-    units = dec.plan_units([0, 1], lambda t: _windows(dec.lengths[t]), margin=64 << 10, slice_bytes=1)
+    units = dec.plan_units([0, 1], lambda t: _windows(dec.lengths[t]), margin=64 << 10, slice_bytes=1, min_span_margins=0)
     a = [u for u in units if u.tid == 0]
     assert [(u.lo, u.hi) for u in a] == _windows(LENGTH)                        # slice_bytes below one window: a slice per window
     assert a[0].left_edge is None and a[0].vlo == dec.spans[0][0] and a[-1].to_end and a[-1].vhi == dec.spans[0][1]
@@ -59,7 +59,7 @@ def test_plan_cuts_whole_windows_in_file_order(sliced):
     assert all(v.vlo < u.vhi for u, v in zip(a, a[1:]))                         # neighbours overlap by their margins
     assert [u.tid for u in units] == [0] * len(a) + [1] * (len(units) - len(a))
     # larger slices: runs of windows; every window in exactly one slice
-    big = dec.plan_units([0], lambda t: _windows(LENGTH), margin=64 << 10, slice_bytes=((dec.spans[0][1] >> 16) - (dec.spans[0][0] >> 16)) // 3)
+    big = dec.plan_units([0], lambda t: _windows(LENGTH), margin=64 << 10, slice_bytes=((dec.spans[0][1] >> 16) - (dec.spans[0][0] >> 16)) // 3, min_span_margins=0)
     assert 3 <= len(big) < 12 and big[0].lo == 0 and big[-1].hi == LENGTH
     assert all(u.hi == v.lo for u, v in zip(big, big[1:]))
     # no windows known / one window: the whole chromosome
@@ -67,8 +67,12 @@ def test_plan_cuts_whole_windows_in_file_order(sliced):
     assert [(u.tid, u.lo, u.hi, u.vlo, u.vhi) for u in whole] == [(t, 0, dec.lengths[t], dec.spans[t][0], dec.spans[t][1]) for t in (0, 1)]
     one = dec.plan_units([1], lambda t: [(0, dec.lengths[1])], margin=64 << 10)
     assert len(one) == 1 and one[0].left_edge is None and one[0].to_end
+    # long reads: behind the first slice a slice spans at least 13 margins, so that the margins stay a small part of what is read
+    wide = dec.plan_units([0], lambda t: _windows(LENGTH), margin=32 << 10, slice_bytes=1)
+    assert (wide[0].lo, wide[0].hi) == (0, WINDOW) and all(u.hi - u.lo >= 13 * (32 << 10) or u.last for u in wide[1:]) and len(wide) == 4
+    assert [w for u in wide for w in u.windows] == _windows(LENGTH)
     # resumed behind a rejected slice
-    rest = dec.plan_units([0, 1], lambda t: _windows(dec.lengths[t]), margin=128 << 10, slice_bytes=1, resume=(0, 500_000))
+    rest = dec.plan_units([0, 1], lambda t: _windows(dec.lengths[t]), margin=128 << 10, slice_bytes=1, resume=(0, 500_000), min_span_margins=0)
     assert rest[0].tid == 0 and rest[0].lo == 500_000 and rest[0].left_edge == (500_000 - (128 << 10)) >> 14 << 14
     assert {u.tid for u in rest} == {0, 1}
 
@@ -125,7 +129,7 @@ def test_windows_on_their_slices_equal_windows_on_the_whole_chromosome(sliced, s
     assert want[0].count("\n") > 40 and sum(bool(r.head) + bool(r.tail) for r in want_results) > 4
 
     per_window = ((dec.spans[0][1] >> 16) - (dec.spans[0][0] >> 16)) // len(windows)
-    units = dec.plan_units([0], lambda t: windows, margin=dec.estimate_reach([0]), slice_bytes=per_window * slice_windows + per_window // 2)
+    units = dec.plan_units([0], lambda t: windows, margin=dec.estimate_reach([0]), slice_bytes=per_window * slice_windows + per_window // 2, min_span_margins=0)
     assert len(units) >= len(windows) // slice_windows - 1 and len(units) > 2
     samples = []
     for u in units:
@@ -146,7 +150,7 @@ def test_windows_on_their_slices_equal_windows_on_the_whole_chromosome(sliced, s
 def test_a_margin_that_is_too_small_is_noticed(sliced):
     _path, table, fasta, dec = sliced
     windows = _windows(LENGTH)
-    units = dec.plan_units([0], lambda t: windows, margin=1, slice_bytes=1)
+    units = dec.plan_units([0], lambda t: windows, margin=1, slice_bytes=1, min_span_margins=0)
     bad = 0
     for u in units[1:-1]:
         t = _range_table(dec, u)

@@ -61,7 +61,7 @@ def test_device_decodes_the_ranges_of_the_plan(sample_files):
         for first, later, slice_bytes in ((1 << 10, 1 << 10, 1), (1 << 20, 2 << 20, 400_000), (1 << 40, 1 << 40, 1)):
             ig.FIRST_GROUP_BYTES, ig.PIPE_GROUP_BYTES = first, later
             dec = ig.DeviceDecoder(path, path + ".bai", head.references, head.lengths, head.header_text, "cuda:0", threads=3)
-            units = dec.plan_units([0, 1, 2], lambda t: _windows(head.lengths[t]), slice_bytes=slice_bytes)
+            units = dec.plan_units([0, 1, 2], lambda t: _windows(head.lengths[t]), slice_bytes=slice_bytes, min_span_margins=0)
             assert len(units) > (20 if slice_bytes == 1 else 5)
             got = []
             for unit, finish, (d_cigar, d_off, d_pos) in dec.units_pipelined(units):
@@ -121,14 +121,14 @@ def test_feed_serves_every_window_from_a_complete_slice(sample_files):
     head = bam.read_bam_header(path)
     tasks = {c: _windows(n) for c, n in zip(head.references, head.lengths)}
     span = helpers.oracle_scan(table, 50)[2][:, 0]
-    got, stats = _serve(path, genome, tasks, {"SVX_SLICE_BYTES": "200000"})
+    got, stats = _serve(path, genome, tasks, {"SVX_SLICE_BYTES": "200000", "SVX_SLICE_MIN_MARGINS": "0"})
     assert stats["engine"] == "gpu" and stats["slices"] > 8 and stats["replans"] == 0
     assert len({id(s) for s in got.values()}) == stats["slices"]
     for (chrom, start), smp in got.items():
         assert len(smp.table) < 0.7 * int((table.tid == table.get_tid(chrom)).sum()) or chrom == "chrB"
         assert _complete(table, span, smp, chrom, start, min(start + WINDOW, head.lengths[head.references.index(chrom)]))
     # a guess that is too small: noticed on the first slice, everything behind it cut again
-    got2, stats2 = _serve(path, genome, tasks, {"SVX_SLICE_BYTES": "200000", "SVX_SLICE_MARGIN": "1"})
+    got2, stats2 = _serve(path, genome, tasks, {"SVX_SLICE_BYTES": "200000", "SVX_SLICE_MIN_MARGINS": "0", "SVX_SLICE_MARGIN": "1"})
     assert stats2["replans"] >= 1
     for (chrom, start), smp in got2.items():
         assert _complete(table, span, smp, chrom, start, min(start + WINDOW, head.lengths[head.references.index(chrom)]))
@@ -145,8 +145,8 @@ def _cli(args, env=None, timeout=900):
 def test_command_line_with_slices_equals_whole_chromosomes(sample_files, device_model, tmp_path):
     path, fa, _table, _genome = sample_files
     outs = {}
-    for name, t, env in (("whole", "1", {"SVX_SLICES": "0"}), ("sliced", "1", {"SVX_SLICE_BYTES": "200000"}),
-                         ("sliced pooled", "3", {"SVX_SLICE_BYTES": "200000"}), ("cut again", "3", {"SVX_SLICE_BYTES": "200000", "SVX_SLICE_MARGIN": "1"}),
+    for name, t, env in (("whole", "1", {"SVX_SLICES": "0"}), ("sliced", "1", {"SVX_SLICE_BYTES": "200000", "SVX_SLICE_MIN_MARGINS": "0"}),
+                         ("sliced pooled", "3", {"SVX_SLICE_BYTES": "200000", "SVX_SLICE_MIN_MARGINS": "0"}), ("cut again", "3", {"SVX_SLICE_BYTES": "200000", "SVX_SLICE_MIN_MARGINS": "0", "SVX_SLICE_MARGIN": "1"}),
                          ("host engine", "1", {"SVX_INGEST": "cpu"})):
         out = str(tmp_path / name.replace(" ", "_"))
         r = _cli(["-o", out, "-b", path, "-m", device_model, "-g", fa, "-n", "HGs", "-s", "3", "--window_size", str(WINDOW), "--batch_size", "64",
