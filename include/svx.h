@@ -21,8 +21,9 @@
 extern "C" {
 #endif
 
-#define SVX_VERSION 380            /* 0.3.0: + svx_bgzf_crc32, svx_bgzf_inflate_fast (360); + svx_bgzf_inflate_fast_on: the two kernels on two streams (370);
-                                    * svx_bgzf_inflate_fast / _on take the inflated byte count and refuse a workspace that is too small (380) */
+#define SVX_VERSION 390            /* 0.3.0: + svx_bgzf_crc32, svx_bgzf_inflate_fast (360); + svx_bgzf_inflate_fast_on: the two kernels on two streams (370);
+                                    * svx_bgzf_inflate_fast / _on take the inflated byte count and refuse a workspace that is too small (380);
+                                    * + svx_cigar_scan_flat: the scan of long alignments in one pass (390) */
 
 #define SVX_OK            0
 #define SVX_EINVAL       (-1)      /* bad argument (null pointer, bad layout...) */
@@ -96,6 +97,20 @@ int svx_cigar_scan(const uint32_t* d_cigar, const uint64_t* d_cig_off,
                    const int32_t* d_ref_start, uint32_t n_aln, int32_t min_sv,
                    SvxGap* d_gaps, uint64_t gaps_cap, uint32_t* d_gap_off,
                    int32_t* d_stats, void* d_ws, void* stream);
+
+/* The same scan -- same inputs, same outputs bit for bit -- for LONG alignments (ONT ultra-long reads, assembly contigs: 10^3-10^6
+ * operations each) in ONE pass: the flat array of words is cut into chunks of 2,048, one wave per chunk whatever alignment the
+ * words belong to; the sums an alignment carries into a chunk and the number of long gaps in front of it come from a decoupled
+ * look-back over the chunks in front (svx_cigar_flat.hip).  svx_cigar_scan walks an alignment of more than 512 words with one
+ * wave, twice (0.17 of the HBM peak on an ONT-shaped launch); this form reads every word once with every wave of the chip.
+ * Slower than svx_cigar_scan on short alignments (a chunk of HiFi reads holds a dozen boundaries): callers pick by the mean
+ * number of words per alignment (svision_amd/kernels.py: >= 1,024).
+ *   n_words_max  an upper bound of d_cig_off[n_aln] - d_cig_off[0] (the launch is sized by it; the offsets are device memory)
+ *   d_ws         svx_cigar_scan_flat_ws_bytes(n_words_max) bytes, 8-byte aligned (SVX_EINVAL if ws_bytes is less) */
+size_t svx_cigar_scan_flat_ws_bytes(uint64_t n_words_max);
+int svx_cigar_scan_flat(const uint32_t* d_cigar, const uint64_t* d_cig_off, const int32_t* d_ref_start, uint32_t n_aln,
+                        uint64_t n_words_max, int32_t min_sv, SvxGap* d_gaps, uint64_t gaps_cap, uint32_t* d_gap_off,
+                        int32_t* d_stats, void* d_ws, uint64_t ws_bytes, void* stream);
 
 /* Similarity-image rasteriser (+ mean subtraction, + layout).
  * Replaces BatchGenerator.next_batch's per-image loop

@@ -245,7 +245,8 @@ class DeviceDecoder:
         units, skipping = [], resume is not None
         for _v, t in have:
             span = self.spans[t]
-            wins = sorted((int(a), int(b)) for a, b in windows_of(t)) if windows_of is not None else None
+            wins = windows_of(t) if windows_of is not None else None
+            wins = sorted((int(a), int(b)) for a, b in wins) if wins else None        # (a reference the job names no window of: whole)
             if skipping:
                 if t != resume[0]:
                     continue

@@ -100,9 +100,15 @@ class CigarScanResult:
         return gaps, off, self.stats.cpu().numpy()
 
 
-def cigar_scan(cigar, cig_off, ref_start, min_sv, gaps_cap=None):
+FLAT_SCAN_FROM = 1024               # mean CIGAR words per alignment from which the one-pass form of the scan (svx_cigar_scan_flat) is the faster one
+
+
+def cigar_scan(cigar, cig_off, ref_start, min_sv, gaps_cap=None, mode=None, n_words=None):
     """cigar: int32/uint32 device tensor of packed BAM CIGAR words; cig_off: int64 [n+1];
-    ref_start: int32 [n].  See include/svx.h svx_cigar_scan."""
+    ref_start: int32 [n].  See include/svx.h svx_cigar_scan.  ``mode``: "groups" (svx_cigar_scan: eight lanes per alignment,
+    three launches -- HiFi-sized alignments), "flat" (svx_cigar_scan_flat: one pass over chunks of the flat word array -- ONT /
+    assembly-sized alignments), None: by the mean number of words per alignment (SVX_SCAN_MODE overrides).  ``n_words``: an upper
+    bound of the words the offsets span (default: the size of ``cigar``)."""
     lib = _lib.load()
     for t, nm in ((cigar, "cigar"), (cig_off, "cig_off"), (ref_start, "ref_start")):
         _require_cuda(t, nm)
@@ -118,14 +124,26 @@ def cigar_scan(cigar, cig_off, ref_start, min_sv, gaps_cap=None):
     gaps = torch.empty(gaps_cap * 6, dtype=torch.int32, device=dev)
     gap_off = torch.empty(n + 1, dtype=torch.int32, device=dev)
     stats = torch.empty((n, 4), dtype=torch.int32, device=dev)
-    ws = torch.empty(max(1, lib.svx_cigar_scan_ws_bytes(n)), dtype=torch.uint8, device=dev)
-    rc = lib.svx_cigar_scan(cigar.data_ptr(), cig_off.data_ptr(), ref_start.data_ptr(), n, int(min_sv),
-                            gaps.data_ptr(), gaps_cap, gap_off.data_ptr(), stats.data_ptr(), ws.data_ptr(),
-                            _stream_ptr(dev))
-    _lib.check(rc, "svx_cigar_scan")
+    words = int(cigar.numel()) if n_words is None else int(n_words)
+    if mode is None:
+        import os
+        mode = os.environ.get("SVX_SCAN_MODE") or ("flat" if n and words >= FLAT_SCAN_FROM * n else "groups")
+    if mode == "flat":
+        ws_bytes = int(lib.svx_cigar_scan_flat_ws_bytes(words))
+        ws = torch.empty(max(8, ws_bytes), dtype=torch.uint8, device=dev)
+        rc = lib.svx_cigar_scan_flat(cigar.data_ptr(), cig_off.data_ptr(), ref_start.data_ptr(), n, words, int(min_sv),
+                                     gaps.data_ptr(), gaps_cap, gap_off.data_ptr(), stats.data_ptr(), ws.data_ptr(), int(ws.numel()),
+                                     _stream_ptr(dev))
+        _lib.check(rc, "svx_cigar_scan_flat")
+    else:
+        ws = torch.empty(max(1, lib.svx_cigar_scan_ws_bytes(n)), dtype=torch.uint8, device=dev)
+        rc = lib.svx_cigar_scan(cigar.data_ptr(), cig_off.data_ptr(), ref_start.data_ptr(), n, int(min_sv),
+                                gaps.data_ptr(), gaps_cap, gap_off.data_ptr(), stats.data_ptr(), ws.data_ptr(),
+                                _stream_ptr(dev))
+        _lib.check(rc, "svx_cigar_scan")
     res = CigarScanResult(gaps, gap_off, stats, n, gaps_cap)
     if auto and res.total() > gaps_cap:       # d_gap_off[n] holds the full count: rerun with the exact capacity
-        return cigar_scan(cigar, cig_off, ref_start, min_sv, gaps_cap=res.total())
+        return cigar_scan(cigar, cig_off, ref_start, min_sv, gaps_cap=res.total(), mode=mode, n_words=n_words)
     return res
 
 

@@ -56,11 +56,15 @@ def test_rasterize_empty():
     assert out.shape == (0, 3, 227, 227)
 
 
+SCAN_MODES = ["groups", "flat"]      # svx_cigar_scan (eight lanes per alignment, three launches) / svx_cigar_scan_flat (one pass over chunks of words)
+
+
+@pytest.mark.parametrize("mode", SCAN_MODES)
 @pytest.mark.parametrize("n_aln,mean_ops,rate", [(1, 5, 0.5), (64, 30, 0.2), (5000, 300, 0.01), (300, 5000, 0.002)])
-def test_cigar_scan_matches_oracle(oracle_lib, n_aln, mean_ops, rate):
+def test_cigar_scan_matches_oracle(oracle_lib, n_aln, mean_ops, rate, mode):
     from oracle import cbind
     cigar, off, ref_start = datagen.random_cigars(n_aln, seed=n_aln, mean_ops=mean_ops, long_gap_rate=rate)
-    res = kernels.cigar_scan(_dev(cigar.view(np.int32)), _dev(off.astype(np.int64)), _dev(ref_start), 50)
+    res = kernels.cigar_scan(_dev(cigar.view(np.int32)), _dev(off.astype(np.int64)), _dev(ref_start), 50, mode=mode)
     gaps, gap_off, stats = res.to_host()
     o_gaps, o_off, o_stats = cbind.cigar_scan(cigar, off, ref_start, 50)
     assert np.array_equal(gap_off, o_off)
@@ -88,13 +92,29 @@ def test_sample_from_device_reads_the_scan_back_through_pinned_memory_and_grows_
         assert sample.gaps.tobytes() == o_gaps.tobytes()
 
 
-def test_cigar_scan_full_size(oracle_lib):
+@pytest.mark.parametrize("mode", SCAN_MODES)
+def test_cigar_scan_on_a_window_of_a_larger_array(oracle_lib, mode):
+    """The offsets of a window's rows point into the chromosome's whole word array (Sample.rescan_window_async): d_cig_off[0] > 0,
+    not a multiple of four, the words in front of and behind the window belong to other alignments."""
+    from oracle import cbind
+    cigar, off, ref_start = datagen.random_cigars(900, seed=31, mean_ops=700, long_gap_rate=0.01, lognormal_sigma=1.0)
+    d_cigar, d_off, d_pos = _dev(cigar.view(np.int32)), _dev(off.astype(np.int64)), _dev(ref_start)
+    for lo, hi in ((0, 900), (1, 2), (137, 612), (899, 900), (450, 450 + 3)):
+        res = kernels.cigar_scan(d_cigar, d_off[lo:hi + 1], d_pos[lo:hi], 50, mode=mode)
+        gaps, gap_off, stats = res.to_host()
+        sub = cigar[int(off[lo]):int(off[hi])]
+        o_gaps, o_off, o_stats = cbind.cigar_scan(sub, (off[lo:hi + 1] - off[lo]).astype(np.uint64), ref_start[lo:hi], 50)
+        assert np.array_equal(gap_off, o_off) and np.array_equal(stats, o_stats) and gaps.tobytes() == o_gaps.tobytes(), (lo, hi)
+
+
+@pytest.mark.parametrize("mode", SCAN_MODES)
+def test_cigar_scan_full_size(oracle_lib, mode):
     """A whole-chromosome-sized batch (1.5 M alignments: several scan steps of 1024 tiles, a last partial tile, a work list
     of tens of thousands of alignments) against the C oracle, plus the size-independent properties of the output."""
     from oracle import cbind
     n_aln = 1_500_003
     cigar, off, ref_start = datagen.random_cigars(n_aln, seed=11, mean_ops=24, long_gap_rate=0.004)
-    res = kernels.cigar_scan(_dev(cigar.view(np.int32)), _dev(off.astype(np.int64)), _dev(ref_start), 50)
+    res = kernels.cigar_scan(_dev(cigar.view(np.int32)), _dev(off.astype(np.int64)), _dev(ref_start), 50, mode=mode)
     gaps, gap_off, stats = res.to_host()
     o_gaps, o_off, o_stats = cbind.cigar_scan(cigar, off, ref_start, 50)
     assert np.array_equal(gap_off, o_off)
@@ -107,11 +127,12 @@ def test_cigar_scan_full_size(oracle_lib):
     assert np.array_equal(np.bincount(g[:, 0], minlength=n_aln), np.diff(gap_off.astype(np.int64)))   # CSR consistent
     words = cigar[off[g[:, 0]].astype(np.int64) + g[:, 1]]
     assert np.array_equal(words >> 4, g[:, 4].astype(np.uint32)) and np.array_equal(words & 15, g[:, 5].astype(np.uint32))
-    again = kernels.cigar_scan(_dev(cigar.view(np.int32)), _dev(off.astype(np.int64)), _dev(ref_start), 50)
+    again = kernels.cigar_scan(_dev(cigar.view(np.int32)), _dev(off.astype(np.int64)), _dev(ref_start), 50, mode=mode)
     assert again.to_host()[0].tobytes() == gaps.tobytes()                # deterministic
 
 
-def test_cigar_scan_ultra_long_reads(oracle_lib):
+@pytest.mark.parametrize("mode", SCAN_MODES)
+def test_cigar_scan_ultra_long_reads(oracle_lib, mode):
     """ONT-like op counts (log-normal around 4,000, tail beyond 10^5): most alignments exceed the 512 words the eight-lane count
     pass keeps for itself and are finished by count_long_kernel; mixed with short ones so that count workgroups hold both kinds,
     gaps on either side of the hand-over, lengths around the threshold (511..516 words, 2047..2049)."""
@@ -128,22 +149,35 @@ def test_cigar_scan_ultra_long_reads(oracle_lib):
     offs = np.zeros(lens.size + 1, np.uint64)
     offs[1:] = np.cumsum(lens)
     rs = np.concatenate([p[2] for p in parts])
-    res = kernels.cigar_scan(_dev(cig.view(np.int32)), _dev(offs.astype(np.int64)), _dev(rs), 50)
+    res = kernels.cigar_scan(_dev(cig.view(np.int32)), _dev(offs.astype(np.int64)), _dev(rs), 50, mode=mode)
     gaps, gap_off, stats = res.to_host()
     o_gaps, o_off, o_stats = cbind.cigar_scan(cig, offs, rs, 50)
     assert np.array_equal(gap_off, o_off)
     assert np.array_equal(stats, o_stats)
     assert gaps.tobytes() == o_gaps.tobytes() and int(gap_off[-1]) > 15_000
-    again = kernels.cigar_scan(_dev(cig.view(np.int32)), _dev(offs.astype(np.int64)), _dev(rs), 50)
+    again = kernels.cigar_scan(_dev(cig.view(np.int32)), _dev(offs.astype(np.int64)), _dev(rs), 50, mode=mode)
     assert again.to_host()[0].tobytes() == gaps.tobytes()                # the long list's order varies, the output does not
 
 
-def test_cigar_scan_ragged_and_empty(oracle_lib):
+@pytest.mark.parametrize("mode", SCAN_MODES)
+def test_cigar_scan_ragged_and_empty(oracle_lib, mode):
     from oracle import cbind
     # empty batch
     res = kernels.cigar_scan(torch.empty(0, dtype=torch.int32, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV),
-                             torch.empty(0, dtype=torch.int32, device=DEV), 50)
+                             torch.empty(0, dtype=torch.int32, device=DEV), 50, mode=mode)
     assert res.total() == 0
+    # a batch of empty CIGARs only; empty ones at the very start and the very end
+    for texts in (["", "", ""], ["", "", "30M60I", "", "10S", "", ""]):
+        ops = [cigar_ref.parse_cigar(t) for t in texts]
+        words = [cigar_ref.pack_cigar(o) for o in ops]
+        off = np.zeros(len(ops) + 1, np.uint64)
+        off[1:] = np.cumsum([len(w) for w in words])
+        cigar = np.asarray([w for ws in words for w in ws] + [0, 0, 0, 0], np.uint32)
+        ref_start = np.arange(len(ops), dtype=np.int32) * 10 + 3
+        res = kernels.cigar_scan(_dev(cigar.view(np.int32)), _dev(off.astype(np.int64)), _dev(ref_start), 50, mode=mode, n_words=int(off[-1]))
+        gaps, gap_off, stats = res.to_host()
+        o_gaps, o_off, o_stats = cbind.cigar_scan(cigar[:int(off[-1])], off, ref_start, 50)
+        assert np.array_equal(gap_off, o_off) and np.array_equal(stats, o_stats) and gaps.tobytes() == o_gaps.tobytes(), texts
     # alignments with empty CIGARs in the middle, all-clip CIGARs, one very long CIGAR
     texts = ["", "10S", "5H10S", "100S2000M300I1500M200D1500M50S", "", "60I", "60D", "49I49D50I50D", "3H7S100M2N5P60I8S2H"]
     ops = [cigar_ref.parse_cigar(t) for t in texts]
@@ -154,13 +188,13 @@ def test_cigar_scan_ragged_and_empty(oracle_lib):
     off[1:] = np.cumsum([len(w) for w in words])
     cigar = np.asarray([w for ws in words for w in ws], np.uint32)
     ref_start = np.arange(len(ops), dtype=np.int32) * 1000 + 7
-    res = kernels.cigar_scan(_dev(cigar.view(np.int32)), _dev(off.astype(np.int64)), _dev(ref_start), 50)
+    res = kernels.cigar_scan(_dev(cigar.view(np.int32)), _dev(off.astype(np.int64)), _dev(ref_start), 50, mode=mode)
     gaps, gap_off, stats = res.to_host()
     o_gaps, o_off, o_stats = cbind.cigar_scan(cigar, off, ref_start, 50)
     assert np.array_equal(gap_off, o_off) and np.array_equal(stats, o_stats) and gaps.tobytes() == o_gaps.tobytes()
     assert int(gap_off[-1]) == 2 + 1 + 1 + 2 + 1 + 40000
     # capacity overflow is reported, not silently truncated
-    small = kernels.cigar_scan(_dev(cigar.view(np.int32)), _dev(off.astype(np.int64)), _dev(ref_start), 50, gaps_cap=16)
+    small = kernels.cigar_scan(_dev(cigar.view(np.int32)), _dev(off.astype(np.int64)), _dev(ref_start), 50, gaps_cap=16, mode=mode)
     assert small.total() == int(gap_off[-1])
     with pytest.raises(Exception):
         small.to_host()
