@@ -96,7 +96,8 @@ __device__ inline void tally_long(uint32_t w, int32_t min_sv, unsigned& ref_span
 // descriptor of a count workgroup for the look-back: [flag:2 | owners:30 | gaps:32]
 constexpr unsigned long long D_AGG = 1ull << 62, D_INC = 2ull << 62, D_FLAG = 3ull << 62;
 __device__ inline unsigned long long d_pack(uint32_t gaps, uint32_t owners) { return (unsigned long long)(owners & 0x3fffffffu) << 32 | gaps; }
-constexpr int LQUADS = 8;                            // 16-byte loads in flight per lane while a wave finishes a long alignment
+constexpr int LQUADS = 8;
+constexpr long long WIDE_FROM = 1024;                // words from which the emit pass takes an alignment in steps of 2,048 instead of 256                            // 16-byte loads in flight per lane while a wave finishes a long alignment
 
 __global__ __launch_bounds__(BLOCK)
 void count_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict__ cig_off,
@@ -330,13 +331,14 @@ void emit_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict_
         const uint64_t b = cig_off[a];
         const long long n = (long long)(cig_off[a + 1] - b);
         uint32_t read_pos = 0, ref_pos = (uint32_t)ref_start[a];
+        long long lim = n;                                     // (the narrow steps mask the words at and behind it)
         // the words of a step are requested two steps ahead (three register sets, statically rotated): the positions
         // are a serial chain over the steps, so an ultra-long read (ONT: 10^4-10^5 ops, 40-400 steps) would otherwise
         // pay one memory round trip per step
         auto load = [&](long long j0, uint32_t (&w)[4]) {
             const long long j = j0 + 4 * lane;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) w[u] = j + u < n ? cigar[b + j + u] : 6u;      // "0P": advances nothing
+            for (int u = 0; u < 4; ++u) w[u] = j + u < lim ? cigar[b + j + u] : 6u;      // "0P": advances nothing
         };
         auto step = [&](long long j0, const uint32_t (&w)[4]) {
             const long long j = j0 + 4 * lane;
@@ -384,19 +386,82 @@ void emit_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict_
             ref_pos += __shfl(irf, WAVE - 1, WAVE);
         };
         constexpr long long STEP = 4 * WAVE;
-        uint32_t w0[4], w1[4], w2[4];
-        load(0, w0);
-        load(STEP, w1);
-        for (long long j0 = 0; j0 < n; j0 += 3 * STEP) {
-            load(j0 + 2 * STEP, w2);
-            step(j0, w0);
-            if (j0 + STEP >= n) break;
-            load(j0 + 3 * STEP, w0);
-            step(j0 + STEP, w1);
-            if (j0 + 2 * STEP >= n) break;
-            load(j0 + 4 * STEP, w1);
-            step(j0 + 2 * STEP, w2);
+        auto narrow = [&](long long jlo, long long jhi) {      // the words [jlo, jhi) of the alignment, 256 per step
+            lim = jhi;
+            uint32_t w0[4], w1[4], w2[4];
+            load(jlo, w0);
+            load(jlo + STEP, w1);
+            for (long long j0 = jlo; j0 < jhi; j0 += 3 * STEP) {
+                load(j0 + 2 * STEP, w2);
+                step(j0, w0);
+                if (j0 + STEP >= jhi) break;
+                load(j0 + 3 * STEP, w0);
+                step(j0 + STEP, w1);
+                if (j0 + 2 * STEP >= jhi) break;
+                load(j0 + 4 * STEP, w1);
+                step(j0 + 2 * STEP, w2);
+            }
+        };
+        if (n <= WIDE_FROM) { narrow(0, n); continue; }
+        // A long alignment (ONT, assembly contigs): 2,048 words per step instead of 256 -- a lane takes 32 CONSECUTIVE words (eight
+        // 16-byte loads), sums their advances and hits, and ONE set of wave prefix sums per step places the lane: an eighth of the
+        // steps of the serial position chain (the longest read of an ONT sample: 10^5 words = 400 narrow steps, each a memory round
+        // trip and a dozen cross-lane operations, which the whole launch waited for) and an eighth of the cross-lane work per
+        // word.  The (at most three) words in front of the first 16-byte boundary and what is left behind the last whole step
+        // go through the narrow steps.
+        auto excl = [&](uint32_t v, uint32_t& total) {
+            uint32_t inc = v;
+#pragma unroll
+            for (int o = 1; o < WAVE; o <<= 1) { const uint32_t up = __shfl_up(inc, o, WAVE); if (lane >= o) inc += up; }
+            total = __shfl(inc, WAVE - 1, WAVE);
+            return inc - v;
+        };
+        long long j = (long long)((4u - (uint32_t)(b & 3u)) & 3u);
+        if (j) narrow(0, j);
+        constexpr long long WSTEP = 2048;
+        for (; j + WSTEP <= n; j += WSTEP) {
+            const uint4* p = reinterpret_cast<const uint4*>(cigar + b + j) + 8 * lane;
+            uint4 w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = p[u];
+            uint32_t tr = 0, tf = 0, nh = 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t x4[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t op = x4[k] & 15u, len = x4[k] >> 4;
+                    tr += adv_read(op) ? len : 0u;
+                    tf += adv_ref(op) ? len : 0u;
+                    nh += (uint32_t)(((op - 1u) < 2u) & ((int32_t)len >= min_sv));
+                }
+                __builtin_amdgcn_sched_barrier(0);         // quad after quad (left alone the scheduler spreads the 32 words over 200 registers)
+            }
+            uint32_t Tr, Tf, Th;
+            uint32_t r = read_pos + excl(tr, Tr), f = ref_pos + excl(tf, Tf);
+            uint64_t slot = (uint64_t)dst + excl(nh, Th);
+            if (nh) {                                      // (rare: the lane walks its 32 words once more, out of the cache)
+                const long long i0 = j + 32 * lane;
+#pragma unroll 1
+                for (long long i = i0; i < i0 + 32; ++i) {
+                    const uint32_t x = cigar[b + i], op = x & 15u, len = x >> 4;
+                    if (((op - 1u) < 2u) & ((int32_t)len >= min_sv)) {
+                        if (slot < gaps_cap) {
+                            SvxGap g;
+                            g.aln = a; g.op = (uint32_t)i;
+                            g.read_pos = (int32_t)r; g.ref_pos = (int32_t)f;
+                            g.len = (int32_t)len; g.kind = op;
+                            gaps[slot] = g;
+                        }
+                        ++slot;
+                    }
+                    r += adv_read(op) ? len : 0u;
+                    f += adv_ref(op) ? len : 0u;
+                }
+            }
+            read_pos += Tr; ref_pos += Tf; dst += Th;
         }
+        if (j < n) narrow(j, n);
     }
 }
 

@@ -26,12 +26,22 @@
 // svx_cigar_scan: 4 B x words + 16 B x alignments read, 16 B x alignments + 24 B x long gaps written.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/svx.h"
 
 namespace {
 
-constexpr int WAVE = 64, FBLOCK = 512, FQ = 8, NW = FBLOCK / WAVE;
-constexpr uint32_t FCH = 4u * FQ * WAVE;             // words per chunk: 2,048
+#ifndef SVX_FLAT_DBG
+#define SVX_FLAT_DBG 0                               // measurements only (wrong output): 1 = no look-back between workgroups, 2 = nothing behind the tallies, 4 = no tallies
+#endif
+#ifndef SVX_FLAT_QUADS
+#define SVX_FLAT_QUADS 8
+#endif
+#ifndef SVX_FLAT_BLOCK
+#define SVX_FLAT_BLOCK 512
+#endif
+constexpr int WAVE = 64, FBLOCK = SVX_FLAT_BLOCK, FQ = SVX_FLAT_QUADS, NW = FBLOCK / WAVE;     // FQ: 16-byte quads per lane (a lane takes 4 FQ CONSECUTIVE words)
+constexpr uint32_t LW = 4u * FQ, FCH = LW * WAVE;    // words per lane (32) and per chunk (2,048)
 constexpr unsigned long long F_VALID = 1ull << 63, F_CLOSED = 1ull << 62, G_AGG = 1ull << 62, G_INC = 2ull << 62, G_FLAG = 3ull << 62;
 
 __device__ inline unsigned wsum(unsigned v)
@@ -71,13 +81,12 @@ __device__ inline void publish(unsigned long long* a, unsigned long long va, uns
     __hip_atomic_store(&b[c], vb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(FBLOCK)
-void cigar_flat_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict__ cig_off, const int32_t* __restrict__ ref_start,
+// one workgroup's tile (NW chunks); every return lies behind the tile's last barrier -- or is taken by the whole workgroup
+__device__ __forceinline__ void flat_tile(const uint32_t* __restrict__ cigar, const uint64_t* __restrict__ cig_off, const int32_t* __restrict__ ref_start,
                        uint32_t n_aln, int32_t min_sv, SvxGap* __restrict__ gaps, uint64_t gaps_cap, uint32_t* __restrict__ gap_off,
-                       int32_t* __restrict__ stats, Desc d, uint32_t n_chunks)
+                       int32_t* __restrict__ stats, Desc d, uint32_t wg)
 {
     const uint32_t lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
-    const uint32_t wg = blockIdx.x;
     const uint32_t c = wg * NW + wv;
     const uint64_t begin = cig_off[0], end = cig_off[n_aln];
     if (begin == end) {                               // no words at all: every alignment is empty; the first chunk says so
@@ -99,51 +108,51 @@ void cigar_flat_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __res
     const bool active = wv < n_act;
     const uint64_t w0 = wg0 + (uint64_t)wv * FCH;
     const uint64_t w1 = min(w0 + FCH, end), wf = max(w0, begin);
-    __shared__ uint4 s_sums[NW][FQ][WAVE];
     __shared__ uint32_t s_loc[NW][5];                 // per chunk: long gaps, state of the alignment open at its end (0 none, 1 whole, 2 a part), its span / qlen / nlen
     __shared__ uint32_t s_wg[4];                      // the workgroup's look-back: gaps in front, carried span / qlen / nlen
+    __shared__ uint64_t s_end[NW][WAVE];              // per chunk: the first 64 alignment ends inside it ...
+    __shared__ uint4 s_pre[NW][WAVE];                 // ... and the chunk's sums below each (what a gap's positions are relative to)
     uint32_t a0 = 0, n_ends = 0, a_tail = 0;
     uint64_t last_end = wf;
     bool tail_open = false, head_carried = false;
-    Sums chunk{0u, 0u, 0u, 0u}, tail_own{0u, 0u, 0u, 0u};
-    uint4 (*const S)[WAVE] = s_sums[wv];
-    auto load_quad = [&](int u) {
-        const uint64_t i0 = w0 + 256ull * u + 4ull * lane;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (i0 + 4 <= end) v = *reinterpret_cast<const uint4*>(cigar + i0);
-        else if (i0 < end) { v.x = cigar[i0]; if (i0 + 1 < end) v.y = cigar[i0 + 1]; if (i0 + 2 < end) v.z = cigar[i0 + 2]; }
-        if (i0 < begin) { v.x = 0u; if (i0 + 1 < begin) v.y = 0u; if (i0 + 2 < begin) v.z = 0u; if (i0 + 3 < begin) v.w = 0u; }
-        return v;
-    };
-    // the sums of the chunk's words below word x (wf <= x <= w1), wave-uniform: the quads below it + part of the one it cuts
+    Sums chunk{0u, 0u, 0u, 0u}, tail_own{0u, 0u, 0u, 0u}, tot{0u, 0u, 0u, 0u};
+    const uint64_t l0 = w0 + (uint64_t)LW * lane;     // this lane's first word
+    // the sums of the chunk's words below word x (wf <= x <= w1), wave-uniform: the lanes below it + part of the one it cuts
     auto below = [&](uint64_t x) {
+        const uint32_t rel = (uint32_t)(x - w0), L = rel / LW, r = rel % LW;
         Sums s{0u, 0u, 0u, 0u};
-#pragma unroll 1
-        for (int u = 0; u < FQ; ++u) {
-            const uint64_t i0 = w0 + 256ull * u + 4ull * lane;
-            if (i0 + 4 <= x) { const uint4 v = S[u][lane]; s.span += v.x; s.qlen += v.y; s.nlen += v.z; s.ngap += v.w; }
-            else if (i0 < x) { for (uint64_t i = max(i0, begin); i < x; ++i) tally(cigar[i], min_sv, s); }
+        if (lane < L) s = tot;
+        if (r) {                                      // the cut lane's first r words, a lane each (LW <= 64)
+            const uint64_t i = w0 + (uint64_t)LW * L + lane;
+            if (lane < r && i >= begin) tally(cigar[i], min_sv, s);
         }
         return wsum(s);
     };
     if (active) {
-    // ---- the chunk's words: lane l, load u = quad (w0 / 4 + 64 u + l); words outside [begin, end) count as "0M".  The sums of
-    // every quad go to LDS (the lane's own 8 x 16 bytes): kept in registers -- with the loops over them unrolled at every use --
-    // the kernel took 512 VGPRs and spilled
-    Sums tot{0u, 0u, 0u, 0u};
+    // ---- the chunk's words: a lane takes LW CONSECUTIVE words (FQ 16-byte loads; the lanes of a load are 128 bytes apart, the
+    // loads of a lane fill its lines); words outside [begin, end) count as "0M".  Nothing but the lane's four sums is kept: a
+    // prefix at a boundary = the lanes below it + part of the one it cuts (first version: quads interleaved over the lanes and
+    // every quad's sums in LDS -- 8 KB per wave, which held the chip to 16 waves per CU).
     {
         uint4 q[FQ];
 #pragma unroll
-        for (int u = 0; u < FQ; ++u) q[u] = load_quad(u);
+        for (int u = 0; u < FQ; ++u) {
+            const uint64_t i0 = l0 + 4ull * u;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (i0 + 4 <= end) v = *reinterpret_cast<const uint4*>(cigar + i0);
+            else if (i0 < end) { v.x = cigar[i0]; if (i0 + 1 < end) v.y = cigar[i0 + 1]; if (i0 + 2 < end) v.z = cigar[i0 + 2]; }
+            if (i0 < begin) { v.x = 0u; if (i0 + 1 < begin) v.y = 0u; if (i0 + 2 < begin) v.z = 0u; if (i0 + 3 < begin) v.w = 0u; }
+            q[u] = v;
+        }
 #pragma unroll
         for (int u = 0; u < FQ; ++u) {
-            Sums su{0u, 0u, 0u, 0u};
-            tally(q[u].x, min_sv, su); tally(q[u].y, min_sv, su); tally(q[u].z, min_sv, su); tally(q[u].w, min_sv, su);
-            S[u][lane] = make_uint4(su.span, su.qlen, su.nlen, su.ngap);
-            add(tot, su);
+            if (SVX_FLAT_DBG & 4) { tot.ngap += q[u].x ^ q[u].y ^ q[u].z ^ q[u].w; continue; }
+            tally(q[u].x, min_sv, tot); tally(q[u].y, min_sv, tot); tally(q[u].z, min_sv, tot); tally(q[u].w, min_sv, tot);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     chunk = wsum(tot);
+    if (SVX_FLAT_DBG & 2) { if (chunk.ngap == 0xffffffffu) gap_off[0] = 1; return; }
     // ---- a0: the alignment that holds word wf = the smallest a with cig_off[a + 1] > wf (64-ary search; wf < end: it exists)
     {
         uint32_t lo = 0, hi = n_aln;                  // the answer lies in [lo, hi)
@@ -222,7 +231,7 @@ void cigar_flat_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __res
         }
         uint32_t gx = 0;
         Sums cx{0u, 0u, 0u, 0u};
-        if (wg > 0) {
+        if (wg > 0 && !(SVX_FLAT_DBG & 1)) {
             bool need_g = true, need_c = head_carried;    // (this wave's a0 = the workgroup's)
             long long j = (long long)wg - 1;
             while (need_g || need_c) {
@@ -284,9 +293,7 @@ void cigar_flat_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __res
     if (lane == 0 && !head_carried) gap_off[a0] = gfront;                        // a0 starts with this chunk's first word
     // ---- the alignments that end in the chunk (lane j: alignment a + j): their statistics and -- they start here as well, a0 apart --
     // their CSR offsets; the alignment open at the chunk's end starts behind the last of them
-    uint64_t e_first = ~0ull;                         // the first 64 ends and the sums below them: what the gaps' positions are relative to
-    Sums p_first{0u, 0u, 0u, 0u};
-    uint32_t k_first = 0;
+    uint32_t k_first = 0;                             // (the first 64 ends and the sums below them go to LDS: what the gaps' positions are relative to)
     {
         Sums prev{0u, 0u, 0u, 0u};                    // the sums below the previous end
         bool first_batch = true;
@@ -305,7 +312,7 @@ void cigar_flat_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __res
             before.span = __shfl_up(mine.span, 1, WAVE); before.qlen = __shfl_up(mine.qlen, 1, WAVE);
             before.nlen = __shfl_up(mine.nlen, 1, WAVE); before.ngap = __shfl_up(mine.ngap, 1, WAVE);
             if (lane == 0) before = prev;
-            if (first_batch) { e_first = lane < k ? e : ~0ull; p_first = mine; k_first = k; }
+            if (first_batch) { s_end[wv][lane] = lane < k ? e : ~0ull; s_pre[wv][lane] = make_uint4(mine.span, mine.qlen, mine.nlen, mine.ngap); k_first = k; }
             if (lane < k) {
                 Sums own = sub(mine, before);
                 if (first_batch && lane == 0 && head_carried) { own.span += carry.span; own.qlen += carry.qlen; own.nlen += carry.nlen; }
@@ -333,66 +340,65 @@ void cigar_flat_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __res
     // ---- the chunk's long gaps: slot = gaps in front of the chunk + gaps of the chunk below the word; positions = the sums from
     // the alignment's start to the word = (chunk below the word) - (chunk below the alignment's start) [+ what a0 carries]
     if (chunk.ngap == 0) return;
-    Sums acc{0u, 0u, 0u, 0u};                         // this lane's quads of the loads in front of u (summed over the wave only where a load has a gap)
-#pragma unroll 1
-    for (int u = 0; u < FQ; ++u) {
-        const uint4 sv = S[u][lane];
-        const Sums mine{sv.x, sv.y, sv.z, sv.w};
-        if (__any(sv.w != 0u)) {
-            const Sums run = wsum(acc);               // the sums of the loads in front of this one
-            Sums inc = mine;                          // exclusive prefix of the lanes' quads of this load
+    Sums at = tot;                                    // exclusive prefix of the lanes' sums: the chunk's words below this lane's first
 #pragma unroll
-            for (int o = 1; o < WAVE; o <<= 1) {
-                const unsigned a = __shfl_up(inc.span, o, WAVE), b2 = __shfl_up(inc.qlen, o, WAVE), c2 = __shfl_up(inc.nlen, o, WAVE), g2 = __shfl_up(inc.ngap, o, WAVE);
-                if ((int)lane >= o) { inc.span += a; inc.qlen += b2; inc.nlen += c2; inc.ngap += g2; }
-            }
-            Sums at = sub(inc, mine);
-            add(at, run);                             // the sums of the chunk's words below this lane's quad
-            const uint64_t i0 = w0 + 256ull * u + 4ull * lane;
-            const uint4 qv = load_quad(u);            // (again: out of the L2)
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const unsigned a = __shfl_up(at.span, o, WAVE), b2 = __shfl_up(at.qlen, o, WAVE), c2 = __shfl_up(at.nlen, o, WAVE), g2 = __shfl_up(at.ngap, o, WAVE);
+        if ((int)lane >= o) { at.span += a; at.qlen += b2; at.nlen += c2; at.ngap += g2; }
+    }
+    at = sub(at, tot);
+    if (tot.ngap == 0) return;
+    // (rare: the lane walks its words once more, out of the cache)
 #pragma unroll 1
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t w = word_of(qv, k);
-                const uint64_t idx = i0 + k;
-                const bool hit = is_gap(w, min_sv);   // (words outside [begin, end) are "0M")
-                if (__any(hit)) {
-                    // the word's alignment = a0 + (ends at or below it); the sums below that alignment's start
-                    uint32_t cnt = 0;
-                    Sums st{0u, 0u, 0u, 0u};
-                    for (uint32_t jj = 0; jj < k_first; ++jj) {
-                        const uint64_t ej = __shfl(e_first, (int)jj, WAVE);
-                        const Sums pj{(unsigned)__shfl((int)p_first.span, (int)jj, WAVE), (unsigned)__shfl((int)p_first.qlen, (int)jj, WAVE),
-                                      (unsigned)__shfl((int)p_first.nlen, (int)jj, WAVE), (unsigned)__shfl((int)p_first.ngap, (int)jj, WAVE)};
-                        if (ej <= idx) { cnt = jj + 1; st = pj; }
-                    }
-                    if (hit) {
-                        uint32_t al = a0 + cnt;
-                        Sums rel = sub(at, st);
-                        if (cnt == 0 && head_carried) { rel.span += carry.span; rel.qlen += carry.qlen; rel.nlen += carry.nlen; }
-                        uint64_t b = cig_off[al];
-                        if (cnt == WAVE) {            // more than 64 alignments end in this chunk and the word lies behind the 64th: by foot
-                            while (al + 1 < n_aln && cig_off[al + 1] <= idx) ++al;
-                            b = cig_off[al];
-                            rel = Sums{0u, 0u, 0u, 0u};
-                            for (uint64_t x = b; x < idx; ++x) tally(cigar[x], min_sv, rel);
-                        }
-                        const uint64_t slot = (uint64_t)gfront + at.ngap;
-                        if (slot < gaps_cap) {
-                            SvxGap g;
-                            g.aln = al; g.op = (uint32_t)(idx - b);
-                            g.read_pos = (int32_t)(rel.qlen + rel.nlen);
-                            g.ref_pos = (int32_t)((uint32_t)ref_start[al] + rel.span - rel.nlen);
-                            g.len = (int32_t)(w >> 4); g.kind = w & 15u;
-                            gaps[slot] = g;
-                        }
-                    }
-                }
-                Sums one{0u, 0u, 0u, 0u};
-                tally(w, min_sv, one);
-                add(at, one);
+    for (uint64_t idx = max(l0, begin); idx < min(l0 + LW, end); ++idx) {
+        const uint32_t w = cigar[idx];
+        if (is_gap(w, min_sv)) {
+            // the word's alignment = a0 + (ends at or below it); the sums below that alignment's start
+            uint32_t cnt = 0;
+            while (cnt < k_first && s_end[wv][cnt] <= idx) ++cnt;
+            uint32_t al = a0 + cnt;
+            Sums rel = at;
+            if (cnt) { const uint4 pv = s_pre[wv][cnt - 1]; rel = sub(at, Sums{pv.x, pv.y, pv.z, pv.w}); }
+            else if (head_carried) { rel.span += carry.span; rel.qlen += carry.qlen; rel.nlen += carry.nlen; }
+            uint64_t b = cig_off[al];
+            if (cnt == WAVE) {                        // more than 64 alignments end in this chunk and the word lies behind the 64th: by foot
+                while (al + 1 < n_aln && cig_off[al + 1] <= idx) ++al;
+                b = cig_off[al];
+                rel = Sums{0u, 0u, 0u, 0u};
+                for (uint64_t x = b; x < idx; ++x) tally(cigar[x], min_sv, rel);
+            }
+            const uint64_t slot = (uint64_t)gfront + at.ngap;
+            if (slot < gaps_cap) {
+                SvxGap g;
+                g.aln = al; g.op = (uint32_t)(idx - b);
+                g.read_pos = (int32_t)(rel.qlen + rel.nlen);
+                g.ref_pos = (int32_t)((uint32_t)ref_start[al] + rel.span - rel.nlen);
+                g.len = (int32_t)(w >> 4); g.kind = w & 15u;
+                gaps[slot] = g;
             }
         }
-        add(acc, mine);
+        tally(w, min_sv, at);
+    }
+}
+
+// Resident workgroups walk the tiles with a grid stride, in order: a launch of one short-lived workgroup per tile (10^4 of them
+// for an ONT chromosome) was bound by the rate at which workgroups are dispatched, not by memory (1.3 TB/s with the loads alone in
+// the kernel).  Tile t's predecessors are taken earlier by the same or by a resident workgroup: the look-back ends.
+__global__ __launch_bounds__(FBLOCK)
+void cigar_flat_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict__ cig_off, const int32_t* __restrict__ ref_start,
+                       uint32_t n_aln, int32_t min_sv, SvxGap* __restrict__ gaps, uint64_t gaps_cap, uint32_t* __restrict__ gap_off,
+                       int32_t* __restrict__ stats, Desc d, uint32_t n_tiles, unsigned int* __restrict__ next_tile)
+{
+    // (tiles are TAKEN in order from a counter, not assigned by index: a workgroup that is not resident yet holds no tile that a
+    // resident one could wait for)
+    __shared__ uint32_t s_tile;
+    for (;;) {
+        if (threadIdx.x == 0) s_tile = atomicAdd(next_tile, 1u);
+        __syncthreads();
+        const uint32_t t = s_tile;
+        if (t >= n_tiles) return;
+        flat_tile(cigar, cig_off, ref_start, n_aln, min_sv, gaps, gaps_cap, gap_off, stats, d, t);
+        __syncthreads();                              // (the tile's LDS -- s_tile included -- is free again)
     }
 }
 
@@ -401,7 +407,7 @@ void cigar_flat_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __res
 extern "C" size_t svx_cigar_scan_flat_ws_bytes(uint64_t n_words_max)
 {
     const size_t groups = ((size_t)((n_words_max + 3 + FCH - 1) / FCH) + 1 + NW - 1) / NW;
-    return 5 * groups * sizeof(unsigned long long);
+    return (5 * groups + 1) * sizeof(unsigned long long);       // (+ the tile counter)
 }
 
 // svx_cigar_scan for long alignments: the same inputs and outputs (include/svx.h), one pass.  n_words_max: an upper bound of
@@ -420,11 +426,14 @@ extern "C" int svx_cigar_scan_flat(const uint32_t* d_cigar, const uint64_t* d_ci
     if (ws_bytes < svx_cigar_scan_flat_ws_bytes(n_words_max)) return SVX_EINVAL;
     const size_t chunks = ((size_t)((n_words_max + 3 + FCH - 1) / FCH) + 1 + NW - 1) / NW;        // workgroups of NW chunks
     if (chunks >= (1ull << 28)) return SVX_EINVAL;
-    if (hipMemsetAsync(d_ws, 0, 5 * chunks * sizeof(unsigned long long), st) != hipSuccess) return SVX_ELAUNCH;
+    if (hipMemsetAsync(d_ws, 0, (5 * chunks + 1) * sizeof(unsigned long long), st) != hipSuccess) return SVX_ELAUNCH;
     if (hipMemsetAsync(d_gap_off + n_aln, 0, sizeof(uint32_t), st) != hipSuccess) return SVX_ELAUNCH;
     unsigned long long* w = static_cast<unsigned long long*>(d_ws);
     Desc d{w, w + chunks, w + 2 * chunks, w + 3 * chunks, w + 4 * chunks};
-    hipLaunchKernelGGL(cigar_flat_kernel, dim3((unsigned)chunks), dim3(FBLOCK), 0, st,
-                       d_cigar, d_cig_off, d_ref_start, n_aln, min_sv, d_gaps, gaps_cap, d_gap_off, d_stats, d, (uint32_t)chunks);
+    const char* gs = getenv("SVX_FLAT_GRID");
+    const unsigned grid = (unsigned)min((size_t)(gs ? atoi(gs) : 768), chunks);       // 256 CUs x 3 resident workgroups of 512 threads
+    hipLaunchKernelGGL(cigar_flat_kernel, dim3(grid), dim3(FBLOCK), 0, st,
+                       d_cigar, d_cig_off, d_ref_start, n_aln, min_sv, d_gaps, gaps_cap, d_gap_off, d_stats, d, (uint32_t)chunks,
+                       reinterpret_cast<unsigned int*>(w + 5 * chunks));
     return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
 }

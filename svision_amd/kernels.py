@@ -100,7 +100,8 @@ class CigarScanResult:
         return gaps, off, self.stats.cpu().numpy()
 
 
-FLAT_SCAN_FROM = 1024               # mean CIGAR words per alignment from which the one-pass form of the scan (svx_cigar_scan_flat) is the faster one
+FLAT_SCAN_FROM = None               # mean CIGAR words per alignment from which svx_cigar_scan_flat is picked: None = never -- measured (round 5,
+                                    # profiles/r05_bench_cigar.json): 590-650 us on the ONT-shaped launch against 520 us of the three-kernel form
 
 
 def cigar_scan(cigar, cig_off, ref_start, min_sv, gaps_cap=None, mode=None, n_words=None):
@@ -127,7 +128,7 @@ def cigar_scan(cigar, cig_off, ref_start, min_sv, gaps_cap=None, mode=None, n_wo
     words = int(cigar.numel()) if n_words is None else int(n_words)
     if mode is None:
         import os
-        mode = os.environ.get("SVX_SCAN_MODE") or ("flat" if n and words >= FLAT_SCAN_FROM * n else "groups")
+        mode = os.environ.get("SVX_SCAN_MODE") or ("flat" if n and FLAT_SCAN_FROM is not None and words >= FLAT_SCAN_FROM * n else "groups")
     if mode == "flat":
         ws_bytes = int(lib.svx_cigar_scan_flat_ws_bytes(words))
         ws = torch.empty(max(8, ws_bytes), dtype=torch.uint8, device=dev)
