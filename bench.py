@@ -65,8 +65,8 @@ GRCH38 = (("chr1", 248956422), ("chr2", 242193529), ("chr3", 198295559), ("chr4"
 LAYER_FLOP = {"conv2": 447_897_600, "conv3": 299_040_768, "conv4": 224_280_576, "conv5": 149_520_384, "fc": 109_092_864}
 LAYER_PIX = {"conv2": 729, "conv3": 169, "conv4": 169, "conv5": 169}
 WINDOW = 10_000_000
-try:                                              # the round's rocprofv3 PMC passes over the device stage (tools/r04_profile.sh)
-    with open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")) as _f:
+try:                                              # the round's rocprofv3 PMC passes over the device stage (tools/r05_profile.sh)
+    with open(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")) as _f:
         TRAFFIC = json.load(_f)
 except (OSError, ValueError):
     TRAFFIC = {}
@@ -525,7 +525,8 @@ def main():
                                     "CNN, vote -- to the end of the cross-rank exchange" % (e2e_block["bam_bytes"], e2e_block["ingest_engine"]))
                                    if headline_e2e else "resident: alignments decoded and in HBM before the timed region (--resident, or a workload without a file leg)",
                    "warm_state": ("`value` is measured in a process that has run --warmup windows through both paths before: the caching allocator holds one block "
-                                  "of min(48 GB, 8 x the file) allocated during set-up, the pinned staging ring and the kernels' code objects exist, and the BAM "
+                                  "of min(48 GB, 8 x the file) allocated during set-up, the pinned staging ring and the kernels' code objects exist, the guess of the slices' margin "
+                                  "(~7 ms of host zlib per file) is cached, and the BAM "
                                   "sits in the page cache it was written through.  e2e_cold_cache is the same leg with the file's pages dropped first; a first "
                                   "command-line run of a fresh process additionally pays the first hipMalloc / hipHostMalloc calls (0.15-0.35 s, measured: "
                                   "tools/e2e_cli_timing.py)") if headline_e2e else None,
