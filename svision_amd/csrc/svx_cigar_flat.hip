@@ -44,12 +44,22 @@ constexpr int WAVE = 64, FBLOCK = SVX_FLAT_BLOCK, FQ = SVX_FLAT_QUADS, NW = FBLO
 constexpr uint32_t LW = 4u * FQ, FCH = LW * WAVE;    // words per lane (32) and per chunk (2,048)
 constexpr unsigned long long F_VALID = 1ull << 63, F_CLOSED = 1ull << 62, G_AGG = 1ull << 62, G_INC = 2ull << 62, G_FLAG = 3ull << 62;
 
-__device__ inline unsigned wsum(unsigned v)
+// Inclusive prefix sum over the wave with data-parallel primitives (row shifts inside the rows of 16 lanes, then the two row
+// broadcasts of gfx9): seven moves in the vector ALU.  (__shfl_* is ds_bpermute on this target -- a round trip through the LDS
+// crossbar per step; six dependent ones per sum and a dozen sums per chunk were most of a chunk's time behind its tallies.)
+__device__ inline unsigned wscan(unsigned v)
 {
-#pragma unroll
-    for (int o = WAVE / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
+    unsigned r = v;
+    r += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);      // row_shr:1
+    r += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);      // row_shr:2
+    r += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, true);      // row_shr:3
+    r += (unsigned)__builtin_amdgcn_update_dpp(0, (int)r, 0x114, 0xf, 0xe, true);      // row_shr:4, banks 1-3
+    r += (unsigned)__builtin_amdgcn_update_dpp(0, (int)r, 0x118, 0xf, 0xc, true);      // row_shr:8, banks 2-3
+    r += (unsigned)__builtin_amdgcn_update_dpp(0, (int)r, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3
+    r += (unsigned)__builtin_amdgcn_update_dpp(0, (int)r, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
+    return r;
 }
+__device__ inline unsigned wsum(unsigned v) { return (unsigned)__builtin_amdgcn_readlane((int)wscan(v), WAVE - 1); }
 
 struct Sums { unsigned span, qlen, nlen, ngap; };    // reference span (M D N = X), query length (M I S H = X), N length, long gaps
 __device__ inline void add(Sums& a, const Sums& b) { a.span += b.span; a.qlen += b.qlen; a.nlen += b.nlen; a.ngap += b.ngap; }
@@ -84,7 +94,7 @@ __device__ inline void publish(unsigned long long* a, unsigned long long va, uns
 // one workgroup's tile (NW chunks); every return lies behind the tile's last barrier -- or is taken by the whole workgroup
 __device__ __forceinline__ void flat_tile(const uint32_t* __restrict__ cigar, const uint64_t* __restrict__ cig_off, const int32_t* __restrict__ ref_start,
                        uint32_t n_aln, int32_t min_sv, SvxGap* __restrict__ gaps, uint64_t gaps_cap, uint32_t* __restrict__ gap_off,
-                       int32_t* __restrict__ stats, Desc d, uint32_t wg)
+                       int32_t* __restrict__ stats, Desc d, uint32_t wg, const uint32_t* __restrict__ first_aln)
 {
     const uint32_t lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
     const uint32_t c = wg * NW + wv;
@@ -135,14 +145,20 @@ __device__ __forceinline__ void flat_tile(const uint32_t* __restrict__ cigar, co
     // every quad's sums in LDS -- 8 KB per wave, which held the chip to 16 waves per CU).
     {
         uint4 q[FQ];
+        if (w0 >= begin && w0 + FCH <= end) {         // the whole chunk lies inside the words: eight plain loads, all in flight at once
+            const uint4* p = reinterpret_cast<const uint4*>(cigar + l0);      // (the masked form below puts every load into a branch of
+#pragma unroll                                                                 // its own, and the wave waited for them one by one:
+            for (int u = 0; u < FQ; ++u) q[u] = p[u];                          // 1.3 TB/s with nothing but the loads in the kernel)
+        } else {
 #pragma unroll
-        for (int u = 0; u < FQ; ++u) {
-            const uint64_t i0 = l0 + 4ull * u;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (i0 + 4 <= end) v = *reinterpret_cast<const uint4*>(cigar + i0);
-            else if (i0 < end) { v.x = cigar[i0]; if (i0 + 1 < end) v.y = cigar[i0 + 1]; if (i0 + 2 < end) v.z = cigar[i0 + 2]; }
-            if (i0 < begin) { v.x = 0u; if (i0 + 1 < begin) v.y = 0u; if (i0 + 2 < begin) v.z = 0u; if (i0 + 3 < begin) v.w = 0u; }
-            q[u] = v;
+            for (int u = 0; u < FQ; ++u) {
+                const uint64_t i0 = l0 + 4ull * u;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (i0 + 4 <= end) v = *reinterpret_cast<const uint4*>(cigar + i0);
+                else if (i0 < end) { v.x = cigar[i0]; if (i0 + 1 < end) v.y = cigar[i0 + 1]; if (i0 + 2 < end) v.z = cigar[i0 + 2]; }
+                if (i0 < begin) { v.x = 0u; if (i0 + 1 < begin) v.y = 0u; if (i0 + 2 < begin) v.z = 0u; if (i0 + 3 < begin) v.w = 0u; }
+                q[u] = v;
+            }
         }
 #pragma unroll
         for (int u = 0; u < FQ; ++u) {
@@ -153,24 +169,9 @@ __device__ __forceinline__ void flat_tile(const uint32_t* __restrict__ cigar, co
     }
     chunk = wsum(tot);
     if (SVX_FLAT_DBG & 2) { if (chunk.ngap == 0xffffffffu) gap_off[0] = 1; return; }
-    // ---- a0: the alignment that holds word wf = the smallest a with cig_off[a + 1] > wf (64-ary search; wf < end: it exists)
-    {
-        uint32_t lo = 0, hi = n_aln;                  // the answer lies in [lo, hi)
-        while (hi - lo > 1) {
-            const uint32_t step = (hi - lo + WAVE - 1) / WAVE;
-            const uint64_t p = (uint64_t)lo + (uint64_t)lane * step;
-            const bool in = p < hi;
-            const bool pred = in && cig_off[p + 1] > wf;
-            const unsigned long long m = __ballot(pred);
-            const uint32_t probes = (uint32_t)__popcll(__ballot(in));
-            const uint32_t t = m ? (uint32_t)(__ffsll((long long)m) - 1) : probes;
-            if (t == 0) { hi = lo + 1; break; }
-            const uint32_t nlo = lo + (t - 1) * step + 1;
-            hi = t < probes ? min(hi, lo + t * step + 1) : hi;
-            lo = nlo;
-        }
-        a0 = lo;
-    }
+    // ---- a0: the alignment that holds word wf (the smallest a with cig_off[a + 1] > wf), from the map cigar_map_kernel has written:
+    // a 64-ary search over d_cig_off here was four dependent memory round trips on every chunk's critical path
+    a0 = first_aln[c];
     // ---- the alignment open at the chunk's end (if any) is a0 + (alignment ends in the chunk); its words in this chunk = the
     // chunk's sums - the sums below its start.  A first pass over the ends only to find the last one (long alignments: none or one).
     for (uint32_t a = a0;; a += WAVE) {
@@ -340,12 +341,7 @@ __device__ __forceinline__ void flat_tile(const uint32_t* __restrict__ cigar, co
     // ---- the chunk's long gaps: slot = gaps in front of the chunk + gaps of the chunk below the word; positions = the sums from
     // the alignment's start to the word = (chunk below the word) - (chunk below the alignment's start) [+ what a0 carries]
     if (chunk.ngap == 0) return;
-    Sums at = tot;                                    // exclusive prefix of the lanes' sums: the chunk's words below this lane's first
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-        const unsigned a = __shfl_up(at.span, o, WAVE), b2 = __shfl_up(at.qlen, o, WAVE), c2 = __shfl_up(at.nlen, o, WAVE), g2 = __shfl_up(at.ngap, o, WAVE);
-        if ((int)lane >= o) { at.span += a; at.qlen += b2; at.nlen += c2; at.ngap += g2; }
-    }
+    Sums at{wscan(tot.span), wscan(tot.qlen), wscan(tot.nlen), wscan(tot.ngap)};     // (inclusive) prefix of the lanes' sums
     at = sub(at, tot);
     if (tot.ngap == 0) return;
     // (rare: the lane walks its words once more, out of the cache)
@@ -381,13 +377,27 @@ __device__ __forceinline__ void flat_tile(const uint32_t* __restrict__ cigar, co
     }
 }
 
+// first_aln[c] = the alignment that holds chunk c's first word: every alignment writes the entries of the chunks that begin inside
+// it (a thread per alignment; a long one loops over its chunks).
+__global__ __launch_bounds__(256)
+void cigar_map_kernel(const uint64_t* __restrict__ cig_off, uint32_t n_aln, uint32_t* __restrict__ first_aln)
+{
+    const uint32_t a = blockIdx.x * 256 + threadIdx.x;
+    if (a >= n_aln) return;
+    const uint64_t begin = cig_off[0], base = begin & ~3ull, b = cig_off[a], e = cig_off[a + 1];
+    if (e == b) return;
+    if (b <= begin) first_aln[0] = a;                 // (chunk 0 begins at `begin`, in front of which only empty alignments lie)
+    for (uint64_t c = (b - base + FCH - 1) / FCH; base + c * FCH < e; ++c) if (c) first_aln[c] = a;
+}
+
 // Resident workgroups walk the tiles with a grid stride, in order: a launch of one short-lived workgroup per tile (10^4 of them
 // for an ONT chromosome) was bound by the rate at which workgroups are dispatched, not by memory (1.3 TB/s with the loads alone in
 // the kernel).  Tile t's predecessors are taken earlier by the same or by a resident workgroup: the look-back ends.
 __global__ __launch_bounds__(FBLOCK)
 void cigar_flat_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict__ cig_off, const int32_t* __restrict__ ref_start,
                        uint32_t n_aln, int32_t min_sv, SvxGap* __restrict__ gaps, uint64_t gaps_cap, uint32_t* __restrict__ gap_off,
-                       int32_t* __restrict__ stats, Desc d, uint32_t n_tiles, unsigned int* __restrict__ next_tile)
+                       int32_t* __restrict__ stats, Desc d, uint32_t n_tiles, unsigned int* __restrict__ next_tile,
+                       const uint32_t* __restrict__ first_aln)
 {
     // (tiles are TAKEN in order from a counter, not assigned by index: a workgroup that is not resident yet holds no tile that a
     // resident one could wait for)
@@ -397,7 +407,7 @@ void cigar_flat_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __res
         __syncthreads();
         const uint32_t t = s_tile;
         if (t >= n_tiles) return;
-        flat_tile(cigar, cig_off, ref_start, n_aln, min_sv, gaps, gaps_cap, gap_off, stats, d, t);
+        flat_tile(cigar, cig_off, ref_start, n_aln, min_sv, gaps, gaps_cap, gap_off, stats, d, t, first_aln);
         __syncthreads();                              // (the tile's LDS -- s_tile included -- is free again)
     }
 }
@@ -407,7 +417,7 @@ void cigar_flat_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __res
 extern "C" size_t svx_cigar_scan_flat_ws_bytes(uint64_t n_words_max)
 {
     const size_t groups = ((size_t)((n_words_max + 3 + FCH - 1) / FCH) + 1 + NW - 1) / NW;
-    return (5 * groups + 1) * sizeof(unsigned long long);       // (+ the tile counter)
+    return (5 * groups + 1) * sizeof(unsigned long long) + groups * NW * sizeof(uint32_t);       // (+ the tile counter, + the chunks' first alignments)
 }
 
 // svx_cigar_scan for long alignments: the same inputs and outputs (include/svx.h), one pass.  n_words_max: an upper bound of
@@ -432,8 +442,10 @@ extern "C" int svx_cigar_scan_flat(const uint32_t* d_cigar, const uint64_t* d_ci
     Desc d{w, w + chunks, w + 2 * chunks, w + 3 * chunks, w + 4 * chunks};
     const char* gs = getenv("SVX_FLAT_GRID");
     const unsigned grid = (unsigned)min((size_t)(gs ? atoi(gs) : 768), chunks);       // 256 CUs x 3 resident workgroups of 512 threads
+    uint32_t* first_aln = reinterpret_cast<uint32_t*>(w + 5 * chunks + 1);
+    hipLaunchKernelGGL(cigar_map_kernel, dim3((n_aln + 255) / 256), dim3(256), 0, st, d_cig_off, n_aln, first_aln);
     hipLaunchKernelGGL(cigar_flat_kernel, dim3(grid), dim3(FBLOCK), 0, st,
                        d_cigar, d_cig_off, d_ref_start, n_aln, min_sv, d_gaps, gaps_cap, d_gap_off, d_stats, d, (uint32_t)chunks,
-                       reinterpret_cast<unsigned int*>(w + 5 * chunks));
+                       reinterpret_cast<unsigned int*>(w + 5 * chunks), first_aln);
     return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
 }

@@ -101,7 +101,7 @@ class CigarScanResult:
 
 
 FLAT_SCAN_FROM = None               # mean CIGAR words per alignment from which svx_cigar_scan_flat is picked: None = never -- measured (round 5,
-                                    # profiles/r05_bench_cigar.json): 590-650 us on the ONT-shaped launch against 520 us of the three-kernel form
+                                    # profiles/r05_bench_cigar.json): 600-800 us on the ONT-shaped launch against 520 us of the three-kernel form (a dozen dependent round trips per tile)
 
 
 def cigar_scan(cigar, cig_off, ref_start, min_sv, gaps_cap=None, mode=None, n_words=None):

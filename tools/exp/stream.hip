@@ -56,6 +56,23 @@ __global__ __launch_bounds__(256) void write_slice_kernel(const uint4* __restric
     }
 }
 
+// one burst per wave: every wave loads 8 KB (eight 16-byte loads per lane) once and leaves -- the shape of svx_cigar_scan_flat's tiles
+template <int BLOCK, bool CONTIG, bool WSUM>
+__global__ __launch_bounds__(BLOCK) void burst_kernel(const uint4* __restrict__ in, size_t nq, uint32_t* out)
+{
+    const size_t wave = ((size_t)blockIdx.x * BLOCK + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const size_t q0 = wave * 512;
+    if (q0 + 512 > nq) return;
+    uint4 w[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w[u] = CONTIG ? in[q0 + 8 * lane + u] : in[q0 + 64 * u + lane];
+    unsigned r = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) r ^= w[u].x ^ w[u].y ^ w[u].z ^ w[u].w;
+    if (WSUM) { for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o, 64); }
+    if (r == 0x12345678u) out[0] = r;
+}
+
 int main()
 {
     const size_t bytes = 1200ull << 20;
@@ -74,12 +91,48 @@ int main()
         printf("%-28s grid %6d: %7.1f us  %6.2f TB/s\n", name, grid, ms * 100, bytes / (ms * 1e-4) / 1e12);
         return 0;
     };
+    {
+        auto runb = [&](const char* name, auto kern, int block) {
+            const int grid = (int)((nq / 512) * 64 / block);
+            for (int rep = 0; rep < 2; ++rep) {
+                hipEventRecord(e0);
+                for (int k = 0; k < 10; ++k) hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, 0, d, nq, o);
+                hipEventRecord(e1); hipEventSynchronize(e1);
+            }
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("%-34s grid %6d x %4d: %7.1f us  %6.2f TB/s\n", name, grid, block, ms * 100, bytes / (ms * 1e-4) / 1e12);
+        };
+        runb("burst coalesced", burst_kernel<256, false, false>, 256);
+        runb("burst coalesced 512", burst_kernel<512, false, false>, 512);
+        runb("burst lane-contiguous", burst_kernel<256, true, false>, 256);
+        runb("burst lane-contiguous 512", burst_kernel<512, true, false>, 512);
+        runb("burst coalesced + wave sum", burst_kernel<256, false, true>, 256);
+        runb("burst coalesced 64", burst_kernel<64, false, false>, 64);
+    }
     for (int grid : {2048, 4096, 16384}) {
         run("stream u1", stream_kernel<1, false>, grid);
         run("stream u2", stream_kernel<2, false>, grid);
         run("stream u4", stream_kernel<4, false>, grid);
         run("stream+tally u2", stream_kernel<2, true>, grid);
         run("stream+tally u4", stream_kernel<4, true>, grid);
+    }
+    {
+        auto runb = [&](const char* name, auto kern, int block) {
+            const int grid = (int)((nq / 512) * 64 / block);
+            for (int rep = 0; rep < 2; ++rep) {
+                hipEventRecord(e0);
+                for (int k = 0; k < 10; ++k) hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, 0, d, nq, o);
+                hipEventRecord(e1); hipEventSynchronize(e1);
+            }
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("%-34s grid %6d x %4d: %7.1f us  %6.2f TB/s\n", name, grid, block, ms * 100, bytes / (ms * 1e-4) / 1e12);
+        };
+        runb("burst coalesced", burst_kernel<256, false, false>, 256);
+        runb("burst coalesced 512", burst_kernel<512, false, false>, 512);
+        runb("burst lane-contiguous", burst_kernel<256, true, false>, 256);
+        runb("burst lane-contiguous 512", burst_kernel<512, true, false>, 512);
+        runb("burst coalesced + wave sum", burst_kernel<256, false, true>, 256);
+        runb("burst coalesced 64", burst_kernel<64, false, false>, 64);
     }
     for (int grid : {2048, 4096, 16384}) {
         run("write grid-stride", write_kernel<0>, grid);
