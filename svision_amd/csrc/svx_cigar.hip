@@ -38,6 +38,21 @@ __device__ inline bool span_ref(uint32_t op) { return (0x18Du >> op) & 1u; }   /
 __device__ inline bool in_query(uint32_t op) { return (0x1B3u >> op) & 1u; }   // 0,1,4,5,7,8
 __device__ inline bool is_clip(uint32_t op)  { return op == 4u || op == 5u; }
 
+// Inclusive prefix sum over the wave in the vector ALU (row shifts inside the rows of 16 lanes + the two row broadcasts of gfx9):
+// seven data-parallel moves instead of six ds_bpermute round trips through the LDS crossbar (what __shfl_up compiles to here).
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    uint32_t r = v;
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);      // row_shr:1
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);      // row_shr:2
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, true);      // row_shr:3
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x114, 0xf, 0xe, true);      // row_shr:4, banks 1-3
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x118, 0xf, 0xc, true);      // row_shr:8, banks 2-3
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
+    return r;
+}
+
 __device__ inline unsigned wave_sum_u(unsigned v)
 {
 #pragma unroll
@@ -254,12 +269,7 @@ void offsets_kernel(uint32_t n_aln, uint32_t* __restrict__ gap_off, unsigned lon
     }
     const uint32_t mine_g = c[0] + c[1] + c[2] + c[3];
     const uint32_t mine_o = (uint32_t)(c[0] != 0u) + (uint32_t)(c[1] != 0u) + (uint32_t)(c[2] != 0u) + (uint32_t)(c[3] != 0u);
-    uint32_t inc_g = mine_g, inc_o = mine_o;
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-        const uint32_t ug = __shfl_up(inc_g, o, WAVE), uo = __shfl_up(inc_o, o, WAVE);
-        if (wl >= o) { inc_g += ug; inc_o += uo; }
-    }
+    const uint32_t inc_g = wave_incl_scan(mine_g), inc_o = wave_incl_scan(mine_o);
     if (wl == WAVE - 1) { s_wave[wv] = inc_g; s_wave[NW + wv] = inc_o; }
     __syncthreads();
     uint32_t pre_g = 0, pre_o = 0, tot_g = 0, tot_o = 0;
@@ -352,12 +362,7 @@ void emit_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict_
                 tf += adv_ref(op) ? len : 0u;
                 hit[u] = ((op - 1u) < 2u) & ((int32_t)len >= min_sv);
             }
-            uint32_t ir = tr, irf = tf;                        // inclusive wave prefix sums of the lane totals
-#pragma unroll
-            for (int o = 1; o < WAVE; o <<= 1) {
-                const uint32_t ur = __shfl_up(ir, o, WAVE), uf = __shfl_up(irf, o, WAVE);
-                if (lane >= o) { ir += ur; irf += uf; }
-            }
+            const uint32_t ir = wave_incl_scan(tr), irf = wave_incl_scan(tf);     // inclusive wave prefix sums of the lane totals
             // slot of a hit = hits in the lanes below (all four of their words) + this lane's earlier hits
             uint32_t mine = 0, all = 0, lower = 0;
 #pragma unroll
@@ -382,8 +387,8 @@ void emit_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict_
                 }
             }
             dst += all;
-            read_pos += __shfl(ir, WAVE - 1, WAVE);
-            ref_pos += __shfl(irf, WAVE - 1, WAVE);
+            read_pos += (uint32_t)__builtin_amdgcn_readlane((int)ir, WAVE - 1);
+            ref_pos += (uint32_t)__builtin_amdgcn_readlane((int)irf, WAVE - 1);
         };
         constexpr long long STEP = 4 * WAVE;
         auto narrow = [&](long long jlo, long long jhi) {      // the words [jlo, jhi) of the alignment, 256 per step
@@ -410,10 +415,8 @@ void emit_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict_
         // word.  The (at most three) words in front of the first 16-byte boundary and what is left behind the last whole step
         // go through the narrow steps.
         auto excl = [&](uint32_t v, uint32_t& total) {
-            uint32_t inc = v;
-#pragma unroll
-            for (int o = 1; o < WAVE; o <<= 1) { const uint32_t up = __shfl_up(inc, o, WAVE); if (lane >= o) inc += up; }
-            total = __shfl(inc, WAVE - 1, WAVE);
+            const uint32_t inc = wave_incl_scan(v);
+            total = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
             return inc - v;
         };
         long long j = (long long)((4u - (uint32_t)(b & 3u)) & 3u);

@@ -264,13 +264,25 @@ __device__ __forceinline__ Tok token(const Lds& t, uint32_t rel)
     return k;
 }
 
+// Inclusive prefix sum over the wave in the vector ALU (row shifts inside the rows of 16 lanes + the two row broadcasts of gfx9):
+// seven data-parallel moves instead of six ds_bpermute round trips through the LDS crossbar (what __shfl_up compiles to here).
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    uint32_t r = v;
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);      // row_shr:1
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);      // row_shr:2
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, true);      // row_shr:3
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x114, 0xf, 0xe, true);      // row_shr:4, banks 1-3
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x118, 0xf, 0xc, true);      // row_shr:8, banks 2-3
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
+    return r;
+}
+
 __device__ __forceinline__ uint32_t wave_excl_sum(uint32_t v, uint32_t* total)
 {
-    const int lane = threadIdx.x;
-    uint32_t inc = v;
-#pragma unroll
-    for (int o = 1; o < LANES; o <<= 1) { const uint32_t u = __shfl_up(inc, o, LANES); if (lane >= o) inc += u; }
-    *total = __shfl(inc, LANES - 1, LANES);
+    const uint32_t inc = wave_incl_scan(v);
+    *total = (uint32_t)__builtin_amdgcn_readlane((int)inc, LANES - 1);
     return inc - v;
 }
 
