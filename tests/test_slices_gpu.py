@@ -160,3 +160,56 @@ def test_command_line_with_slices_equals_whole_chromosomes(sample_files, device_
     assert outs["whole"]["HGs.svision.s3.vcf"].count("\n") > 60
     for name in outs:
         assert outs[name] == outs["whole"], name
+
+
+def test_a_slice_the_device_refuses_is_served_by_the_host_engine(sample_files, device_model, tmp_path, caplog):
+    """An entry of chrA's LINEAR index that points into the middle of a record, half-way through the chromosome: the slices in
+    front of it come from the device engine, the slice that walks into it is refused, and the host reader's table of the whole
+    chromosome serves every window that had not been handed over; chrB and chrC come from the device engine again.  Every window
+    still sees every record it can touch, and the command line writes what it writes from an intact index."""
+    import logging
+    import shutil
+    import struct as st
+    path, fa, table, genome = sample_files
+    head = bam.read_bam_header(path)
+    raw = bytearray(open(path + ".bai", "rb").read())
+    at = 8
+    n_bin, = st.unpack_from("<i", raw, at); at += 4
+    for _ in range(n_bin):
+        _bin, n_chunk = st.unpack_from("<Ii", raw, at); at += 8 + 16 * n_chunk
+    n_intv, = st.unpack_from("<i", raw, at); at += 4
+    vals = list(st.unpack_from("<%dQ" % n_intv, raw, at))
+    k = n_intv // 2
+    while vals[k] == vals[k - 1] or vals[k] == 0:
+        k += 1
+    st.pack_into("<Q", raw, at + 8 * k, vals[k] + 5)               # five bytes into the record it pointed at
+    bad = str(tmp_path / "bad.bam")
+    shutil.copy(path, bad)
+    with open(bad + ".bai", "wb") as f:
+        f.write(raw)
+    tasks = {c: _windows(n) for c, n in zip(head.references, head.lengths)}
+    span = helpers.oracle_scan(table, 50)[2][:, 0]
+    import svision_amd.ingest_gpu as ig
+    saved = ig.FIRST_GROUP_BYTES, ig.PIPE_GROUP_BYTES, ig.LARGE_GROUP_BYTES
+    ig.FIRST_GROUP_BYTES = ig.PIPE_GROUP_BYTES = ig.LARGE_GROUP_BYTES = 1 << 20      # several inflate launches per chromosome: the refusal comes late
+    try:
+        with caplog.at_level(logging.WARNING):
+            got, stats = _serve(bad, genome, tasks, {"SVX_SLICE_BYTES": "200000", "SVX_SLICE_MIN_MARGINS": "0"})
+    finally:
+        ig.FIRST_GROUP_BYTES, ig.PIPE_GROUP_BYTES, ig.LARGE_GROUP_BYTES = saved
+    assert stats["engine"] == "gpu" and any("on the host" in r.getMessage() for r in caplog.records)
+    kinds = {}
+    for (chrom, start), smp in got.items():
+        assert _complete(table, span, smp, chrom, start, min(start + WINDOW, head.lengths[head.references.index(chrom)])), (chrom, start)
+        kinds.setdefault(chrom, []).append(type(smp.table.cigar).__name__)
+    assert kinds["chrA"][0] == "LazyCigar" and kinds["chrA"][-1] != "LazyCigar"      # device slices first, the host's table behind them
+    assert set(kinds["chrC"]) == {"LazyCigar"}
+    outs = {}
+    for name, b in (("intact", path), ("damaged", bad)):
+        out = str(tmp_path / name)
+        r = _cli(["-o", out, "-b", b, "-m", device_model, "-g", fa, "-n", "HGs", "-s", "3", "--window_size", str(WINDOW), "--batch_size", "64",
+                  "--qname", "-t", "3"], env={"SVX_SLICE_BYTES": "200000", "SVX_SLICE_MIN_MARGINS": "0", "SVX_FIRST_GROUP_MB": "1", "SVX_PIPE_GROUP_MB": "1",
+                                              "SVX_LARGE_GROUP_MB": "1"})
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[name] = open(os.path.join(out, "HGs.svision.s3.vcf")).read()
+    assert outs["damaged"] == outs["intact"] and outs["intact"].count("\n") > 60
