@@ -355,19 +355,28 @@ def main():
         hot.reset_timing()
         done = {}
         sample = lambda chrom, start: hot.feed.get(chrom, block=True, start=start)[1]     # noqa: E731  (the resident Sample, or the one that served the window)
-        for res in hot.run_windows(seq, rescan=rescan):
-            images += res.n_images
-            done[res.wid] = res
-        lo = 0
-        while lo < len(seq):                                           # maximal runs of ascending windows of one chromosome
+        # maximal runs of ascending windows of one chromosome; a run is voted and stitched as soon as its last window is through
+        # (as the command line writes a chromosome when its last window is done, cli._run_pooled), while the device works on the others
+        runs, run_of, lo = [], {}, 0
+        while lo < len(seq):
             hi = lo + 1
             while hi < len(seq) and seq[hi][0] == seq[hi - 1][0] and seq[hi][1] == seq[hi - 1][2]:
                 hi += 1
-            sites += distinct_sites([done[w] for w in range(lo, hi)])  # a site spanning a window boundary counts once
-            for vcf_text, score_text in stitch_windows([done[w] for w in range(lo, hi)], opts, sample).values():
-                records += vcf_text.count("\n")
-                scores += [float(s) for s in score_text.split()]
+            for w in range(lo, hi):
+                run_of[w] = len(runs)
+            runs.append([lo, hi, hi - lo])
             lo = hi
+        for res in hot.run_windows(seq, rescan=rescan):
+            images += res.n_images
+            done[res.wid] = res
+            run = runs[run_of[res.wid]]
+            run[2] -= 1
+            if run[2] == 0:
+                part = [done.pop(w) for w in range(run[0], run[1])]
+                sites += distinct_sites(part)                                  # a site spanning a window boundary counts once
+                for vcf_text, score_text in stitch_windows(part, opts, sample).values():
+                    records += vcf_text.count("\n")
+                    scores += [float(s_) for s_ in score_text.split()]
         return sites, images, records, scores
 
     if strong:

@@ -14,7 +14,7 @@ threads = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1]
 d = tempfile.mkdtemp()
 cfg = synth.SimConfig(contigs=[("chr%d" % (21 + i), length) for i in range(n_contigs)], coverage=30, seed=1)
 t = time.time(); table, genome, _ = synth.simulate(cfg); print("simulate %.1fs, %d records" % (time.time() - t, len(table)), flush=True)
-t = time.time(); bam.write_bam(os.path.join(d, "s.bam"), table); print("write bam %.1fs, %.1f MB" % (time.time() - t, os.path.getsize(os.path.join(d, "s.bam")) / 1e6), flush=True)
+t = time.time(); bam.write_bam(os.path.join(d, "s.bam"), table, index=True); print("write bam %.1fs, %.1f MB" % (time.time() - t, os.path.getsize(os.path.join(d, "s.bam")) / 1e6), flush=True)
 bam.write_fasta(os.path.join(d, "g.fa"), genome)
 ck.write_checkpoint(os.path.join(d, "m.ckpt"), random_weights(0))
 import subprocess

@@ -10,6 +10,8 @@ import numpy as np
 import torch
 
 from svision_amd import _lib, kernels, synth
+if os.environ.get("SVX_EXP_LIB"):
+    _lib.LIB_PATH = os.environ["SVX_EXP_LIB"]
 from svision_amd.io import bam
 
 mb = float(sys.argv[1]) if len(sys.argv) > 1 else 4
