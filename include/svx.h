@@ -21,9 +21,9 @@
 extern "C" {
 #endif
 
-#define SVX_VERSION 390            /* 0.3.0: + svx_bgzf_crc32, svx_bgzf_inflate_fast (360); + svx_bgzf_inflate_fast_on: the two kernels on two streams (370);
+#define SVX_VERSION 400            /* 0.3.0: + svx_bgzf_crc32, svx_bgzf_inflate_fast (360); + svx_bgzf_inflate_fast_on: the two kernels on two streams (370);
                                     * svx_bgzf_inflate_fast / _on take the inflated byte count and refuse a workspace that is too small (380);
-                                    * + svx_cigar_scan_flat: the scan of long alignments in one pass (390) */
+                                    * + svx_cigar_scan_flat: the scan of long alignments in one pass (390); svx_cigar_scan takes the word count of its launch (400) */
 
 #define SVX_OK            0
 #define SVX_EINVAL       (-1)      /* bad argument (null pointer, bad layout...) */
@@ -90,11 +90,14 @@ size_t svx_cigar_scan_ws_bytes(uint32_t n_aln);
  *               query_len (M,I,S,H,=,X)
  *   d_ws        scratch of svx_cigar_scan_ws_bytes(n_aln) bytes, 8-byte aligned, contents ignored
  *   n_aln       < 2^30
+ *   n_words     the CIGAR words of the launch (= d_cig_off[n_aln], which the caller knows as the length of its array; 0 = not
+ *               known).  Only the shape of the count pass depends on it -- four lanes per alignment when the alignments average
+ *               at most 256 words, eight otherwise --, never a result
  * Three launches (count -> offsets, its prefix over the tiles by a decoupled look-back -> emit), no atomics on results.
  * H is treated as S (the reference rewrites H to S, collect_signatures.py:91);
  * N advances the read position only (analyze_reads.py:831-832). */
 int svx_cigar_scan(const uint32_t* d_cigar, const uint64_t* d_cig_off,
-                   const int32_t* d_ref_start, uint32_t n_aln, int32_t min_sv,
+                   const int32_t* d_ref_start, uint32_t n_aln, uint64_t n_words, int32_t min_sv,
                    SvxGap* d_gaps, uint64_t gaps_cap, uint32_t* d_gap_off,
                    int32_t* d_stats, void* d_ws, void* stream);
 

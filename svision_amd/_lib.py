@@ -27,7 +27,7 @@ SYMBOLS = {
     "svx_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "svx_crc32c": (_u32, [_vp, _sz]),
     "svx_cigar_scan_ws_bytes": (_sz, [_u32]),
-    "svx_cigar_scan": (ctypes.c_int, [_vp, _vp, _vp, _u32, _i32, _vp, _u64, _vp, _vp, _vp, _vp]),
+    "svx_cigar_scan": (ctypes.c_int, [_vp, _vp, _vp, _u32, _u64, _i32, _vp, _u64, _vp, _vp, _vp, _vp]),
     "svx_cigar_scan_flat_ws_bytes": (_sz, [_u64]),
     "svx_cigar_scan_flat": (ctypes.c_int, [_vp, _vp, _vp, _u32, _u64, _i32, _vp, _u64, _vp, _vp, _vp, _u64, _vp]),
     "svx_rasterize": (ctypes.c_int, [_vp, _u32, _vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float), _vp]),
@@ -79,7 +79,7 @@ class SvxMissing(SvxError):
 _lib = None
 
 
-ABI_VERSION = 390                     # SVX_VERSION of include/svx.h this binding was written against
+ABI_VERSION = 400                     # SVX_VERSION of include/svx.h this binding was written against
 
 
 def load():

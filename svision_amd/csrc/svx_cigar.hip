@@ -23,6 +23,7 @@
 //                      keep op order.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/svx.h"
 
 namespace {
@@ -60,19 +61,23 @@ __device__ inline unsigned wave_sum_u(unsigned v)
     return v;
 }
 
-#ifndef SVX_CGROUP
-#define SVX_CGROUP 8
-#define SVX_CQUADS 2
-#endif
-constexpr int CGROUP = SVX_CGROUP;                  // lanes per alignment in the count pass
-constexpr int CQUADS = SVX_CQUADS;                  // 16-byte loads in flight per lane
-constexpr int ALN_PER_CBLOCK = BLOCK / CGROUP;      // alignments per workgroup of the count pass
-constexpr int LONG_Q = 128;                         // quads (512 words) of an alignment the eight-lane count pass handles itself
+// The count pass gives an alignment G lanes that keep Q 16-byte loads in flight each (template parameters: the entry point picks
+// <4, 4> for launches whose alignments average at most SHORT_MEAN words -- HiFi: sixteen alignments per wave, whose per-alignment
+// instructions are the larger half of the pass -- and <8, 2> otherwise).
+constexpr int LONG_Q = 128;                         // quads (512 words) of an alignment the count pass's groups handle themselves
+constexpr uint64_t SHORT_MEAN = 256;
 
-__device__ inline unsigned cgroup_sum(unsigned v)
+// Sum over the G lanes of an alignment, complete in the group's FIRST lane only (the others end with partial sums: nothing
+// reads them): row shifts in the vector ALU (the groups lie inside the rows of 16 lanes; a lane beyond the row reads 0) -- three
+// fused shift-adds where __shfl_xor was three ds_bpermute round trips, five sums per alignment.
+template <int G>
+__device__ __forceinline__ unsigned cgroup_sum(unsigned v)
 {
-#pragma unroll
-    for (int o = CGROUP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    static_assert(G == 4 || G == 8 || G == 16, "groups lie inside a row of 16 lanes");
+    if (G >= 16) v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x108, 0xf, 0xf, true);     // row_shl:8
+    if (G >= 8)  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xf, 0xf, true);     // row_shl:4
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x102, 0xf, 0xf, true);                       // row_shl:2
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true);                       // row_shl:1
     return v;
 }
 
@@ -80,12 +85,20 @@ __device__ inline unsigned cgroup_sum(unsigned v)
 // ALU, not by memory (PMC, profiles/r04_pmc_cigar.txt: 605 VALU instructions per wave of eight alignments, the SIMD's vector
 // port busy for the whole launch), so the instruction count per word is its speed: a signed one-bit field extract turns "is this
 // op in the set" into an AND mask in one instruction (v_bfe_i32: 0 or -1), where shift / and / compare / select took three.
-__device__ inline void tally(uint32_t w, int32_t min_sv, unsigned& ref_span, unsigned& qlen, unsigned& ngap)
+// Round 5: the extract's offset is the WORD itself -- the instruction reads the offset's low five bits, op and the length's
+// lowest bit, so the sets are written twice (bits 0-8 and 16-24) and `w & 15` is gone; "at least min_sv bases" is one unsigned
+// compare of the word with min_sv << 4 (scan_threshold()).
+constexpr uint32_t K_REF = 0x018D018Du, K_QRY = 0x01B301B3u, K_GAP = 0x00060006u;      // M D N = X (reference_end) | M I S H = X | I D
+__device__ inline uint32_t scan_threshold(int32_t min_sv)
 {
-    const uint32_t op = w & 15u, len = w >> 4;
-    ref_span += len & (uint32_t)__builtin_amdgcn_sbfe(0x18D, op, 1u);      // M D N = X (reference_end)
-    qlen += len & (uint32_t)__builtin_amdgcn_sbfe(0x1B3, op, 1u);          // M I S H = X
-    ngap -= (uint32_t)((int32_t)len >= min_sv ? __builtin_amdgcn_sbfe(0x6, op, 1u) : 0);      // I, D of at least min_sv bases
+    return min_sv <= 0 ? 0u : min_sv >= (1 << 28) ? 0xFFFFFFFFu : (uint32_t)min_sv << 4;      // (0xFFFFFFFF is op 15: in no set)
+}
+__device__ inline void tally(uint32_t w, uint32_t m16, unsigned& ref_span, unsigned& qlen, unsigned& ngap)
+{
+    const uint32_t len = w >> 4;
+    ref_span += len & (uint32_t)__builtin_amdgcn_sbfe(K_REF, w, 1u);
+    qlen += len & (uint32_t)__builtin_amdgcn_sbfe(K_QRY, w, 1u);
+    ngap -= (uint32_t)(w >= m16 ? __builtin_amdgcn_sbfe(K_GAP, w, 1u) : 0);                 // I, D of at least min_sv bases
 }
 
 // (the same in the form the long-alignment loop at the end of the count pass keeps: there a wave streams ONE alignment, bound by
@@ -114,7 +127,8 @@ __device__ inline unsigned long long d_pack(uint32_t gaps, uint32_t owners) { re
 constexpr int LQUADS = 8;
 constexpr long long WIDE_FROM = 1024;                // words from which the emit pass takes an alignment in steps of 2,048 instead of 256                            // 16-byte loads in flight per lane while a wave finishes a long alignment
 
-__global__ __launch_bounds__(BLOCK)
+template <int G, int Q>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8)))
 void count_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict__ cig_off,
                   uint32_t n_aln, int32_t min_sv, uint32_t* __restrict__ gap_off, int32_t* __restrict__ stats,
                   unsigned long long* __restrict__ desc, uint32_t n_tiles)
@@ -123,13 +137,16 @@ void count_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict
     // launch of its own -- 5 us of a 70 us scan; there are more count workgroups than tiles)
     if (threadIdx.x == 0 && blockIdx.x < n_tiles) desc[blockIdx.x] = 0ull;
     if (threadIdx.x == 0 && blockIdx.x == 0) gap_off[n_aln] = 0u;        // (the total: written with atomicMax by the offsets pass, see there)
-    const int sub = threadIdx.x & (CGROUP - 1);
+    const int sub = threadIdx.x & (G - 1);
     const int wl = threadIdx.x & (WAVE - 1);
-    const int gshift = wl & ~(CGROUP - 1);
-    const uint32_t a = blockIdx.x * ALN_PER_CBLOCK + (threadIdx.x / CGROUP);
+    const int gshift = wl & ~(G - 1);
+    const uint32_t a = blockIdx.x * (BLOCK / G) + (threadIdx.x / G);
     const bool live = a < n_aln;
-    const uint64_t full = cig_off[n_aln] >> 2;           // quads that lie entirely inside the array
-    const uint64_t b = live ? cig_off[a] : 0, e = live ? cig_off[a + 1] : 0;
+    const uint32_t m16 = scan_threshold(min_sv);
+    const uint64_t total = cig_off[n_aln];
+    const uint64_t full = total >> 2;                    // quads that lie entirely inside the array
+    const uint32_t ac = min(a, n_aln - 1);               // (n_aln > 0: the entry point launches nothing otherwise)
+    const uint64_t b = cig_off[ac], e_next = cig_off[ac + 1], e = live ? e_next : b;       // (both loads in flight at once)
     const long long n = (long long)(e - b);
     const uint64_t q0 = b >> 2, q_end = min((e + 3) >> 2, full);
     // an alignment of more than LONG_Q quads (ONT: 10^3-10^5 ops) is only STARTED by its eight lanes -- for them it would be
@@ -138,73 +155,81 @@ void count_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict
     // pipeline's registers cost every HiFi launch a third of its occupancy: 163 instead of 74; until round 4 a list + a
     // kernel of its own).  All sums are modular and additive: the corrections (computed from q_end) and the two partial
     // sums simply add up.
-    const bool is_long = q_end - q0 > (uint64_t)LONG_Q;
-    const uint64_t q1 = is_long ? q0 + LONG_Q : q_end;
+    const bool some = q0 < q_end;
+    const bool is_long = some && q_end - q0 > (uint64_t)LONG_Q;
+    const uint32_t nq = some ? (is_long ? (uint32_t)LONG_Q : (uint32_t)(q_end - q0)) : 0u;      // quads taken here
     // the words at either end for the clip runs, the neighbours' words inside the first / last quad (lanes 0-2
     // look before b and from e on), the alignment's words beyond the last whole quad of the array (at most 3,
-    // last alignments only), then the quads
+    // last alignments only), then the quads.  Everything is addressed from the alignment's own first word / quad / end with
+    // 32-bit offsets (round 5: the 64-bit compares and selects around every load were a sixth of the kernel's vector instructions).
+    const uint32_t* __restrict__ cb = cigar + b;
+    const uint32_t* __restrict__ ce = cigar + e;
     const long long it = n - 1 - sub;
-    const uint32_t w_head = sub < n ? cigar[b + sub] : 0u;
-    const uint32_t w_tail = it >= 0 ? cigar[b + it] : 0u;
-    const uint64_t fl = (b & ~3ull) + sub, ft = e + sub, tg = max(b, 4 * full) + sub;
-    const uint32_t w_before = (q0 < q_end && sub < 3 && fl < b) ? cigar[fl] : 0u;
-    const uint32_t w_after = (q0 < q_end && sub < 3 && ft < 4 * q_end) ? cigar[ft] : 0u;
-    const uint32_t w_loose = (sub < 3 && tg < e) ? cigar[tg] : 0u;
+    const uint32_t w_head = sub < n ? cb[sub] : 0u;
+    const uint32_t w_tail = it >= 0 ? ce[-1 - sub] : 0u;
+    const int lead_in = (int)(b & 3ull);                                 // words of the neighbour in front inside the first quad
+    const int trail_in = (int)(uint32_t)(4 * q_end - e);                 // words behind e inside the last quad taken: -3 .. 3, as the low word says
+    const uint64_t lb = max(b, 4 * full);
+    const int loose_n = e > lb ? (int)(uint32_t)(e - lb) : 0;            // <= 3: total < 4 * full + 4
+    const uint32_t w_before = (some && sub < lead_in) ? cb[sub - lead_in] : 0u;
+    const uint32_t w_after = (some && sub < trail_in) ? ce[sub] : 0u;
+    const uint32_t w_loose = sub < loose_n ? cigar[lb + sub] : 0u;
     unsigned ref_span = 0, qlen = 0, ngap = 0;
     const uint4* __restrict__ quads = reinterpret_cast<const uint4*>(cigar);
-    for (uint64_t q = q0 + sub; q < q1; q += CQUADS * CGROUP) {
-        uint4 w[CQUADS];
+    const uint4* __restrict__ qb = quads + q0;
+    for (uint32_t q = sub; q < nq; q += Q * G) {
+        uint4 w[Q];
 #pragma unroll
-        for (int u = 0; u < CQUADS; ++u) w[u] = quads[min(q + u * CGROUP, q1 - 1)];    // clamped, dropped below when out of range
+        for (int u = 0; u < Q; ++u) w[u] = qb[min(q + u * G, nq - 1)];        // clamped, dropped below when out of range
 #pragma unroll
-        for (int u = 0; u < CQUADS; ++u) {
-            const bool in = q + u * CGROUP < q1;
-            tally(in ? w[u].x : 0u, min_sv, ref_span, qlen, ngap); tally(in ? w[u].y : 0u, min_sv, ref_span, qlen, ngap);
-            tally(in ? w[u].z : 0u, min_sv, ref_span, qlen, ngap); tally(in ? w[u].w : 0u, min_sv, ref_span, qlen, ngap);
+        for (int u = 0; u < Q; ++u) {
+            const bool in = q + u * G < nq;
+            tally(in ? w[u].x : 0u, m16, ref_span, qlen, ngap); tally(in ? w[u].y : 0u, m16, ref_span, qlen, ngap);
+            tally(in ? w[u].z : 0u, m16, ref_span, qlen, ngap); tally(in ? w[u].w : 0u, m16, ref_span, qlen, ngap);
         }
     }
-    tally(w_loose, min_sv, ref_span, qlen, ngap);
+    tally(w_loose, m16, ref_span, qlen, ngap);
     {
         unsigned fr = 0, fq = 0, fn = 0;
-        tally(w_before, min_sv, fr, fq, fn);
-        tally(w_after, min_sv, fr, fq, fn);
+        tally(w_before, m16, fr, fq, fn);
+        tally(w_after, m16, fr, fq, fn);
         ref_span -= fr; qlen -= fq; ngap -= fn;
     }
-    ngap = cgroup_sum(ngap);
-    ref_span = cgroup_sum(ref_span);
-    qlen = cgroup_sum(qlen);
+    ngap = cgroup_sum<G>(ngap);
+    ref_span = cgroup_sum<G>(ref_span);
+    qlen = cgroup_sum<G>(qlen);
     if (live && sub == 0) gap_off[a] = ngap;             // (turned into an offset by the offsets pass)
     if (stats) {
         unsigned lead = 0, trail = 0;
         long long n_lead = 0;                                  // words in the leading clip run
         {
-            const unsigned m = (unsigned)(__ballot(sub < n && is_clip(w_head & 15u)) >> gshift) & ((1u << CGROUP) - 1u);
-            int run = __ffs((int)~m) - 1;                      // 0..CGROUP
+            const unsigned m = (unsigned)(__ballot(sub < n && is_clip(w_head & 15u)) >> gshift) & ((1u << G) - 1u);
+            int run = __ffs((int)~m) - 1;                      // 0..G
             if (sub < run) lead += w_head >> 4;
             n_lead = run;
-            for (long long base = CGROUP; run == CGROUP && base < n; base += CGROUP) {     // longer runs: rare
+            for (long long base = G; run == G && base < n; base += G) {     // longer runs: rare
                 const long long i = base + sub;
                 const uint32_t w = i < n ? cigar[b + i] : 0u;
-                const unsigned mm = (unsigned)(__ballot(i < n && is_clip(w & 15u)) >> gshift) & ((1u << CGROUP) - 1u);
+                const unsigned mm = (unsigned)(__ballot(i < n && is_clip(w & 15u)) >> gshift) & ((1u << G) - 1u);
                 run = __ffs((int)~mm) - 1;
                 if (sub < run) lead += w >> 4;
                 n_lead += run;
             }
         }
         if (n_lead < n) {                                      // an all-clip CIGAR is all leading clip
-            const unsigned m = (unsigned)(__ballot(it >= n_lead && is_clip(w_tail & 15u)) >> gshift) & ((1u << CGROUP) - 1u);
+            const unsigned m = (unsigned)(__ballot(it >= n_lead && is_clip(w_tail & 15u)) >> gshift) & ((1u << G) - 1u);
             int run = __ffs((int)~m) - 1;
             if (sub < run) trail += w_tail >> 4;
-            for (long long base = CGROUP; run == CGROUP && base < n - n_lead; base += CGROUP) {
+            for (long long base = G; run == G && base < n - n_lead; base += G) {
                 const long long i = n - 1 - base - sub;
                 const uint32_t w = i >= n_lead ? cigar[b + i] : 0u;
-                const unsigned mm = (unsigned)(__ballot(i >= n_lead && is_clip(w & 15u)) >> gshift) & ((1u << CGROUP) - 1u);
+                const unsigned mm = (unsigned)(__ballot(i >= n_lead && is_clip(w & 15u)) >> gshift) & ((1u << G) - 1u);
                 run = __ffs((int)~mm) - 1;
                 if (sub < run) trail += w >> 4;
             }
         }
-        lead = cgroup_sum(lead);
-        trail = cgroup_sum(trail);
+        lead = cgroup_sum<G>(lead);
+        trail = cgroup_sum<G>(trail);
         if (live && sub == 0) {
             int4 s4;
             s4.x = (int)ref_span; s4.y = (int)lead; s4.z = (int)trail; s4.w = (int)qlen;
@@ -487,7 +512,7 @@ extern "C" size_t svx_cigar_scan_ws_bytes(uint32_t n_aln)
 }
 
 extern "C" int svx_cigar_scan(const uint32_t* d_cigar, const uint64_t* d_cig_off,
-                              const int32_t* d_ref_start, uint32_t n_aln, int32_t min_sv,
+                              const int32_t* d_ref_start, uint32_t n_aln, uint64_t n_words, int32_t min_sv,
                               SvxGap* d_gaps, uint64_t gaps_cap, uint32_t* d_gap_off,
                               int32_t* d_stats, void* d_ws, void* stream)
 {
@@ -500,12 +525,17 @@ extern "C" int svx_cigar_scan(const uint32_t* d_cigar, const uint64_t* d_cig_off
     if (d_stats && (reinterpret_cast<uintptr_t>(d_stats) & 15u)) return SVX_EINVAL;
     if ((reinterpret_cast<uintptr_t>(d_ws) & 7u) || (reinterpret_cast<uintptr_t>(d_cigar) & 15u) || (reinterpret_cast<uintptr_t>(d_gap_off) & 15u)) return SVX_EINVAL;
     if (n_aln >= (1u << 30)) return SVX_EINVAL;            // (the look-back descriptors keep the owner count in 30 bits)
-    const uint32_t count_blocks = (n_aln + ALN_PER_CBLOCK - 1) / ALN_PER_CBLOCK;
     unsigned long long* desc = static_cast<unsigned long long*>(d_ws);
     uint2* totals = reinterpret_cast<uint2*>(static_cast<char*>(d_ws) + ws_totals_offset(n_aln));
     uint2* work = reinterpret_cast<uint2*>(static_cast<char*>(d_ws) + ws_work_offset(n_aln));
     const uint32_t n_tiles = (n_aln + OTILE - 1) / OTILE;
-    hipLaunchKernelGGL(count_kernel, dim3(count_blocks), dim3(BLOCK), 0, st, d_cigar, d_cig_off, n_aln, min_sv, d_gap_off, d_stats, desc, n_tiles);
+    // the count pass's shape: short alignments (HiFi) four lanes each, long or unknown ones eight (SVX_COUNT_LANES=4|8: A/B runs)
+    static const int forced = getenv("SVX_COUNT_LANES") ? atoi(getenv("SVX_COUNT_LANES")) : 0;
+    const bool narrow = forced ? forced == 4 : (n_words != 0 && n_words <= SHORT_MEAN * (uint64_t)n_aln);
+    if (narrow)
+        hipLaunchKernelGGL((count_kernel<4, 4>), dim3((n_aln + BLOCK / 4 - 1) / (BLOCK / 4)), dim3(BLOCK), 0, st, d_cigar, d_cig_off, n_aln, min_sv, d_gap_off, d_stats, desc, n_tiles);
+    else
+        hipLaunchKernelGGL((count_kernel<8, 2>), dim3((n_aln + BLOCK / 8 - 1) / (BLOCK / 8)), dim3(BLOCK), 0, st, d_cigar, d_cig_off, n_aln, min_sv, d_gap_off, d_stats, desc, n_tiles);
     hipLaunchKernelGGL(offsets_kernel, dim3(n_tiles), dim3(BLOCK), 0, st, n_aln, d_gap_off, desc, totals, work);
     // resident waves (8 workgroups per CU at most); small inputs get one wave per 4 alignments
     const uint32_t emit_blocks = min(2048u, (n_aln + 15u) / 16u);

@@ -106,8 +106,8 @@ FLAT_SCAN_FROM = None               # mean CIGAR words per alignment from which 
 
 def cigar_scan(cigar, cig_off, ref_start, min_sv, gaps_cap=None, mode=None, n_words=None):
     """cigar: int32/uint32 device tensor of packed BAM CIGAR words; cig_off: int64 [n+1];
-    ref_start: int32 [n].  See include/svx.h svx_cigar_scan.  ``mode``: "groups" (svx_cigar_scan: eight lanes per alignment,
-    three launches -- HiFi-sized alignments), "flat" (svx_cigar_scan_flat: one pass over chunks of the flat word array -- ONT /
+    ref_start: int32 [n].  See include/svx.h svx_cigar_scan.  ``mode``: "groups" (svx_cigar_scan: four or eight lanes per alignment
+    by the launch's mean words per alignment -- "groups4" / "groups8" fix the shape --, three launches), "flat" (svx_cigar_scan_flat: one pass over chunks of the flat word array -- ONT /
     assembly-sized alignments), None: by the mean number of words per alignment (SVX_SCAN_MODE overrides).  ``n_words``: an upper
     bound of the words the offsets span (default: the size of ``cigar``)."""
     lib = _lib.load()
@@ -138,7 +138,8 @@ def cigar_scan(cigar, cig_off, ref_start, min_sv, gaps_cap=None, mode=None, n_wo
         _lib.check(rc, "svx_cigar_scan_flat")
     else:
         ws = torch.empty(max(1, lib.svx_cigar_scan_ws_bytes(n)), dtype=torch.uint8, device=dev)
-        rc = lib.svx_cigar_scan(cigar.data_ptr(), cig_off.data_ptr(), ref_start.data_ptr(), n, int(min_sv),
+        hint = {"groups": words, "groups4": 1, "groups8": 0}[mode]          # (the count pass's shape follows the word count; never a result)
+        rc = lib.svx_cigar_scan(cigar.data_ptr(), cig_off.data_ptr(), ref_start.data_ptr(), n, hint, int(min_sv),
                                 gaps.data_ptr(), gaps_cap, gap_off.data_ptr(), stats.data_ptr(), ws.data_ptr(),
                                 _stream_ptr(dev))
         _lib.check(rc, "svx_cigar_scan")

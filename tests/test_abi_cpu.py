@@ -14,7 +14,7 @@ def test_library_exports_header_symbols():
     lib = _lib.load()
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.svx_version() == 390
+    assert lib.svx_version() == 400
     assert lib.svx_strerror(0) == b"ok" and b"capacity" in lib.svx_strerror(-2)
     assert lib.svx_cigar_scan_ws_bytes(0) >= 0 and lib.svx_cigar_scan_ws_bytes(10_000_000) > 40_000_000
 

@@ -11,9 +11,9 @@ from tests import datagen
 dev = torch.device("cuda:0")
 reps = int(os.environ.get("REPS", "20"))
 out = {}
-SIZES = ((2_000_000, 150), (100_000, 150), (50_000, 6000), (35_000, -5000), (416_000, 145))      # negative: log-normal op counts (sigma 0.7) around the median
+SIZES = ((2_000_000, 150), (100_000, 150), (50_000, 6000), (35_000, -5000), (416_000, 145), (250_000, 300), (150_000, 500), (100_000, 800))      # negative: log-normal op counts (sigma 0.7) around the median
 if os.environ.get("ONLY"):
-    SIZES = (SIZES[int(os.environ["ONLY"])],)
+    SIZES = tuple(SIZES[int(i)] for i in os.environ["ONLY"].split(","))
 for na, mean_ops in SIZES:
     cigar, off, ref_start = datagen.random_cigars(na, seed=5, mean_ops=abs(mean_ops), long_gap_rate=0.0005, lognormal_sigma=0.7 if mean_ops < 0 else None)
     d_c = torch.from_numpy(cigar.view(np.int32)).to(dev); d_o = torch.from_numpy(off.astype(np.int64)).to(dev); d_r = torch.from_numpy(ref_start).to(dev)

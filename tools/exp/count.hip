@@ -44,7 +44,7 @@ int main(int argc, char** argv)
     printf("count_kernel G%d Q%d %u x %d: %7.1f us  %5.2f TB/s\n", CGROUP, CQUADS, n_aln, mean, ms * 100, bytes / (ms * 1e-4) / 1e12);
     for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0);
-        for (int k = 0; k < 10; ++k) svx_cigar_scan(d_c, d_o, d_p, n_aln, 50, d_gaps, 1 << 20, d_g, d_s, d_ws, nullptr);
+        for (int k = 0; k < 10; ++k) svx_cigar_scan(d_c, d_o, d_p, n_aln, 0, 50, d_gaps, 1 << 20, d_g, d_s, d_ws, nullptr);
         hipEventRecord(e1); hipEventSynchronize(e1);
     }
     hipEventElapsedTime(&ms, e0, e1);
