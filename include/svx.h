@@ -23,7 +23,7 @@ extern "C" {
 
 #define SVX_VERSION 400            /* 0.3.0: + svx_bgzf_crc32, svx_bgzf_inflate_fast (360); + svx_bgzf_inflate_fast_on: the two kernels on two streams (370);
                                     * svx_bgzf_inflate_fast / _on take the inflated byte count and refuse a workspace that is too small (380);
-                                    * + svx_cigar_scan_flat: the scan of long alignments in one pass (390); svx_cigar_scan takes the word count of its launch (400) */
+                                    * + svx_cigar_scan_flat: the scan of long alignments in one pass (390); svx_cigar_scan takes the word count of its launch, its workspace's size and shape flags (400) */
 
 #define SVX_OK            0
 #define SVX_EINVAL       (-1)      /* bad argument (null pointer, bad layout...) */
@@ -64,8 +64,16 @@ uint32_t    svx_crc32c(const void* data, size_t n);
 
 #define SVX_SCAN_FAILED   0xFFFFFFFFu
 
-/* Bytes of device scratch svx_cigar_scan needs for n_aln alignments. */
-size_t svx_cigar_scan_ws_bytes(uint32_t n_aln);
+/* Bytes of device scratch svx_cigar_scan needs for n_aln alignments of n_words CIGAR words (the frame records of its long
+ * alignments take n_words / 32 bytes of it). */
+size_t svx_cigar_scan_ws_bytes(uint32_t n_aln, uint64_t n_words);
+
+/* flags of svx_cigar_scan: 0 = the count pass's shape follows the launch's mean words per alignment; the bits fix it (A/B runs,
+ * tests) -- never a result */
+#define SVX_SCAN_LANES4   1u       /* four lanes per alignment (default up to 256 words per alignment) */
+#define SVX_SCAN_LANES8   2u       /* eight */
+#define SVX_SCAN_SHARED   4u       /* a workgroup's waves share the frames of its long alignments (default from 1,024 words per alignment) */
+#define SVX_SCAN_UNSHARED 8u       /* a long alignment is finished by its own wave */
 
 /* Per-alignment CIGAR / segment scan.
  * Replaces the Python loop of analyze_inside_align
@@ -88,18 +96,19 @@ size_t svx_cigar_scan_ws_bytes(uint32_t n_aln);
  *   d_stats     [n_aln][4] out, may be NULL: ref_span (M,D,N,=,X),
  *               lead_clip (leading S/H), trail_clip (trailing S/H),
  *               query_len (M,I,S,H,=,X)
- *   d_ws        scratch of svx_cigar_scan_ws_bytes(n_aln) bytes, 8-byte aligned, contents ignored
+ *   d_ws        scratch of ws_bytes >= svx_cigar_scan_ws_bytes(n_aln, n_words) bytes, 16-byte aligned, contents ignored
  *   n_aln       < 2^30
- *   n_words     the CIGAR words of the launch (= d_cig_off[n_aln], which the caller knows as the length of its array; 0 = not
- *               known).  Only the shape of the count pass depends on it -- four lanes per alignment when the alignments average
- *               at most 256 words, eight otherwise --, never a result
+ *   n_words     the CIGAR words d_cigar holds, >= d_cig_off[n_aln] (the caller knows it as the length of its array; an array that
+ *               holds more than it said: SVX_SCAN_FAILED in d_gap_off[n_aln]).  It sizes the frame records and picks the count pass's shape
  * Three launches (count -> offsets, its prefix over the tiles by a decoupled look-back -> emit), no atomics on results.
+ * An alignment of more than 512 words is cut into frames of 2,048 words whose sums the count pass keeps: the emit pass reads
+ * only the frames that hold a long gap.
  * H is treated as S (the reference rewrites H to S, collect_signatures.py:91);
  * N advances the read position only (analyze_reads.py:831-832). */
 int svx_cigar_scan(const uint32_t* d_cigar, const uint64_t* d_cig_off,
                    const int32_t* d_ref_start, uint32_t n_aln, uint64_t n_words, int32_t min_sv,
                    SvxGap* d_gaps, uint64_t gaps_cap, uint32_t* d_gap_off,
-                   int32_t* d_stats, void* d_ws, void* stream);
+                   int32_t* d_stats, void* d_ws, uint64_t ws_bytes, uint32_t flags, void* stream);
 
 /* The same scan -- same inputs, same outputs bit for bit -- for LONG alignments (ONT ultra-long reads, assembly contigs: 10^3-10^6
  * operations each) in ONE pass: the flat array of words is cut into chunks of 2,048, one wave per chunk whatever alignment the

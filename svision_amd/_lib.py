@@ -26,8 +26,8 @@ SYMBOLS = {
     "svx_version": (ctypes.c_int, []),
     "svx_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "svx_crc32c": (_u32, [_vp, _sz]),
-    "svx_cigar_scan_ws_bytes": (_sz, [_u32]),
-    "svx_cigar_scan": (ctypes.c_int, [_vp, _vp, _vp, _u32, _u64, _i32, _vp, _u64, _vp, _vp, _vp, _vp]),
+    "svx_cigar_scan_ws_bytes": (_sz, [_u32, _u64]),
+    "svx_cigar_scan": (ctypes.c_int, [_vp, _vp, _vp, _u32, _u64, _i32, _vp, _u64, _vp, _vp, _vp, _u64, _u32, _vp]),
     "svx_cigar_scan_flat_ws_bytes": (_sz, [_u64]),
     "svx_cigar_scan_flat": (ctypes.c_int, [_vp, _vp, _vp, _u32, _u64, _i32, _vp, _u64, _vp, _vp, _vp, _u64, _vp]),
     "svx_rasterize": (ctypes.c_int, [_vp, _u32, _vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float), _vp]),

@@ -66,6 +66,7 @@ __device__ inline unsigned wave_sum_u(unsigned v)
 // instructions are the larger half of the pass -- and <8, 2> otherwise).
 constexpr int LONG_Q = 128;                         // quads (512 words) of an alignment the count pass's groups handle themselves
 constexpr uint64_t SHORT_MEAN = 256;
+constexpr uint64_t SHARE_MEAN = 1024;                // mean words per alignment from which the workgroup's waves share its alignments' frames
 
 // Sum over the G lanes of an alignment, complete in the group's FIRST lane only (the others end with partial sums: nothing
 // reads them): row shifts in the vector ALU (the groups lie inside the rows of 16 lanes; a lane beyond the row reads 0) -- three
@@ -101,14 +102,60 @@ __device__ inline void tally(uint32_t w, uint32_t m16, unsigned& ref_span, unsig
     ngap -= (uint32_t)(w >= m16 ? __builtin_amdgcn_sbfe(K_GAP, w, 1u) : 0);                 // I, D of at least min_sv bases
 }
 
-// (the same in the form the long-alignment loop at the end of the count pass keeps: there a wave streams ONE alignment, bound by
-// the round trips of its loads, and the select-based form schedules 4 % better between them)
-__device__ inline void tally_long(uint32_t w, int32_t min_sv, unsigned& ref_span, unsigned& qlen, unsigned& ngap)
+// ---- Frames.  An alignment of more than LONG_Q quads (ONT, assembly contigs: 10^3-10^6 ops) is cut into FRAMES of 512 quads
+// (2,048 words) behind its first LONG_Q quads: frame k = quads [q0 + LONG_Q + 512 k, ... + 512) up to the alignment's last whole
+// quad.  A frame belongs to ONE alignment, a wave takes it in one step (eight 16-byte loads per lane), and the count pass leaves
+// its sums -- read advance, reference advance, long gaps -- in a record of its own, frames[first quad >> 7] (first quads of
+// different frames lie at least 128 quads apart: the records need no allocation and no initialisation).  The emit pass turns
+// the records of an alignment into the positions in front of every frame with one wave prefix sum and reads only the frames
+// that hold a long gap -- a quarter of them on ONT data -- where until round 5 it walked every word of every gap owner again,
+// one frame after the other (the serial position chain).
+constexpr int LQUADS = 8;                           // 16-byte loads in flight per lane while a wave takes a frame
+constexpr uint32_t FRAME_Q = 512;
+__host__ __device__ inline uint64_t frame_slots(uint64_t n_words) { return (n_words >> 9) + 2; }      // records: one per 128 quads of the array
+constexpr uint32_t K_SKIP = 0x00080008u;             // N: advances the read position, not the reference position (analyze_reads.py:831-832)
+
+__device__ __forceinline__ uint32_t wave_total(uint32_t v)
 {
-    const uint32_t op = w & 15u, len = w >> 4;
-    ref_span += len & (0u - ((0x18Du >> op) & 1u));
-    qlen += len & (0u - ((0x1B3u >> op) & 1u));
-    ngap += (uint32_t)((op - 1u) < 2u) & (uint32_t)((int32_t)len >= min_sv);
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v), WAVE - 1);
+}
+
+// one frame of alignment `al` in the count pass: quads [F, qe), lane-strided (every load instruction one KB)
+__device__ __forceinline__ void count_frame(const uint4* __restrict__ quads, uint64_t F, uint64_t qe, uint32_t al, uint32_t m16,
+                                            uint4* __restrict__ frames, uint64_t n_slots, uint32_t* __restrict__ gap_off, int32_t* __restrict__ stats, int wl)
+{
+    unsigned r = 0, l = 0, g = 0, x = 0;
+    const uint32_t nq = (uint32_t)(qe - F);              // 1 .. FRAME_Q
+    // every load is issued before the first tally (the fences keep the scheduler from holding some back behind the tallies of
+    // others: a round trip each), and none sits in a branch of its own (a load whose value is only used under a condition is
+    // moved under it: eight round trips): the last frame of an alignment clamps the quad index and masks with AND
+    uint4 w[LQUADS];
+    uint32_t keep[LQUADS];
+    const uint4* __restrict__ p = quads + F;
+#pragma unroll
+    for (int u = 0; u < LQUADS; ++u) {
+        const uint32_t qi = (uint32_t)wl + (uint32_t)u * WAVE;
+        w[u] = p[min(qi, nq - 1u)];
+        keep[u] = qi < nq ? ~0u : 0u;                    // ("0M" is inert)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < LQUADS; ++u) {
+        const uint32_t w4[4] = {w[u].x & keep[u], w[u].y & keep[u], w[u].z & keep[u], w[u].w & keep[u]};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            tally(w4[k], m16, r, l, g);
+            x += (w4[k] >> 4) & (uint32_t)__builtin_amdgcn_sbfe(K_SKIP, w4[k], 1u);
+        }
+        __builtin_amdgcn_sched_barrier(0);               // quad after quad: left alone the scheduler spreads the 32 tallies over 160 registers
+    }
+    r = wave_total(r); l = wave_total(l); g = wave_total(g); x = wave_total(x);
+    if (wl == 0) {
+        if ((F >> 7) < n_slots) frames[F >> 7] = make_uint4(l + x, r - x, g, 0u);      // M I N S H = X | M D = X | long gaps  (n_slots: the caller's word count, checked below)
+        // (atomics: performed in the L2, behind the leaders' stores to the same words, which were acknowledged before the first frame)
+        if (stats) { atomicAdd(reinterpret_cast<unsigned*>(stats) + 4 * (size_t)al, r); atomicAdd(reinterpret_cast<unsigned*>(stats) + 4 * (size_t)al + 3, l); }
+        if (g) atomicAdd(&gap_off[al], g);
+    }
 }
 
 // Count pass.  HiFi CIGARs are 30-300 ops: a whole wave per alignment leaves most lanes idle and the
@@ -124,19 +171,20 @@ __device__ inline void tally_long(uint32_t w, int32_t min_sv, unsigned& ref_span
 // descriptor of a count workgroup for the look-back: [flag:2 | owners:30 | gaps:32]
 constexpr unsigned long long D_AGG = 1ull << 62, D_INC = 2ull << 62, D_FLAG = 3ull << 62;
 __device__ inline unsigned long long d_pack(uint32_t gaps, uint32_t owners) { return (unsigned long long)(owners & 0x3fffffffu) << 32 | gaps; }
-constexpr int LQUADS = 8;
-constexpr long long WIDE_FROM = 1024;                // words from which the emit pass takes an alignment in steps of 2,048 instead of 256                            // 16-byte loads in flight per lane while a wave finishes a long alignment
 
-template <int G, int Q>
+template <int G, int Q, bool SHARE>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8)))
 void count_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict__ cig_off,
                   uint32_t n_aln, int32_t min_sv, uint32_t* __restrict__ gap_off, int32_t* __restrict__ stats,
-                  unsigned long long* __restrict__ desc, uint32_t n_tiles)
+                  unsigned long long* __restrict__ desc, uint32_t n_tiles, uint4* __restrict__ frames, uint64_t n_words)
 {
     // (the look-back descriptors of the offsets pass behind this kernel start out empty: zeroed here instead of by a memset
     // launch of its own -- 5 us of a 70 us scan; there are more count workgroups than tiles)
     if (threadIdx.x == 0 && blockIdx.x < n_tiles) desc[blockIdx.x] = 0ull;
-    if (threadIdx.x == 0 && blockIdx.x == 0) gap_off[n_aln] = 0u;        // (the total: written with atomicMax by the offsets pass, see there)
+    // (the total: written with atomicMax by the offsets pass, see there.  A caller whose array holds more words than it said
+    // gets SVX_SCAN_FAILED instead: the frame records are sized by that number)
+    if (threadIdx.x == 0 && blockIdx.x == 0) gap_off[n_aln] = cig_off[n_aln] > n_words ? SVX_SCAN_FAILED : 0u;
+    const uint64_t n_slots = frame_slots(n_words);
     const int sub = threadIdx.x & (G - 1);
     const int wl = threadIdx.x & (WAVE - 1);
     const int gshift = wl & ~(G - 1);
@@ -236,33 +284,42 @@ void count_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict
             reinterpret_cast<int4*>(stats)[a] = s4;
         }
     }
-    // ---- the long alignments of this wave, one after the other: everything behind their first LONG_Q quads, 64 lanes with
-    // LQUADS 16-byte loads in flight each (2048 words per step); the sums are added to what the leaders have just stored
-    unsigned long long lm = __ballot(is_long && sub == 0);
-    if (lm) __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): the leaders' stores above are acknowledged by the L2 before the atomics below go there
-    while (lm) {
-        const int src = __ffsll((long long)lm) - 1;
-        lm &= lm - 1;
-        const uint64_t qa = __shfl(q0, src, WAVE) + LONG_Q, qb = __shfl(q_end, src, WAVE);
-        const uint32_t al = __shfl(a, src, WAVE);
-        unsigned r2 = 0, l2 = 0, g2 = 0;
+    // ---- the frames of the long alignments.  SHARE = false (launches of short alignments, where a long one is an exception): the
+    // wave takes the frames of its own long alignments, one after the other.  SHARE = true (ONT, contigs: every alignment is long
+    // and their lengths spread over two orders of magnitude): the WORKGROUP's waves take the frames of all its alignments in
+    // turn -- the launch ends with its slowest wave, and a wave that owned eight log-normal lengths was twice the mean.
+    if constexpr (!SHARE) {
+        unsigned long long lm = __ballot(is_long && sub == 0);
+        if (lm) __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): the leaders' stores above are acknowledged by the L2 before the atomics go there
+        while (lm) {
+            const int src = __ffsll((long long)lm) - 1;
+            lm &= lm - 1;
+            const uint64_t qa = __shfl(q0, src, WAVE) + LONG_Q, qb = __shfl(q_end, src, WAVE);
+            const uint32_t al = __shfl(a, src, WAVE);
 #pragma clang loop unroll(disable)
-        for (uint64_t q = qa + wl; q < qb; q += (uint64_t)LQUADS * WAVE) {
-            uint4 w[LQUADS];
-#pragma unroll
-            for (int u = 0; u < LQUADS; ++u) w[u] = quads[min(q + (uint64_t)u * WAVE, qb - 1)];
-#pragma unroll
-            for (int u = 0; u < LQUADS; ++u) {
-                const bool in = q + (uint64_t)u * WAVE < qb;
-                tally_long(in ? w[u].x : 0u, min_sv, r2, l2, g2); tally_long(in ? w[u].y : 0u, min_sv, r2, l2, g2);
-                tally_long(in ? w[u].z : 0u, min_sv, r2, l2, g2); tally_long(in ? w[u].w : 0u, min_sv, r2, l2, g2);
-                __builtin_amdgcn_sched_barrier(0);           // quad after quad: left alone the scheduler spreads the 32 tallies over 160 registers
-            }
+            for (uint64_t F = qa; F < qb; F += FRAME_Q) count_frame(quads, F, min(F + FRAME_Q, qb), al, m16, frames, n_slots, gap_off, stats, wl);
         }
-        r2 = wave_sum_u(r2); l2 = wave_sum_u(l2); g2 = wave_sum_u(g2);
-        if (wl == 0) {                                   // (atomics: performed in the L2, behind this wave's own stores to the same words)
-            if (stats) { atomicAdd(reinterpret_cast<unsigned*>(stats) + 4 * (size_t)al, r2); atomicAdd(reinterpret_cast<unsigned*>(stats) + 4 * (size_t)al + 3, l2); }
-            if (g2) atomicAdd(&gap_off[al], g2);
+    } else {
+        constexpr int NG = BLOCK / G;                    // alignments of the workgroup (<= 64: one per lane below)
+        __shared__ uint4 s_long[NG];                     // [alignment, first frame's quad (64 bit), quads behind it (0: not a long one)]
+        if (sub == 0) {
+            const uint64_t qa = q0 + LONG_Q;
+            s_long[threadIdx.x / G] = make_uint4(a, (uint32_t)qa, (uint32_t)(qa >> 32), is_long ? (uint32_t)(q_end - qa) : 0u);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0), then the barrier: every leader's stores are acknowledged before any wave's atomics
+        __syncthreads();
+        const uint4 ent = wl < NG ? s_long[wl] : make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t nf = (ent.w + FRAME_Q - 1) / FRAME_Q;           // frames of alignment `wl` of the workgroup
+        const uint32_t incl = wave_incl_scan(nf);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
+        // (frames cost the same, so the waves take them in turn: no counter)
+        const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        for (uint32_t t = wv; t < total; t += BLOCK / WAVE) {
+            const int i = __ffsll((long long)__ballot(incl > t)) - 1;                          // the alignment frame t belongs to
+            const uint32_t k = t - ((uint32_t)__builtin_amdgcn_readlane((int)incl, i) - (uint32_t)__builtin_amdgcn_readlane((int)nf, i));
+            const uint64_t qa = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)ent.y, i) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)ent.z, i) << 32;
+            const uint64_t qb = qa + (uint32_t)__builtin_amdgcn_readlane((int)ent.w, i), F = qa + (uint64_t)k * FRAME_Q;
+            count_frame(quads, F, min(F + FRAME_Q, qb), (uint32_t)__builtin_amdgcn_readlane((int)ent.x, i), m16, frames, n_slots, gap_off, stats, wl);
         }
     }
 }
@@ -353,9 +410,10 @@ void offsets_kernel(uint32_t n_aln, uint32_t* __restrict__ gap_off, unsigned lon
 __global__ __launch_bounds__(BLOCK)
 void emit_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict__ cig_off,
                  const int32_t* __restrict__ ref_start, int32_t min_sv, SvxGap* __restrict__ gaps, uint64_t gaps_cap,
-                 const uint2* __restrict__ totals, const uint2* __restrict__ work)
+                 const uint2* __restrict__ totals, const uint2* __restrict__ work, uint32_t n_aln, const uint4* __restrict__ frames, uint64_t n_slots)
 {
     const int lane = threadIdx.x & (WAVE - 1);
+    const uint64_t full = cig_off[n_aln] >> 2;             // quads that lie entirely inside the array
     const uint32_t n_work = totals->y;                     // alignments owning a long gap
     const uint32_t n_waves = gridDim.x * (BLOCK / WAVE);
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -432,68 +490,50 @@ void emit_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict_
                 step(j0 + 2 * STEP, w2);
             }
         };
-        if (n <= WIDE_FROM) { narrow(0, n); continue; }
-        // A long alignment (ONT, assembly contigs): 2,048 words per step instead of 256 -- a lane takes 32 CONSECUTIVE words (eight
-        // 16-byte loads), sums their advances and hits, and ONE set of wave prefix sums per step places the lane: an eighth of the
-        // steps of the serial position chain (the longest read of an ONT sample: 10^5 words = 400 narrow steps, each a memory round
-        // trip and a dozen cross-lane operations, which the whole launch waited for) and an eighth of the cross-lane work per
-        // word.  The (at most three) words in front of the first 16-byte boundary and what is left behind the last whole step
-        // go through the narrow steps.
+        // the count pass's own test (there: is_long), from the same offsets
+        const uint64_t e = b + (uint64_t)n, q0 = b >> 2, q_end = min((e + 3) >> 2, full);
+        if (!(q0 < q_end && q_end - q0 > (uint64_t)LONG_Q)) { narrow(0, n); continue; }
+        // A long alignment (ONT, assembly contigs).  Behind its first LONG_Q quads lie its frames, whose sums the count pass has
+        // left in `frames`: 64 records per step become the positions and the output slot in front of every frame (one set of wave
+        // prefix sums), and only a frame that holds a long gap is walked -- eight narrow steps from the frame's own positions.
+        // (Round 4 walked every word of a gap owner in 256-word steps, round 5's first form in 2,048-word steps: a serial chain of
+        // one memory round trip per step, 40-400 steps for an ONT read, all of whose words were read a second time.)
         auto excl = [&](uint32_t v, uint32_t& total) {
             const uint32_t inc = wave_incl_scan(v);
             total = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
             return inc - v;
         };
-        long long j = (long long)((4u - (uint32_t)(b & 3u)) & 3u);
-        if (j) narrow(0, j);
-        constexpr long long WSTEP = 2048;
-        for (; j + WSTEP <= n; j += WSTEP) {
-            const uint4* p = reinterpret_cast<const uint4*>(cigar + b + j) + 8 * lane;
-            uint4 w[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) w[u] = p[u];
-            uint32_t tr = 0, tf = 0, nh = 0;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const uint32_t x4[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t op = x4[k] & 15u, len = x4[k] >> 4;
-                    tr += adv_read(op) ? len : 0u;
-                    tf += adv_ref(op) ? len : 0u;
-                    nh += (uint32_t)(((op - 1u) < 2u) & ((int32_t)len >= min_sv));
-                }
-                __builtin_amdgcn_sched_barrier(0);         // quad after quad (left alone the scheduler spreads the 32 words over 200 registers)
+        const uint64_t qa = q0 + LONG_Q;
+        const uint32_t n_frames = ((uint32_t)(q_end - qa) + FRAME_Q - 1) / FRAME_Q;
+        auto record = [&](uint32_t k) {
+            const uint64_t slot = (qa >> 7) + 4ull * k;
+            return (k < n_frames && slot < n_slots) ? frames[slot] : make_uint4(0u, 0u, 0u, 0u);
+        };
+        uint4 rec = record((uint32_t)lane);                    // (requested before the head is walked)
+        narrow(0, 4 * (long long)qa - (long long)b);
+        for (uint32_t k0 = 0; k0 < n_frames; k0 += WAVE) {
+            if (k0) rec = record(k0 + (uint32_t)lane);
+            uint32_t Tr, Tf, Tg;
+            const uint32_t er = excl(rec.x, Tr), ef = excl(rec.y, Tf), eg = excl(rec.z, Tg);
+            unsigned long long hot = __ballot(rec.z != 0u);
+            while (hot) {
+                const int i = __ffsll((long long)hot) - 1;
+                hot &= hot - 1;
+                const long long j = 4 * (long long)(qa + (uint64_t)(k0 + (uint32_t)i) * FRAME_Q) - (long long)b;      // the frame's first word, counted from the alignment's
+                const uint32_t keep_r = read_pos, keep_f = ref_pos, keep_d = dst;
+                read_pos += (uint32_t)__builtin_amdgcn_readlane((int)er, i); ref_pos += (uint32_t)__builtin_amdgcn_readlane((int)ef, i);
+                dst += (uint32_t)__builtin_amdgcn_readlane((int)eg, i);
+                narrow(j, min(j + 4 * (long long)FRAME_Q, min(n, 4 * (long long)q_end - (long long)b)));
+                read_pos = keep_r; ref_pos = keep_f; dst = keep_d;
             }
-            uint32_t Tr, Tf, Th;
-            uint32_t r = read_pos + excl(tr, Tr), f = ref_pos + excl(tf, Tf);
-            uint64_t slot = (uint64_t)dst + excl(nh, Th);
-            if (nh) {                                      // (rare: the lane walks its 32 words once more, out of the cache)
-                const long long i0 = j + 32 * lane;
-#pragma unroll 1
-                for (long long i = i0; i < i0 + 32; ++i) {
-                    const uint32_t x = cigar[b + i], op = x & 15u, len = x >> 4;
-                    if (((op - 1u) < 2u) & ((int32_t)len >= min_sv)) {
-                        if (slot < gaps_cap) {
-                            SvxGap g;
-                            g.aln = a; g.op = (uint32_t)i;
-                            g.read_pos = (int32_t)r; g.ref_pos = (int32_t)f;
-                            g.len = (int32_t)len; g.kind = op;
-                            gaps[slot] = g;
-                        }
-                        ++slot;
-                    }
-                    r += adv_read(op) ? len : 0u;
-                    f += adv_ref(op) ? len : 0u;
-                }
-            }
-            read_pos += Tr; ref_pos += Tf; dst += Th;
+            read_pos += Tr; ref_pos += Tf; dst += Tg;
         }
-        if (j < n) narrow(j, n);
+        const long long jt = 4 * (long long)q_end - (long long)b;      // what lies behind the array's last whole quad (at most three words)
+        if (jt < n) narrow(jt, n);
     }
 }
 
-// workspace: [desc: one 64-bit descriptor per tile of the offsets pass (zeroed by the count pass)][totals: uint2] | [work: uint2 per alignment]
+// workspace: [desc: one 64-bit descriptor per tile of the offsets pass (zeroed by the count pass)][totals: uint2] | [work: uint2 per alignment] | [frames: uint4 per 128 quads]
 inline size_t ws_totals_offset(uint32_t n_aln)
 {
     const size_t tiles = ((size_t)n_aln + OTILE - 1) / OTILE;
@@ -503,18 +543,22 @@ inline size_t ws_work_offset(uint32_t n_aln)
 {
     return (ws_totals_offset(n_aln) + sizeof(uint2) + 255) & ~(size_t)255;
 }
+inline size_t ws_frames_offset(uint32_t n_aln)
+{
+    return (ws_work_offset(n_aln) + (size_t)n_aln * sizeof(uint2) + 255) & ~(size_t)255;
+}
 
 }  // namespace
 
-extern "C" size_t svx_cigar_scan_ws_bytes(uint32_t n_aln)
+extern "C" size_t svx_cigar_scan_ws_bytes(uint32_t n_aln, uint64_t n_words)
 {
-    return ws_work_offset(n_aln) + (size_t)n_aln * sizeof(uint2);
+    return ws_frames_offset(n_aln) + (size_t)frame_slots(n_words) * sizeof(uint4);
 }
 
 extern "C" int svx_cigar_scan(const uint32_t* d_cigar, const uint64_t* d_cig_off,
                               const int32_t* d_ref_start, uint32_t n_aln, uint64_t n_words, int32_t min_sv,
                               SvxGap* d_gaps, uint64_t gaps_cap, uint32_t* d_gap_off,
-                              int32_t* d_stats, void* d_ws, void* stream)
+                              int32_t* d_stats, void* d_ws, uint64_t ws_bytes, uint32_t flags, void* stream)
 {
     if (!d_gap_off) return SVX_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -523,23 +567,30 @@ extern "C" int svx_cigar_scan(const uint32_t* d_cigar, const uint64_t* d_cig_off
     }
     if (!d_cigar || !d_cig_off || !d_ref_start || !d_ws || (!d_gaps && gaps_cap)) return SVX_EINVAL;
     if (d_stats && (reinterpret_cast<uintptr_t>(d_stats) & 15u)) return SVX_EINVAL;
-    if ((reinterpret_cast<uintptr_t>(d_ws) & 7u) || (reinterpret_cast<uintptr_t>(d_cigar) & 15u) || (reinterpret_cast<uintptr_t>(d_gap_off) & 15u)) return SVX_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(d_ws) & 15u) || (reinterpret_cast<uintptr_t>(d_cigar) & 15u) || (reinterpret_cast<uintptr_t>(d_gap_off) & 15u)) return SVX_EINVAL;
     if (n_aln >= (1u << 30)) return SVX_EINVAL;            // (the look-back descriptors keep the owner count in 30 bits)
+    if (ws_bytes < svx_cigar_scan_ws_bytes(n_aln, n_words)) return SVX_EINVAL;
+    if (flags & ~(uint32_t)(SVX_SCAN_LANES4 | SVX_SCAN_LANES8 | SVX_SCAN_SHARED | SVX_SCAN_UNSHARED)) return SVX_EINVAL;
     unsigned long long* desc = static_cast<unsigned long long*>(d_ws);
     uint2* totals = reinterpret_cast<uint2*>(static_cast<char*>(d_ws) + ws_totals_offset(n_aln));
     uint2* work = reinterpret_cast<uint2*>(static_cast<char*>(d_ws) + ws_work_offset(n_aln));
+    uint4* frames = reinterpret_cast<uint4*>(static_cast<char*>(d_ws) + ws_frames_offset(n_aln));
+    const uint64_t n_slots = frame_slots(n_words);
     const uint32_t n_tiles = (n_aln + OTILE - 1) / OTILE;
-    // the count pass's shape: short alignments (HiFi) four lanes each, long or unknown ones eight (SVX_COUNT_LANES=4|8: A/B runs)
-    static const int forced = getenv("SVX_COUNT_LANES") ? atoi(getenv("SVX_COUNT_LANES")) : 0;
-    const bool narrow = forced ? forced == 4 : (n_words != 0 && n_words <= SHORT_MEAN * (uint64_t)n_aln);
-    if (narrow)
-        hipLaunchKernelGGL((count_kernel<4, 4>), dim3((n_aln + BLOCK / 4 - 1) / (BLOCK / 4)), dim3(BLOCK), 0, st, d_cigar, d_cig_off, n_aln, min_sv, d_gap_off, d_stats, desc, n_tiles);
-    else
-        hipLaunchKernelGGL((count_kernel<8, 2>), dim3((n_aln + BLOCK / 8 - 1) / (BLOCK / 8)), dim3(BLOCK), 0, st, d_cigar, d_cig_off, n_aln, min_sv, d_gap_off, d_stats, desc, n_tiles);
+    // the count pass's shape, by the launch's mean words per alignment (the flags fix it: A/B runs and tests): short alignments
+    // (HiFi) four lanes each and a long one finished by its own wave; long ones eight lanes, their frames shared by the workgroup
+    const bool narrow = (flags & SVX_SCAN_LANES4) ? true : (flags & SVX_SCAN_LANES8) ? false : n_words <= SHORT_MEAN * (uint64_t)n_aln;
+    const bool share = (flags & SVX_SCAN_SHARED) ? true : (flags & SVX_SCAN_UNSHARED) ? false : n_words > SHARE_MEAN * (uint64_t)n_aln;
+    static const unsigned count_lds = getenv("SVX_COUNT_LDS") ? (unsigned)atoi(getenv("SVX_COUNT_LDS")) : 0u;      // (experiment: caps the workgroups per CU)
+#define SVX_COUNT(G, Q, S) hipLaunchKernelGGL((count_kernel<G, Q, S>), dim3((n_aln + BLOCK / G - 1) / (BLOCK / G)), dim3(BLOCK), count_lds, st, \
+                                              d_cigar, d_cig_off, n_aln, min_sv, d_gap_off, d_stats, desc, n_tiles, frames, n_words)
+    if (narrow) { if (share) SVX_COUNT(4, 4, true); else SVX_COUNT(4, 4, false); }
+    else        { if (share) SVX_COUNT(8, 2, true); else SVX_COUNT(8, 2, false); }
+#undef SVX_COUNT
     hipLaunchKernelGGL(offsets_kernel, dim3(n_tiles), dim3(BLOCK), 0, st, n_aln, d_gap_off, desc, totals, work);
     // resident waves (8 workgroups per CU at most); small inputs get one wave per 4 alignments
     const uint32_t emit_blocks = min(2048u, (n_aln + 15u) / 16u);
     hipLaunchKernelGGL(emit_kernel, dim3(emit_blocks), dim3(BLOCK), 0, st, d_cigar, d_cig_off, d_ref_start, min_sv, d_gaps, gaps_cap,
-                       totals, work);
+                       totals, work, n_aln, frames, n_slots);
     return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
 }

@@ -76,7 +76,7 @@ SCAN_FAILED = 0xFFFFFFFF            # SVX_SCAN_FAILED (include/svx.h): d_gap_off
 
 def check_scan_total(total):
     if total == SCAN_FAILED:
-        raise _lib.SvxError("svx_cigar_scan: the offsets pass gave up waiting for a tile in front of it (SVX_SCAN_FAILED)")
+        raise _lib.SvxError("svx_cigar_scan: SVX_SCAN_FAILED (the offsets pass gave up waiting for a tile in front of it, or the CIGAR array holds more words than the caller said)")
     return total
 
 
@@ -107,7 +107,7 @@ FLAT_SCAN_FROM = None               # mean CIGAR words per alignment from which 
 def cigar_scan(cigar, cig_off, ref_start, min_sv, gaps_cap=None, mode=None, n_words=None):
     """cigar: int32/uint32 device tensor of packed BAM CIGAR words; cig_off: int64 [n+1];
     ref_start: int32 [n].  See include/svx.h svx_cigar_scan.  ``mode``: "groups" (svx_cigar_scan: four or eight lanes per alignment
-    by the launch's mean words per alignment -- "groups4" / "groups8" fix the shape --, three launches), "flat" (svx_cigar_scan_flat: one pass over chunks of the flat word array -- ONT /
+    by the launch's mean words per alignment -- "groups4" / "groups8" / "groups4s" / "groups8s" fix the shape (lanes, s: frames shared by the workgroup) --, three launches), "flat" (svx_cigar_scan_flat: one pass over chunks of the flat word array -- ONT /
     assembly-sized alignments), None: by the mean number of words per alignment (SVX_SCAN_MODE overrides).  ``n_words``: an upper
     bound of the words the offsets span (default: the size of ``cigar``)."""
     lib = _lib.load()
@@ -137,10 +137,10 @@ def cigar_scan(cigar, cig_off, ref_start, min_sv, gaps_cap=None, mode=None, n_wo
                                      _stream_ptr(dev))
         _lib.check(rc, "svx_cigar_scan_flat")
     else:
-        ws = torch.empty(max(1, lib.svx_cigar_scan_ws_bytes(n)), dtype=torch.uint8, device=dev)
-        hint = {"groups": words, "groups4": 1, "groups8": 0}[mode]          # (the count pass's shape follows the word count; never a result)
-        rc = lib.svx_cigar_scan(cigar.data_ptr(), cig_off.data_ptr(), ref_start.data_ptr(), n, hint, int(min_sv),
-                                gaps.data_ptr(), gaps_cap, gap_off.data_ptr(), stats.data_ptr(), ws.data_ptr(),
+        ws = torch.empty(max(16, lib.svx_cigar_scan_ws_bytes(n, words)), dtype=torch.uint8, device=dev)
+        flags = {"groups": 0, "groups4": 1 | 8, "groups8": 2 | 8, "groups4s": 1 | 4, "groups8s": 2 | 4}[mode]      # SVX_SCAN_LANES4/8 | SVX_SCAN_(UN)SHARED: the count pass's shape, never a result
+        rc = lib.svx_cigar_scan(cigar.data_ptr(), cig_off.data_ptr(), ref_start.data_ptr(), n, words, int(min_sv),
+                                gaps.data_ptr(), gaps_cap, gap_off.data_ptr(), stats.data_ptr(), ws.data_ptr(), int(ws.numel()), flags,
                                 _stream_ptr(dev))
         _lib.check(rc, "svx_cigar_scan")
     res = CigarScanResult(gaps, gap_off, stats, n, gaps_cap)

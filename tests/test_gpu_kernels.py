@@ -56,7 +56,7 @@ def test_rasterize_empty():
     assert out.shape == (0, 3, 227, 227)
 
 
-SCAN_MODES = ["groups4", "groups8", "flat"]      # svx_cigar_scan (four / eight lanes per alignment in the count pass, three launches) / svx_cigar_scan_flat (one pass over chunks of words)
+SCAN_MODES = ["groups4", "groups8", "groups4s", "groups8s", "flat"]      # svx_cigar_scan (four / eight lanes per alignment in the count pass, three launches) / svx_cigar_scan_flat (one pass over chunks of words)
 
 
 @pytest.mark.parametrize("mode", SCAN_MODES)
