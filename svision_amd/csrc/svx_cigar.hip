@@ -66,7 +66,8 @@ __device__ inline unsigned wave_sum_u(unsigned v)
 // instructions are the larger half of the pass -- and <8, 2> otherwise).
 constexpr int LONG_Q = 128;                         // quads (512 words) of an alignment the count pass's groups handle themselves
 constexpr uint64_t SHORT_MEAN = 256;
-constexpr uint64_t SHARE_MEAN = 1024;                // mean words per alignment from which the workgroup's waves share its alignments' frames
+constexpr uint64_t SHARE_MEAN = 1024;                // mean words per alignment from which the frames get a launch of their own (frames_kernel)
+constexpr uint32_t MIN_RANGE_SHIFT = 11;             // a range of frames_kernel: at least one frame's words
 
 // Sum over the G lanes of an alignment, complete in the group's FIRST lane only (the others end with partial sums: nothing
 // reads them): row shifts in the vector ALU (the groups lie inside the rows of 16 lanes; a lane beyond the row reads 0) -- three
@@ -102,39 +103,53 @@ __device__ inline void tally(uint32_t w, uint32_t m16, unsigned& ref_span, unsig
     ngap -= (uint32_t)(w >= m16 ? __builtin_amdgcn_sbfe(K_GAP, w, 1u) : 0);                 // I, D of at least min_sv bases
 }
 
-// ---- Frames.  An alignment of more than LONG_Q quads (ONT, assembly contigs: 10^3-10^6 ops) is cut into FRAMES of 512 quads
-// (2,048 words) behind its first LONG_Q quads: frame k = quads [q0 + LONG_Q + 512 k, ... + 512) up to the alignment's last whole
-// quad.  A frame belongs to ONE alignment, a wave takes it in one step (eight 16-byte loads per lane), and the count pass leaves
-// its sums -- read advance, reference advance, long gaps -- in a record of its own, frames[first quad >> 7] (first quads of
-// different frames lie at least 128 quads apart: the records need no allocation and no initialisation).  The emit pass turns
-// the records of an alignment into the positions in front of every frame with one wave prefix sum and reads only the frames
-// that hold a long gap -- a quarter of them on ONT data -- where until round 5 it walked every word of every gap owner again,
-// one frame after the other (the serial position chain).
-constexpr int LQUADS = 8;                           // 16-byte loads in flight per lane while a wave takes a frame
-constexpr uint32_t FRAME_Q = 512;
+// ---- Frames.  An alignment of more than LONG_Q quads (ONT, assembly contigs: 10^3-10^6 ops) is cut into FRAMES of 128 quads
+// (512 words) behind its first LONG_Q quads: frame f = quads [q0 + LONG_Q + 128 f, ... + 128) up to the alignment's last whole
+// quad.  A frame belongs to ONE alignment, and the count pass leaves its sums -- read advance, reference advance, long gaps --
+// in a record of its own, frames[first quad >> 7] (first quads of different frames lie at least 128 quads apart: the records need
+// no allocation and no initialisation).  A wave takes four frames in one STEP (2,048 words: eight 16-byte loads per lane, a
+// row of sixteen lanes on each frame -- 256 consecutive bytes per load -- so that a frame's sums are row shifts).  The emit pass turns
+// the records of an alignment into the positions in front of every frame with one wave prefix sum per 64 frames and walks only
+// the frames that hold a long gap -- one in fourteen on ONT data -- where until round 5 it walked every word of every gap owner
+// again, one step after the other (the serial position chain).
+constexpr int LQUADS = 8;                           // 16-byte loads in flight per lane while a wave takes a step
+constexpr uint32_t FRAME_Q = 128, STEP_Q = 512;
 __host__ __device__ inline uint64_t frame_slots(uint64_t n_words) { return (n_words >> 9) + 2; }      // records: one per 128 quads of the array
 constexpr uint32_t K_SKIP = 0x00080008u;             // N: advances the read position, not the reference position (analyze_reads.py:831-832)
 
-__device__ __forceinline__ uint32_t wave_total(uint32_t v)
+// inclusive sums inside the rows of sixteen lanes (a row's last lane: the row's sum) and, from them, over the wave (lane 63)
+__device__ __forceinline__ uint32_t row_incl_scan(uint32_t v)
 {
-    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v), WAVE - 1);
+    uint32_t r = v;
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);      // row_shr:1
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);      // row_shr:2
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, true);      // row_shr:3
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x114, 0xf, 0xe, true);      // row_shr:4, banks 1-3
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x118, 0xf, 0xc, true);      // row_shr:8, banks 2-3
+    return r;
+}
+__device__ __forceinline__ uint32_t rows_to_wave(uint32_t r)
+{
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3
+    r += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
+    return r;
 }
 
-// one frame of alignment `al` in the count pass: quads [F, qe), lane-strided (every load instruction one KB)
-__device__ __forceinline__ void count_frame(const uint4* __restrict__ quads, uint64_t F, uint64_t qe, uint32_t al, uint32_t m16,
-                                            uint4* __restrict__ frames, uint64_t n_slots, uint32_t* __restrict__ gap_off, int32_t* __restrict__ stats, int wl)
+// one step of alignment `al` in the count pass: quads [S, qe), at most STEP_Q of them, S a frame's first quad
+__device__ __forceinline__ void count_step(const uint4* __restrict__ quads, uint64_t S, uint64_t qe, uint32_t al, uint32_t m16,
+                                           uint4* __restrict__ frames, uint64_t n_slots, uint32_t* __restrict__ gap_off, int32_t* __restrict__ stats, int wl)
 {
     unsigned r = 0, l = 0, g = 0, x = 0;
-    const uint32_t nq = (uint32_t)(qe - F);              // 1 .. FRAME_Q
+    const uint32_t nq = (uint32_t)(qe - S);              // 1 .. STEP_Q
     // every load is issued before the first tally (the fences keep the scheduler from holding some back behind the tallies of
     // others: a round trip each), and none sits in a branch of its own (a load whose value is only used under a condition is
-    // moved under it: eight round trips): the last frame of an alignment clamps the quad index and masks with AND
+    // moved under it: eight round trips): the last step of an alignment clamps the quad index and masks with AND
     uint4 w[LQUADS];
     uint32_t keep[LQUADS];
-    const uint4* __restrict__ p = quads + F;
+    const uint4* __restrict__ p = quads + S;
 #pragma unroll
     for (int u = 0; u < LQUADS; ++u) {
-        const uint32_t qi = (uint32_t)wl + (uint32_t)u * WAVE;
+        const uint32_t qi = ((uint32_t)wl >> 4) * FRAME_Q + (uint32_t)u * 16u + ((uint32_t)wl & 15u);      // a row of lanes = a frame, 256 consecutive bytes per load
         w[u] = p[min(qi, nq - 1u)];
         keep[u] = qi < nq ? ~0u : 0u;                    // ("0M" is inert)
     }
@@ -149,10 +164,13 @@ __device__ __forceinline__ void count_frame(const uint4* __restrict__ quads, uin
         }
         __builtin_amdgcn_sched_barrier(0);               // quad after quad: left alone the scheduler spreads the 32 tallies over 160 registers
     }
-    r = wave_total(r); l = wave_total(l); g = wave_total(g); x = wave_total(x);
-    if (wl == 0) {
-        if ((F >> 7) < n_slots) frames[F >> 7] = make_uint4(l + x, r - x, g, 0u);      // M I N S H = X | M D = X | long gaps  (n_slots: the caller's word count, checked below)
-        // (atomics: performed in the L2, behind the leaders' stores to the same words, which were acknowledged before the first frame)
+    r = row_incl_scan(r); l = row_incl_scan(l); g = row_incl_scan(g); x = row_incl_scan(x);
+    const uint64_t F = S + (uint64_t)(wl >> 4) * FRAME_Q;                   // the frame of this lane's row
+    if ((wl & 15) == 15 && F < qe && (F >> 7) < n_slots)                    // (n_slots: the caller's word count, checked by the count pass)
+        frames[F >> 7] = make_uint4(l + x, r - x, g, 0u);                   // M I N S H = X | M D = X | long gaps
+    r = rows_to_wave(r); l = rows_to_wave(l); g = rows_to_wave(g);
+    if (wl == WAVE - 1) {
+        // (atomics: performed in the L2, behind the leaders' stores to the same words, which were acknowledged before the first step)
         if (stats) { atomicAdd(reinterpret_cast<unsigned*>(stats) + 4 * (size_t)al, r); atomicAdd(reinterpret_cast<unsigned*>(stats) + 4 * (size_t)al + 3, l); }
         if (g) atomicAdd(&gap_off[al], g);
     }
@@ -176,7 +194,8 @@ template <int G, int Q, bool SHARE>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8)))
 void count_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict__ cig_off,
                   uint32_t n_aln, int32_t min_sv, uint32_t* __restrict__ gap_off, int32_t* __restrict__ stats,
-                  unsigned long long* __restrict__ desc, uint32_t n_tiles, uint4* __restrict__ frames, uint64_t n_words)
+                  unsigned long long* __restrict__ desc, uint32_t n_tiles, uint4* __restrict__ frames, uint64_t n_words,
+                  uint4* __restrict__ range_aln, uint32_t range_shift)
 {
     // (the look-back descriptors of the offsets pass behind this kernel start out empty: zeroed here instead of by a memset
     // launch of its own -- 5 us of a 70 us scan; there are more count workgroups than tiles)
@@ -286,8 +305,10 @@ void count_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict
     }
     // ---- the frames of the long alignments.  SHARE = false (launches of short alignments, where a long one is an exception): the
     // wave takes the frames of its own long alignments, one after the other.  SHARE = true (ONT, contigs: every alignment is long
-    // and their lengths spread over two orders of magnitude): the WORKGROUP's waves take the frames of all its alignments in
-    // turn -- the launch ends with its slowest wave, and a wave that owned eight log-normal lengths was twice the mean.
+    // and their lengths spread over two orders of magnitude -- a launch that leaves the frames to the waves that own the alignments
+    // ends with its slowest wave, at twice the mean; shared by the workgroup: 1.5 x): the frames are left to frames_kernel, which
+    // cuts the ARRAY into ranges of equal size, and all this pass adds is the map the ranges start from -- the alignment that
+    // holds a range's first word, written by that alignment's leader (a range is 2^range_shift words).
     if constexpr (!SHARE) {
         unsigned long long lm = __ballot(is_long && sub == 0);
         if (lm) __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): the leaders' stores above are acknowledged by the L2 before the atomics go there
@@ -297,29 +318,65 @@ void count_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict
             const uint64_t qa = __shfl(q0, src, WAVE) + LONG_Q, qb = __shfl(q_end, src, WAVE);
             const uint32_t al = __shfl(a, src, WAVE);
 #pragma clang loop unroll(disable)
-            for (uint64_t F = qa; F < qb; F += FRAME_Q) count_frame(quads, F, min(F + FRAME_Q, qb), al, m16, frames, n_slots, gap_off, stats, wl);
+            for (uint64_t S = qa; S < qb; S += STEP_Q) count_step(quads, S, min(S + STEP_Q, qb), al, m16, frames, n_slots, gap_off, stats, wl);
         }
     } else {
-        constexpr int NG = BLOCK / G;                    // alignments of the workgroup (<= 64: one per lane below)
-        __shared__ uint4 s_long[NG];                     // [alignment, first frame's quad (64 bit), quads behind it (0: not a long one)]
-        if (sub == 0) {
-            const uint64_t qa = q0 + LONG_Q;
-            s_long[threadIdx.x / G] = make_uint4(a, (uint32_t)qa, (uint32_t)(qa >> 32), is_long ? (uint32_t)(q_end - qa) : 0u);
-        }
-        __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0), then the barrier: every leader's stores are acknowledged before any wave's atomics
-        __syncthreads();
-        const uint4 ent = wl < NG ? s_long[wl] : make_uint4(0u, 0u, 0u, 0u);
-        const uint32_t nf = (ent.w + FRAME_Q - 1) / FRAME_Q;           // frames of alignment `wl` of the workgroup
-        const uint32_t incl = wave_incl_scan(nf);
-        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
-        // (frames cost the same, so the waves take them in turn: no counter)
-        const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-        for (uint32_t t = wv; t < total; t += BLOCK / WAVE) {
-            const int i = __ffsll((long long)__ballot(incl > t)) - 1;                          // the alignment frame t belongs to
-            const uint32_t k = t - ((uint32_t)__builtin_amdgcn_readlane((int)incl, i) - (uint32_t)__builtin_amdgcn_readlane((int)nf, i));
-            const uint64_t qa = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)ent.y, i) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)ent.z, i) << 32;
-            const uint64_t qb = qa + (uint32_t)__builtin_amdgcn_readlane((int)ent.w, i), F = qa + (uint64_t)k * FRAME_Q;
-            count_frame(quads, F, min(F + FRAME_Q, qb), (uint32_t)__builtin_amdgcn_readlane((int)ent.x, i), m16, frames, n_slots, gap_off, stats, wl);
+        if (live && sub == 0)
+            for (uint64_t r = a ? (b + (1ull << range_shift) - 1) >> range_shift : 0ull; (r << range_shift) < e; ++r) range_aln[r] = make_uint4(a, (uint32_t)b, (uint32_t)(b >> 32), (uint32_t)min((uint64_t)n, 0xFFFFFFFFull));      // (words in front of the first alignment: its ranges too)
+    }
+}
+
+// The frames of a launch of long alignments (count_kernel<.., true> in front of it).  A wave takes one range of the array
+// -- 2^range_shift words: every wave the same number of frames, give or take one -- and in it every frame that STARTS there:
+// from the alignment that holds the range's first word (the count pass's map) it walks the offsets, 64 per load, with scalar
+// arithmetic; four frames are one count_step.  The leaders' stores of the count pass are complete (a launch of their own lies
+// between), the sums of an alignment's frames reach them as atomics.
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8)))
+void frames_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict__ cig_off, uint32_t n_aln, int32_t min_sv,
+                   uint32_t* __restrict__ gap_off, int32_t* __restrict__ stats, uint4* __restrict__ frames, uint64_t n_words,
+                   const uint4* __restrict__ range_aln, uint32_t range_shift)
+{
+    const int wl = threadIdx.x & (WAVE - 1);
+    const uint64_t range = (uint64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)));
+    const uint64_t total = cig_off[n_aln], full = total >> 2;
+    const uint64_t lo = range << (range_shift - 2), hi = lo + (1ull << (range_shift - 2));      // in quads
+    if ((range << range_shift) >= total) return;
+    const uint32_t m16 = scan_threshold(min_sv);
+    const uint64_t n_slots = frame_slots(n_words);
+    const uint4* __restrict__ quads = reinterpret_cast<const uint4*>(cigar);
+    // one alignment: the frames of it that start in [lo, hi); false: its first frame, and so every later alignment's, starts behind the range
+    auto take = [&](uint32_t a, uint64_t b, uint64_t e) {
+        const uint64_t q0 = b >> 2, q_end = min((e + 3) >> 2, full), qa = q0 + LONG_Q;
+        if (qa >= hi) return false;
+        if (!(q0 < q_end && q_end - q0 > (uint64_t)LONG_Q)) return true;
+        const uint64_t k = qa >= lo ? 0ull : (lo - qa + STEP_Q - 1) / STEP_Q;
+        const uint64_t stop = min(hi, q_end);
+#pragma clang loop unroll(disable)
+        for (uint64_t S = qa + k * STEP_Q; S < stop; S += STEP_Q) count_step(quads, S, min(S + STEP_Q, q_end), a, m16, frames, n_slots, gap_off, stats, wl);
+        return true;
+    };
+    // the alignment that holds the range's first word comes with its offsets (the map's entry: one load in front of the frame's),
+    // the ones behind it -- if the range reaches that far -- from the offsets array, 64 per load
+    uint4 ent = range_aln[range];
+    ent.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent.x); ent.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent.y);
+    ent.z = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent.z); ent.w = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent.w);
+    uint32_t a = ent.x;
+    {
+        const uint64_t b = (uint64_t)ent.y | (uint64_t)ent.z << 32;
+        uint64_t e = b + ent.w;
+        if (ent.w == 0xFFFFFFFFu) e = cig_off[a + 1];      // (an alignment of 2^32 words or more)
+        if (!take(a, b, e)) return;
+        if ((e >> 2) + LONG_Q >= hi) return;             // (the next alignment starts at or behind e)
+        ++a;
+    }
+    for (;;) {
+        const uint32_t idx = min(a + (uint32_t)wl, n_aln);
+        const uint64_t o0 = cig_off[idx], o1 = cig_off[min(idx + 1u, n_aln)];
+        for (int i = 0; i < WAVE; ++i, ++a) {
+            if (a >= n_aln) return;
+            const uint64_t b = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)o0, i) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(o0 >> 32), i) << 32;
+            const uint64_t e = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)o1, i) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(o1 >> 32), i) << 32;
+            if (!take(a, b, e)) return;
         }
     }
 }
@@ -492,44 +549,58 @@ void emit_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict_
         };
         // the count pass's own test (there: is_long), from the same offsets
         const uint64_t e = b + (uint64_t)n, q0 = b >> 2, q_end = min((e + 3) >> 2, full);
-        if (!(q0 < q_end && q_end - q0 > (uint64_t)LONG_Q)) { narrow(0, n); continue; }
+        const bool is_long = q0 < q_end && q_end - q0 > (uint64_t)LONG_Q;
         // A long alignment (ONT, assembly contigs).  Behind its first LONG_Q quads lie its frames, whose sums the count pass has
         // left in `frames`: 64 records per step become the positions and the output slot in front of every frame (one set of wave
-        // prefix sums), and only a frame that holds a long gap is walked -- eight narrow steps from the frame's own positions.
+        // prefix sums), and only a frame that holds a long gap is walked -- two narrow steps from the frame's own positions.
         // (Round 4 walked every word of a gap owner in 256-word steps, round 5's first form in 2,048-word steps: a serial chain of
         // one memory round trip per step, 40-400 steps for an ONT read, all of whose words were read a second time.)
+        // The pieces of an alignment -- its head, its frames with a gap, what lies behind the array's last whole quad (at most
+        // three words) -- go through ONE call of narrow() in a loop: four inlined copies cost 124 registers against 76.
         auto excl = [&](uint32_t v, uint32_t& total) {
             const uint32_t inc = wave_incl_scan(v);
             total = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
             return inc - v;
         };
         const uint64_t qa = q0 + LONG_Q;
-        const uint32_t n_frames = ((uint32_t)(q_end - qa) + FRAME_Q - 1) / FRAME_Q;
+        const uint32_t n_frames = is_long ? ((uint32_t)(q_end - qa) + FRAME_Q - 1) / FRAME_Q : 0u;
+        const long long j_tail = 4 * (long long)q_end - (long long)b;
         auto record = [&](uint32_t k) {
-            const uint64_t slot = (qa >> 7) + 4ull * k;
+            const uint64_t slot = (qa >> 7) + (uint64_t)k;
             return (k < n_frames && slot < n_slots) ? frames[slot] : make_uint4(0u, 0u, 0u, 0u);
         };
         uint4 rec = record((uint32_t)lane);                    // (requested before the head is walked)
-        narrow(0, 4 * (long long)qa - (long long)b);
-        for (uint32_t k0 = 0; k0 < n_frames; k0 += WAVE) {
-            if (k0) rec = record(k0 + (uint32_t)lane);
-            uint32_t Tr, Tf, Tg;
-            const uint32_t er = excl(rec.x, Tr), ef = excl(rec.y, Tf), eg = excl(rec.z, Tg);
-            unsigned long long hot = __ballot(rec.z != 0u);
-            while (hot) {
+        uint32_t base_r = 0, base_f = 0, base_d = 0;           // the positions and the slot in front of the current batch of 64 frames
+        uint32_t er = 0, ef = 0, eg = 0, Tr = 0, Tf = 0, Tg = 0, k0 = 0;
+        unsigned long long hot = 0;
+        auto batch = [&]() {
+            er = excl(rec.x, Tr); ef = excl(rec.y, Tf); eg = excl(rec.z, Tg);
+            hot = __ballot(rec.z != 0u);
+        };
+        int stage = 0;                                         // 0: the head (a short alignment: all of it), 1: frames, 2: the tail
+        long long jlo = 0, jhi = is_long ? 4 * (long long)qa - (long long)b : n;
+        for (;;) {
+            narrow(jlo, jhi);
+            if (!is_long || stage == 2) break;
+            if (stage == 0) { base_r = read_pos; base_f = ref_pos; base_d = dst; stage = 1; batch(); }
+            while (!hot) {
+                base_r += Tr; base_f += Tf; base_d += Tg; k0 += WAVE;
+                if (k0 >= n_frames) break;
+                rec = record(k0 + (uint32_t)lane);
+                batch();
+            }
+            if (hot) {
                 const int i = __ffsll((long long)hot) - 1;
                 hot &= hot - 1;
-                const long long j = 4 * (long long)(qa + (uint64_t)(k0 + (uint32_t)i) * FRAME_Q) - (long long)b;      // the frame's first word, counted from the alignment's
-                const uint32_t keep_r = read_pos, keep_f = ref_pos, keep_d = dst;
-                read_pos += (uint32_t)__builtin_amdgcn_readlane((int)er, i); ref_pos += (uint32_t)__builtin_amdgcn_readlane((int)ef, i);
-                dst += (uint32_t)__builtin_amdgcn_readlane((int)eg, i);
-                narrow(j, min(j + 4 * (long long)FRAME_Q, min(n, 4 * (long long)q_end - (long long)b)));
-                read_pos = keep_r; ref_pos = keep_f; dst = keep_d;
+                jlo = 4 * (long long)(qa + (uint64_t)(k0 + (uint32_t)i) * FRAME_Q) - (long long)b;      // the frame's first word, counted from the alignment's
+                jhi = min(jlo + 4 * (long long)FRAME_Q, min(n, j_tail));
+                read_pos = base_r + (uint32_t)__builtin_amdgcn_readlane((int)er, i); ref_pos = base_f + (uint32_t)__builtin_amdgcn_readlane((int)ef, i);
+                dst = base_d + (uint32_t)__builtin_amdgcn_readlane((int)eg, i);
+                continue;
             }
-            read_pos += Tr; ref_pos += Tf; dst += Tg;
+            if (j_tail >= n) break;
+            stage = 2; read_pos = base_r; ref_pos = base_f; dst = base_d; jlo = j_tail; jhi = n;
         }
-        const long long jt = 4 * (long long)q_end - (long long)b;      // what lies behind the array's last whole quad (at most three words)
-        if (jt < n) narrow(jt, n);
     }
 }
 
@@ -547,12 +618,16 @@ inline size_t ws_frames_offset(uint32_t n_aln)
 {
     return (ws_work_offset(n_aln) + (size_t)n_aln * sizeof(uint2) + 255) & ~(size_t)255;
 }
+inline size_t ws_ranges_offset(uint32_t n_aln, uint64_t n_words)
+{
+    return ws_frames_offset(n_aln) + (size_t)frame_slots(n_words) * sizeof(uint4);
+}
 
 }  // namespace
 
 extern "C" size_t svx_cigar_scan_ws_bytes(uint32_t n_aln, uint64_t n_words)
 {
-    return ws_frames_offset(n_aln) + (size_t)frame_slots(n_words) * sizeof(uint4);
+    return ws_ranges_offset(n_aln, n_words) + ((size_t)(n_words >> MIN_RANGE_SHIFT) + 2) * sizeof(uint4);
 }
 
 extern "C" int svx_cigar_scan(const uint32_t* d_cigar, const uint64_t* d_cig_off,
@@ -581,12 +656,21 @@ extern "C" int svx_cigar_scan(const uint32_t* d_cigar, const uint64_t* d_cig_off
     // (HiFi) four lanes each and a long one finished by its own wave; long ones eight lanes, their frames shared by the workgroup
     const bool narrow = (flags & SVX_SCAN_LANES4) ? true : (flags & SVX_SCAN_LANES8) ? false : n_words <= SHORT_MEAN * (uint64_t)n_aln;
     const bool share = (flags & SVX_SCAN_SHARED) ? true : (flags & SVX_SCAN_UNSHARED) ? false : n_words > SHARE_MEAN * (uint64_t)n_aln;
+    uint4* range_aln = reinterpret_cast<uint4*>(static_cast<char*>(d_ws) + ws_ranges_offset(n_aln, n_words));
+    uint32_t range_shift = MIN_RANGE_SHIFT;              // ranges of frames_kernel: one frame's words -- measured (ONT-shaped launch): 275 us, 286 / 296 / 332 us with ranges of 2 / 4 / 16 frames
+    static const int forced_shift = getenv("SVX_RANGE_SHIFT") ? atoi(getenv("SVX_RANGE_SHIFT")) : 0;      // (experiment)
+    if (forced_shift >= (int)MIN_RANGE_SHIFT) range_shift = (uint32_t)forced_shift;
     static const unsigned count_lds = getenv("SVX_COUNT_LDS") ? (unsigned)atoi(getenv("SVX_COUNT_LDS")) : 0u;      // (experiment: caps the workgroups per CU)
 #define SVX_COUNT(G, Q, S) hipLaunchKernelGGL((count_kernel<G, Q, S>), dim3((n_aln + BLOCK / G - 1) / (BLOCK / G)), dim3(BLOCK), count_lds, st, \
-                                              d_cigar, d_cig_off, n_aln, min_sv, d_gap_off, d_stats, desc, n_tiles, frames, n_words)
+                                              d_cigar, d_cig_off, n_aln, min_sv, d_gap_off, d_stats, desc, n_tiles, frames, n_words, range_aln, range_shift)
     if (narrow) { if (share) SVX_COUNT(4, 4, true); else SVX_COUNT(4, 4, false); }
     else        { if (share) SVX_COUNT(8, 2, true); else SVX_COUNT(8, 2, false); }
 #undef SVX_COUNT
+    if (share) {
+        const uint64_t n_ranges = (n_words >> range_shift) + 1;
+        hipLaunchKernelGGL(frames_kernel, dim3((uint32_t)((n_ranges + BLOCK / WAVE - 1) / (BLOCK / WAVE))), dim3(BLOCK), 0, st,
+                           d_cigar, d_cig_off, n_aln, min_sv, d_gap_off, d_stats, frames, n_words, range_aln, range_shift);
+    }
     hipLaunchKernelGGL(offsets_kernel, dim3(n_tiles), dim3(BLOCK), 0, st, n_aln, d_gap_off, desc, totals, work);
     // resident waves (8 workgroups per CU at most); small inputs get one wave per 4 alignments
     const uint32_t emit_blocks = min(2048u, (n_aln + 15u) / 16u);

@@ -3,7 +3,7 @@ mkdir -p gpurun_out/r05g
 timeout 300 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "cigar or scan" --timeout 60 2>&1 | tail -4
 R=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-for only in 3 2; do
+for only in 3 4; do
 rm -rf /tmp/rp_$only
 ONLY=$only REPS=20 timeout 90 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$only -- python $R/tools/bench_cigar.py > $R/gpurun_out/r05g/p$only.log 2>&1
 f=$(find /tmp/rp_$only -name "*kernel_stats.csv" | head -1); cp $f $R/gpurun_out/r05g/size${only}_kernel_stats.csv
