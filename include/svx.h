@@ -65,14 +65,14 @@ uint32_t    svx_crc32c(const void* data, size_t n);
 #define SVX_SCAN_FAILED   0xFFFFFFFFu
 
 /* Bytes of device scratch svx_cigar_scan needs for n_aln alignments of n_words CIGAR words (the frame records of its long
- * alignments take n_words / 32 bytes of it). */
+ * alignments and the map of their launch take n_words * 5 / 128 bytes of it). */
 size_t svx_cigar_scan_ws_bytes(uint32_t n_aln, uint64_t n_words);
 
 /* flags of svx_cigar_scan: 0 = the count pass's shape follows the launch's mean words per alignment; the bits fix it (A/B runs,
  * tests) -- never a result */
 #define SVX_SCAN_LANES4   1u       /* four lanes per alignment (default up to 256 words per alignment) */
 #define SVX_SCAN_LANES8   2u       /* eight */
-#define SVX_SCAN_SHARED   4u       /* a workgroup's waves share the frames of its long alignments (default from 1,024 words per alignment) */
+#define SVX_SCAN_SHARED   4u       /* the frames of long alignments in a launch of their own, equal ranges of the array (default from 1,024 words per alignment) */
 #define SVX_SCAN_UNSHARED 8u       /* a long alignment is finished by its own wave */
 
 /* Per-alignment CIGAR / segment scan.
@@ -101,8 +101,9 @@ size_t svx_cigar_scan_ws_bytes(uint32_t n_aln, uint64_t n_words);
  *   n_words     the CIGAR words d_cigar holds, >= d_cig_off[n_aln] (the caller knows it as the length of its array; an array that
  *               holds more than it said: SVX_SCAN_FAILED in d_gap_off[n_aln]).  It sizes the frame records and picks the count pass's shape
  * Three launches (count -> offsets, its prefix over the tiles by a decoupled look-back -> emit), no atomics on results.
- * An alignment of more than 512 words is cut into frames of 2,048 words whose sums the count pass keeps: the emit pass reads
- * only the frames that hold a long gap.
+ * An alignment of more than 512 words is cut into frames of 512 words whose sums the count pass keeps: the emit pass walks
+ * only the frames that hold a long gap.  A launch of long alignments (more than 1,024 words each on average: ONT, contigs)
+ * takes the frames in a launch of its own between count and offsets, the array cut into equal ranges.
  * H is treated as S (the reference rewrites H to S, collect_signatures.py:91);
  * N advances the read position only (analyze_reads.py:831-832). */
 int svx_cigar_scan(const uint32_t* d_cigar, const uint64_t* d_cig_off,

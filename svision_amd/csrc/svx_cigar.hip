@@ -322,7 +322,7 @@ void count_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict
         }
     } else {
         if (live && sub == 0)
-            for (uint64_t r = a ? (b + (1ull << range_shift) - 1) >> range_shift : 0ull; (r << range_shift) < e; ++r) range_aln[r] = make_uint4(a, (uint32_t)b, (uint32_t)(b >> 32), (uint32_t)min((uint64_t)n, 0xFFFFFFFFull));      // (words in front of the first alignment: its ranges too)
+            for (uint64_t r = a ? (b + (1ull << range_shift) - 1) >> range_shift : b >> range_shift; (r << range_shift) < e; ++r) range_aln[r] = make_uint4(a, (uint32_t)b, (uint32_t)(b >> 32), (uint32_t)min((uint64_t)n, 0xFFFFFFFFull));      // (the first alignment: the range its first word lies in too)
     }
 }
 
@@ -340,7 +340,7 @@ void frames_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restric
     const uint64_t range = (uint64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)));
     const uint64_t total = cig_off[n_aln], full = total >> 2;
     const uint64_t lo = range << (range_shift - 2), hi = lo + (1ull << (range_shift - 2));      // in quads
-    if ((range << range_shift) >= total) return;
+    if ((range << range_shift) >= total || ((range + 1) << range_shift) <= cig_off[0]) return;      // behind the last alignment / in front of the first (a window of a larger array)
     const uint32_t m16 = scan_threshold(min_sv);
     const uint64_t n_slots = frame_slots(n_words);
     const uint4* __restrict__ quads = reinterpret_cast<const uint4*>(cigar);

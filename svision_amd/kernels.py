@@ -104,12 +104,13 @@ FLAT_SCAN_FROM = None               # mean CIGAR words per alignment from which 
                                     # profiles/r05_bench_cigar.json): 600-800 us on the ONT-shaped launch against 520 us of the three-kernel form (a dozen dependent round trips per tile)
 
 
-def cigar_scan(cigar, cig_off, ref_start, min_sv, gaps_cap=None, mode=None, n_words=None):
+def cigar_scan(cigar, cig_off, ref_start, min_sv, gaps_cap=None, mode=None, n_words=None, span_words=None):
     """cigar: int32/uint32 device tensor of packed BAM CIGAR words; cig_off: int64 [n+1];
     ref_start: int32 [n].  See include/svx.h svx_cigar_scan.  ``mode``: "groups" (svx_cigar_scan: four or eight lanes per alignment
     by the launch's mean words per alignment -- "groups4" / "groups8" / "groups4s" / "groups8s" fix the shape (lanes, s: frames shared by the workgroup) --, three launches), "flat" (svx_cigar_scan_flat: one pass over chunks of the flat word array -- ONT /
     assembly-sized alignments), None: by the mean number of words per alignment (SVX_SCAN_MODE overrides).  ``n_words``: an upper
-    bound of the words the offsets span (default: the size of ``cigar``)."""
+    bound of the offsets' last entry (default: the size of ``cigar``); ``span_words``: the words between the offsets' first and last
+    entry where that is less (a window of a larger array), for the choice of the shape."""
     lib = _lib.load()
     for t, nm in ((cigar, "cigar"), (cig_off, "cig_off"), (ref_start, "ref_start")):
         _require_cuda(t, nm)
@@ -139,13 +140,15 @@ def cigar_scan(cigar, cig_off, ref_start, min_sv, gaps_cap=None, mode=None, n_wo
     else:
         ws = torch.empty(max(16, lib.svx_cigar_scan_ws_bytes(n, words)), dtype=torch.uint8, device=dev)
         flags = {"groups": 0, "groups4": 1 | 8, "groups8": 2 | 8, "groups4s": 1 | 4, "groups8s": 2 | 4}[mode]      # SVX_SCAN_LANES4/8 | SVX_SCAN_(UN)SHARED: the count pass's shape, never a result
+        if mode == "groups" and span_words is not None and n:        # a window of a larger array: the library's own rule (svx_cigar.hip SHORT_MEAN / SHARE_MEAN) on the window's words
+            flags = (1 if span_words <= 256 * n else 2) | (4 if span_words > 1024 * n else 8)
         rc = lib.svx_cigar_scan(cigar.data_ptr(), cig_off.data_ptr(), ref_start.data_ptr(), n, words, int(min_sv),
                                 gaps.data_ptr(), gaps_cap, gap_off.data_ptr(), stats.data_ptr(), ws.data_ptr(), int(ws.numel()), flags,
                                 _stream_ptr(dev))
         _lib.check(rc, "svx_cigar_scan")
     res = CigarScanResult(gaps, gap_off, stats, n, gaps_cap)
     if auto and res.total() > gaps_cap:       # d_gap_off[n] holds the full count: rerun with the exact capacity
-        return cigar_scan(cigar, cig_off, ref_start, min_sv, gaps_cap=res.total(), mode=mode, n_words=n_words)
+        return cigar_scan(cigar, cig_off, ref_start, min_sv, gaps_cap=res.total(), mode=mode, n_words=n_words, span_words=span_words)
     return res
 
 

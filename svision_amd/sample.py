@@ -164,7 +164,8 @@ class Sample:
         if host is None:
             host = torch.empty(max(need, 1 << 20), dtype=torch.int32, pin_memory=True)
         with torch.cuda.stream(self._scan_stream):
-            res = kernels.cigar_scan(d_cigar, d_off[lo:hi + 1], d_pos[lo:hi], self.min_sv, gaps_cap=capd)
+            res = kernels.cigar_scan(d_cigar, d_off[lo:hi + 1], d_pos[lo:hi], self.min_sv, gaps_cap=capd,
+                                     n_words=int(table.cig_off[hi]), span_words=int(table.cig_off[hi] - table.cig_off[lo]))
             host[:n + 1].copy_(res.gap_off, non_blocking=True)
             host[n + 1:n + 1 + capd * 6].copy_(res.gaps[:capd * 6], non_blocking=True)
             host[n + 1 + capd * 6:need].copy_(res.stats.view(-1), non_blocking=True)
