@@ -322,7 +322,7 @@ void count_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict
         }
     } else {
         if (live && sub == 0)
-            for (uint64_t r = a ? (b + (1ull << range_shift) - 1) >> range_shift : b >> range_shift; (r << range_shift) < e; ++r) range_aln[r] = make_uint4(a, (uint32_t)b, (uint32_t)(b >> 32), (uint32_t)min((uint64_t)n, 0xFFFFFFFFull));      // (the first alignment: the range its first word lies in too)
+            for (uint64_t r = a ? (b + (1ull << range_shift) - 1) >> range_shift : b >> range_shift; (r << range_shift) < e && r <= (n_words >> range_shift); ++r) range_aln[r] = make_uint4(a, (uint32_t)b, (uint32_t)(b >> 32), (uint32_t)min((uint64_t)n, 0xFFFFFFFFull));      // (the first alignment: the range its first word lies in too)
     }
 }
 

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import cigar_ref, encode_ref
-from svision_amd import kernels
+from svision_amd import _lib, kernels
 from tests import datagen
 
 pytestmark = pytest.mark.gpu
@@ -157,6 +157,52 @@ def test_cigar_scan_ultra_long_reads(oracle_lib, mode):
     assert gaps.tobytes() == o_gaps.tobytes() and int(gap_off[-1]) > 15_000
     again = kernels.cigar_scan(_dev(cig.view(np.int32)), _dev(offs.astype(np.int64)), _dev(rs), 50, mode=mode)
     assert again.to_host()[0].tobytes() == gaps.tobytes()                # the long list's order varies, the output does not
+
+
+@pytest.mark.parametrize("mode", SCAN_MODES)
+def test_cigar_scan_frame_edges(oracle_lib, mode):
+    """Round 5: an alignment of more than 512 words is cut into frames of 512 words behind its first 128 quads, four frames per
+    step, and the emit pass walks only frames that hold a long gap, from positions it derives from the frames' sums.  Directed
+    cases: long gaps and N ops (read advance without reference advance) on either side of every edge -- head | first frame,
+    frame | frame, step | step, the last whole quad, the alignment's last word --, for all four positions of the alignment's
+    first word inside its quad, with a neighbour whose first words are long gaps too, and an array that ends inside a quad."""
+    from oracle import cbind
+    rng = np.random.default_rng(5)
+    aligns = []
+    for lead in range(4):                                  # 1-op fillers shift the next alignment's first word through the quad
+        for n in (512, 513, 516, 517, 1023, 1024, 1025, 1028, 2559, 2560, 2561, 2564, 2565, 4608 + 3, 70_001):
+            kinds = rng.choice([0, 7, 8, 1, 2], size=n, p=[0.3, 0.4, 0.1, 0.1, 0.1]).astype(np.uint32)
+            lens = rng.integers(1, 30, n).astype(np.uint32)
+            edges = [e for e in (0, 1, 2, 3, 508, 509, 510, 511, 512, 513, 515, 516, 1020, 1023, 1024, 1027, 1028, 1535, 1536, 2047, 2048, 2049,
+                                 2556, 2559, 2560, 2563, 2564, 4607, 4608, 4609, n - 5, n - 4, n - 3, n - 2, n - 1) if 0 <= e < n]
+            for j, e in enumerate(edges):
+                if j % 3 == 0: kinds[e], lens[e] = 1 + (j // 3) % 2, 50 + j          # a long I / D
+                elif j % 3 == 1: kinds[e], lens[e] = 3, 1000 + j                      # N
+            aligns.append((lens << 4 | kinds).astype(np.uint32))
+            aligns.append(np.asarray([(60 << 4) | 1, (3 << 4) | 7][:1 + (len(aligns) % 2)], np.uint32))   # a short neighbour that starts with a long gap
+        aligns.append(np.asarray([(5 << 4) | 7] * (lead + 1), np.uint32)[:1])
+        aligns.append(np.asarray([(7 << 4) | 0], np.uint32))
+    aligns.append(np.tile(aligns[0], 3)[:1024 + (2 - sum(len(a) for a in aligns)) % 4].copy())      # the array's last alignment is a long one and ends inside a quad
+    off = np.zeros(len(aligns) + 1, np.uint64)
+    off[1:] = np.cumsum([len(a) for a in aligns])
+    cigar = np.concatenate(aligns)
+    assert int(off[-1]) % 4 != 0 and len({int(o) % 4 for o in off[:-1][[len(a) > 512 for a in aligns]]}) == 4
+    ref_start = rng.integers(0, 1 << 28, len(aligns)).astype(np.int32)
+    padded = np.concatenate([cigar, np.zeros((-cigar.size) % 4, np.uint32)])
+    res = kernels.cigar_scan(_dev(padded.view(np.int32)), _dev(off.astype(np.int64)), _dev(ref_start), 50, mode=mode, n_words=int(off[-1]))
+    gaps, gap_off, stats = res.to_host()
+    o_gaps, o_off, o_stats = cbind.cigar_scan(cigar, off, ref_start, 50)
+    assert np.array_equal(gap_off, o_off) and np.array_equal(stats, o_stats)
+    assert gaps.tobytes() == o_gaps.tobytes() and int(gap_off[-1]) > 500
+
+
+def test_cigar_scan_refuses_an_array_longer_than_the_caller_said(oracle_lib):
+    """svx_cigar_scan sizes its frame records by n_words: offsets that reach beyond it are answered with SVX_SCAN_FAILED in
+    d_gap_off[n_aln] (kernels: SvxError on read-back), never with records written outside the workspace."""
+    cigar, off, ref_start = datagen.random_cigars(200, seed=3, mean_ops=3000, long_gap_rate=0.01)
+    for mode in ("groups8s", "groups4"):
+        with pytest.raises(_lib.SvxError):
+            kernels.cigar_scan(_dev(cigar.view(np.int32)), _dev(off.astype(np.int64)), _dev(ref_start), 50, mode=mode, n_words=int(off[-1]) // 2).total()
 
 
 @pytest.mark.parametrize("mode", SCAN_MODES)
