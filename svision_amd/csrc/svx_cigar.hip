@@ -63,8 +63,11 @@ __device__ inline unsigned wave_sum_u(unsigned v)
 
 // The count pass gives an alignment G lanes that keep Q 16-byte loads in flight each (template parameters: the entry point picks
 // <4, 4> for launches whose alignments average at most SHORT_MEAN words -- HiFi: sixteen alignments per wave, whose per-alignment
-// instructions are the larger half of the pass -- and <8, 2> otherwise).
+// instructions are the larger half of the pass -- and <8, 4> otherwise).
 constexpr int LONG_Q = 128;                         // quads (512 words) of an alignment the count pass's groups handle themselves
+#ifndef SVX_WIDE_Q
+#define SVX_WIDE_Q 4                                 // 16-byte loads in flight per lane of the eight-lane count pass
+#endif
 constexpr uint64_t SHORT_MEAN = 256;
 constexpr uint64_t SHARE_MEAN = 1024;                // mean words per alignment from which the frames get a launch of their own (frames_kernel)
 constexpr uint32_t MIN_RANGE_SHIFT = 11;             // a range of frames_kernel: at least one frame's words
@@ -664,7 +667,7 @@ extern "C" int svx_cigar_scan(const uint32_t* d_cigar, const uint64_t* d_cig_off
 #define SVX_COUNT(G, Q, S) hipLaunchKernelGGL((count_kernel<G, Q, S>), dim3((n_aln + BLOCK / G - 1) / (BLOCK / G)), dim3(BLOCK), count_lds, st, \
                                               d_cigar, d_cig_off, n_aln, min_sv, d_gap_off, d_stats, desc, n_tiles, frames, n_words, range_aln, range_shift)
     if (narrow) { if (share) SVX_COUNT(4, 4, true); else SVX_COUNT(4, 4, false); }
-    else        { if (share) SVX_COUNT(8, 2, true); else SVX_COUNT(8, 2, false); }
+    else        { if (share) SVX_COUNT(8, SVX_WIDE_Q, true); else SVX_COUNT(8, SVX_WIDE_Q, false); }
 #undef SVX_COUNT
     if (share) {
         const uint64_t n_ranges = (n_words >> range_shift) + 1;
