@@ -37,9 +37,24 @@
 namespace {
 
 constexpr int LANES = 64;
-constexpr int LB = 10, DB = 8;                       // root bits of the literal / length and the distance table
-constexpr int LIT_CAP = (1 << LB) + 512, DIST_CAP = (1 << DB) + 512;      // + sub-tables (zlib's ENOUGH for 286 / 30 symbols, 15-bit codes)
-constexpr int SEG_BITS = 512;                        // compressed bits per lane and chunk
+#ifndef SVX_TOK_LB
+#define SVX_TOK_LB 9
+#define SVX_TOK_DB 7
+#endif
+#ifndef SVX_TOK_WAVES
+#define SVX_TOK_WAVES 4
+#endif
+// Root bits of the literal / length and the distance table, and the entries they can need with their sub-tables: zlib's ENOUGH
+// (inftrees.h: 852 entries for 286 symbols at 9 root bits, 592 for 30 symbols at 6, codes of up to 15 bits; a sub-table spans
+// the longest code below its root entry, there as here) -- more root bits need no more sub-table entries.  Round 5: 9 / 7 bits
+// instead of 10 / 8 and the builder's scratch inside the chunk buffer: 9.9 KB of LDS per wave instead of 14.1, SIXTEEN waves
+// per CU instead of eleven -- the kernel's time follows its waves almost linearly (34 / 42 / 56 / 83 ms at 11 / 8 / 6 / 4 per CU).
+constexpr int LB = SVX_TOK_LB, DB = SVX_TOK_DB;
+constexpr int LIT_CAP = (1 << LB) + (LB >= 9 ? 340 : 512), DIST_CAP = (1 << DB) + 528;
+#ifndef SVX_TOK_SEG
+#define SVX_TOK_SEG 512
+#endif
+constexpr int SEG_BITS = SVX_TOK_SEG;                // compressed bits per lane and chunk
 constexpr int CHUNK_WORDS = LANES * SEG_BITS / 32 + 8;                    // staged dwords: the chunk + what the last tokens may read behind it
 enum { K_BAD = 0, K_LIT = 1, K_LEN = 2, K_EOB = 3, K_SUB = 4 };
 enum { INF_OK = 0, INF_BAD_TYPE = 1, INF_BAD_STORED = 2, INF_BAD_TABLE = 3, INF_BAD_CODE = 4, INF_OUT_OVERRUN = 5, INF_IN_OVERRUN = 6, INF_SHORT = 7,
@@ -71,13 +86,16 @@ struct DistPayload {
 struct ClenPayload { __device__ __forceinline__ uint32_t operator()(int s) const { return (uint32_t)K_LIT << 4 | (uint32_t)s << 8; } };
 
 struct Lds {
-    uint32_t lit[LIT_CAP];                           // 6 KB
-    uint32_t dist[DIST_CAP];                         // 3 KB (also: the code-length code's table, scratch of the literal table's build)
+    uint32_t lit[LIT_CAP];                           // 3.3 KB
+    uint32_t dist[DIST_CAP];                         // 2.6 KB (also: the code-length code's table, scratch of the literal table's build)
     uint32_t chunk[CHUNK_WORDS];                     // 4 KB: the compressed bytes of the chunk in hand
-    uint16_t code[320];                              // canonical code of every symbol
-    uint8_t lens[320];                               // code lengths: literal / length symbols at 0, distance symbols at 288
-    uint8_t cl[32];
+    // what the table builder reads and its scratch live in the chunk buffer (staged only when the tables stand): its first KB is
+    // build_tables' tmp, then
+    __device__ __forceinline__ uint8_t* lens() { return reinterpret_cast<uint8_t*>(chunk) + 1024; }       // [320] code lengths: literal / length symbols at 0, distance symbols at 288
+    __device__ __forceinline__ uint8_t* cl() { return reinterpret_cast<uint8_t*>(chunk) + 1344; }         // [32] lengths of the code-length code
+    __device__ __forceinline__ uint16_t* code() { return reinterpret_cast<uint16_t*>(chunk) + 704; }      // [320] canonical code of every symbol
 };
+static_assert(sizeof(Lds) <= 10240 && LANES * SEG_BITS / 8 >= 2048, "sixteen waves per CU; the builder's scratch fits the chunk buffer");
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ void lds_fence() { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); }   // lgkmcnt(0); one wave: in order
@@ -296,7 +314,7 @@ __device__ __forceinline__ void put32(uint8_t* p, uint32_t v) { __builtin_memcpy
 // one coalesced load, the positions of 64 sequences' outputs and literals two wave prefix sums.  stream_cnt[b] = (sequences,
 // literal bytes).  Not SPLIT: headers and literals interleaved (bgzf_lz_kernel walks them), stream_cnt[b].x = the stream's bytes.
 template <bool SPLIT>
-__global__ __launch_bounds__(LANES)
+__global__ __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(SVX_TOK_WAVES, 8)))
 void bgzf_tokens_kernel(const uint8_t* __restrict__ comp, const uint64_t* __restrict__ src_off, const uint32_t* __restrict__ src_len,
                         const uint64_t* __restrict__ dst_off, uint32_t n_blocks, uint8_t* __restrict__ streams, uint2* __restrict__ stream_cnt,
                         uint32_t* __restrict__ status)
@@ -349,20 +367,20 @@ void bgzf_tokens_kernel(const uint8_t* __restrict__ comp, const uint64_t* __rest
         if (type == 3) { err = INF_BAD_TYPE; break; }
         int nlen = 288, ndist = 30;
         if (type == 1) {                             // fixed code (RFC 1951 3.2.6)
-            for (int s = lane; s < 288; s += LANES) t.lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
-            if (lane < 32) t.lens[288 + lane] = lane < 30 ? 5 : 0;
+            for (int s = lane; s < 288; s += LANES) t.lens()[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+            if (lane < 32) t.lens()[288 + lane] = lane < 30 ? 5 : 0;
             lds_fence();
         } else {                                     // dynamic code (3.2.7)
             nlen = (int)hr.bits(5) + 257; ndist = (int)hr.bits(5) + 1;
             const int ncode = (int)hr.bits(4) + 4;
             if (nlen > 286 || ndist > 30) { err = INF_BAD_TABLE; break; }
-            if (lane < 32) t.cl[lane] = 0;
+            if (lane < 32) t.cl()[lane] = 0;
             lds_fence();
-            for (int i = 0; i < ncode; ++i) { const uint32_t v = hr.bits(3); if (lane == 0) t.cl[CLEN_ORDER[i]] = (uint8_t)v; }
+            for (int i = 0; i < ncode; ++i) { const uint32_t v = hr.bits(3); if (lane == 0) t.cl()[CLEN_ORDER[i]] = (uint8_t)v; }
             lds_fence();
             // the code-length code: a 7-bit table in the distance table's place (scratch: the chunk buffer)
-            if (!build_tables(t.cl, 19, 7, t.dist, 128, t.code, reinterpret_cast<uint8_t*>(t.chunk), ClenPayload{})) { err = INF_BAD_TABLE; break; }
-            for (int s = lane; s < 320; s += LANES) t.lens[s] = 0;
+            if (!build_tables(t.cl(), 19, 7, t.dist, 128, t.code(), reinterpret_cast<uint8_t*>(t.chunk), ClenPayload{})) { err = INF_BAD_TABLE; break; }
+            for (int s = lane; s < 320; s += LANES) t.lens()[s] = 0;
             lds_fence();
             int i = 0;
             while (i < nlen + ndist) {
@@ -375,25 +393,25 @@ void bgzf_tokens_kernel(const uint8_t* __restrict__ comp, const uint64_t* __rest
                 if (sym == 16) {
                     if (i == 0) { err = INF_BAD_TABLE; break; }
                     const int j = i - 1;
-                    value = uni((int)t.lens[j < nlen ? j : 288 + (j - nlen)]);
+                    value = uni((int)t.lens()[j < nlen ? j : 288 + (j - nlen)]);
                     rep = 3 + (int)hr.bits(2);
                 } else if (sym == 17) { value = 0; rep = 3 + (int)hr.bits(3); }
                 else if (sym == 18) { value = 0; rep = 11 + (int)hr.bits(7); }
                 if (i + rep > nlen + ndist) { err = INF_BAD_TABLE; break; }
-                for (int r = lane; r < rep; r += LANES) { const int x = i + r; t.lens[x < nlen ? x : 288 + (x - nlen)] = (uint8_t)value; }
+                for (int r = lane; r < rep; r += LANES) { const int x = i + r; t.lens()[x < nlen ? x : 288 + (x - nlen)] = (uint8_t)value; }
                 lds_fence();
                 i += rep;
             }
             if (err != INF_OK) break;
-            if (uni((int)t.lens[256]) == 0) { err = INF_BAD_TABLE; break; }
+            if (uni((int)t.lens()[256]) == 0) { err = INF_BAD_TABLE; break; }
         }
         P += hr.fed;
 #if SVX_TOK_DBG & 1
-        build_tables(t.lens, nlen, LB, t.lit, LIT_CAP, t.code, reinterpret_cast<uint8_t*>(t.dist), LitPayload{});
-        build_tables(t.lens + 288, ndist, DB, t.dist, DIST_CAP, t.code, reinterpret_cast<uint8_t*>(t.chunk), DistPayload{});
+        build_tables(t.lens(), nlen, LB, t.lit, LIT_CAP, t.code(), reinterpret_cast<uint8_t*>(t.dist), LitPayload{});
+        build_tables(t.lens() + 288, ndist, DB, t.dist, DIST_CAP, t.code(), reinterpret_cast<uint8_t*>(t.chunk), DistPayload{});
 #endif
-        if (!build_tables(t.lens, nlen, LB, t.lit, LIT_CAP, t.code, reinterpret_cast<uint8_t*>(t.dist), LitPayload{}) ||
-            !build_tables(t.lens + 288, ndist, DB, t.dist, DIST_CAP, t.code, reinterpret_cast<uint8_t*>(t.chunk), DistPayload{})) { err = INF_BAD_TABLE; break; }
+        if (!build_tables(t.lens(), nlen, LB, t.lit, LIT_CAP, t.code(), reinterpret_cast<uint8_t*>(t.dist), LitPayload{}) ||
+            !build_tables(t.lens() + 288, ndist, DB, t.dist, DIST_CAP, t.code(), reinterpret_cast<uint8_t*>(t.chunk), DistPayload{})) { err = INF_BAD_TABLE; break; }
         // ---- the block's tokens, chunk by chunk
         bool eob = false;
         while (!eob && err == INF_OK) {
@@ -733,8 +751,9 @@ extern "C" int svx_bgzf_inflate_fast_on(const uint8_t* d_comp, const uint64_t* d
             (void)hipStreamWaitEvent(sa, ready, 0);
             (void)hipEventDestroy(ready);
         }
-        if (wave_lz) hipLaunchKernelGGL(bgzf_tokens_kernel<true>, dim3(n_blocks), dim3(LANES), 0, sa, d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, streams, stream_cnt, d_status);
-        else hipLaunchKernelGGL(bgzf_tokens_kernel<false>, dim3(n_blocks), dim3(LANES), 0, sa, d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, streams, stream_cnt, d_status);
+        static const unsigned tok_lds = getenv("SVX_TOK_LDS") ? (unsigned)atoi(getenv("SVX_TOK_LDS")) : 0u;      // (experiment: extra LDS per wave = fewer waves per CU)
+        if (wave_lz) hipLaunchKernelGGL(bgzf_tokens_kernel<true>, dim3(n_blocks), dim3(LANES), tok_lds, sa, d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, streams, stream_cnt, d_status);
+        else hipLaunchKernelGGL(bgzf_tokens_kernel<false>, dim3(n_blocks), dim3(LANES), tok_lds, sa, d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, streams, stream_cnt, d_status);
         if (sa != sb) {
             hipEvent_t done;
             if (hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) return SVX_ELAUNCH;

@@ -11,3 +11,13 @@ done
 cd $R
 REPS=50 timeout 200 python tools/bench_cigar.py > gpurun_out/r05scan/bench_cigar.json 2>/dev/null; cat gpurun_out/r05scan/bench_cigar.json
 SVX_SCAN_MODE=flat REPS=50 ONLY=3,2 timeout 200 python tools/bench_cigar.py > gpurun_out/r05scan/bench_cigar_flat.json 2>/dev/null; cat gpurun_out/r05scan/bench_cigar_flat.json
+# PMC passes (separate runs; rocprofv3 --pmc without trace flags): bytes fetched / written and vector instructions per launch
+cd /tmp
+pmc() { tag=$1; shift; counters=$1; shift; rm -rf /tmp/rp_pmc_$tag; timeout 200 rocprofv3 --pmc $counters --output-format csv -d /tmp/rp_pmc_$tag -- "$@" > $R/gpurun_out/r05scan/pmc_$tag.log 2>&1; python $R/tools/pmc_summary.py /tmp/rp_pmc_$tag > $R/gpurun_out/r05scan/pmc_$tag.txt; }
+ONLY=4 REPS=5 pmc cigar_hifi_fetch "FETCH_SIZE" python $R/tools/bench_cigar.py
+ONLY=4 REPS=5 pmc cigar_hifi_write "WRITE_SIZE" python $R/tools/bench_cigar.py
+ONLY=4 REPS=5 pmc cigar_hifi_sq "SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES" python $R/tools/bench_cigar.py
+ONLY=3 REPS=5 pmc cigar_ont_fetch "FETCH_SIZE" python $R/tools/bench_cigar.py
+ONLY=3 REPS=5 pmc cigar_ont_write "WRITE_SIZE" python $R/tools/bench_cigar.py
+ONLY=3 REPS=5 pmc cigar_ont_sq "SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES" python $R/tools/bench_cigar.py
+cd $R; tail -n 12 gpurun_out/r05scan/pmc_cigar_*_fetch.txt gpurun_out/r05scan/pmc_cigar_*_write.txt
