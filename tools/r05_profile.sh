@@ -38,14 +38,7 @@ python $REPO/tools/kstats.py $OUT/b_device_stage_kernel_stats.csv > $OUT/b_devic
 # 5. the file-inclusive leg kernel by kernel
 run e2e_trace rocprofv3 --kernel-trace --output-format csv -d /tmp/rp_e2e_trace -- python $REPO/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-calibration --no-other-engine --no-cold-leg
 timeout 120 python $REPO/tools/e2e_kernel_timeline.py /tmp/rp_e2e_trace 7 > $OUT/e2e_kernel_timeline.txt
-# 6. the scan (both forms) and the rasteriser export, timed and traced AFTER the round's last kernel commit
-timeout 300 python $REPO/tools/bench_cigar.py > $OUT/bench_cigar.json 2> /dev/null
-SVX_SCAN_MODE=flat timeout 300 python $REPO/tools/bench_cigar.py > $OUT/bench_cigar_flat.json 2> /dev/null
-ONLY=4 REPS=20 run cigar_trace rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_cigar_trace -- python $REPO/tools/bench_cigar.py
-stats cigar_trace cigar_kernel_stats.csv
-ONLY=3 REPS=20 run cigar_ont_trace rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_cigar_ont_trace -- python $REPO/tools/bench_cigar.py
-stats cigar_ont_trace cigar_ont_kernel_stats.csv
-ONLY=4 REPS=5 pmc cigar "SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES FETCH_SIZE WRITE_SIZE" python $REPO/tools/bench_cigar.py
+# 6. the scan: tools/r05_profile_scan.sh (its own script: run after the scan's last kernel commit); the rasteriser export
 run raster_trace rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_raster_trace -- python $REPO/tools/microbench.py
 stats raster_trace raster_microbench_kernel_stats.csv
 # 7. what the section 8(f)2 / 8(f)3 kernels would cost or save inside -t N (the decision of DESIGN.md: retired there)
