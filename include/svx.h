@@ -101,8 +101,8 @@ size_t svx_cigar_scan_ws_bytes(uint32_t n_aln, uint64_t n_words);
  *   n_words     the CIGAR words d_cigar holds, >= d_cig_off[n_aln] (the caller knows it as the length of its array; an array that
  *               holds more than it said: SVX_SCAN_FAILED in d_gap_off[n_aln]).  It sizes the frame records and picks the count pass's shape
  * Three launches (count -> offsets, its prefix over the tiles by a decoupled look-back -> emit), no atomics on results.
- * An alignment of more than 512 words is cut into frames of 512 words whose sums the count pass keeps: the emit pass walks
- * only the frames that hold a long gap.  A launch of long alignments (more than 1,024 words each on average: ONT, contigs)
+ * An alignment of more than 512 words (1,024 in launches of 257-1,024 words per alignment) is cut, behind that head, into frames
+ * of 512 words whose sums the count pass keeps: the emit pass walks only the frames that hold a long gap.  A launch of long alignments (more than 1,024 words each on average: ONT, contigs)
  * takes the frames in a launch of its own between count and offsets, the array cut into equal ranges.
  * H is treated as S (the reference rewrites H to S, collect_signatures.py:91);
  * N advances the read position only (analyze_reads.py:831-832). */

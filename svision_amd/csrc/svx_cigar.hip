@@ -64,7 +64,9 @@ __device__ inline unsigned wave_sum_u(unsigned v)
 // The count pass gives an alignment G lanes that keep Q 16-byte loads in flight each (template parameters: the entry point picks
 // <4, 4> for launches whose alignments average at most SHORT_MEAN words -- HiFi: sixteen alignments per wave, whose per-alignment
 // instructions are the larger half of the pass -- and <8, 4> otherwise).
-constexpr int LONG_Q = 128;                         // quads (512 words) of an alignment the count pass's groups handle themselves
+constexpr uint32_t LONG_Q = 128, MID_LONG_Q = 256;   // quads of an alignment the count pass's groups handle themselves (its head; longer: frames behind it) -- 512 words,
+                                                    // or 1,024 in launches of 257-1,024 words per alignment (there most alignments then have no frames at all: a step
+                                                    // of a wave for the 300 words behind a 512-word head cost more than the head)
 #ifndef SVX_WIDE_Q
 #define SVX_WIDE_Q 4                                 // 16-byte loads in flight per lane of the eight-lane count pass
 #endif
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8)))
 void count_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict__ cig_off,
                   uint32_t n_aln, int32_t min_sv, uint32_t* __restrict__ gap_off, int32_t* __restrict__ stats,
                   unsigned long long* __restrict__ desc, uint32_t n_tiles, uint4* __restrict__ frames, uint64_t n_words,
-                  uint4* __restrict__ range_aln, uint32_t range_shift)
+                  uint4* __restrict__ range_aln, uint32_t range_shift, uint32_t long_q)
 {
     // (the look-back descriptors of the offsets pass behind this kernel start out empty: zeroed here instead of by a memset
     // launch of its own -- 5 us of a 70 us scan; there are more count workgroups than tiles)
@@ -226,8 +228,8 @@ void count_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict
     // kernel of its own).  All sums are modular and additive: the corrections (computed from q_end) and the two partial
     // sums simply add up.
     const bool some = q0 < q_end;
-    const bool is_long = some && q_end - q0 > (uint64_t)LONG_Q;
-    const uint32_t nq = some ? (is_long ? (uint32_t)LONG_Q : (uint32_t)(q_end - q0)) : 0u;      // quads taken here
+    const bool is_long = some && q_end - q0 > (uint64_t)long_q;
+    const uint32_t nq = some ? (is_long ? long_q : (uint32_t)(q_end - q0)) : 0u;      // quads taken here
     // the words at either end for the clip runs, the neighbours' words inside the first / last quad (lanes 0-2
     // look before b and from e on), the alignment's words beyond the last whole quad of the array (at most 3,
     // last alignments only), then the quads.  Everything is addressed from the alignment's own first word / quad / end with
@@ -318,7 +320,7 @@ void count_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict
         while (lm) {
             const int src = __ffsll((long long)lm) - 1;
             lm &= lm - 1;
-            const uint64_t qa = __shfl(q0, src, WAVE) + LONG_Q, qb = __shfl(q_end, src, WAVE);
+            const uint64_t qa = __shfl(q0, src, WAVE) + long_q, qb = __shfl(q_end, src, WAVE);
             const uint32_t al = __shfl(a, src, WAVE);
 #pragma clang loop unroll(disable)
             for (uint64_t S = qa; S < qb; S += STEP_Q) count_step(quads, S, min(S + STEP_Q, qb), al, m16, frames, n_slots, gap_off, stats, wl);
@@ -337,7 +339,7 @@ void count_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8)))
 void frames_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict__ cig_off, uint32_t n_aln, int32_t min_sv,
                    uint32_t* __restrict__ gap_off, int32_t* __restrict__ stats, uint4* __restrict__ frames, uint64_t n_words,
-                   const uint4* __restrict__ range_aln, uint32_t range_shift)
+                   const uint4* __restrict__ range_aln, uint32_t range_shift, uint32_t long_q)
 {
     const int wl = threadIdx.x & (WAVE - 1);
     const uint64_t range = (uint64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)));
@@ -349,9 +351,9 @@ void frames_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restric
     const uint4* __restrict__ quads = reinterpret_cast<const uint4*>(cigar);
     // one alignment: the frames of it that start in [lo, hi); false: its first frame, and so every later alignment's, starts behind the range
     auto take = [&](uint32_t a, uint64_t b, uint64_t e) {
-        const uint64_t q0 = b >> 2, q_end = min((e + 3) >> 2, full), qa = q0 + LONG_Q;
+        const uint64_t q0 = b >> 2, q_end = min((e + 3) >> 2, full), qa = q0 + long_q;
         if (qa >= hi) return false;
-        if (!(q0 < q_end && q_end - q0 > (uint64_t)LONG_Q)) return true;
+        if (!(q0 < q_end && q_end - q0 > (uint64_t)long_q)) return true;
         const uint64_t k = qa >= lo ? 0ull : (lo - qa + STEP_Q - 1) / STEP_Q;
         const uint64_t stop = min(hi, q_end);
 #pragma clang loop unroll(disable)
@@ -369,7 +371,7 @@ void frames_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restric
         uint64_t e = b + ent.w;
         if (ent.w == 0xFFFFFFFFu) e = cig_off[a + 1];      // (an alignment of 2^32 words or more)
         if (!take(a, b, e)) return;
-        if ((e >> 2) + LONG_Q >= hi) return;             // (the next alignment starts at or behind e)
+        if ((e >> 2) + long_q >= hi) return;             // (the next alignment starts at or behind e)
         ++a;
     }
     for (;;) {
@@ -470,7 +472,7 @@ void offsets_kernel(uint32_t n_aln, uint32_t* __restrict__ gap_off, unsigned lon
 __global__ __launch_bounds__(BLOCK)
 void emit_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict__ cig_off,
                  const int32_t* __restrict__ ref_start, int32_t min_sv, SvxGap* __restrict__ gaps, uint64_t gaps_cap,
-                 const uint2* __restrict__ totals, const uint2* __restrict__ work, uint32_t n_aln, const uint4* __restrict__ frames, uint64_t n_slots)
+                 const uint2* __restrict__ totals, const uint2* __restrict__ work, uint32_t n_aln, const uint4* __restrict__ frames, uint64_t n_slots, uint32_t long_q)
 {
     const int lane = threadIdx.x & (WAVE - 1);
     const uint64_t full = cig_off[n_aln] >> 2;             // quads that lie entirely inside the array
@@ -552,7 +554,7 @@ void emit_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict_
         };
         // the count pass's own test (there: is_long), from the same offsets
         const uint64_t e = b + (uint64_t)n, q0 = b >> 2, q_end = min((e + 3) >> 2, full);
-        const bool is_long = q0 < q_end && q_end - q0 > (uint64_t)LONG_Q;
+        const bool is_long = q0 < q_end && q_end - q0 > (uint64_t)long_q;
         // A long alignment (ONT, assembly contigs).  Behind its first LONG_Q quads lie its frames, whose sums the count pass has
         // left in `frames`: 64 records per step become the positions and the output slot in front of every frame (one set of wave
         // prefix sums), and only a frame that holds a long gap is walked -- two narrow steps from the frame's own positions.
@@ -565,7 +567,7 @@ void emit_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict_
             total = (uint32_t)__builtin_amdgcn_readlane((int)inc, WAVE - 1);
             return inc - v;
         };
-        const uint64_t qa = q0 + LONG_Q;
+        const uint64_t qa = q0 + long_q;
         const uint32_t n_frames = is_long ? ((uint32_t)(q_end - qa) + FRAME_Q - 1) / FRAME_Q : 0u;
         const long long j_tail = 4 * (long long)q_end - (long long)b;
         auto record = [&](uint32_t k) {
@@ -659,25 +661,26 @@ extern "C" int svx_cigar_scan(const uint32_t* d_cigar, const uint64_t* d_cig_off
     // (HiFi) four lanes each and a long one finished by its own wave; long ones eight lanes, their frames shared by the workgroup
     const bool narrow = (flags & SVX_SCAN_LANES4) ? true : (flags & SVX_SCAN_LANES8) ? false : n_words <= SHORT_MEAN * (uint64_t)n_aln;
     const bool share = (flags & SVX_SCAN_SHARED) ? true : (flags & SVX_SCAN_UNSHARED) ? false : n_words > SHARE_MEAN * (uint64_t)n_aln;
+    const uint32_t long_q = (!narrow && !share) ? MID_LONG_Q : LONG_Q;
     uint4* range_aln = reinterpret_cast<uint4*>(static_cast<char*>(d_ws) + ws_ranges_offset(n_aln, n_words));
     uint32_t range_shift = MIN_RANGE_SHIFT;              // ranges of frames_kernel: one frame's words -- measured (ONT-shaped launch): 275 us, 286 / 296 / 332 us with ranges of 2 / 4 / 16 frames
     static const int forced_shift = getenv("SVX_RANGE_SHIFT") ? atoi(getenv("SVX_RANGE_SHIFT")) : 0;      // (experiment)
     if (forced_shift >= (int)MIN_RANGE_SHIFT) range_shift = (uint32_t)forced_shift;
     static const unsigned count_lds = getenv("SVX_COUNT_LDS") ? (unsigned)atoi(getenv("SVX_COUNT_LDS")) : 0u;      // (experiment: caps the workgroups per CU)
 #define SVX_COUNT(G, Q, S) hipLaunchKernelGGL((count_kernel<G, Q, S>), dim3((n_aln + BLOCK / G - 1) / (BLOCK / G)), dim3(BLOCK), count_lds, st, \
-                                              d_cigar, d_cig_off, n_aln, min_sv, d_gap_off, d_stats, desc, n_tiles, frames, n_words, range_aln, range_shift)
+                                              d_cigar, d_cig_off, n_aln, min_sv, d_gap_off, d_stats, desc, n_tiles, frames, n_words, range_aln, range_shift, long_q)
     if (narrow) { if (share) SVX_COUNT(4, 4, true); else SVX_COUNT(4, 4, false); }
     else        { if (share) SVX_COUNT(8, SVX_WIDE_Q, true); else SVX_COUNT(8, SVX_WIDE_Q, false); }
 #undef SVX_COUNT
     if (share) {
         const uint64_t n_ranges = (n_words >> range_shift) + 1;
         hipLaunchKernelGGL(frames_kernel, dim3((uint32_t)((n_ranges + BLOCK / WAVE - 1) / (BLOCK / WAVE))), dim3(BLOCK), 0, st,
-                           d_cigar, d_cig_off, n_aln, min_sv, d_gap_off, d_stats, frames, n_words, range_aln, range_shift);
+                           d_cigar, d_cig_off, n_aln, min_sv, d_gap_off, d_stats, frames, n_words, range_aln, range_shift, long_q);
     }
     hipLaunchKernelGGL(offsets_kernel, dim3(n_tiles), dim3(BLOCK), 0, st, n_aln, d_gap_off, desc, totals, work);
     // resident waves (8 workgroups per CU at most); small inputs get one wave per 4 alignments
     const uint32_t emit_blocks = min(2048u, (n_aln + 15u) / 16u);
     hipLaunchKernelGGL(emit_kernel, dim3(emit_blocks), dim3(BLOCK), 0, st, d_cigar, d_cig_off, d_ref_start, min_sv, d_gaps, gaps_cap,
-                       totals, work, n_aln, frames, n_slots);
+                       totals, work, n_aln, frames, n_slots, long_q);
     return hipGetLastError() == hipSuccess ? SVX_OK : SVX_ELAUNCH;
 }
