@@ -408,8 +408,7 @@ def _worker_main(conn):
     # by hand, rarely.
     import gc
     import time
-    gc.collect()
-    gc.freeze()
+    gc.freeze()                               # (everything inherited from the owner, its garbage included, is never collected here: HelperPool.__init__)
     gc.disable()
     held = {}
     n_done = 0
@@ -483,6 +482,12 @@ class HelperPool:
     def __init__(self, n_workers, options, sample=None, table=None, fasta=None, want_tsv=False):
         _POOL_STATE.update(sample=sample, table=table, fasta=fasta, options=options, want_tsv=want_tsv)
         ctx = mp.get_context("fork")                         # helpers inherit the resident host arrays copy-on-write
+        # Cyclic garbage that holds device objects (a traceback that kept a failed call's tensors and events alive, say) is
+        # collected HERE, by the process that owns the device: a forked helper that collected it would free them through a
+        # runtime it must not touch (a segmentation fault in the helpers' first collection, seen once a test in the same process
+        # had raised out of kernels.cigar_scan).
+        import gc
+        gc.collect()
         self.conns, self.procs = [], []
         for _ in range(n_workers):
             a, b = ctx.Pipe(duplex=True)
