@@ -86,12 +86,14 @@ class AlexNet(torch.nn.Module):
         self.register_buffer("conv1_hwio", f32(params["conv1/weights"]).to(device))
         self.register_buffer("conv1_base", torch.from_numpy(base.astype(np.float32)).to(device))
         for name, nin, nout in _FCS:
-            w = np.asarray(params[f"{name}/weights"], np.float32)
+            # the checkpoint's [in, out] matrix goes to the device as it is and is permuted THERE (pure permutations: the same
+            # values bit for bit) -- on the host the three transposes were 0.43 s of a command line's 0.86 s before its first window
+            w = f32(params[f"{name}/weights"]).to(device)
             if name == "fc6":
                 # rows (h,w,c) of the reference's NHWC flatten -> (c/8, h, w, c%8): pool5 is flattened in C8
-                w = w.reshape(6, 6, 32, 8, nout).transpose(2, 0, 1, 3, 4).reshape(nin, nout)
-            wt = torch.from_numpy(np.ascontiguousarray(w.T))                                              # [out,in]
-            self.register_buffer(f"{name}_w", (kernels.pack_fc_weights(wt) if name != "fc8" else wt).to(device))
+                w = w.reshape(6, 6, 32, 8, nout).permute(2, 0, 1, 3, 4).reshape(nin, nout)
+            wt = w.t()                                                                                    # [out,in]
+            self.register_buffer(f"{name}_w", kernels.pack_fc_weights(wt) if name != "fc8" else wt.contiguous())
             self.register_buffer(f"{name}_b", f32(params[f"{name}/biases"]).to(device))
 
     def _convs(self, records):
