@@ -479,13 +479,27 @@ void emit_kernel(const uint32_t* __restrict__ cigar, const uint64_t* __restrict_
     const uint32_t n_work = totals->y;                     // alignments owning a long gap
     const uint32_t n_waves = gridDim.x * (BLOCK / WAVE);
     const unsigned long long below = (1ull << lane) - 1ull;
-    for (uint32_t k = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6); k < n_work; k += n_waves) {
-        const uint2 item = work[k];
+    // An owner's item, offsets and reference start are the head of a chain of dependent loads (item -> offsets -> records and
+    // words -> ...) that the wave would walk afresh for each of its owners: they are requested ahead -- the item two owners, the
+    // offsets one owner in front of their use -- at wave-uniform addresses (scalar loads into scalar registers: no vector
+    // register is held for them).
+    const uint32_t k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6)));
+    auto item_of = [&](uint32_t k) { return k < n_work ? work[k] : make_uint2(0u, 0u); };
+    uint2 item = item_of(k0), item_next = item_of(k0 + n_waves);
+    uint64_t off_b = cig_off[item.x], off_e = cig_off[item.x + 1];
+    int32_t start_ref = ref_start[item.x];
+    for (uint32_t k = k0; k < n_work; k += n_waves) {
         const uint32_t a = item.x;
         uint32_t dst = item.y;
-        const uint64_t b = cig_off[a];
-        const long long n = (long long)(cig_off[a + 1] - b);
-        uint32_t read_pos = 0, ref_pos = (uint32_t)ref_start[a];
+        const uint64_t b = off_b;
+        const long long n = (long long)(off_e - b);
+        uint32_t read_pos = 0, ref_pos = (uint32_t)start_ref;
+        // (the next owner's offsets and the item behind it: in flight while this owner is walked; n_aln > 0 here, and item_of()
+        // answers alignment 0 behind the list's end: valid addresses)
+        item = item_next;
+        item_next = item_of(k + 2 * n_waves);
+        off_b = cig_off[item.x]; off_e = cig_off[item.x + 1];
+        start_ref = ref_start[item.x];
         long long lim = n;                                     // (the narrow steps mask the words at and behind it)
         // the words of a step are requested two steps ahead (three register sets, statically rotated): the positions
         // are a serial chain over the steps, so an ultra-long read (ONT: 10^4-10^5 ops, 40-400 steps) would otherwise
