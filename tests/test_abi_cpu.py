@@ -26,3 +26,20 @@ def test_device_ops_refuse_cpu_tensors():
     from svision_amd import kernels
     with pytest.raises(_lib.SvxError):
         kernels.rasterize(torch.zeros((1, 12), dtype=torch.int32))
+
+
+def test_scan_flags_and_argument_counts_follow_the_header():
+    """The ctypes signatures carry as many arguments as the header's declarations (a call with one too few reads garbage), and the
+    shape flags kernels.cigar_scan passes are the header's SVX_SCAN_* values."""
+    header = open(os.path.join(ROOT, "include", "svx.h")).read()
+    flags = {k: int(v) for k, v in re.findall(r"#define\s+(SVX_SCAN_(?:LANES4|LANES8|SHARED|UNSHARED))\s+(\d+)u", header)}
+    assert flags == {"SVX_SCAN_LANES4": 1, "SVX_SCAN_LANES8": 2, "SVX_SCAN_SHARED": 4, "SVX_SCAN_UNSHARED": 8}
+    src = open(os.path.join(ROOT, "svision_amd", "kernels.py")).read()
+    assert '"groups4": 1 | 8, "groups8": 2 | 8, "groups4s": 1 | 4, "groups8s": 2 | 4' in src
+    text = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)
+    for name, (_res, args) in _lib.SYMBOLS.items():
+        m = re.search(r"\b%s\s*\(([^;{]*?)\)\s*;" % name, text, flags=re.S)
+        assert m, name
+        params = m.group(1).strip()
+        n = 0 if params in ("", "void") else params.count(",") + 1
+        assert n == len(args), (name, n, len(args))
