@@ -231,6 +231,88 @@ def resolve_defaults(args):
     return args
 
 
+def median_leg(legs):
+    """The repeat with the median wall time (upper median of an even count).  `seconds` is already the max over the ranks, so
+    every rank picks the same repeat."""
+    order = sorted(range(len(legs)), key=lambda i: legs[i]["seconds"])
+    return legs[order[len(order) // 2]]
+
+
+def repeats_summary(legs, rate):
+    """min / median / max of the repeats' rates (`rate`: leg -> sites/s) and their wall seconds, in run order."""
+    vals = sorted(rate(l) for l in legs)
+    return {"n": len(legs), "min": vals[0], "median": rate(median_leg(legs)), "max": vals[-1],
+            "seconds": [round(l["seconds"], 4) for l in legs]}
+
+
+def _clip(text, n):
+    text = str(text)
+    return text if len(text) <= n else text[:n - 3] + "..."
+
+
+LINE_LIMIT = 4096                             # bytes of the stdout line (VERDICT r5: a 29 KB line was not parsed by the driver)
+
+
+def compact_line(full, detail_path=None):
+    """The ONE stdout line: the contract's keys, the roofline and cpu_baseline objects, the parity verdict -- numbers only, every
+    string clipped -- built from the full record (which goes to --detail).  Always < LINE_LIMIT bytes and strict JSON
+    (no NaN / Infinity: such a value becomes null)."""
+    def num(v):
+        if isinstance(v, (bool, type(None), str)):
+            return v
+        if isinstance(v, (int, np.integer)):
+            return int(v)
+        v = float(v)
+        return v if np.isfinite(v) else None
+
+    cfg, rf = full.get("config", {}), full.get("roofline", {})
+    line = {k: num(full.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                          "scaling", "vs_baseline", "dtype", "data")}
+    if full.get("value_repeats"):
+        line["value_repeats"] = {k: ([num(x) for x in v] if isinstance(v, list) else num(v)) for k, v in full["value_repeats"].items()}
+    e2e = full.get("e2e") or {}
+    line["config"] = {
+        "workload": _clip(cfg.get("workload", ""), 240),
+        "timed_region": _clip(cfg.get("timed_region_kind") or cfg.get("timed_region", ""), 160),
+        "batch": num(cfg.get("batch")), "windows": num(full.get("steps")),
+        "sites_per_step": num(cfg.get("sites_per_step")), "images_per_site": num(cfg.get("images_per_site")),
+        "images_per_s": num(cfg.get("images_per_s")),
+        "resident_sites_per_s": num(cfg.get("resident_sites_per_s")),
+        "file_inclusive_over_resident": num(cfg.get("file_inclusive_over_resident")),
+        "bam_bytes": num(e2e.get("bam_bytes")), "ingest_engine": e2e.get("ingest_engine"),
+        "host_cores": num(cfg.get("host_cores")), "host_workers_per_rank": num(cfg.get("host_workers_per_rank")),
+        "rccl_world": num(cfg.get("rccl_world")), "imbalance": num(cfg.get("imbalance")),
+        "parallelism": _clip(cfg.get("parallelism", ""), 140),
+    }
+    cold = full.get("e2e_cold_cache") or {}
+    if cold:
+        line["config"]["cold_page_cache_sites_per_s"] = num(cold.get("value"))
+    line["roofline"] = {"kernel": _clip(rf.get("kernel_short") or rf.get("kernel", ""), 200)}
+    for k in ("bound", "achieved", "peak", "unit", "frac", "frac_stage_alone", "frac_algorithmic", "dense_stage_frac", "traffic",
+              "ms_per_batch", "device_busy_frac"):
+        line["roofline"][k] = num(rf.get(k))
+    hbm = full.get("roofline_hbm")
+    if hbm:
+        line["roofline_hbm"] = {k: num(v) if not isinstance(v, str) else _clip(v, 120) for k, v in hbm.items()}
+    cpu = full.get("cpu_baseline")
+    if cpu:
+        line["cpu_baseline"] = {"value": num(cpu.get("value")), "unit": cpu.get("unit"), "cores": num(cpu.get("cores")), "kind": cpu.get("kind"),
+                                "sample": _clip(cpu.get("sample_short") or cpu.get("sample", ""), 260)}
+    par = full.get("parity_check")
+    if par:
+        line["parity_check"] = {k: (num(v) if not isinstance(v, (list, dict)) else v) for k, v in par.items() if k != "per_window"}
+    if detail_path:
+        line["detail"] = detail_path
+    text = json.dumps(line, allow_nan=False)
+    if len(text) >= LINE_LIMIT:                   # cannot happen with the clips above; if it ever does, the strings go first
+        for obj, key in ((line["config"], "workload"), (line["roofline"], "kernel"), (line.get("cpu_baseline", {}), "sample"), (line["config"], "parallelism")):
+            if key in obj:
+                obj[key] = _clip(obj[key], 60)
+        text = json.dumps(line, allow_nan=False)
+    assert len(text) < LINE_LIMIT, len(text)
+    return text
+
+
 def rank_command(n_ranks, port, argv):
     """The launcher line of `python bench.py --gpus N` without a launcher: N ranks of this script on one node, rendezvous on
     127.0.0.1 (the container's host name may not resolve), the caller's own arguments passed through."""
@@ -297,6 +379,11 @@ def main():
     ap.add_argument("--no-cold-leg", action="store_true", help="skip the file-inclusive leg with the BAM's pages dropped from the page cache first (`e2e_cold_cache`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-calibration", action="store_true", help="skip the per-kernel timings outside the timed region")
+    ap.add_argument("--repeats", type=int, default=3, help="timed repeats of the job (each one times exactly --steps windows between its own barriers); "
+                                                           "`value` / `ms_per_step` are the repeat with the MEDIAN wall time, value_repeats holds min / median / max")
+    ap.add_argument("--detail", default="bench_detail.json", help="where the full record goes (decoder traces, per-kernel rooflines, the other legs, notes); "
+                                                                  "stdout carries ONE compact JSON line (< 4 KB) whose numbers are a subset of it")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity leg (the device path's TSV / site keys / softmax against the CPU port's on the windows the CPU baseline runs)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
@@ -347,7 +434,7 @@ def main():
 
     from svision_amd.pipeline import distinct_sites, stitch_windows
 
-    def run(seq, rescan=True):
+    def run(seq, rescan=True, sink=None):
         """seq: windows in task order (a chromosome's windows contiguous).  Windows complete in any order; a run of
         consecutive windows of one chromosome is one per-chromosome vote (sites spanning a window boundary are written once)."""
         sites = images = records = 0
@@ -369,6 +456,8 @@ def main():
         for res in hot.run_windows(seq, rescan=rescan):
             images += res.n_images
             done[res.wid] = res
+            if sink is not None:                                                  # the parity leg: the window's TSV text and predictions
+                sink[(res.chrom, res.start, res.end)] = (res.tsv, res.classes, res.probs)
             run = runs[run_of[res.wid]]
             run[2] -= 1
             if run[2] == 0:
@@ -420,26 +509,34 @@ def main():
     # ---- the timed region of `value`: the job from its BAM (file-inclusive).  Its own barrier + synchronize on both sides,
     # max over ranks (run_from_file).
     e2e_block = e2e_other = None
+    e2e_legs = []
     if e2e is not None and not args.resident:
-        net.executed.zero_()
-        e2e_block = run_from_file(args, e2e, hot, run, fasta, opts, dev, sync_all, cores, world, workers, grouped, engine=os.environ.get("SVX_INGEST", "auto"), keep=True)
-        e2e_block["stage"] = stage_stats()
+        for _r in range(max(1, args.repeats)):
+            net.executed.zero_()
+            leg = run_from_file(args, e2e, hot, run, fasta, opts, dev, sync_all, cores, world, workers, grouped, engine=os.environ.get("SVX_INGEST", "auto"), keep=True)
+            leg["stage"] = stage_stats()
+            e2e_legs.append(leg)
+        e2e_block = median_leg(e2e_legs)
     # ---- the same job with the alignments decoded and resident in HBM (the headline of rounds 1-3; --resident: `value`)
-    sync_all()
-    net.executed.zero_()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    sites, images, records, scores = run(timed)
-    # the single cross-shard exchange of the job: score range + record gather (dist.py)
-    sdist.exchange_score_range(scores)
-    sdist.gather_texts({"rank%d" % rank: "%d records" % records})
-    sync_all()
-    dt = time.perf_counter() - t0
-    if os.environ.get("SVX_TIMING") and rank == 0:
-        print("owner thread seconds over %.3f s: %s" % (dt, {k: round(v, 3) for k, v in getattr(hot, "owner_profile", {}).items()}), file=sys.stderr)
-    res_stage = stage_stats()
-    tot, tmax = reduce_sum_max([sites, images, dt])
-    res_sites, res_images, dt = float(tot[0]), float(tot[1]), float(tmax[2])
+    res_legs = []
+    for _r in range(max(1, args.repeats)):
+        sync_all()
+        net.executed.zero_()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sites, images, records, scores = run(timed)
+        # the single cross-shard exchange of the job: score range + record gather (dist.py)
+        sdist.exchange_score_range(scores)
+        sdist.gather_texts({"rank%d" % rank: "%d records" % records})
+        sync_all()
+        dt = time.perf_counter() - t0
+        if os.environ.get("SVX_TIMING") and rank == 0:
+            print("owner thread seconds over %.3f s: %s" % (dt, {k: round(v, 3) for k, v in getattr(hot, "owner_profile", {}).items()}), file=sys.stderr)
+        st = stage_stats()
+        tot, tmax = reduce_sum_max([sites, images, dt])
+        res_legs.append({"seconds": float(tmax[2]), "sites": float(tot[0]), "images": float(tot[1]), "stage": st})
+    res_leg = median_leg(res_legs)
+    res_stage, res_sites, res_images, dt = res_leg["stage"], res_leg["sites"], res_leg["images"], res_leg["seconds"]
     sweep = []
     if e2e is not None and args.e2e_sweep:
         for spec in args.e2e_sweep.split(";"):
@@ -471,10 +568,7 @@ def main():
         # on the device; the other: libdeflate on the host's threads)
         first = e2e_block["ingest_engine"] if e2e_block is not None else None
         other = os.environ.get("SVX_INGEST", "auto") if first is None else ("cpu" if first == "gpu" else "gpu")
-        e2e_other = run_from_file(args, e2e, hot, run, fasta, opts, dev, sync_all, cores, world, workers, grouped, engine=other, keep=False)
-    elif e2e is not None:
-        import shutil
-        shutil.rmtree(e2e["dir"], ignore_errors=True)
+        e2e_other = run_from_file(args, e2e, hot, run, fasta, opts, dev, sync_all, cores, world, workers, grouped, engine=other, keep=True)
 
     # the N-GPU first-contact checklist (every rank takes part in the two small gathers)
     file_bytes = [int(e2e["bytes"]) if e2e is not None else 0]
@@ -590,11 +684,21 @@ def main():
                      "resident_leg": {"frac_executed": rep_res["executed_tflops"] * 1e12 / F32_MFMA_PEAK, "ms_per_batch": rep_res["ms_batch"],
                                       "batches": rep_res["batches"], "device_busy_frac": rep_res["busy"]}},
     }
+    line["config"]["timed_region_kind"] = (("file-inclusive: BAM on local disk (%.2f GB, page cache warm) -> read, device BGZF inflate + record walk, scan, collection, "
+                                            "encode + CNN, vote, cross-rank exchange" % (e2e_block["bam_bytes"] / 1e9)) if headline_e2e else
+                                           "resident: alignments decoded and in HBM before the timed region")
+    line["roofline"]["kernel_short"] = ("device stage per batch of %d images: encode_conv1 + conv_wave_list x4 (fp32 MFMA 32x32x2, active pixels) + pool/LRN x2 + "
+                                        "fc_splitk x2 + fc8_softmax; HIP events around every launch of the timed region" % B)
+    legs = e2e_legs if headline_e2e else res_legs
+    line["value_repeats"] = repeats_summary(legs, lambda l: l["sites"] / l["seconds"])
+    line["resident_repeats"] = repeats_summary(res_legs, lambda l: l["sites"] / l["seconds"])
     if e2e_block is not None:
-        e2e_block.pop("stage", None)
+        for l in e2e_legs:
+            l.pop("stage", None)
         e2e_block["resident_sites_per_s"] = res_sites / dt
         e2e_block["ratio_to_resident"] = e2e_block["value"] / max(res_sites / dt, 1e-9)
         line["e2e"] = e2e_block
+        line["e2e_repeats"] = [l for l in e2e_legs if l is not e2e_block]
     if e2e_cold is not None:
         e2e_cold["ratio_to_resident"] = e2e_cold["value"] / max(res_sites / dt, 1e-9)
         e2e_cold["note"] = ("the file-inclusive leg once more with the BAM (and its index) dropped from the page cache first (fsync + posix_fadvise DONTNEED; "
@@ -608,13 +712,101 @@ def main():
         line["e2e_sweep"] = sweep
     if calib:
         line["roofline_kernels"] = calib
+        scan_k, ras_k = calib.get("cigar_scan (4 kernels)"), next((v for k, v in calib.items() if k.startswith("raster_kernel")), None)
+        if scan_k and ras_k:                  # the two HBM-bound kernels of the path, beside the MFMA-bound stage
+            line["roofline_hbm"] = {"peak": HBM_PEAK / 1e9, "unit": "GB/s", "cigar_scan_achieved": scan_k["achieved"], "cigar_scan_frac": scan_k["frac"],
+                                    "raster_achieved": ras_k["achieved"], "raster_frac": ras_k["frac"]}
+    # ---- parity leg (untimed): the windows the CPU baseline is about to run, through the path `value` was measured on, with the
+    # helpers returning their TSV text and the owner keeping the predictions
+    gpu_side = None
+    parity_windows = cpu_pool.windows_of_run(e2e["windows"] if headline_e2e else windows) if cpu_pool is not None and not args.no_parity else []
+    if parity_windows:
+        gpu_side = {}
+        hot.pool.set_option("want_tsv", True)
+        hot.keep_predictions = True
+        if headline_e2e:
+            sub = dict(e2e, header_references=e2e["references"], windows=parity_windows)
+            sub["references"] = [n for n in e2e["references"] if any(w[0] == n for w in parity_windows)]
+            run_from_file(args, sub, hot, run, fasta, opts, dev, sync_all, cores, world, workers, grouped,
+                          engine=os.environ.get("SVX_INGEST", "auto"), keep=True, sink=gpu_side)
+        else:
+            run(parity_windows, sink=gpu_side)
+        hot.keep_predictions = False
     hot.close()
+    if e2e is not None:
+        import shutil
+        shutil.rmtree(e2e["dir"], ignore_errors=True)
+    parity_ok = True
     if cpu_pool is not None:
-        line["cpu_baseline"] = cpu_pool.run(windows)
+        line["cpu_baseline"], cpu_side = cpu_pool.run(e2e["windows"] if headline_e2e and parity_windows else windows)
+        if gpu_side is not None:
+            line["parity_check"] = parity_check(gpu_side, cpu_side, "file-inclusive" if headline_e2e else "resident")
+            parity_ok = line["parity_check"]["ok"]
     if rank == 0:
-        print(json.dumps(line))
+        detail = None
+        if args.detail:
+            try:
+                with open(args.detail, "w") as f:
+                    json.dump(line, f, indent=1, default=str)
+                detail = args.detail
+            except OSError as exc:
+                print("bench: could not write %s: %s" % (args.detail, exc), file=sys.stderr)
+        print(json.dumps({k: line[k] for k in ("value_repeats", "resident_repeats", "parity_check") if k in line}), file=sys.stderr)
+        sys.stderr.flush()
+        print(compact_line(line, detail))
+        sys.stdout.flush()
     if grouped:
         tdist.destroy_process_group()
+    if not parity_ok:
+        print("bench: PARITY MISMATCH between the device path and the CPU port: %s" % json.dumps(line["parity_check"], default=str)[:2000], file=sys.stderr)
+        sys.exit(3)
+
+
+SOFTMAX_TOL = 1e-3                            # BASELINE.json north_star: CNN softmax within 1e-3 fp32
+
+
+def parity_check(gpu_side, cpu_side, path):
+    """The device path against the CPU port on the windows both ran.  gpu_side: {window: (TSV text, classes, probs)} from the
+    pipeline `value` was measured on; cpu_side: per CPU-baseline process {window, tsv_sha, sites_sha, n_lines, index (the TSV
+    lines it classified), classes, probs}.  Bit-exact: the window's segment TSV (every pair line: region key, both segments,
+    lengths -- output_clusters.py:84-89) and the ordered list of distinct site keys; within SOFTMAX_TOL: the softmax of every
+    image the port classified (predict.py:209)."""
+    import hashlib
+    per, seen = [], {}
+    tsv_equal = sites_equal = True
+    worst, images, class_diff = 0.0, 0, 0
+    for c in cpu_side:
+        w = tuple(c["window"])
+        if w not in gpu_side:
+            per.append({"window": list(w), "error": "not run by the device leg"})
+            tsv_equal = sites_equal = False
+            continue
+        tsv, classes, probs = gpu_side[w]
+        if w not in seen:
+            regions = []
+            for ln in (tsv or "").splitlines():
+                r = ln.split("\t", 1)[0]
+                if not regions or regions[-1] != r:
+                    regions.append(r)
+            seen[w] = (hashlib.sha256((tsv or "").encode()).hexdigest(), hashlib.sha256("\n".join(regions).encode()).hexdigest(),
+                       (tsv or "").count("\n"), len(set(regions)))
+        g_tsv, g_sites, g_lines, g_nsites = seen[w]
+        t_ok, s_ok = g_tsv == c["tsv_sha"] and g_lines == c["n_lines"], g_sites == c["sites_sha"]
+        tsv_equal, sites_equal = tsv_equal and t_ok, sites_equal and s_ok
+        delta = 0.0
+        if len(c["index"]) and t_ok:
+            idx = np.asarray(c["index"], np.int64)
+            delta = float(np.abs(np.asarray(probs)[idx].astype(np.float64) - c["probs"].astype(np.float64)).max())
+            class_diff += int((np.asarray(classes)[idx] != c["classes"]).sum())
+            images += len(idx)
+        worst = max(worst, delta)
+        per.append({"window": list(w), "lines": g_lines, "sites": g_nsites, "tsv_equal": t_ok, "sites_equal": s_ok,
+                    "images_compared": len(c["index"]) if t_ok else 0, "max_softmax_delta": delta})
+    ok = bool(tsv_equal and sites_equal and worst <= SOFTMAX_TOL and per)
+    return {"ok": ok, "path": path, "windows": len(seen), "tsv_equal": bool(tsv_equal), "sites_equal": bool(sites_equal),
+            "tsv_lines": int(sum(v[2] for v in seen.values())), "sites": int(sum(v[3] for v in seen.values())),
+            "images_compared": images, "max_softmax_delta": worst, "softmax_tol": SOFTMAX_TOL, "argmax_differs": class_diff,
+            "per_window": per}
 
 
 def cached_fraction(path):
@@ -677,7 +869,7 @@ def filesystem_of(path):
     return best[1]
 
 
-def run_from_file(args, e2e, hot, run, fasta, opts, dev, sync_all, cores, world, workers, grouped, engine="cpu", keep=False, cold=False):
+def run_from_file(args, e2e, hot, run, fasta, opts, dev, sync_all, cores, world, workers, grouped, engine="cpu", keep=False, cold=False, sink=None):
     """The file-inclusive leg (wall of Step 1 + Step 2 with the BAM on local disk): a timed region of its
     own that starts with nothing but the file -- svx_bam_stream_* reads and inflates it on host threads chromosome by
     chromosome, every chromosome is uploaded and scanned on the device when it arrives and handed to the helpers through
@@ -702,7 +894,7 @@ def run_from_file(args, e2e, hot, run, fasta, opts, dev, sync_all, cores, world,
     feed = ChromosomeFeed(e2e["path"], fasta, opts, refs, header_refs, lens, device=dev, index=e2e["path"] + ".bai", threads=threads, engine=engine, tasks=tasks)
     hot.feed = feed
     try:
-        sites, images, records, scores = run(e2e["windows"], rescan=False)
+        sites, images, records, scores = run(e2e["windows"], rescan=False, sink=sink)
         sdist.exchange_score_range(scores)
         sdist.gather_texts({"rank%d" % sdist.world()[0]: "%d records" % records})
         sync_all()
@@ -876,13 +1068,14 @@ def _cpu_worker(conn, table, fasta, opts):
             sample = Sample.with_scan(sub, fasta, opts.min_sv_size, scan)
             net = TorchAlexNet(random_weights(0), device="cpu")
         _sigs, clusters = detect_window(opts, sample, chrom, start, end)
-        lines = collect_pair_lines(clusters, opts)
+        all_lines = collect_pair_lines(clusters, opts)
         regions = []
-        for ln in lines:                                      # this process's share of the window's sites
+        for ln in all_lines:                                  # this process's share of the window's sites
             if not regions or regions[-1] != ln.region:
                 regions.append(ln.region)
         mine = set(regions[part::parts])
-        lines = [ln for ln in lines if ln.region in mine]
+        index = [i for i, ln in enumerate(all_lines) if ln.region in mine]
+        lines = [all_lines[i] for i in index]
         B = 128                                               # reference default batch (SVision:88)
         recs = np.asarray([ln.record() for ln in lines], np.int32).reshape(-1, 12)
         done, outs = 0, []
@@ -897,7 +1090,17 @@ def _cpu_worker(conn, table, fasta, opts):
             voter.feed_batch([ln.label() for ln in lines[:done]], np.concatenate([o[0] for o in outs]), np.concatenate([o[1] for o in outs]))
             voter.finish()
             sites = len({ln.region for ln in lines[:done]})
-        conn.send((sites, done, time.perf_counter() - t0))
+        seconds = time.perf_counter() - t0
+        # what bench.py's parity_check compares with the device path (outside this process's own seconds): digests of the window's
+        # whole TSV and of its ordered site keys, and the softmax of the images classified here
+        import hashlib
+        text = "".join(ln.text() for ln in all_lines)
+        side = {"window": (chrom, start, end), "tsv_sha": hashlib.sha256(text.encode()).hexdigest(),
+                "sites_sha": hashlib.sha256("\n".join(regions).encode()).hexdigest(), "n_lines": len(all_lines),
+                "index": np.asarray(index[:done], np.int64),
+                "classes": np.concatenate([o[0] for o in outs])[:done] if outs else np.empty(0, np.int64),
+                "probs": np.concatenate([o[1] for o in outs])[:done] if outs else np.empty((0, 5), np.float32)}
+        conn.send((sites, done, seconds, side))
 
 
 class CpuBaselinePool:
@@ -916,9 +1119,21 @@ class CpuBaselinePool:
             self.conns.append(a)
             self.procs.append(p)
 
+    def windows_of_run(self, windows):
+        """The distinct windows run(windows) hands to the processes, in order."""
+        P = len(self.conns)
+        per_win = max(1, P // max(len(windows), 1))
+        out = []
+        for i in range(P):
+            w = tuple(windows[(i // per_win) % len(windows)])
+            if w not in out:
+                out.append(w)
+        return out
+
     def run(self, windows, images_per_proc=None):
         """Every process takes 1/P of the sites of one window (round-robin over the windows) and at most `images_per_proc`
-        of their images: about 10-30 s of wall time; value = sites classified by the pool / wall time."""
+        of their images: about 10-30 s of wall time; value = sites classified by the pool / wall time.
+        -> (the cpu_baseline object, per process what parity_check compares)."""
         P = len(self.conns)
         if images_per_proc is None:                           # ~20 s of wall: a 1-thread process classifies 15-80 images per second
             images_per_proc = 192 if P >= 64 else 1536
@@ -934,11 +1149,13 @@ class CpuBaselinePool:
         for p in self.procs:
             p.join(timeout=5)
         sites, images = sum(g[0] for g in got), sum(g[1] for g in got)
-        return {"value": sites / wall, "unit": "sites/s", "cores": P, "kind": "port", "cpus_visible": self.visible,
+        short = ("%d single-thread processes (the reference's -t P): oracle C scan + host collection of one 10 Mb window each, oracle C rasteriser + "
+                 "PyTorch-CPU fp32 AlexNet (batch 128) + vote on <= %d images: %d sites, %d images in %.1f s wall" % (P, images_per_proc, sites, images, wall))
+        return {"value": sites / wall, "unit": "sites/s", "cores": P, "kind": "port", "cpus_visible": self.visible, "sample_short": short,
                 "sample": "pool of %d single-thread processes (the reference's -t P, SVision:261,311), each: C oracle scan of its window's "
                           "chromosome, host collection of one 10 Mb window, then C oracle rasteriser + PyTorch-CPU fp32 AlexNet (batch 128, "
                           "1 thread) + vote on its 1/%d share of that window's sites, capped at %d images: %d sites, %d images in %.1f s "
-                          "wall (slowest process %.1f s)" % (P, per_win, images_per_proc, sites, images, wall, max(g[2] for g in got))}
+                          "wall (slowest process %.1f s)" % (P, per_win, images_per_proc, sites, images, wall, max(g[2] for g in got))}, [g[3] for g in got]
 
 
 if __name__ == "__main__":

@@ -36,7 +36,7 @@ _PAD_REC = parse_data_fields(PAD_DATA.split("_"))
 
 class WindowResult:
     __slots__ = ("chrom", "start", "end", "lines", "n_images", "packed", "vcf", "scores", "n_sites", "n_records",
-                 "records", "done_event", "t_device", "wid", "tsv", "head", "tail", "edges", "sample")
+                 "records", "done_event", "t_device", "wid", "tsv", "head", "tail", "edges", "sample", "classes", "probs")
 
 
 def _collect_lines(sample, options, chrom, start, end):
@@ -397,6 +397,7 @@ def _worker_main(conn):
        owner -> ("scan", min_sv, gaps.npy, gap_off.npy, stats.npy)   (HelperPool.attach_scan: helpers forked before the scan)
        owner -> ("chrom", key, meta) / ("drop", key)   a chromosome of a file-driven run arrives in / leaves shared memory
                                                         (ingest.ChromosomeFeed); key None = the Sample of the fork / "scan"
+       owner -> ("opt", name, value)   a pool option changed (HelperPool.set_option: want_tsv on for bench.py's parity leg)
        owner -> ("stop",)"""
     sample, options = _POOL_STATE["sample"], _POOL_STATE["options"]
     from .segmentplot import run_hash_lineplot
@@ -432,6 +433,9 @@ def _worker_main(conn):
             continue
         if msg[0] == "drop":
             samples.pop(msg[1], None)
+            continue
+        if msg[0] == "opt":
+            _POOL_STATE[msg[1]] = msg[2]
             continue
         if msg[0] == "scan":                                  # forked before the device scan existed: build the Sample now
             from .sample import Sample
@@ -512,6 +516,11 @@ class HelperPool:
         for c in self.conns:
             c.send(("scan", sample.min_sv, *paths))
 
+    def set_option(self, name, value):
+        """Change a pool option (``want_tsv``) in every helper; takes effect with the next window a helper finishes."""
+        for c in self.conns:
+            c.send(("opt", name, value))
+
     def close(self):
         for c in self.conns:
             try:
@@ -589,6 +598,7 @@ class PooledHotPath(HotPath):
         self._helper_has_dict = [False] * len(self.conns)              # per helper: has it received the header's sequence dictionary
         self._feed = None
         self.feed = feed if feed is not None else StaticFeed(sample)   # where a chromosome's Sample comes from
+        self.keep_predictions = False                                  # WindowResult.classes / .probs: the window's predictions in TSV order (bench.py's parity leg)
 
     @property
     def feed(self):
@@ -673,6 +683,7 @@ class PooledHotPath(HotPath):
         scans = collections.deque()     # handles of the window scans enqueued ahead (Sample.rescan_window_async)
         ahead = min(16, len(self.conns) + 2)    # every helper can turn idle in one burst; a scan takes ~15 ms on the saturated device
         remaining = len(windows)
+        kept = {}                     # wid -> [(window offset, classes, probs)] (keep_predictions)
         prof = self.owner_profile = collections.defaultdict(float)
         clock = time.perf_counter
         t_loop = clock()
@@ -771,6 +782,8 @@ class PooledHotPath(HotPath):
                     if w is None or w.get("drop"):
                         continue
                     w["chunks"].append((w_off, classes[g_off:g_off + k], probs[g_off:g_off + k]))     # groups complete in launch order: window order
+                    if self.keep_predictions:
+                        kept.setdefault(wid, []).append((w_off, np.array(classes[g_off:g_off + k]), np.array(probs[g_off:g_off + k])))
                     w["got"] += k
                     touched[wid] = True
                 for wid in touched:
@@ -815,6 +828,11 @@ class PooledHotPath(HotPath):
                     res.vcf, res.scores, res.n_sites, res.n_images = vcf, scores, n_sites, n_images
                     res.head, res.tail, res.edges = head, tail, edges
                     res.n_records = vcf.count("\n")
+                    res.classes = res.probs = None
+                    if self.keep_predictions:
+                        parts = sorted(kept.pop(wid, []), key=lambda t: t[0])
+                        res.classes = np.concatenate([t[1] for t in parts]) if parts else np.empty(0, np.int64)
+                        res.probs = np.concatenate([t[2] for t in parts]) if parts else np.empty((0, 5), np.float32)
                     del busy[ci]
                     idle.append(ci)
                     remaining -= 1

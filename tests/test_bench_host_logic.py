@@ -163,3 +163,66 @@ def test_more_ranks_than_devices_is_refused_under_nccl(monkeypatch):
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
     with pytest.raises(RuntimeError, match="8 ranks on this node but 2 visible GPU"):
         sdist.init_from_env()
+
+
+def test_stdout_line_is_compact_strict_json_whatever_the_record_holds():
+    """a 29 KB line (decoder traces inside) was not parsed by the driver.  The stdout line is built from the full
+    record by bench.compact_line: < 4 KB, strict JSON, the contract's keys + roofline + cpu_baseline + parity verdict."""
+    import json
+    b = _bench()
+    with open(os.path.join(ROOT, "profiles", "r05_bench_steps20_a.json")) as f:
+        full = json.load(f)                                   # a real full record of round 5 (29 KB)
+    assert len(json.dumps(full)) > 20000
+    full["value_repeats"] = {"n": 3, "min": 3500.0, "median": 3600.0, "max": 3700.0, "seconds": [0.39, 0.38, 0.40]}
+    full["parity_check"] = {"ok": True, "path": "file-inclusive", "windows": 16, "tsv_equal": True, "sites_equal": True, "tsv_lines": 29000,
+                            "sites": 1100, "images_compared": 24576, "max_softmax_delta": 3.1e-6, "softmax_tol": 1e-3, "argmax_differs": 0,
+                            "per_window": [{"window": ["chr1", 0, 10000000], "lines": 1800}] * 16}
+    full["roofline"]["traffic"] = float("nan")                # a NaN must not reach the line (json.dumps would print a bare NaN)
+    full["config"]["workload"] = full["config"]["workload"] * 20
+    text = b.compact_line(full, "bench_detail.json")
+    assert len(text) < 4096 and "\n" not in text
+    line = json.loads(text, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))      # strict: no NaN / Infinity
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "parity_check", "value_repeats"):
+        assert key in line, key
+    assert line["value"] == full["value"] and line["ms_per_step"] == full["ms_per_step"] and line["steps"] == full["steps"]
+    for key in ("workload", "timed_region", "batch", "windows", "sites_per_step", "images_per_site", "resident_sites_per_s"):
+        assert key in line["config"], key
+    for key in ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_stage_alone", "frac_algorithmic", "traffic"):
+        assert key in line["roofline"], key
+    assert line["roofline"]["traffic"] is None and line["roofline"]["bound"] == "mfma"
+    assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-9
+    assert set(line["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"}
+    assert "per_window" not in line["parity_check"] and line["parity_check"]["ok"] is True
+    assert not any(k in line for k in ("e2e", "e2e_cold_cache", "roofline_kernels"))       # those live in the detail file only
+
+
+def test_median_leg_and_repeats_summary():
+    b = _bench()
+    legs = [{"seconds": 0.40, "sites": 1400}, {"seconds": 0.36, "sites": 1400}, {"seconds": 0.38, "sites": 1400}]
+    assert b.median_leg(legs) is legs[2]
+    rep = b.repeats_summary(legs, lambda l: l["sites"] / l["seconds"])
+    assert rep["n"] == 3 and rep["min"] < rep["median"] < rep["max"] and rep["median"] == 1400 / 0.38
+    assert b.median_leg(legs[:1]) is legs[0] and b.median_leg(legs[:2]) is legs[0]         # upper median of an even count = the slower one
+
+
+def test_parity_check_compares_digests_and_softmax():
+    import hashlib
+    b = _bench()
+    tsv = "chr1+10+20+5\tA\n" "chr1+10+20+5\tB\n" "chr1+90+99+7\tC\n"
+    regions = ["chr1+10+20+5", "chr1+90+99+7"]
+    probs = np.full((3, 5), 0.2, np.float32)
+    gpu = {("chr1", 0, 100): (tsv, np.zeros(3, np.int64), probs)}
+    cpu = [{"window": ("chr1", 0, 100), "tsv_sha": hashlib.sha256(tsv.encode()).hexdigest(),
+            "sites_sha": hashlib.sha256("\n".join(regions).encode()).hexdigest(), "n_lines": 3, "index": np.array([0, 2]),
+            "classes": np.zeros(2, np.int64), "probs": probs[[0, 2]] + np.float32(5e-4)}]
+    out = b.parity_check(gpu, cpu, "resident")
+    assert out["ok"] and out["tsv_equal"] and out["sites_equal"] and out["windows"] == 1 and out["images_compared"] == 2
+    assert 4e-4 < out["max_softmax_delta"] < 6e-4 and out["sites"] == 2 and out["tsv_lines"] == 3
+    cpu[0]["probs"] = probs[[0, 2]] + np.float32(2e-3)
+    assert not b.parity_check(gpu, cpu, "resident")["ok"]                                  # beyond the 1e-3 the north star allows
+    cpu[0]["probs"] = probs[[0, 2]]
+    cpu[0]["tsv_sha"] = "0" * 64
+    bad = b.parity_check(gpu, cpu, "resident")
+    assert not bad["ok"] and not bad["tsv_equal"] and bad["sites_equal"]
+    assert not b.parity_check({}, cpu, "resident")["ok"]                                   # a window the device leg never ran
