@@ -131,6 +131,7 @@ class ChromosomeFeed:
         self._epoch, self._replan, self._acked = 0, None, (0, 0)   # slices cut again with a larger margin (_run -> _decode)
         self._t0 = time.perf_counter()
         self._stop = False
+        self._b_done = False                                   # stage B has left its loop (whatever the reason): nothing will be acknowledged any more
         self._slot_lock, self._free_slots, self._n_slots = threading.Lock(), [], 0
         self.thread = threading.Thread(target=self._run, name="svx-feed", daemon=True)
         self.thread.start()
@@ -306,6 +307,7 @@ class ChromosomeFeed:
             except queue.Empty:
                 pass
         finally:
+            self._b_done = True                                # stage A's settle() / put() must not wait for acknowledgements that cannot come
             try:
                 spill.put(None)
             except NameError:
@@ -380,7 +382,7 @@ class ChromosomeFeed:
         import logging
 
         def put(item):
-            while not self._stop:
+            while not self._stop and not self._b_done:
                 try:
                     decoded.put(item, timeout=0.2)
                     return True
@@ -417,7 +419,7 @@ class ChromosomeFeed:
 
         def settle():
             """Wait until stage B has looked at everything put in this epoch: the LAST slice may be the one it rejects."""
-            while not self._stop and replan_wanted() is None and self._acked != (state["epoch"], state["put"]) and state["put"]:
+            while not self._stop and not self._b_done and replan_wanted() is None and self._acked != (state["epoch"], state["put"]) and state["put"]:
                 time.sleep(0.0005)
             return replan_wanted()
 

@@ -274,6 +274,15 @@ class DeviceDecoder:
                 # length in front of it -- and the slice holds the records in front of THAT one)
                 vlo, vhi = voff_at(span, lo - margin), (span[1] if j == len(wins) and hi >= self.lengths[t] else voff_at(span, hi + 2 * margin))
                 vhi = max(vhi, vlo)
+                if vhi == vlo and vlo < span[1]:
+                    # Both look-ups found the SAME record: either a coverage gap (it starts behind the slice) or ONE record that spans
+                    # the whole slice, margins included (a small --window_size under a long read or contig) -- then it, and every
+                    # record behind it that starts inside the windows, must not be dropped as "a slice without a record" (ADVICE r5).
+                    # The slice takes the records up to the next entry of the index that lies behind this one: it is never empty
+                    # here, and the consumer's completeness check (ChromosomeFeed._slice_complete) sees the spanning record.
+                    tail = span[2][max(0, (hi + 2 * margin) >> 14):]
+                    later = tail[tail > vlo]
+                    vhi = int(min(int(later[0]), int(span[1]))) if later.size else int(span[1])
                 units.append(Unit(t, lo, hi, vlo, vhi, left_edge=None if vlo == span[0] else max(0, (lo - margin) >> 14 << 14), to_end=vhi == span[1],
                                   first=i == 0, last=j == len(wins), windows=wins[i:j]))
                 i = j
