@@ -111,20 +111,6 @@ int svx_cigar_scan(const uint32_t* d_cigar, const uint64_t* d_cig_off,
                    SvxGap* d_gaps, uint64_t gaps_cap, uint32_t* d_gap_off,
                    int32_t* d_stats, void* d_ws, uint64_t ws_bytes, uint32_t flags, void* stream);
 
-/* The same scan -- same inputs, same outputs bit for bit -- for LONG alignments (ONT ultra-long reads, assembly contigs: 10^3-10^6
- * operations each) in ONE pass: the flat array of words is cut into chunks of 2,048, one wave per chunk whatever alignment the
- * words belong to; the sums an alignment carries into a chunk and the number of long gaps in front of it come from a decoupled
- * look-back over the chunks in front (svx_cigar_flat.hip).  svx_cigar_scan walks an alignment of more than 512 words with one
- * wave, twice (0.17 of the HBM peak on an ONT-shaped launch); this form reads every word once with every wave of the chip.
- * Slower than svx_cigar_scan on short alignments (a chunk of HiFi reads holds a dozen boundaries): callers pick by the mean
- * number of words per alignment (svision_amd/kernels.py: >= 1,024).
- *   n_words_max  an upper bound of d_cig_off[n_aln] - d_cig_off[0] (the launch is sized by it; the offsets are device memory)
- *   d_ws         svx_cigar_scan_flat_ws_bytes(n_words_max) bytes, 8-byte aligned (SVX_EINVAL if ws_bytes is less) */
-size_t svx_cigar_scan_flat_ws_bytes(uint64_t n_words_max);
-int svx_cigar_scan_flat(const uint32_t* d_cigar, const uint64_t* d_cig_off, const int32_t* d_ref_start, uint32_t n_aln,
-                        uint64_t n_words_max, int32_t min_sv, SvxGap* d_gaps, uint64_t gaps_cap, uint32_t* d_gap_off,
-                        int32_t* d_stats, void* d_ws, uint64_t ws_bytes, void* stream);
-
 /* Similarity-image rasteriser (+ mean subtraction, + layout).
  * Replaces BatchGenerator.next_batch's per-image loop
  * (reference src/network/create_batch.py:103-152) and PlotSingleImg.plot
@@ -294,24 +280,13 @@ void           svx_bam_export(void* handle, int threads, int32_t* tid, int32_t* 
 const uint8_t* svx_bam_seq(void* handle);
 void           svx_bam_close(void* handle);
 
-/* BGZF inflate on the device (svx_inflate.hip): every block of a launch decoded by one lane, all blocks in parallel.
- * Replaces the host-side DEFLATE decoding of htslib / pysam behind run_collection.py:23-26 where host cores are the
- * scarce resource.  d_comp: the compressed bytes as they sit in the file (16-byte aligned -- SVX_EINVAL otherwise --,
- * readable up to the next multiple of 16 behind the last payload); d_src_off / d_src_len [n]: byte offset in d_comp and size of every block's
- * DEFLATE payload (behind the block header, in front of CRC32 + ISIZE); d_dst_off [n + 1]: running sum of the ISIZE
- * fields = where every block's bytes go in d_out; d_status [n]: 0 = the block inflated to exactly ISIZE bytes,
- * anything else = corrupt (the caller falls back to the host decoder). */
-int            svx_bgzf_inflate(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len,
-                                const uint64_t* d_dst_off, uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, void* stream);
-/* svx_bgzf_inflate picks between two versions of the lane-per-block kernel by the size of the launch; by name:
- * _lds: the lane's symbol tables in LDS (420 B per lane: 98,304 blocks on the chip at once; 64-74 ms per round),
- * _private: the literal / length symbols in private memory (96 B of LDS per lane: 196,608 blocks at once; 68-125 ms),
- * which takes the launches the first would need two rounds for. */
-int            svx_bgzf_inflate_lds(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len,
-                                    const uint64_t* d_dst_off, uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, void* stream);
-int            svx_bgzf_inflate_private(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len,
-                                        const uint64_t* d_dst_off, uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, void* stream);
-/* The same contract in two kernels (svx_inflate2.hip): (A) one WAVE per block decodes the Huffman code in parallel -- 64
+/* BGZF inflate on the device (svx_inflate2.hip).  Replaces the host-side DEFLATE decoding of htslib / pysam behind
+ * run_collection.py:23-26 where host cores are the scarce resource.  d_comp: the compressed bytes as they sit in the file
+ * (16-byte aligned -- SVX_EINVAL otherwise --, readable up to the next multiple of 16 behind the last payload); d_src_off /
+ * d_src_len [n]: byte offset in d_comp and size of every block's DEFLATE payload (behind the block header, in front of CRC32 +
+ * ISIZE); d_dst_off [n + 1]: running sum of the ISIZE fields = where every block's bytes go in d_out; d_status [n]: 0 = the
+ * block inflated to exactly ISIZE bytes, anything else = corrupt (the caller falls back to the host decoder).
+ * Two kernels: (A) one WAVE per block decodes the Huffman code in parallel -- 64
  * segments of the compressed bits per step, every lane from its segment's first bit, re-synchronised with its predecessor --
  * and transcodes the tokens into a byte-aligned LZ sequence stream; (B) one LANE per block copies literals and matches
  * from that stream.  inflated_bytes: d_dst_off[n] - d_dst_off[0] (the caller summed the ISIZE fields on the host).  d_ws: at least
@@ -332,17 +307,12 @@ int            svx_bgzf_inflate_fast_on(const uint8_t* d_comp, const uint64_t* d
                                         uint32_t* d_status, void* d_ws, uint64_t ws_bytes, void* stream_tokens, void* stream_lz);
 /* CRC32 of every inflated block against the block's footer -- the four bytes behind its DEFLATE payload in d_comp (RFC 1952
  * 2.3.1) -- what htslib checks on every block behind pysam's fetch (/root/reference/src/collection/run_collection.py:23-26).
- * d_out / d_dst_off / d_comp / d_src_off / d_src_len: as svx_bgzf_inflate took and wrote them.  d_status [n]: left alone where
+ * d_out / d_dst_off / d_comp / d_src_off / d_src_len: as svx_bgzf_inflate_fast took and wrote them.  d_status [n]: left alone where
  * the CRC agrees or a status is already set, SVX_INFLATE_BAD_CRC where it differs.  One wave per block, coalesced dword
  * reads, one LDS look-up per byte (svx_crc.hip). */
 #define SVX_INFLATE_BAD_CRC 9
 int            svx_bgzf_crc32(const uint8_t* d_out, const uint64_t* d_dst_off, const uint8_t* d_comp, const uint64_t* d_src_off,
                               const uint32_t* d_src_len, uint32_t n_blocks, uint32_t* d_status, void* stream);
-/* the same contract, one WAVE per block (uniform control flow; its time is proportional to the launch -- 17 ms per 5,120
- * blocks -- where the lane kernel needs 60+ ms for one block as for 98 k: the faster one below ~20 k blocks per launch) */
-int            svx_bgzf_inflate_wave(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len,
-                                     const uint64_t* d_dst_off, uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, void* stream);
-
 /* BAM records in an inflated stream on the device -> packed arrays (svx_bamdev.hip).  d_starts [n_starts + 1]: byte
  * offsets in d_raw of known record starts (from the .bai linear index), ascending, the last entry = end of the part.
  *   svx_bam_walk_count    d_counts [n_starts][4] = records, CIGAR words, QNAME bytes (one separator per record) between

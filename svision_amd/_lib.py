@@ -28,8 +28,6 @@ SYMBOLS = {
     "svx_crc32c": (_u32, [_vp, _sz]),
     "svx_cigar_scan_ws_bytes": (_sz, [_u32, _u64]),
     "svx_cigar_scan": (ctypes.c_int, [_vp, _vp, _vp, _u32, _u64, _i32, _vp, _u64, _vp, _vp, _vp, _u64, _u32, _vp]),
-    "svx_cigar_scan_flat_ws_bytes": (_sz, [_u64]),
-    "svx_cigar_scan_flat": (ctypes.c_int, [_vp, _vp, _vp, _u32, _u64, _i32, _vp, _u64, _vp, _vp, _vp, _u64, _vp]),
     "svx_rasterize": (ctypes.c_int, [_vp, _u32, _vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float), _vp]),
     "svx_encode_conv1": (ctypes.c_int, [_vp, _u32, _vp, _vp, _vp, ctypes.c_int, _u32, ctypes.c_float, ctypes.c_float,
                                         ctypes.c_float, _vp, _vp]),
@@ -49,10 +47,6 @@ SYMBOLS = {
     "svx_bam_export": (None, [_vp, ctypes.c_int] + [_vp] * 13),
     "svx_bam_seq": (_vp, [_vp]),
     "svx_bam_close": (None, [_vp]),
-    "svx_bgzf_inflate": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
-    "svx_bgzf_inflate_wave": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
-    "svx_bgzf_inflate_lds": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
-    "svx_bgzf_inflate_private": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
     "svx_bgzf_inflate_fast_ws_bytes": (_sz, [_u64, _u32]),
     "svx_bgzf_inflate_fast": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _u64, _vp, _vp, _vp, _u64, _vp]),
     "svx_bgzf_inflate_fast_on": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _u64, _vp, _vp, _vp, _u64, _vp, _vp]),
@@ -65,6 +59,16 @@ SYMBOLS = {
     "svx_bam_stream_open": (_vp, [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int]),
     "svx_bam_stream_next": (_vp, [_vp, _vp]),
     "svx_bam_stream_close": (None, [_vp]),
+}
+# every symbol include/svx_experimental.h declares: implementations the default path never calls (tests, A/B measurements)
+EXPERIMENTAL = {
+    "svx_cigar_scan_flat_ws_bytes": (_sz, [_u64]),
+    "svx_cigar_scan_flat": (ctypes.c_int, [_vp, _vp, _vp, _u32, _u64, _i32, _vp, _u64, _vp, _vp, _vp, _u64, _vp]),
+    "svx_bgzf_inflate": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
+    "svx_bgzf_inflate_wave": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
+    "svx_bgzf_inflate_lds": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
+    "svx_bgzf_inflate_private": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp]),
+    "svx_bgzf_inflate_fast_lz": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _u64, _vp, _vp, _vp, _u64, ctypes.c_int, _vp, _vp]),
 }
 
 
@@ -91,7 +95,7 @@ def load():
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C svision_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
         lib = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SYMBOLS.items():
+        for name, (res, args) in list(SYMBOLS.items()) + list(EXPERIMENTAL.items()):
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args

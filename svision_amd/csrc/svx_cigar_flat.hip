@@ -380,14 +380,20 @@ __device__ __forceinline__ void flat_tile(const uint32_t* __restrict__ cigar, co
 // first_aln[c] = the alignment that holds chunk c's first word: every alignment writes the entries of the chunks that begin inside
 // it (a thread per alignment; a long one loops over its chunks).
 __global__ __launch_bounds__(256)
-void cigar_map_kernel(const uint64_t* __restrict__ cig_off, uint32_t n_aln, uint32_t* __restrict__ first_aln)
+// n_first: the entries first_aln has (sized from the caller's n_words_max).  An array that holds more words than the caller said
+// would be written behind its end: the entries stay inside, and the launch is marked failed (SVX_SCAN_FAILED in gap_off[n_aln], as
+// svx_cigar_scan answers the same mistake -- ADVICE r5).
+__global__ __launch_bounds__(256)
+void cigar_map_kernel(const uint64_t* __restrict__ cig_off, uint32_t n_aln, uint32_t* __restrict__ first_aln, uint64_t n_first,
+                      uint64_t n_words_max, uint32_t* __restrict__ gap_off)
 {
     const uint32_t a = blockIdx.x * 256 + threadIdx.x;
     if (a >= n_aln) return;
     const uint64_t begin = cig_off[0], base = begin & ~3ull, b = cig_off[a], e = cig_off[a + 1];
+    if (a == n_aln - 1 && e - begin > n_words_max) atomicMax(&gap_off[n_aln], SVX_SCAN_FAILED);
     if (e == b) return;
     if (b <= begin) first_aln[0] = a;                 // (chunk 0 begins at `begin`, in front of which only empty alignments lie)
-    for (uint64_t c = (b - base + FCH - 1) / FCH; base + c * FCH < e; ++c) if (c) first_aln[c] = a;
+    for (uint64_t c = (b - base + FCH - 1) / FCH; base + c * FCH < e && c < n_first; ++c) if (c) first_aln[c] = a;
 }
 
 // Resident workgroups walk the tiles with a grid stride, in order: a launch of one short-lived workgroup per tile (10^4 of them
@@ -443,7 +449,7 @@ extern "C" int svx_cigar_scan_flat(const uint32_t* d_cigar, const uint64_t* d_ci
     const char* gs = getenv("SVX_FLAT_GRID");
     const unsigned grid = (unsigned)min((size_t)(gs ? atoi(gs) : 768), chunks);       // 256 CUs x 3 resident workgroups of 512 threads
     uint32_t* first_aln = reinterpret_cast<uint32_t*>(w + 5 * chunks + 1);
-    hipLaunchKernelGGL(cigar_map_kernel, dim3((n_aln + 255) / 256), dim3(256), 0, st, d_cig_off, n_aln, first_aln);
+    hipLaunchKernelGGL(cigar_map_kernel, dim3((n_aln + 255) / 256), dim3(256), 0, st, d_cig_off, n_aln, first_aln, (uint64_t)chunks * NW, n_words_max, d_gap_off);
     hipLaunchKernelGGL(cigar_flat_kernel, dim3(grid), dim3(FBLOCK), 0, st,
                        d_cigar, d_cig_off, d_ref_start, n_aln, min_sv, d_gaps, gaps_cap, d_gap_off, d_stats, d, (uint32_t)chunks,
                        reinterpret_cast<unsigned int*>(w + 5 * chunks), first_aln);

@@ -723,9 +723,10 @@ extern "C" size_t svx_bgzf_inflate_fast_ws_bytes(uint64_t inflated_bytes, uint32
 extern "C" __attribute__((visibility("hidden"))) int svx_bgzf_inflate_wave_only(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len, const uint64_t* d_dst_off,
                                           uint32_t n_blocks, uint8_t* d_out, uint32_t* d_status, uint32_t only, void* stream);
 
-extern "C" int svx_bgzf_inflate_fast_on(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len, const uint64_t* d_dst_off,
+// (include/svx_experimental.h: the LZ kernel by name -- 0 = by the size of the launch, 1 = lane per block, 2 = wave per block)
+extern "C" int svx_bgzf_inflate_fast_lz(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len, const uint64_t* d_dst_off,
                                         uint32_t n_blocks, uint64_t inflated_bytes, uint8_t* d_out, uint32_t* d_status, void* d_ws, uint64_t ws_bytes,
-                                        void* stream_tokens, void* stream_lz)
+                                        int lz_kernel, void* stream_tokens, void* stream_lz)
 {
     if (n_blocks == 0) return SVX_OK;
     if (!d_comp || !d_src_off || !d_src_len || !d_dst_off || !d_out || !d_status || !d_ws) return SVX_EINVAL;
@@ -737,10 +738,11 @@ extern "C" int svx_bgzf_inflate_fast_on(const uint8_t* d_comp, const uint64_t* d
     uint2* stream_cnt = static_cast<uint2*>(d_ws);
     uint8_t* streams = static_cast<uint8_t*>(d_ws) + (((size_t)8 * n_blocks + 255) & ~(size_t)255);
     // which LZ kernel: one wave per block (B': ~1 ms per block, 1,024 blocks at once) below WAVE_LZ_BELOW blocks, one lane per
-    // block (B: ~25 ms whatever the launch holds + 0.1 ms per 1,000 blocks) above.  SVX_LZ=wave|lane: by name (measurements).
-    const char* lz = getenv("SVX_LZ");
-    const char* below = getenv("SVX_WAVE_LZ_BELOW");
-    const bool wave_lz = lz ? lz[0] == 'w' : n_blocks < (below ? (uint32_t)atoi(below) : (uint32_t)WAVE_LZ_BELOW);
+    // block (B: ~25 ms whatever the launch holds + 0.1 ms per 1,000 blocks) above.  lz_kernel 1 | 2: by name (measurements; an
+    // argument, not the environment: launches of several threads are in flight at once -- ADVICE r5).
+    static const uint32_t below = getenv("SVX_WAVE_LZ_BELOW") ? (uint32_t)atoi(getenv("SVX_WAVE_LZ_BELOW")) : (uint32_t)WAVE_LZ_BELOW;
+    if (lz_kernel < 0 || lz_kernel > 2) return SVX_EINVAL;
+    const bool wave_lz = lz_kernel ? lz_kernel == 2 : n_blocks < below;
     const char* only = getenv("SVX_INFLATE2_ONLY");                          // measurements: "A" = kernel A alone (the output stays unwritten),
     if (!only && getenv("SVX_INFLATE2_ONLY_A")) only = "A";                  // "B" = kernel B alone on the streams an earlier call left in the same workspace
     if (!only || only[0] != 'B') {
@@ -768,6 +770,13 @@ extern "C" int svx_bgzf_inflate_fast_on(const uint8_t* d_comp, const uint64_t* d
     if (hipGetLastError() != hipSuccess) return SVX_ELAUNCH;
     // the (pathological) blocks whose sequence stream did not fit its slot: the wave-per-block kernel, those blocks only
     return svx_bgzf_inflate_wave_only(d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, d_out, d_status, INF_TOKENS_OVERFLOW, stream_lz);
+}
+
+extern "C" int svx_bgzf_inflate_fast_on(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len, const uint64_t* d_dst_off,
+                                        uint32_t n_blocks, uint64_t inflated_bytes, uint8_t* d_out, uint32_t* d_status, void* d_ws, uint64_t ws_bytes,
+                                        void* stream_tokens, void* stream_lz)
+{
+    return svx_bgzf_inflate_fast_lz(d_comp, d_src_off, d_src_len, d_dst_off, n_blocks, inflated_bytes, d_out, d_status, d_ws, ws_bytes, 0, stream_tokens, stream_lz);
 }
 
 extern "C" int svx_bgzf_inflate_fast(const uint8_t* d_comp, const uint64_t* d_src_off, const uint32_t* d_src_len, const uint64_t* d_dst_off,

@@ -443,20 +443,12 @@ def launch_inflate(lib, variant, comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, 
     ``tokens_stream``: the "fast" form's first kernel goes there (svx_bgzf_inflate_fast_on), the rest stays on the current stream."""
     st = _stream_ptr(device)
     lz = None
-    if variant in ("fast-lane", "fast-wave"):                 # the "fast" form with its LZ kernel by name (tests, measurements): SVX_LZ
+    if variant in ("fast-lane", "fast-wave"):                 # the "fast" form with its LZ kernel by name (tests, measurements)
         lz, variant = variant[5:], "fast"
     if variant == "fast":
         d_ws = ws if ws is not None else inflate_workspace(lib, variant, inflated_bytes, n_blocks, device)
         ws_bytes = int(d_ws.numel())
-        import os
-        saved = os.environ.get("SVX_LZ")
-        if lz is not None:
-            os.environ["SVX_LZ"] = lz
-        try:
-            rc = _launch_fast(lib, comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, inflated_bytes, out_ptr, status_ptr, d_ws, ws_bytes, tokens_stream, st)
-        finally:
-            if lz is not None:
-                os.environ.pop("SVX_LZ", None) if saved is None else os.environ.__setitem__("SVX_LZ", saved)
+        rc = _launch_fast(lib, comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, inflated_bytes, out_ptr, status_ptr, d_ws, ws_bytes, tokens_stream, st, lz)
         _lib.check(rc, "svx_bgzf_inflate (%s)" % variant)
         return
     fn = {"lds": lib.svx_bgzf_inflate_lds, "private": lib.svx_bgzf_inflate_private, "wave": lib.svx_bgzf_inflate_wave,
@@ -465,7 +457,11 @@ def launch_inflate(lib, variant, comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, 
     _lib.check(rc, "svx_bgzf_inflate (%s)" % variant)
 
 
-def _launch_fast(lib, comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, inflated_bytes, out_ptr, status_ptr, d_ws, ws_bytes, tokens_stream, st):
+def _launch_fast(lib, comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, inflated_bytes, out_ptr, status_ptr, d_ws, ws_bytes, tokens_stream, st, lz=None):
+    if lz is not None:                                        # the LZ kernel by name: an argument of the experimental entry point (svx_experimental.h)
+        tok = ctypes.c_void_p(tokens_stream.cuda_stream) if tokens_stream is not None else st
+        return lib.svx_bgzf_inflate_fast_lz(comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, int(inflated_bytes), out_ptr, status_ptr, d_ws.data_ptr(), ws_bytes,
+                                            {"lane": 1, "wave": 2}[lz], tok, st)
     if tokens_stream is not None:
         return lib.svx_bgzf_inflate_fast_on(comp_ptr, src_ptr, len_ptr, dst_ptr, n_blocks, int(inflated_bytes), out_ptr, status_ptr, d_ws.data_ptr(), ws_bytes,
                                             ctypes.c_void_p(tokens_stream.cuda_stream), st)

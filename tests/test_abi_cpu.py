@@ -1,4 +1,5 @@
-"""CPU test: libsvx.so loads and exports every symbol include/svx.h declares (no compute)."""
+"""CPU test: libsvx.so loads and exports every symbol include/svx.h (the product contract) and include/svx_experimental.h
+(implementations the default path never calls) declare (no compute)."""
 import os
 import re
 
@@ -11,8 +12,12 @@ def test_library_exports_header_symbols():
     header = open(os.path.join(ROOT, "include", "svx.h")).read()
     declared = set(re.findall(r"\b(svx_[a-z_0-9]+)\s*\(", header))
     assert declared == set(_lib.SYMBOLS), (declared, set(_lib.SYMBOLS))
+    exp_header = open(os.path.join(ROOT, "include", "svx_experimental.h")).read()
+    exp_body = re.sub(r"/\*.*?\*/", " ", exp_header, flags=re.S)
+    experimental = set(re.findall(r"\b(svx_[a-z_0-9]+)\s*\(", exp_body))
+    assert experimental == set(_lib.EXPERIMENTAL) and not experimental & declared
     lib = _lib.load()
-    for name in declared:
+    for name in declared | experimental:
         assert getattr(lib, name) is not None
     assert lib.svx_version() == 400
     assert lib.svx_strerror(0) == b"ok" and b"capacity" in lib.svx_strerror(-2)
@@ -36,8 +41,8 @@ def test_scan_flags_and_argument_counts_follow_the_header():
     assert flags == {"SVX_SCAN_LANES4": 1, "SVX_SCAN_LANES8": 2, "SVX_SCAN_SHARED": 4, "SVX_SCAN_UNSHARED": 8}
     src = open(os.path.join(ROOT, "svision_amd", "kernels.py")).read()
     assert '"groups4": 1 | 8, "groups8": 2 | 8, "groups4s": 1 | 4, "groups8s": 2 | 4' in src
-    text = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)
-    for name, (_res, args) in _lib.SYMBOLS.items():
+    text = re.sub(r"/\*.*?\*/", " ", header + open(os.path.join(ROOT, "include", "svx_experimental.h")).read(), flags=re.S)
+    for name, (_res, args) in list(_lib.SYMBOLS.items()) + list(_lib.EXPERIMENTAL.items()):
         m = re.search(r"\b%s\s*\(([^;{]*?)\)\s*;" % name, text, flags=re.S)
         assert m, name
         params = m.group(1).strip()

@@ -200,7 +200,7 @@ def test_cigar_scan_refuses_an_array_longer_than_the_caller_said(oracle_lib):
     """svx_cigar_scan sizes its frame records by n_words: offsets that reach beyond it are answered with SVX_SCAN_FAILED in
     d_gap_off[n_aln] (kernels: SvxError on read-back), never with records written outside the workspace."""
     cigar, off, ref_start = datagen.random_cigars(200, seed=3, mean_ops=3000, long_gap_rate=0.01)
-    for mode in ("groups8s", "groups4"):
+    for mode in ("groups8s", "groups4", "flat"):              # (flat: svx_experimental.h; its chunk map stays inside the workspace too)
         with pytest.raises(_lib.SvxError):
             kernels.cigar_scan(_dev(cigar.view(np.int32)), _dev(off.astype(np.int64)), _dev(ref_start), 50, mode=mode, n_words=int(off[-1]) // 2).total()
 
