@@ -280,7 +280,7 @@ def compact_line(full, detail_path=None):
         "resident_sites_per_s": num(cfg.get("resident_sites_per_s")),
         "file_inclusive_over_resident": num(cfg.get("file_inclusive_over_resident")),
         "bam_bytes": num(e2e.get("bam_bytes")), "ingest_engine": e2e.get("ingest_engine"),
-        "host_cores": num(cfg.get("host_cores")), "host_workers_per_rank": num(cfg.get("host_workers_per_rank")),
+        "host_cores": num(cfg.get("host_cores")), "host_cpus_pinned": num(cfg.get("host_cpus_pinned")), "host_workers_per_rank": num(cfg.get("host_workers_per_rank")),
         "rccl_world": num(cfg.get("rccl_world")), "imbalance": num(cfg.get("imbalance")),
         "parallelism": _clip(cfg.get("parallelism", ""), 140),
     }
@@ -383,6 +383,9 @@ def main():
                                                            "`value` / `ms_per_step` are the repeat with the MEDIAN wall time, value_repeats holds min / median / max")
     ap.add_argument("--detail", default="bench_detail.json", help="where the full record goes (decoder traces, per-kernel rooflines, the other legs, notes); "
                                                                   "stdout carries ONE compact JSON line (< 4 KB) whose numbers are a subset of it")
+    ap.add_argument("--host-cpus", type=int, default=0, help="pin this rank and everything it forks or starts afterwards (host helpers, pread / decode threads, the runtime's own threads) "
+                                                             "to K CPUs (sched_setaffinity after the workload is built, before the first fork): the host budget an N-rank run on "
+                                                             "this box leaves a rank (VERDICT r5 item 5).  0: no pinning")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity leg (the device path's TSV / site keys / softmax against the CPU port's on the windows the CPU baseline runs)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -396,6 +399,13 @@ def main():
     # ---- untimed set-up.  Order matters: everything that forks (simulation pool, CPU-baseline pool, host helpers)
     # happens before the first HIP call (forking with a live GPU context makes the driver evict / restore the queues)
     parts, windows, strong, total_windows, e2e = build_workload(args, rank, world, cores)
+    if args.host_cpus > 0:
+        # the K CPUs of this rank: disjoint sets per rank, taken from the CPUs the process may run on
+        allowed = sorted(os.sched_getaffinity(0))
+        k = min(args.host_cpus, len(allowed))
+        os.sched_setaffinity(0, set(allowed[(rank * k) % len(allowed):][:k]) or set(allowed[:k]))
+        cores, visible_cpus = effective_cpus()
+        workers = args.workers if args.workers > 0 else max(1, min(8, 2 * cores // world))
     opts = options_ns(args.batch)
     if args.workload == "contig":             # SVision:161-180, collect_signatures.py:125
         opts.contig, opts.min_support = True, 1
@@ -645,7 +655,7 @@ def main():
                    "first_contact": contact,
                    "rank_mb": [round(v, 1) for v in getattr(args, "rank_mb", [])] or None,
                    "imbalance": (max(args.rank_mb) / (sum(args.rank_mb) / len(args.rank_mb)) if getattr(args, "rank_mb", None) else None),
-                   "host_workers_per_rank": workers, "host_modules_compiled": not build_host.compiled_state()[1], "host_cores": cores, "host_cpus_visible": visible_cpus, "streams": args.streams, "batches_per_launch": args.launch_batches,
+                   "host_cpus_pinned": args.host_cpus or None, "host_workers_per_rank": workers, "host_modules_compiled": not build_host.compiled_state()[1], "host_cores": cores, "host_cpus_visible": visible_cpus, "streams": args.streams, "batches_per_launch": args.launch_batches,
                    "parallelism": "one process per GPU, chromosomes per rank, no data-path collective "
                                   "(score-range all_reduce + record gather once)"},
         "roofline": {"kernel": "device stage per batch of %d images (a graph replay carries --launch-batches of them): encode_conv1_kernel (rasterise + sparse conv1) + "
