@@ -144,6 +144,11 @@ def _simulate_contig(job):
         segment = bam.encode_reference_segment(part, seq="random", seed=seed)
         if part is table:
             table.tid[:] = 0
+        if job.get("spill_dir"):                 # whole-genome files: the compressed bytes wait on disk, not in the parent's memory (62 GB)
+            path = os.path.join(job["spill_dir"], "segment_%s.bin" % name)
+            with open(path, "wb") as f:
+                f.write(segment["data"])
+            segment["data_path"], segment["data"] = path, None
     return table, genome[name], segment
 
 
@@ -177,13 +182,19 @@ def build_workload(args, rank, world, cores):
             small = dict(job_contigs(args.e2e_windows)) if total_windows > args.e2e_windows else length_of
             e2e_prefix = {n: min(small[n], length_of[n]) for n in shard if n in small}
     k = 0
+    bam_dir = None
+    if e2e_prefix:
+        import tempfile
+        bam_dir = tempfile.mkdtemp(prefix="svx_bench_bam_", dir=args.bam_dir)
     for j in jobs:
         if j["name"] in e2e_prefix:
             j["e2e"] = (k, e2e_prefix[j["name"]])
+            if sum(e2e_prefix.values()) > 1_200_000_000:                  # > ~24 GB of file: see _simulate_contig
+                j["spill_dir"] = bam_dir
             k += 1
     if len(jobs) > 1:
         import multiprocessing as mp
-        pool = mp.get_context("fork").Pool(min(len(jobs), max(1, cores // world)))     # before the first HIP call
+        pool = mp.get_context("fork").Pool(min(len(jobs), args.sim_procs or max(1, cores // world)))     # before the first HIP call
         try:
             made = pool.map(_simulate_contig, jobs, chunksize=1)
         finally:
@@ -200,9 +211,8 @@ def build_workload(args, rank, world, cores):
         windows = [w for name, length, _t, _g in parts for w in windows_of(name, length)]
     e2e = None
     if e2e_prefix:
-        import tempfile
         names = [j["name"] for j in jobs if "e2e" in j]
-        d = tempfile.mkdtemp(prefix="svx_bench_bam_", dir=args.bam_dir)
+        d = bam_dir
         path = os.path.join(d, "rank%d.bam" % rank)
         segs = [seg for _t, _g, seg in made if seg is not None]
         bam.write_bam_segments(path, names, [dict((j["name"], j["length"]) for j in jobs)[n] for n in names], segs, index=True)
@@ -212,7 +222,7 @@ def build_workload(args, rank, world, cores):
     return parts, windows, strong, total_windows, e2e
 
 
-MAX_FILE_WINDOWS = 100                        # 19 GB of BAM (46 GB inflated) written during set-up: what a default-sized run may cost
+MAX_FILE_WINDOWS = 100                        # 19 GB of BAM (46 GB inflated) written during set-up: what a default-sized run may cost (an explicit --e2e-windows may ask for more)
 
 
 def resolve_defaults(args):
@@ -376,6 +386,8 @@ def main():
                          "= a 19 GB file); 0 = no file leg (`value` is then the resident leg)")
     ap.add_argument("--decode-threads", type=int, default=0, help="inflate threads of the e2e leg per rank (default: cores / ranks - helpers - 2, at most 128)")
     ap.add_argument("--bam-dir", default=None, help="where the synthetic BAM of the e2e leg is written (default: the temp directory)")
+    ap.add_argument("--sim-procs", type=int, default=0, help="processes that simulate + compress the workload during set-up (default: the usable CPUs per rank; "
+                                                             "fewer for the whole-genome file: a process holds a chromosome's records, inflated and compressed)")
     ap.add_argument("--no-cold-leg", action="store_true", help="skip the file-inclusive leg with the BAM's pages dropped from the page cache first (`e2e_cold_cache`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-calibration", action="store_true", help="skip the per-kernel timings outside the timed region")

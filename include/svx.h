@@ -21,9 +21,10 @@
 extern "C" {
 #endif
 
-#define SVX_VERSION 400            /* 0.3.0: + svx_bgzf_crc32, svx_bgzf_inflate_fast (360); + svx_bgzf_inflate_fast_on: the two kernels on two streams (370);
+#define SVX_VERSION 410            /* 0.3.0: + svx_bgzf_crc32, svx_bgzf_inflate_fast (360); + svx_bgzf_inflate_fast_on: the two kernels on two streams (370);
                                     * svx_bgzf_inflate_fast / _on take the inflated byte count and refuse a workspace that is too small (380);
-                                    * + svx_cigar_scan_flat: the scan of long alignments in one pass (390); svx_cigar_scan takes the word count of its launch, its workspace's size and shape flags (400) */
+                                    * + svx_cigar_scan_flat: the scan of long alignments in one pass (390); svx_cigar_scan takes the word count of its launch, its workspace's size and shape flags (400);
+                                    * the exports the default path never calls moved to svx_experimental.h, + svx_bgzf_inflate_fast_lz there (410) */
 
 #define SVX_OK            0
 #define SVX_EINVAL       (-1)      /* bad argument (null pointer, bad layout...) */

@@ -83,7 +83,7 @@ class SvxMissing(SvxError):
 _lib = None
 
 
-ABI_VERSION = 400                     # SVX_VERSION of include/svx.h this binding was written against
+ABI_VERSION = 410                     # SVX_VERSION of include/svx.h this binding was written against
 
 
 def load():

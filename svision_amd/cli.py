@@ -335,7 +335,7 @@ def _run_streaming(options, feed, tasks, chroms, seg_dir, pred_dir):
     import time as _time
     _t0 = _time.time()
     net = load_network(options.model_path)
-    hot = HotPath(None, options, net, n_streams=3)
+    hot = HotPath(None, options, net, n_streams=3, lazy_graphs=True)      # a command line captures the launch shapes it meets (pipeline.DeviceStage)
     _t1 = _time.time()
     for chrom in chroms:
         prefix = os.path.join(pred_dir, "%s.predict.s%s" % (chrom, options.min_support))
@@ -391,7 +391,7 @@ def _run_pooled(options, feed, tasks, chroms, seg_dir, pred_dir, pool=None):
     import time as _time
     _t0 = _time.time()
     static = getattr(feed, "sample", None)
-    hot = PooledHotPath(static, options, net, n_workers=options.thread_num, n_streams=3, max_inflight=6, want_tsv=True, pool=pool, feed=feed)
+    hot = PooledHotPath(static, options, net, n_workers=options.thread_num, n_streams=3, max_inflight=6, want_tsv=True, pool=pool, feed=feed, lazy_graphs=True)
     _t1 = _time.time()
     done = {}
 

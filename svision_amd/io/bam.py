@@ -775,7 +775,16 @@ def write_bam_segments(path, references, lengths, segments, index=True):
         f.write(head_bytes)
         base = len(head_bytes)
         for seg in segments:
-            f.write(seg["data"])
+            n_data = 0
+            if seg.get("data") is None and seg.get("data_path"):      # a segment that waits in a file of its own (bench.py: whole-genome jobs)
+                import shutil
+                with open(seg["data_path"], "rb") as g:
+                    shutil.copyfileobj(g, f, 64 << 20)
+                n_data = os.path.getsize(seg["data_path"])
+                os.remove(seg["data_path"])
+            else:
+                f.write(seg["data"])
+                n_data = len(seg["data"])
             if index and seg["tid"] >= 0:
                 t, coff, ro = seg["tid"], seg["coff"] + base, seg["rec_off"]
                 blk = ro // _MAX_BLOCK
@@ -791,7 +800,7 @@ def write_bam_segments(path, references, lengths, segments, index=True):
                         chunks.append([v0, v1])
                     for w in range(int(beg[i]) >> 14, ((int(end[i]) - 1) >> 14) + 1):
                         linear[t].setdefault(w, v0)
-            base += len(seg["data"])
+            base += n_data
         f.write(_BGZF_EOF)
     if index:
         _dump_bai(path + ".bai", bins, linear)

@@ -66,13 +66,16 @@ class AlexNet(torch.nn.Module):
     """Inference-only AlexNet holding device-layout parameters.  ``active=False`` computes conv2..conv5 at every pixel
     (same kernels in dense mode; the test suite requires both settings to agree bit for bit)."""
 
-    def __init__(self, params, device="cuda", mean=(104.0, 117.0, 124.0), active=True):
+    def __init__(self, params, device="cuda", mean=(104.0, 117.0, 124.0), active=True, packed=None):
         super().__init__()
         from .. import kernels
-        validate_params(params)
         self.active = bool(active)
         self._background = None
         self.executed = None            # optional int64 device tensor [5]: running executed-pixel / image counts (bench)
+        if packed is not None:          # device-layout tensors of an earlier process (weight_cache.load): one upload, views
+            self._adopt(packed, device)
+            return
+        validate_params(params)
 
         def f32(a):
             return torch.from_numpy(np.array(a, np.float32, copy=True))
@@ -95,6 +98,37 @@ class AlexNet(torch.nn.Module):
             wt = w.t()                                                                                    # [out,in]
             self.register_buffer(f"{name}_w", kernels.pack_fc_weights(wt) if name != "fc8" else wt.contiguous())
             self.register_buffer(f"{name}_b", f32(params[f"{name}/biases"]).to(device))
+
+    _BG = ("conv2", "conv3", "conv4", "conv5")
+
+    def packed_tensors(self, with_background=True):
+        """{name: CPU float32 tensor} of everything a later process needs instead of the checkpoint: the buffers in their
+        device layouts and (GPU only: they are computed with the kernels) the background activations."""
+        out = {name: buf.detach().cpu() for name, buf in self.named_buffers()}
+        if with_background and self.conv1_base.is_cuda:
+            for k, v in self.background().items():
+                out["background/" + k] = v.detach().cpu()
+        return out
+
+    def _adopt(self, packed, device):
+        blob, names = packed
+        want = {"conv1_hwio", "conv1_base"} | {f"{n}_{s}" for n in ("conv2", "conv3", "conv4", "conv5", "fc6", "fc7", "fc8") for s in "wb"}
+        if not want <= set(names):
+            raise ValueError("packed weights lack %s" % sorted(want - set(names)))
+        import warnings
+        with warnings.catch_warnings():                                  # (torch warns about tensors over read-only memory; this one is only copied from)
+            warnings.simplefilter("ignore", UserWarning)
+            host = torch.from_numpy(np.asarray(blob))
+        dev_blob = host.to(device) if torch.device(device).type != "cpu" else host.clone()       # ONE host-to-device copy
+
+        def view(name):
+            shape, off = names[name]
+            n = int(np.prod(shape)) if shape else 1
+            return dev_blob[off:off + n].view(*shape)
+        for name in sorted(want):
+            self.register_buffer(name, view(name))
+        if all("background/" + k in names for k in self._BG):
+            self._background = {k: view("background/" + k) for k in self._BG}
 
     def _convs(self, records):
         """records int32 [B,12] -> pool5 activations, C8 [B,32,6,6,8]."""

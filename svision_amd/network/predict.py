@@ -21,7 +21,26 @@ def load_network(model_path, device="cuda"):
     from .tf_checkpoint import read_checkpoint
     key = (model_path, str(device))
     if key not in _MODEL_CACHE:
-        _MODEL_CACHE[key] = AlexNet(read_checkpoint(model_path), device=device)
+        # the device-layout weights of this checkpoint as an earlier process left them (weight_cache.py: digest of the bundle's
+        # bytes in the file name), else the bundle itself -- and the layouts are left behind for the next process
+        from . import weight_cache
+        net = path = None
+        if weight_cache.enabled():
+            from .. import _lib
+            digest = weight_cache.checkpoint_digest(model_path, abi=_lib.ABI_VERSION)
+            if digest is not None:
+                path = weight_cache.cache_path(model_path, digest)
+                packed = weight_cache.load(path)
+                if packed is not None:
+                    try:
+                        net = AlexNet(None, device=device, packed=packed)
+                    except (ValueError, RuntimeError):
+                        net = None
+        if net is None:
+            net = AlexNet(read_checkpoint(model_path), device=device)
+            if path is not None:
+                weight_cache.save(path, net.packed_tensors())
+        _MODEL_CACHE[key] = net
     return _MODEL_CACHE[key]
 
 

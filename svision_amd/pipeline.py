@@ -177,7 +177,7 @@ class DeviceStage:
     grouping changes no result; it divides the fc6 / fc7 weight traffic per image (218 MB per launch whatever its size) and
     the share of partly filled tile rounds of the convolutions."""
 
-    def __init__(self, net, batch, device, n_streams=2, use_graph=True, launch_batches=4):
+    def __init__(self, net, batch, device, n_streams=2, use_graph=True, launch_batches=4, lazy=False):
         self.net, self.batch, self.device = net, batch, torch.device(device)
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
         self.use_graph = use_graph
@@ -186,26 +186,36 @@ class DeviceStage:
             sizes.add(batch * k)
             k //= 2
         self.sizes = sorted(sizes, reverse=True)
-        self.slots = []                                       # per stream: {images per launch: (records, packed out, graph)}
-        for s in self.streams:
-            slot = {}
-            for size in self.sizes:
-                rec = torch.zeros((size, 12), dtype=torch.int32, device=self.device)
-                rec[:] = torch.tensor(_PAD_REC, dtype=torch.int32, device=self.device)
-                out = torch.empty((size, 12), dtype=torch.float32, device=self.device)   # softmax[5], class, logits[5], 0
-                graph = None
-                with torch.cuda.stream(s):
-                    for _ in range(2):                       # the model's background tensors and the allocator's blocks before capture
-                        self._body(rec, out)
-                s.synchronize()
-                if use_graph:
-                    graph = torch.cuda.CUDAGraph()
-                    # thread_local: the feeder thread of a file-driven run (ingest.ChromosomeFeed) uploads and synchronises on
-                    # its own stream while this thread captures; in the default global mode any such call invalidates the capture
-                    with torch.cuda.graph(graph, stream=s, capture_error_mode="thread_local"):
-                        self._body(rec, out)
-                slot[size] = (rec, out, graph)
-            self.slots.append(slot)
+        # per stream: {images per launch: (records, packed out, graph)}.  ``lazy``: a slot is built -- two eager passes, then the
+        # capture -- when its first launch comes (a command line that classifies one small chromosome uses two or three of the
+        # nine; a bench or a service builds them all up front so that no launch of a timed region pays for a capture)
+        self.slots = [{} for _ in self.streams]
+        if not lazy:
+            for k in range(n_streams):
+                for size in self.sizes:
+                    self._slot(k, size)
+
+    def _slot(self, k, size):
+        slot = self.slots[k].get(size)
+        if slot is None:
+            s = self.streams[k]
+            rec = torch.zeros((size, 12), dtype=torch.int32, device=self.device)
+            rec[:] = torch.tensor(_PAD_REC, dtype=torch.int32, device=self.device)
+            out = torch.empty((size, 12), dtype=torch.float32, device=self.device)   # softmax[5], class, logits[5], 0
+            graph = None
+            s.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(s):
+                for _ in range(2 if self.use_graph else 1):      # the model's background tensors and the allocator's blocks before capture
+                    self._body(rec, out)
+            s.synchronize()
+            if self.use_graph:
+                graph = torch.cuda.CUDAGraph()
+                # thread_local: the feeder thread of a file-driven run (ingest.ChromosomeFeed) uploads and synchronises on
+                # its own stream while this thread captures; in the default global mode any such call invalidates the capture
+                with torch.cuda.graph(graph, stream=s, capture_error_mode="thread_local"):
+                    self._body(rec, out)
+            slot = self.slots[k][size] = (rec, out, graph)
+        return slot
 
     def _body(self, rec, out):
         self.net.predict_records_packed(rec, out=out)        # no image tensor: encoding is fused into the first layer
@@ -230,7 +240,7 @@ class DeviceStage:
             b = next(size for size in self.sizes if size <= n - lo)
             k = self._next = (getattr(self, "_next", -1) + 1) % n_streams     # round-robin continues across calls
             s = self.streams[k]
-            rec, o, graph = self.slots[k][b]
+            rec, o, graph = self._slot(k, b)
             if k not in used:
                 if after is None:
                     s.wait_stream(main)
@@ -270,11 +280,11 @@ class HotPath:
     """Single-process form: collect -> device -> vote, with the device work of window k overlapped
     with the host collection of window k+1."""
 
-    def __init__(self, sample, options, net, device="cuda", n_streams=2, use_graph=True, launch_batches=4):
+    def __init__(self, sample, options, net, device="cuda", n_streams=2, use_graph=True, launch_batches=4, lazy_graphs=False):
         self.sample, self.options, self.net = sample, options, net
         self.device = torch.device(device)
         self.batch = options.batch_size
-        self.stage = DeviceStage(net, self.batch, self.device, n_streams, use_graph, launch_batches)
+        self.stage = DeviceStage(net, self.batch, self.device, n_streams, use_graph, launch_batches, lazy=lazy_graphs)
         self.batch_events = []           # (start, end) event pair of every batch, on the batch's stream
         self.record_timing = bool(os.environ.get("SVX_TIMING"))      # bench.py switches it on; a plain run records no timing events
         self.device_images = 0           # images (padding included) launched since reset_timing()
@@ -587,8 +597,8 @@ class PooledHotPath(HotPath):
     """Owner process = device feeder; the helpers of a :class:`HelperPool` do the Python glue."""
 
     def __init__(self, sample, options, net, device="cuda", n_workers=8, n_streams=2, use_graph=True, max_inflight=3, launch_batches=4,
-                 want_tsv=False, pool=None, feed=None):
-        super().__init__(sample, options, net, device, n_streams, use_graph, launch_batches)
+                 want_tsv=False, pool=None, feed=None, lazy_graphs=False):
+        super().__init__(sample, options, net, device, n_streams, use_graph, launch_batches, lazy_graphs=lazy_graphs)
         self.pool = pool if pool is not None else HelperPool(n_workers, options, sample=sample, want_tsv=want_tsv)
         self.conns, self.procs = self.pool.conns, self.pool.procs
         self.max_inflight = max_inflight

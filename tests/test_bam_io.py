@@ -457,3 +457,27 @@ def test_host_engine_verifies_the_bgzf_crc(tmp_path):
             % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), bad))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, SVX_BGZF_CRC="0"))
     assert r.returncode == 0 and r.stdout.strip() == str(len(table)), r.stderr[-1500:]
+
+
+def test_segments_waiting_in_files_give_the_same_bam(tmp_path):
+    """bench.py's whole-genome job keeps every reference's compressed segment in a file of its own until the BAM is put
+    together (write_bam_segments: data_path): the BAM and its index are the bytes of the in-memory route."""
+    from svision_amd import synth
+    cfg = synth.SimConfig(contigs=[("a", 120_000), ("b", 90_000)], coverage=6, read_len_mean=4000, read_len_sd=600, seed=3)
+    table, _genome, _svs = synth.simulate(cfg)
+    segs = []
+    for t in (0, 1):
+        part = table.subset(np.flatnonzero(table.tid == t))
+        segs.append(bam.encode_reference_segment(part, seq="random", seed=t))
+    p1, p2 = str(tmp_path / "mem.bam"), str(tmp_path / "file.bam")
+    bam.write_bam_segments(p1, ["a", "b"], [120_000, 90_000], segs, index=True)
+    spilled = []
+    for i, s in enumerate(segs):
+        path = str(tmp_path / ("seg%d.bin" % i))
+        with open(path, "wb") as f:
+            f.write(s["data"])
+        spilled.append(dict(s, data=None, data_path=path))
+    bam.write_bam_segments(p2, ["a", "b"], [120_000, 90_000], spilled, index=True)
+    assert open(p1, "rb").read() == open(p2, "rb").read() and open(p1 + ".bai", "rb").read() == open(p2 + ".bai", "rb").read()
+    assert not os.path.exists(spilled[0]["data_path"])                # the segment files are consumed
+    assert len(bam.read_bam(p2)) == len(table)

@@ -362,3 +362,51 @@ def test_cli_batch_size_does_not_change_results(checkpoint, tmp_path):
                                     "-g", fa, "-n", "S", "-s", "3", "--window_size", "60000", "--batch_size", str(bs)])
         texts[bs] = open(cli.run(opts)).read()
     assert len(set(texts.values())) == 1 and texts[64].count("\n") > 20
+
+
+def test_network_adopted_from_the_weight_cache_equals_the_network_built_from_the_checkpoint(tmp_path, monkeypatch):
+    """weight_cache.py: the second process on a checkpoint adopts the first one's device-layout weights and background
+    activations from one blob -- same buffers, same predictions, bit for bit -- and lazily captured launch graphs give what
+    eagerly captured ones give."""
+    from oracle import alexnet_ref
+    from svision_amd.network import predict, weight_cache
+    from svision_amd.pipeline import DeviceStage
+    monkeypatch.setenv("SVX_CACHE_DIR", str(tmp_path / "cache"))
+    prefix = str(tmp_path / "m.ckpt")
+    ck.write_checkpoint(prefix, alexnet_ref.random_params(seed=11))
+    predict._MODEL_CACHE.clear()
+    first = predict.load_network(prefix, device="cuda:0")            # reads the bundle, packs, leaves the blob behind
+    blobs = os.listdir(tmp_path / "cache")
+    assert len(blobs) == 1 and blobs[0].startswith("m.ckpt.svx-packed-")
+    predict._MODEL_CACHE.clear()
+    second = predict.load_network(prefix, device="cuda:0")           # adopts the blob
+    assert second is not first and second._background is not None     # the backgrounds came with it (no kernel ran for them)
+    a, b = dict(first.named_buffers()), dict(second.named_buffers())
+    assert set(a) == set(b)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    for k, v in first.background().items():
+        assert torch.equal(v, second._background[k]), k
+    case = _case()
+    bed = tmp_path / "chrB.bed"
+    bed.write_text(case["chroms"]["chrB"]["tsv"])
+    gen = BatchGenerator(str(bed), nb_classes=5, batch_size=64, layout="NCHW")
+    records, _labels = gen.next_records(64)
+    rec = torch.from_numpy(np.asarray(records, np.int32)).cuda()
+    p1, p2 = first.predict_records_packed(rec), second.predict_records_packed(rec)
+    assert torch.equal(p1, p2)
+    # lazily built launch slots (the command line) == eagerly built ones (bench, services)
+    eager, lazy = DeviceStage(first, 64, "cuda:0", n_streams=2, launch_batches=2), DeviceStage(second, 64, "cuda:0", n_streams=2, launch_batches=2, lazy=True)
+    assert all(len(s) == 2 for s in eager.slots) and all(len(s) == 0 for s in lazy.slots)
+    big = rec.repeat(3, 1)                                               # 192 images: one launch of 128 and one of 64
+    o1, o2 = torch.empty((192, 6), device="cuda:0"), torch.empty((192, 6), device="cuda:0")
+    eager.run(big, o1)
+    lazy.run(big, o2)
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2) and torch.equal(o1[:64], p1[:, :6])
+    assert sum(len(s) for s in lazy.slots) == 2                          # only the shapes it met
+    predict._MODEL_CACHE.clear()
+    monkeypatch.setenv("SVX_WEIGHT_CACHE", "0")
+    third = predict.load_network(prefix, device="cuda:0")
+    assert third._background is None and torch.equal(third.fc6_w, first.fc6_w)
+    predict._MODEL_CACHE.clear()
