@@ -60,45 +60,89 @@ __device__ inline float4 elem_group(const unsigned* bits, int e, float m0, float
     return v;
 }
 
+// NCHW group without a branch.  The three planes are ONE array of 681 rows x 256 bits: element e sits in row R = e / 227 (plane
+// R / 227) at column c = e % 227, so the four elements of a group are four consecutive bits of a 64-bit window of that array -- 29
+// bits farther on (256 - 227 unused bits per row) for the elements behind the end of a row, which continue in the next row, i.e.
+// possibly in the next PLANE: the mean follows the row.  (Round 6.  The form above leaves the groups that straddle a row to the
+// per-element path: one lane in 57, so practically every wave ran both paths -- ~125 vector instructions per 16 bytes where this
+// takes ~45; with it a quarter of the waves keeps the memory system as busy, and FEWER waves in flight write faster:
+// tools/exp/raster_bw.hip, profiles/r06_raster_bw.txt.)
+__device__ inline float4 elem_group_rows(const unsigned* bits, int e, float m0, float m1, float m2)
+{
+    const int R = e / IMG, c = e - R * IMG;
+    const int A = R * (32 * ROW_WORDS) + c, wi = A >> 5, sh = A & 31;
+    const unsigned long long win = (((unsigned long long)bits[wi + 1] << 32) | bits[wi]) >> sh;
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool wrap = c + i >= IMG;
+        const unsigned b = (unsigned)(win >> (i + (wrap ? 32 * ROW_WORDS - IMG : 0))) & 1u;
+        const int Ri = R + (wrap ? 1 : 0);
+        const float mean = Ri < IMG ? m0 : (Ri < 2 * IMG ? m1 : m2);
+        v[i] = b ? 255.0f - mean : -mean;
+    }
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// A RESIDENT grid: workgroup w takes the work items (image, strip) w, w + grid, ...; a work item is one contiguous slice of
+// one image.  NCHW launches run one workgroup per CU (svx_rasterize): a write-only stream is fastest with few waves in flight
+// (a float4 fill of the same 1.27 GB: 6.5 TB/s from 256 workgroups, 5.3 from 2,048, 4.1 from 4,096), and the branch-free group
+// above is cheap enough for four waves per CU to produce what the CU can write.
 template <int LAYOUT>
 __global__ __launch_bounds__(BLOCK)
 void raster_kernel(const int32_t* __restrict__ records, uint32_t n, float* __restrict__ out,
                    int strips, float m0, float m1, float m2)
 {
     constexpr int layout = LAYOUT;
-    // plane 0: all segments, plane 1: columns with >= 2 hits, plane 2: reverse segments
-    __shared__ unsigned bits[3 * PLANE_WORDS];
+    // plane 0: all segments, plane 1: columns with >= 2 hits, plane 2: reverse segments (+ 4 zero words: elem_group_rows reads
+    // one word beyond the last row's)
+    __shared__ unsigned bits[3 * PLANE_WORDS + 4];
     __shared__ unsigned colcnt[IMG];
     __shared__ unsigned colmask[ROW_WORDS];
-
-    const uint32_t img = blockIdx.x / strips;
-    const int strip = blockIdx.x - img * strips;
     const int tid = threadIdx.x;
-
-    draw_planes<BLOCK>(records + (size_t)img * 12, bits, colcnt, colmask);
-
-    // stream this block's slice [e_lo, e_hi) of the image
-    const int per = (IMG_ELEMS + strips - 1) / strips;
-    const int e_lo = strip * per;
-    const int e_hi = min(IMG_ELEMS, e_lo + per);
-    if (e_lo >= e_hi) return;
-    const long long base = (long long)img * IMG_ELEMS;       // global float index of element 0
-    float* gout = out + base;
-    // global float indices; 16-byte groups are aligned on the tensor base (assumed 16 B aligned)
-    const long long g_lo = base + e_lo, g_hi = base + e_hi;
-    const long long q_lo = (g_lo + 3) >> 2, q_hi = g_hi >> 2;   // full float4 groups [q_lo, q_hi)
-    if (q_lo >= q_hi) {                                          // tiny slice: scalar only
-        for (int e = e_lo + tid; e < e_hi; e += BLOCK) gout[e] = elem_value(bits, e, layout, m0, m1, m2);
-        return;
+    if (tid < 4) bits[3 * PLANE_WORDS + tid] = 0;
+    const int per = ((IMG_ELEMS + strips - 1) / strips + 3) & ~3;
+    const long long items = (long long)n * strips;
+    int drawn = -1;
+    for (long long item = blockIdx.x; item < items; item += gridDim.x) {
+        const int img = (int)(item / strips), strip = (int)(item - (long long)img * strips);
+        if (img != drawn) {
+            __syncthreads();                                  // (the previous item's readers are through with the planes)
+            draw_planes<BLOCK>(records + (size_t)img * 12, bits, colcnt, colmask);
+            drawn = img;
+        }
+        // stream this item's slice [e_lo, e_hi) of the image: 16-byte stores aligned on the TENSOR (image bases are only 4-byte
+        // aligned: 618,348 % 16 = 12), the elements in front of the first and behind the last full group one by one
+        const int e_lo = strip * per;
+        const int e_hi = min(IMG_ELEMS, e_lo + per);
+        if (e_lo >= e_hi) continue;
+        const long long base = (long long)img * IMG_ELEMS;   // global float index of element 0
+        float* gout = out + base;
+        const int skew = (int)((4 - (base & 3)) & 3);         // the image's first group boundary
+        const int g_lo = e_lo <= skew ? skew : skew + ((e_lo - skew + 3) & ~3);
+        const int g_hi = skew + ((e_hi - skew) & ~3);
+        if (g_lo >= g_hi) {                                   // tiny slice: scalar only
+            for (int e = e_lo + tid; e < e_hi; e += BLOCK) gout[e] = elem_value(bits, e, layout, m0, m1, m2);
+            continue;
+        }
+        if (tid < g_lo - e_lo) gout[e_lo + tid] = elem_value(bits, e_lo + tid, layout, m0, m1, m2);
+        if (tid < e_hi - g_hi) gout[g_hi + tid] = elem_value(bits, g_hi + tid, layout, m0, m1, m2);
+        for (int e = g_lo + 4 * tid; e < g_hi; e += 4 * BLOCK)
+            *reinterpret_cast<float4*>(gout + e) = LAYOUT == SVX_LAYOUT_NCHW ? elem_group_rows(bits, e, m0, m1, m2)
+                                                                            : elem_group<LAYOUT>(bits, e, m0, m1, m2);
     }
-    const int head_end = (int)(q_lo * 4 - base);                 // elements [e_lo, head_end) scalar
-    const int tail_beg = (int)(q_hi * 4 - base);                 // elements [tail_beg, e_hi) scalar
-    if (tid < head_end - e_lo) gout[e_lo + tid] = elem_value(bits, e_lo + tid, layout, m0, m1, m2);
-    if (tid < e_hi - tail_beg) gout[tail_beg + tid] = elem_value(bits, tail_beg + tid, layout, m0, m1, m2);
-    float4* out4 = reinterpret_cast<float4*>(out);
-    for (long long q = q_lo + tid; q < q_hi; q += BLOCK) {
-        out4[q] = elem_group<LAYOUT>(bits, (int)(q * 4 - base), m0, m1, m2);
+}
+
+int device_cus()
+{
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        n = cus;
     }
+    return n;
 }
 
 }  // namespace
@@ -111,10 +155,12 @@ extern "C" int svx_rasterize(const int32_t* d_records, uint32_t n, float* d_out,
     if (layout != SVX_LAYOUT_NHWC && layout != SVX_LAYOUT_NCHW) return SVX_EINVAL;
     if ((reinterpret_cast<uintptr_t>(d_out) & 15u) != 0) return SVX_EINVAL;
     if ((uint64_t)n * 16 > 0x7fffffffull) return SVX_EINVAL;
-    // enough workgroups to cover 256 CUs several times over even for one CNN batch
+    // NCHW: one resident workgroup per CU, an image cut into as many slices as it takes to give every CU one (a launch of one CNN
+    // batch: 4 slices per image).  NHWC (per-element arithmetic: three times the instructions per byte): eight workgroups per CU.
+    const int resident = device_cus() * (layout == SVX_LAYOUT_NCHW ? 1 : 8);
     int strips = 1;
-    while (strips < 16 && (uint64_t)n * strips < 2048) strips *= 2;
-    dim3 grid(n * strips), block(BLOCK);
+    while (strips < 16 && (uint64_t)n * strips < (uint64_t)resident) strips *= 2;
+    dim3 grid((unsigned)min((uint64_t)n * strips, (uint64_t)resident)), block(BLOCK);
     if (layout == SVX_LAYOUT_NCHW)
         hipLaunchKernelGGL(raster_kernel<SVX_LAYOUT_NCHW>, grid, block, 0, static_cast<hipStream_t>(stream),
                            d_records, n, d_out, strips, mean[0], mean[1], mean[2]);

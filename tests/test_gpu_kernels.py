@@ -17,7 +17,7 @@ def _dev(a, dtype=None):
 
 
 @pytest.mark.parametrize("layout", ["NHWC", "NCHW"])
-@pytest.mark.parametrize("n", [1, 3, 64, 257])
+@pytest.mark.parametrize("n", [1, 3, 64, 130, 257, 600])       # (130: two slices per image, more items than resident workgroups; 600: several images per workgroup)
 def test_rasterize_matches_oracle(oracle_lib, layout, n):
     from oracle import cbind
     rec = datagen.random_records(n, seed=100 + n)
