@@ -84,6 +84,50 @@ __device__ inline float4 elem_group_rows(const unsigned* bits, int e, float m0, 
     return make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// NHWC: element e of the image is (pixel e / 3, channel e % 3).  After the planes are drawn they are INTERLEAVED once per image
+// into `tri`: row r = 768 bits (24 words), bit 3 c + ch = plane ch at (r, c) -- 32 pixels of the three planes become three words
+// through a 256-entry table that spreads a byte over every third bit -- so that the four elements of a group are again four
+// consecutive bits of a 64-bit window; the (at most three) elements behind the end of a row are the first bits of the next row's
+// first word.  681 % 3 == 0: the channel of element e + i is (e % 3 + i) % 3 whatever the row.
+constexpr int TRI_ROW_WORDS = 3 * ROW_WORDS;                 // 24
+constexpr int TRI_ROW_ELEMS = 3 * IMG;                       // 681 elements (bits) of a row in use
+constexpr int TRI_WORDS = (IMG + 1) * TRI_ROW_WORDS;         // + one row: the look-ahead word of the last row
+
+__device__ inline void interleave_planes(const unsigned* bits, unsigned* tri, const unsigned* spread, int tid)
+{
+    for (int u = tid; u < IMG * ROW_WORDS; u += BLOCK) {     // unit u: 32 pixels of row u / 8
+        const unsigned p0 = bits[u], p1 = bits[PLANE_WORDS + u], p2 = bits[2 * PLANE_WORDS + u];
+        unsigned long long t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            t[j] = (unsigned long long)(spread[(p0 >> (8 * j)) & 255u] | (spread[(p1 >> (8 * j)) & 255u] << 1) | (spread[(p2 >> (8 * j)) & 255u] << 2));
+        const unsigned long long lo = t[0] | (t[1] << 24) | (t[2] << 48);          // bits 0..63 of the 96
+        const unsigned hi = (unsigned)(t[2] >> 16) | (unsigned)(t[3] << 8);        // bits 64..95
+        unsigned* o = tri + 3 * u;                             // (u = r * 8 + wj -> word r * 24 + 3 wj)
+        o[0] = (unsigned)lo; o[1] = (unsigned)(lo >> 32); o[2] = hi;
+    }
+    if (tid < TRI_ROW_WORDS) tri[IMG * TRI_ROW_WORDS + tid] = 0;
+}
+
+__device__ inline float4 elem_group_tri(const unsigned* tri, int e, float m0, float m1, float m2)
+{
+    const int r = e / TRI_ROW_ELEMS, o = e - r * TRI_ROW_ELEMS;
+    const int A = r * (32 * TRI_ROW_WORDS) + o, wi = A >> 5, sh = A & 31;
+    const unsigned long long win = (((unsigned long long)tri[wi + 1] << 32) | tri[wi]) >> sh;
+    const unsigned nx = tri[(r + 1) * TRI_ROW_WORDS];
+    const int ch0 = e - 3 * (e / 3);
+    const float ma = ch0 == 0 ? m0 : (ch0 == 1 ? m1 : m2), mb = ch0 == 0 ? m1 : (ch0 == 1 ? m2 : m0), mc = ch0 == 0 ? m2 : (ch0 == 1 ? m0 : m1);
+    const float mean[4] = {ma, mb, mc, ma};
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int over = o + i - TRI_ROW_ELEMS;                // >= 0: the element is bit `over` of the next row
+        const unsigned b = over >= 0 ? (nx >> over) & 1u : (unsigned)(win >> i) & 1u;
+        v[i] = b ? 255.0f - mean[i] : -mean[i];
+    }
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // A RESIDENT grid: workgroup w takes the work items (image, strip) w, w + grid, ...; a work item is one contiguous slice of
 // one image.  NCHW launches run one workgroup per CU (svx_rasterize): a write-only stream is fastest with few waves in flight
 // (a float4 fill of the same 1.27 GB: 6.5 TB/s from 256 workgroups, 5.3 from 2,048, 4.1 from 4,096), and the branch-free group
@@ -99,8 +143,16 @@ void raster_kernel(const int32_t* __restrict__ records, uint32_t n, float* __res
     __shared__ unsigned bits[3 * PLANE_WORDS + 4];
     __shared__ unsigned colcnt[IMG];
     __shared__ unsigned colmask[ROW_WORDS];
+    __shared__ unsigned tri[LAYOUT == SVX_LAYOUT_NHWC ? TRI_WORDS : 1];          // NHWC: the planes interleaved (elem_group_tri)
+    __shared__ unsigned spread[LAYOUT == SVX_LAYOUT_NHWC ? 256 : 1];             // byte -> its bits at every third position
     const int tid = threadIdx.x;
     if (tid < 4) bits[3 * PLANE_WORDS + tid] = 0;
+    if (LAYOUT == SVX_LAYOUT_NHWC) {
+        unsigned sp = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sp |= (((unsigned)tid >> k) & 1u) << (3 * k);
+        spread[tid & 255] = sp;                                // (BLOCK == 256: one entry per thread; visible behind draw_planes' barriers)
+    }
     const int per = ((IMG_ELEMS + strips - 1) / strips + 3) & ~3;
     const long long items = (long long)n * strips;
     int drawn = -1;
@@ -109,6 +161,7 @@ void raster_kernel(const int32_t* __restrict__ records, uint32_t n, float* __res
         if (img != drawn) {
             __syncthreads();                                  // (the previous item's readers are through with the planes)
             draw_planes<BLOCK>(records + (size_t)img * 12, bits, colcnt, colmask);
+            if (LAYOUT == SVX_LAYOUT_NHWC) { interleave_planes(bits, tri, spread, tid); __syncthreads(); }
             drawn = img;
         }
         // stream this item's slice [e_lo, e_hi) of the image: 16-byte stores aligned on the TENSOR (image bases are only 4-byte
@@ -129,7 +182,7 @@ void raster_kernel(const int32_t* __restrict__ records, uint32_t n, float* __res
         if (tid < e_hi - g_hi) gout[g_hi + tid] = elem_value(bits, g_hi + tid, layout, m0, m1, m2);
         for (int e = g_lo + 4 * tid; e < g_hi; e += 4 * BLOCK)
             *reinterpret_cast<float4*>(gout + e) = LAYOUT == SVX_LAYOUT_NCHW ? elem_group_rows(bits, e, m0, m1, m2)
-                                                                            : elem_group<LAYOUT>(bits, e, m0, m1, m2);
+                                                                            : elem_group_tri(tri, e, m0, m1, m2);
     }
 }
 
@@ -155,9 +208,9 @@ extern "C" int svx_rasterize(const int32_t* d_records, uint32_t n, float* d_out,
     if (layout != SVX_LAYOUT_NHWC && layout != SVX_LAYOUT_NCHW) return SVX_EINVAL;
     if ((reinterpret_cast<uintptr_t>(d_out) & 15u) != 0) return SVX_EINVAL;
     if ((uint64_t)n * 16 > 0x7fffffffull) return SVX_EINVAL;
-    // NCHW: one resident workgroup per CU, an image cut into as many slices as it takes to give every CU one (a launch of one CNN
-    // batch: 4 slices per image).  NHWC (per-element arithmetic: three times the instructions per byte): eight workgroups per CU.
-    const int resident = device_cus() * (layout == SVX_LAYOUT_NCHW ? 1 : 8);
+    // one resident workgroup per CU, an image cut into as many slices as it takes to give every CU one (a launch of one CNN
+    // batch: 4 slices per image)
+    const int resident = device_cus();
     int strips = 1;
     while (strips < 16 && (uint64_t)n * strips < (uint64_t)resident) strips *= 2;
     dim3 grid((unsigned)min((uint64_t)n * strips, (uint64_t)resident)), block(BLOCK);
