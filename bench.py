@@ -65,11 +65,19 @@ GRCH38 = (("chr1", 248956422), ("chr2", 242193529), ("chr3", 198295559), ("chr4"
 LAYER_FLOP = {"conv2": 447_897_600, "conv3": 299_040_768, "conv4": 224_280_576, "conv5": 149_520_384, "fc": 109_092_864}
 LAYER_PIX = {"conv2": 729, "conv3": 169, "conv4": 169, "conv5": 169}
 WINDOW = 10_000_000
-try:                                              # the round's rocprofv3 PMC passes over the device stage (tools/r05_profile.sh)
-    with open(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")) as _f:
-        TRAFFIC = json.load(_f)
-except (OSError, ValueError):
-    TRAFFIC = {}
+def _pmc_traffic():
+    """The newest profiles/rNN_pmc_traffic.json: the round's rocprofv3 PMC passes over the device stage (tools/r06_profile.sh)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                return json.load(f)
+        except (OSError, ValueError):
+            continue
+    return {}
+
+
+TRAFFIC = _pmc_traffic()
 
 
 def random_weights(seed=0):

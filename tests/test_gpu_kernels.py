@@ -556,3 +556,48 @@ def test_pool_reads_inactive_pixels_from_the_background(c, hw, lrn):
     assert torch.equal(got, want) and not torch.isnan(got).any()
     with pytest.raises(Exception):
         kernels.bias_relu_pool_lrn(holes, bias, lrn=lrn, active_rows=rows)
+
+
+def test_scan_lookback_makes_progress_on_a_busy_chip(oracle_lib):
+    """The offsets pass's decoupled look-back assumes that the workgroups in front of a tile are dispatched (include/svx.h: it
+    fails loudly -- SVX_SCAN_FAILED -- rather than hang or answer wrongly).  In the pipeline the scan's launches co-run with the
+    inflate's tokens kernel, which owns every CU while it runs, and with the convolutions: 1,000 scans of a
+    several-tile batch launched while a side stream keeps the chip full of tokens + LZ launches -- never a failure, always the
+    same bytes."""
+    import struct
+    import zlib
+    from oracle import cbind
+    rng = np.random.default_rng(17)
+    blocks = []
+    for _ in range(48):                                       # 48 distinct blocks, repeated: ~3,000 blocks (190 MB inflated) per launch
+        payload = bytes(rng.integers(0, 7, 65280, dtype=np.uint8) + 65)
+        co = zlib.compressobj(1, zlib.DEFLATED, -15)
+        cdata = co.compress(payload) + co.flush()
+        blocks.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(cdata) + 25) + cdata
+                      + struct.pack("<II", zlib.crc32(payload) & 0xFFFFFFFF, len(payload)))
+    raw = np.frombuffer(b"".join(blocks * 64), np.uint8)
+    src_off, src_len, isize, _blk = kernels.bgzf_block_table(raw)
+    padded = np.zeros((raw.size + 31) // 16 * 16, np.uint8)
+    padded[:raw.size] = raw
+    d_comp = torch.from_numpy(padded).to(DEV)
+    cigar, off, ref_start = datagen.random_cigars(40_000, seed=23, mean_ops=160, long_gap_rate=0.002)     # 40 tiles of 1,024 alignments
+    d_c, d_o, d_r = _dev(cigar.view(np.int32)), _dev(off.astype(np.int64)), _dev(ref_start)
+    o_gaps, o_off, o_stats = cbind.cigar_scan(cigar, off, ref_start, 50)
+    side = torch.cuda.Stream(device=DEV)
+    first = None
+    for rep in range(1000):
+        if rep % 10 == 0:                                     # keep inflate work (tokens + LZ of ~3,000 blocks per launch) queued beside the scans
+            with torch.cuda.stream(side):
+                _out, status = kernels.bgzf_inflate(d_comp, src_off, src_len, isize, wave="fast", crc=False)
+        res = kernels.cigar_scan(d_c, d_o, d_r, 50, gaps_cap=1 << 16)
+        total = res.total()                                   # raises SvxError on SVX_SCAN_FAILED
+        if first is None:
+            gaps, gap_off, stats = res.to_host()
+            assert gaps.tobytes() == o_gaps.tobytes() and np.array_equal(gap_off, o_off) and np.array_equal(stats, o_stats) and total > 0
+            first = (total, res.gaps[:total * 6].clone(), res.gap_off.clone())
+        else:
+            assert total == first[0]
+            if rep % 50 == 0:
+                assert torch.equal(res.gaps[:total * 6], first[1]) and torch.equal(res.gap_off, first[2])
+    side.synchronize()
+    assert not bool(status.any())

@@ -392,7 +392,7 @@ def test_network_adopted_from_the_weight_cache_equals_the_network_built_from_the
     bed.write_text(case["chroms"]["chrB"]["tsv"])
     gen = BatchGenerator(str(bed), nb_classes=5, batch_size=64, layout="NCHW")
     records, _labels = gen.next_records(64)
-    rec = torch.from_numpy(np.asarray(records, np.int32)).cuda()
+    rec = records.contiguous()                                           # int32 device tensor [64, 12]
     p1, p2 = first.predict_records_packed(rec), second.predict_records_packed(rec)
     assert torch.equal(p1, p2)
     # lazily built launch slots (the command line) == eagerly built ones (bench, services)
