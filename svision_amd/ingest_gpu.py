@@ -23,7 +23,10 @@ from .io.bam import AlignmentTable, read_bai_linear
 
 FIRST_GROUP_BYTES = 192 << 20            # the first launch is small (~7 k blocks: the wave-per-block kernel): the pipeline starts after ~0.1 s
 STAGE_BYTES = 64 << 20                   # a pinned staging slot of the pipelined reader (ring of eight)
-PIPE_GROUP_BYTES = 600 << 20             # parts_pipelined, the groups behind the first: ~21 k blocks.  (Round 3 / early round 4: 768 MB, then 2.5 GB
+PIPE_GROUP_BYTES = 400 << 20             # the SECOND group: two slices (~14 k blocks) -- a ramp 192 / 400 / 600 MB.  Round 6, measured (profiles/r06_group_sweep.txt):
+                                         # the five-window chr21 job (BASELINE configs[1]) is cut [1, 2, 2] instead of [1, 4] and takes 0.142 s instead of 0.172
+                                         # (its second and third window no longer wait for the inflate of all four); 20 windows, cfg1, ONT: unchanged (+-1 %)
+                                         # parts_pipelined, the groups behind the first two: ~21 k blocks.  (Round 3 / early round 4: 768 MB, then 2.5 GB
 LARGE_GROUP_BYTES = 600 << 20            # -- a launch of the lane-per-block kernel cost 60-90 ms whatever it held.  The two-kernel inflate is
 LARGE_GROUP_BLOCKS = 94_000              # proportional to the launch, and once the read-backs no longer blocked each other (launch(), streams.py)
                                          # a steady flow of small groups beat the large ones: the CNN behind never runs out of chromosomes.)
