@@ -6,9 +6,11 @@ Workloads (synthetic: the reference ships no BAM; svision_amd/synth.py, fixed se
   wg (default)    BASELINE.json configs[2] stand-in, the config the metric is quoted on: 24 contigs with the GRCh38
                   primary lengths (3.1 Gb, 322 collection windows), HiFi reads N(15 kb, 2 kb) at 30x with planted SVs,
                   chromosomes LPT-sharded over the ranks exactly as the command line does it
-                  (svision_amd.dist.shard_chromosomes, cli.load_rank_table).  Strong scaling: the job is the genome,
-                  whatever N.  `--steps K` makes the job exactly K windows: every chromosome keeps a prefix, the
-                  windows apportioned to the chromosomes by length (K < 24: the K longest chromosomes, one window each).
+                  (svision_amd.dist.shard_chromosomes, cli.load_rank_table).  `--steps K` (default 20) = K windows PER RANK:
+                  the job is exactly K x N windows -- every chromosome keeps a prefix, the windows apportioned to the
+                  chromosomes by length (fewer than 24: the longest chromosomes, one window each) -- sharded by chromosome:
+                  WEAK scaling (the path partitions, no data-path collective); `steps` in the line is K, `config.windows`
+                  K x N.  Without --steps (`--resident`), or once K x N reaches 322, the job is the genome whatever N: strong.
   cfg2            BASELINE.json configs[1] stand-in: a chr21-sized contig (46,709,983 bp), same read model.  N > 1:
                   every rank owns its own such shard (weak scaling).
 
@@ -23,11 +25,16 @@ timed region starts with nothing but that file and ends after the cross-rank exc
   device  similarity-image encoding + AlexNet fp32, batches of 64 candidate images
   host    per-site vote -> VCF body lines + scores
 
-A *step* is one collection window of the reference driver (10 Mb, SVision:88).  value = candidate sites (distinct region
+A *step* is one collection window of the reference driver (10 Mb, SVision:88) -- on every rank at once under weak scaling.
+`value` is the median of --repeats (3) timed repeats of the whole job, each between its own barriers.  value = candidate sites (distinct region
 keys of the chromosomes' segment TSVs: a site spanning a window boundary counts once) per second, whole job; ms_per_step
 follows it.  `config.resident_sites_per_s` is the same job with the alignments already decoded and resident in HBM (the
 headline of rounds 1-3): what the device pipeline does once ingestion is out of the way.  No data-path collective; one
-score-range all_reduce + one record gather at the end, inside the timed region.  Prints ONE JSON line on rank 0.
+score-range all_reduce + one record gather at the end, inside the timed region.  Rank 0 prints ONE compact JSON line (< 4 KB:
+the contract's keys, roofline, cpu_baseline, parity_check); the full record (every leg, decoder traces, per-kernel rooflines) goes
+to --detail (bench_detail.json).  After the timed legs the windows the CPU baseline is about to run go through the device path
+once more (untimed) with the helpers returning their TSV text and the owner keeping the predictions: `parity_check` compares them
+with the CPU port's (TSV and site keys bit-exact, softmax within 1e-3) and the process exits 3 on a mismatch.
 `--gpus N` without a launcher environment starts the N ranks itself (torch.distributed.run, one per GPU, RCCL).
 """
 import argparse
@@ -174,20 +181,25 @@ def build_workload(args, rank, world, cores):
         if args.e2e_windows:
             e2e_prefix = {name: min(args.contig_len, args.e2e_windows * WINDOW)}
     else:
-        contigs = list(GRCH38) if args.workload == "contig" else job_contigs(args.steps)
+        # wg with --steps K: K windows PER RANK -- the job is K x N windows of the genome (a prefix of every chromosome), sharded by
+        # chromosome: weak scaling, as a path that partitions with no data-path collective is to be reported.  Without --steps (or
+        # once K x N reaches the genome's 322 windows) the job is the genome whatever N: strong scaling.
+        full_windows = sum(len(windows_of(n, l)) for n, l in GRCH38)
+        wg_windows = args.steps * world if args.steps else None
+        contigs = list(GRCH38) if args.workload == "contig" else job_contigs(wg_windows)
         shards = sdist.shard_chromosomes([n for n, _l in contigs], [l for _n, l in contigs], world)
         shard = shards[rank]
         length_of = dict(contigs)
         args.rank_mb = [sum(length_of[c] for c in sh) / 1e6 for sh in shards]               # the LPT loads, for the report
         jobs = [dict(name=n, length=l, coverage=2.0 if args.workload == "contig" else args.coverage, seed=100 + i,
                      kind="contig" if args.workload == "contig" else None) for i, (n, l) in enumerate(contigs) if n in shard]
-        strong = True
+        strong = args.workload == "contig" or wg_windows is None or wg_windows >= full_windows
         total_windows = len(contigs) if args.workload == "contig" else sum(len(windows_of(n, l)) for n, l in contigs)
         if args.e2e_windows and args.workload == "contig":
             e2e_prefix = {n: length_of[n] for n in shard}               # --contig: one task per chromosome, the file holds all of them
         if args.e2e_windows and args.workload == "wg":
             # the file-inclusive leg runs on a bounded job: the same chromosomes, every one cut to its share of --e2e-windows
-            small = dict(job_contigs(args.e2e_windows)) if total_windows > args.e2e_windows else length_of
+            small = dict(job_contigs(args.e2e_windows * world)) if total_windows > args.e2e_windows * world else length_of
             e2e_prefix = {n: min(small[n], length_of[n]) for n in shard if n in small}
     k = 0
     bam_dir = None
@@ -292,7 +304,7 @@ def compact_line(full, detail_path=None):
     line["config"] = {
         "workload": _clip(cfg.get("workload", ""), 240),
         "timed_region": _clip(cfg.get("timed_region_kind") or cfg.get("timed_region", ""), 160),
-        "batch": num(cfg.get("batch")), "windows": num(full.get("steps")),
+        "batch": num(cfg.get("batch")), "windows": num(cfg.get("windows", full.get("steps"))),
         "sites_per_step": num(cfg.get("sites_per_step")), "images_per_site": num(cfg.get("images_per_site")),
         "images_per_s": num(cfg.get("images_per_s")),
         "resident_sites_per_s": num(cfg.get("resident_sites_per_s")),
@@ -370,7 +382,7 @@ def first_contact(world, grouped, backend, rank_mb, rank_file_bytes, identities)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="windows of the job (wg: whole job, default 20 -- the windows the job's BAM is written for; with --resident all 322; cfg2 / ont: per rank, default 200)")
+    ap.add_argument("--steps", type=int, default=None, help="windows per rank (wg: default 20 -- the job is steps x ranks windows of the genome, sharded by chromosome; with --resident and no --steps all 322 windows whatever the ranks; cfg2 / ont: default 200)")
     ap.add_argument("--resident", action="store_true", help="`value` = the resident leg (alignments decoded and in HBM before the timed region; the headline of rounds 1-3): for jobs whose BAM would be too large to write during set-up (the whole genome: 62 GB)")
     ap.add_argument("--no-other-engine", action="store_true", help="skip the file-inclusive leg with the other ingest engine")
     ap.add_argument("--e2e-sweep", default=None, help="experiments: further file-inclusive legs in the same process, one per ';'-separated set of "
@@ -378,7 +390,7 @@ def main():
                                                       "a set may be repeated; their seconds go to stderr and to the line's `e2e_sweep`")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", choices=("cfg1", "cfg2", "wg", "ont", "contig"), default="wg",
-                    help="wg: 24 GRCh38-length contigs sharded over the ranks (strong scaling, the default: the config the metric is quoted on); "
+                    help="wg: 24 GRCh38-length contigs sharded over the ranks (the default: the config the metric is quoted on; --steps K = K windows per rank, weak scaling; without --steps the whole genome, strong scaling); "
                          "cfg2: chr21-sized HiFi sample per rank (weak scaling); ont: chr21-sized ONT ultra-long stand-in per rank (BASELINE configs[3] stress: ~5,000 CIGAR ops per read); "
                          "contig: --contig mode, two haplotypes of ~2 Mb assembly contigs on the 24 GRCh38-length chromosomes, one task per chromosome")
     ap.add_argument("--batch", type=int, default=64, help="candidate images per CNN batch (BASELINE configs[1])")
@@ -498,7 +510,8 @@ def main():
                     scores += [float(s_) for s_ in score_text.split()]
         return sites, images, records, scores
 
-    if strong:
+    sharded = args.workload in ("wg", "contig")                       # the rank runs its LPT shard of one job (the others: a job of its own per rank)
+    if sharded:
         timed = list(windows)                                         # this rank's share of the job
         steps_job = total_windows
     else:
@@ -615,7 +628,10 @@ def main():
     job_s = e2e_block["seconds"] if headline_e2e else dt
     job_sites = e2e_block["sites"] if headline_e2e else res_sites
     job_images = e2e_block["images"] if headline_e2e else res_images
-    job_steps = e2e_block["windows"] if headline_e2e else steps_job
+    # windows of the whole job (all ranks), and the line's `steps`: strong scaling -- the job's windows; weak -- the windows of ONE rank
+    # (a step = one window on every rank at once; value = the sites of all ranks / the slowest rank's time)
+    job_windows = e2e_block["windows"] if headline_e2e else (steps_job if sharded else steps_job * world)
+    job_steps = job_windows if strong else max(1, int(round(job_windows / world)))
 
     def stage_report(st, wall):
         frac = {k: float(st["pix"][i] / (st["images"] * LAYER_PIX[k])) for i, k in enumerate(("conv2", "conv3", "conv4", "conv5"))}
@@ -635,7 +651,8 @@ def main():
                 ("cfg1 stand-in (BASELINE.md section 2: the demo BAM is absent): one 75 Mb contig, synthetic HiFi N(15kb,2kb) reads, %gx, -s 5"
                  % args.coverage) if args.workload == "cfg1" else
                 ("cfg3 stand-in: synthetic whole-genome HiFi, 24 contigs of GRCh38 length (N(15kb,2kb) reads, %gx), "
-                 "chromosomes LPT-sharded over the ranks" % args.coverage) if strong else
+                 "chromosomes LPT-sharded over the ranks%s" % (args.coverage, "" if strong else "; --steps windows per rank (a prefix of every chromosome)"))
+                if args.workload == "wg" else
                 ("cfg4 stand-in on one contig per rank: synthetic ONT ultra-long chr21 (%d bp, log-normal reads, median 50 kb, "
                  "5 %% small events, %gx)" % (args.contig_len, args.coverage)) if args.workload == "ont" else
                 ("cfg2 stand-in: synthetic HiFi chr21 (%d bp, N(15kb,2kb) reads, %gx)" % (args.contig_len, args.coverage)))
@@ -666,7 +683,7 @@ def main():
                    "step": ("one chromosome" if args.workload == "contig" else "one 10 Mb collection window") +
                            " through [file -> inflate -> records ->] scan -> collection -> encode + CNN (batches of %d candidate images, fp32) -> vote" % B,
                    "batch": B, "alignments_rank0": len(table), "cigar_ops_rank0": int(table.cigar.size),
-                   "windows_rank0": len(windows), "sites_per_step": job_sites / max(job_steps * (1 if strong or headline_e2e else world), 1),
+                   "windows_rank0": len(windows), "windows": job_windows, "sites_per_step": job_sites / max(job_windows, 1),
                    "images_per_site": job_images / max(job_sites, 1), "images_per_s": job_images / job_s,
                    "resident_sites_per_s": res_sites / dt, "resident_seconds": dt, "resident_steps": steps_job,
                    "resident_ms_per_step": dt / max(steps_job, 1) * 1e3,
