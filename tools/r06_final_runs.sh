@@ -19,3 +19,8 @@ except Exception as ex:
     print(sys.argv[1], "ERR", ex)
 P
 done
+# multi-rank rehearsals on ONE GPU (gloo: RCCL refuses two ranks on a device): the N-rank code path of the line, not a measurement
+if [ "${RANKS:-1}" = 1 ]; then
+  SVX_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline --no-calibration --no-cold-leg --no-other-engine --detail $O/2ranks.detail.json > $O/2ranks.json 2> $O/2ranks.err; echo "2 ranks rc=$?"; cut -c1-900 $O/2ranks.json
+  SVX_DIST_BACKEND=gloo python bench.py --gpus 8 --steps 5 --warmup 2 --no-cpu-baseline --no-calibration --no-cold-leg --no-other-engine --detail $O/8ranks.detail.json > $O/8ranks.json 2> $O/8ranks.err; echo "8 ranks rc=$?"; cut -c1-900 $O/8ranks.json
+fi
