@@ -321,6 +321,9 @@ def compact_line(full, detail_path=None):
     for k in ("bound", "achieved", "peak", "unit", "frac", "frac_stage_alone", "frac_algorithmic", "dense_stage_frac", "traffic",
               "ms_per_batch", "device_busy_frac"):
         line["roofline"][k] = num(rf.get(k))
+    dom = rf.get("dominant_kernel")
+    if dom:
+        line["roofline"]["dominant_kernel"] = {k: (num(v) if not isinstance(v, str) else _clip(v, 60)) for k, v in dom.items()}
     hbm = full.get("roofline_hbm")
     if hbm:
         line["roofline_hbm"] = {k: num(v) if not isinstance(v, str) else _clip(v, 120) for k, v in hbm.items()}
@@ -759,6 +762,16 @@ def main():
         line["e2e_sweep"] = sweep
     if calib:
         line["roofline_kernels"] = calib
+        k3 = [calib.get("conv_wave_list_kernel %s" % n) for n in ("conv3", "conv4", "conv5")]
+        if all(k3):
+            # the launch that dominates the stage (rocprofv3's conv_wave_list_kernel<3>: conv3, conv4, conv5 -- 59 % of the stage's kernel
+            # time), timed live with HIP events on this run's own records: what profiles/rNN_b_device_stage_kernel_stats.csv must agree with
+            t_us = sum(k["us"] for k in k3)
+            executed = sum(k["achieved"] * k["us"] for k in k3) / t_us                      # TFLOP/s over the three launches
+            dense = sum(LAYER_FLOP[n] for n in ("conv3", "conv4", "conv5")) * B * max(1, args.launch_batches) / (t_us * 1e-6) / 1e12
+            line["roofline"]["dominant_kernel"] = {"name": "conv_wave_list_kernel<3>", "launches": "conv3, conv4, conv5 of %d images" % (B * max(1, args.launch_batches)),
+                                                   "avg_us": t_us / 3, "achieved": executed, "frac": executed * 1e12 / F32_MFMA_PEAK,
+                                                   "frac_algorithmic": dense * 1e12 / F32_MFMA_PEAK}
         scan_k, ras_k = calib.get("cigar_scan (4 kernels)"), next((v for k, v in calib.items() if k.startswith("raster_kernel")), None)
         if scan_k and ras_k:                  # the two HBM-bound kernels of the path, beside the MFMA-bound stage
             line["roofline_hbm"] = {"peak": HBM_PEAK / 1e9, "unit": "GB/s", "cigar_scan_achieved": scan_k["achieved"], "cigar_scan_frac": scan_k["frac"],
