@@ -283,7 +283,12 @@ class ChromosomeFeed:
                 if arrays is not None:                         # device engine: the host copy of the CIGAR words follows later
                     meta["lazy_cigar"] = int(table.cigar.size)
                     meta["spilled"] = threading.Event()
-                    spill.put((table, meta["spilled"]))
+                    spill.put((table, meta["spilled"], sample))
+                else:
+                    # host engine: the upload served the scan and nothing else (windows of a file-driven run are never scanned
+                    # again: their chromosome's Sample is final) -- the slice's device arrays go back to the allocator now, not when
+                    # the whole chromosome has been voted (a chromosome's slices held their buffers until release())
+                    sample.device_buffers = None
                 if dec is not None:
                     dec._mark("handed over %s [%s, %s) (scan + slot writes)" % (self.references[tid], lo, hi))
                     dec.first_handover.set()                    # (the decoder holds its second launch back for this, ingest_gpu.py)
@@ -366,11 +371,15 @@ class ChromosomeFeed:
             job = jobs.get()
             if job is None:
                 return
-            table, done = job
+            table, done, sample = job
             try:
                 with torch.cuda.stream(stream):
                     spill_cigar(table)
+                    if sample.device_buffers is not None:      # (the arrays were last used on this stream: the spill's copy)
+                        for t in sample.device_buffers[:3]:
+                            t.record_stream(stream)
                 table._d_cigar = None
+                sample.device_buffers = None                   # the device arrays of the slice: scanned, spilled, never read again
             except BaseException as exc:                       # noqa: BLE001 -- a helper that needs the words would wait for ever
                 self.error = self.error or exc
             finally:
