@@ -138,6 +138,14 @@ def job_contigs(steps):
     return [(n, min(l, kk * WINDOW)) for (n, l, _w), kk in zip(full, k)]
 
 
+def wg_job(steps, world):
+    """The `wg` job of an N-rank run: --steps K = K windows PER RANK -> exactly K x N windows of the genome (job_contigs), weak
+    scaling; no --steps, or K x N >= the genome's 322 windows: the genome whatever N, strong scaling.  -> (contigs, strong?)."""
+    full = sum(len(windows_of(n, l)) for n, l in GRCH38)
+    want = steps * world if steps else None
+    return job_contigs(want), (want is None or want >= full)
+
+
 def _simulate_contig(job):
     """job: dict(name, length, coverage, seed, kind, e2e=(tid in the rank's file, prefix length) or None) ->
     (AlignmentTable, genome bytes, BGZF segment of the prefix or None) of one contig (runs in a forked worker)."""
@@ -184,16 +192,15 @@ def build_workload(args, rank, world, cores):
         # wg with --steps K: K windows PER RANK -- the job is K x N windows of the genome (a prefix of every chromosome), sharded by
         # chromosome: weak scaling, as a path that partitions with no data-path collective is to be reported.  Without --steps (or
         # once K x N reaches the genome's 322 windows) the job is the genome whatever N: strong scaling.
-        full_windows = sum(len(windows_of(n, l)) for n, l in GRCH38)
-        wg_windows = args.steps * world if args.steps else None
-        contigs = list(GRCH38) if args.workload == "contig" else job_contigs(wg_windows)
+        wg_contigs, wg_strong = wg_job(args.steps, world)
+        contigs = list(GRCH38) if args.workload == "contig" else wg_contigs
         shards = sdist.shard_chromosomes([n for n, _l in contigs], [l for _n, l in contigs], world)
         shard = shards[rank]
         length_of = dict(contigs)
         args.rank_mb = [sum(length_of[c] for c in sh) / 1e6 for sh in shards]               # the LPT loads, for the report
         jobs = [dict(name=n, length=l, coverage=2.0 if args.workload == "contig" else args.coverage, seed=100 + i,
                      kind="contig" if args.workload == "contig" else None) for i, (n, l) in enumerate(contigs) if n in shard]
-        strong = args.workload == "contig" or wg_windows is None or wg_windows >= full_windows
+        strong = args.workload == "contig" or wg_strong
         total_windows = len(contigs) if args.workload == "contig" else sum(len(windows_of(n, l)) for n, l in contigs)
         if args.e2e_windows and args.workload == "contig":
             e2e_prefix = {n: length_of[n] for n in shard}               # --contig: one task per chromosome, the file holds all of them

@@ -226,3 +226,21 @@ def test_parity_check_compares_digests_and_softmax():
     bad = b.parity_check(gpu, cpu, "resident")
     assert not bad["ok"] and not bad["tsv_equal"] and bad["sites_equal"]
     assert not b.parity_check({}, cpu, "resident")["ok"]                                   # a window the device leg never ran
+
+
+def test_wg_steps_are_windows_per_rank():
+    """Round 6: `--steps K` of the wg workload = K windows per rank (weak scaling: the path partitions by chromosome with no
+    data-path collective) -- the job is exactly K x N windows, LPT-sharded; at K x N >= 322 it is the genome whatever N (strong)."""
+    from svision_amd import dist as sdist
+    b = _bench()
+    for k, world in ((20, 1), (20, 2), (20, 8), (5, 8), (40, 8)):
+        contigs, strong = b.wg_job(k, world)
+        n = sum(len(b.windows_of(name, length)) for name, length in contigs)
+        assert n == k * world and not strong, (k, world, n)
+        shards = sdist.shard_chromosomes([c for c, _l in contigs], [l for _c, l in contigs], world)
+        loads = [sum(len(b.windows_of(c, dict(contigs)[c])) for c in sh) for sh in shards]
+        assert sum(loads) == k * world and min(loads) >= 1
+        assert max(loads) <= 1.5 * k + 1                       # chromosomes are not divisible: LPT keeps the ranks within half a job of K
+    for k, world in ((None, 1), (None, 8), (322, 1), (100, 4), (50, 8)):
+        contigs, strong = b.wg_job(k, world)
+        assert strong and contigs == list(b.GRCH38)
