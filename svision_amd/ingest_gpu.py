@@ -183,7 +183,9 @@ def cut_groups(tids, size_of, first_limits, limit, merge_last=True):
         cur_bytes += size_of(t)
     if cur:
         groups.append(cur)
-    if merge_last and len(groups) > 2 and sum(size_of(t) for t in groups[-1]) * 2 <= limit:
+    # (round 6: a QUARTER of a group, half until then -- with the LZ launches of round 5 a remainder of a third to a half of a group is
+    # better off on its own: cfg1's [1, 2, 3, 2] slices per launch take 0.193 s, [1, 2, 5] 0.210; profiles/r06_group_sweep.txt)
+    if merge_last and len(groups) > 2 and sum(size_of(t) for t in groups[-1]) * 4 <= limit:
         groups[-2:] = [groups[-2] + groups[-1]]
     return groups
 
