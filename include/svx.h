@@ -21,10 +21,11 @@
 extern "C" {
 #endif
 
-#define SVX_VERSION 410            /* 0.3.0: + svx_bgzf_crc32, svx_bgzf_inflate_fast (360); + svx_bgzf_inflate_fast_on: the two kernels on two streams (370);
+#define SVX_VERSION 420            /* 0.3.0: + svx_bgzf_crc32, svx_bgzf_inflate_fast (360); + svx_bgzf_inflate_fast_on: the two kernels on two streams (370);
                                     * svx_bgzf_inflate_fast / _on take the inflated byte count and refuse a workspace that is too small (380);
                                     * + svx_cigar_scan_flat: the scan of long alignments in one pass (390); svx_cigar_scan takes the word count of its launch, its workspace's size and shape flags (400);
-                                    * the exports the default path never calls moved to svx_experimental.h, + svx_bgzf_inflate_fast_lz there (410) */
+                                    * the exports the default path never calls moved to svx_experimental.h, + svx_bgzf_inflate_fast_lz there (410);
+                                    * svx_bam_walk_extract takes the number of records (a wave per record copies: ONT-shaped slices 14.7 -> ~1 ms) (420) */
 
 #define SVX_OK            0
 #define SVX_EINVAL       (-1)      /* bad argument (null pointer, bad layout...) */
@@ -323,11 +324,15 @@ int            svx_bgzf_crc32(const uint8_t* d_out, const uint64_t* d_dst_off, c
  *   svx_bam_walk_extract  d_base [n_starts][3] = exclusive prefix sums of the first three counts; fills tid / pos / flag /
  *                         mapq / l_seq [records], cig_off / name_off [records + 1] (offsets of each record's words / name;
  *                         the closing entry = the totals: ABI 370, the caller appended it before),
- *                         cigar [words], names [bytes] ('\n' behind every name) */
+ *                         cigar [words], names [bytes] ('\n' behind every name).  n_records = the sum of the records counts
+ *                         (ABI 420: a lane per start notes where every record lies, a wave per record copies it -- d_tid / d_pos
+ *                         carry the record's byte offset between the two launches; d_raw is read in aligned dwords: readable
+ *                         up to the next multiple of 4 behind its last byte) */
 int            svx_bam_walk_count(const uint8_t* d_raw, const uint64_t* d_starts, uint32_t n_starts, uint64_t* d_counts, void* stream);
 int            svx_bam_walk_extract(const uint8_t* d_raw, const uint64_t* d_starts, uint32_t n_starts, const uint64_t* d_base,
                                     int32_t* d_tid, int32_t* d_pos, uint16_t* d_flag, uint8_t* d_mapq, int32_t* d_l_seq,
-                                    int64_t* d_cig_off, uint32_t* d_cigar, int64_t* d_name_off, uint8_t* d_names, void* stream);
+                                    int64_t* d_cig_off, uint32_t* d_cigar, int64_t* d_name_off, uint8_t* d_names, uint32_t n_records,
+                                    void* stream);
 /* host helpers of the device-side ingestion: parallel positional read into caller memory; the whole BGZF blocks of a
  * buffer (payload offset / size, ISIZE, file offset; -> their number or -1, *used = bytes they cover); QNAME ids by
  * first occurrence (-> number of distinct names, written '\n'-separated to uniq) */

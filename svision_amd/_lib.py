@@ -52,7 +52,7 @@ SYMBOLS = {
     "svx_bgzf_inflate_fast_on": (ctypes.c_int, [_vp, _vp, _vp, _vp, _u32, _u64, _vp, _vp, _vp, _u64, _vp, _vp]),
     "svx_bgzf_crc32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp]),
     "svx_bam_walk_count": (ctypes.c_int, [_vp, _vp, _u32, _vp, _vp]),
-    "svx_bam_walk_extract": (ctypes.c_int, [_vp, _vp, _u32, _vp] + [_vp] * 9 + [_vp]),
+    "svx_bam_walk_extract": (ctypes.c_int, [_vp, _vp, _u32, _vp] + [_vp] * 9 + [_u32, _vp]),
     "svx_read_range": (ctypes.c_int, [ctypes.c_char_p, _u64, _u64, _vp, ctypes.c_int]),
     "svx_bgzf_index": (ctypes.c_int64, [_vp, _u64, _u64, _u64, _vp, _vp, _vp, _vp, _vp]),
     "svx_name_ids": (ctypes.c_int64, [_vp, _vp, _u64, _vp, _vp, _vp]),
@@ -83,7 +83,7 @@ class SvxMissing(SvxError):
 _lib = None
 
 
-ABI_VERSION = 410                     # SVX_VERSION of include/svx.h this binding was written against
+ABI_VERSION = 420                     # SVX_VERSION of include/svx.h this binding was written against
 
 
 def load():

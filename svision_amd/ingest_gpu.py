@@ -669,7 +669,7 @@ class DeviceDecoder:
                     d_cigar = d_cigar_all[w0:w0 + max(words, 1)]
                     _lib.check(lib.svx_bam_walk_extract(d_raw.data_ptr(), d_tab[at:].data_ptr(), n_starts, d_base.data_ptr(), d_tid.data_ptr(),
                                                         d_pos.data_ptr(), d_flag.data_ptr(), d_mapq.data_ptr(), d_lseq.data_ptr(), d_cig_off.data_ptr(),
-                                                        d_cigar.data_ptr(), d_name_off.data_ptr(), d_names.data_ptr(), st), "svx_bam_walk_extract")
+                                                        d_cigar.data_ptr(), d_name_off.data_ptr(), d_names.data_ptr(), n, st), "svx_bam_walk_extract")
                     h_pack = h_pack_all[p0:p0 + size]
                     h_pack.copy_(d_pack, non_blocking=True)
                     # svx_cigar_scan reads the offsets and positions where they are: views of the group's pack buffer, which
@@ -952,7 +952,7 @@ class DeviceDecoder:
         d_names = torch.empty(max(name_bytes, 1), dtype=torch.uint8, device=dev)
         _lib.check(lib.svx_bam_walk_extract(d_raw.data_ptr(), d_starts.data_ptr(), n_starts, d_base.data_ptr(), d_tid.data_ptr(), d_pos.data_ptr(),
                                             d_flag.data_ptr(), d_mapq.data_ptr(), d_lseq.data_ptr(), d_cig_off.data_ptr(), d_cigar.data_ptr(),
-                                            d_name_off.data_ptr(), d_names.data_ptr(), st), "svx_bam_walk_extract")
+                                            d_name_off.data_ptr(), d_names.data_ptr(), n, st), "svx_bam_walk_extract")
         t1 = time.perf_counter()
         alloc = self.alloc_for() if self.alloc_for is not None else (lambda _name, dtype, k: np.empty(k, dtype))
 

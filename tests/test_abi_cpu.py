@@ -19,7 +19,7 @@ def test_library_exports_header_symbols():
     lib = _lib.load()
     for name in declared | experimental:
         assert getattr(lib, name) is not None
-    assert lib.svx_version() == 410
+    assert lib.svx_version() == 420
     assert lib.svx_strerror(0) == b"ok" and b"capacity" in lib.svx_strerror(-2)
     assert lib.svx_cigar_scan_ws_bytes(0, 0) >= 0 and lib.svx_cigar_scan_ws_bytes(10_000_000, 0) > 40_000_000
     assert lib.svx_cigar_scan_ws_bytes(1000, 1 << 30) - lib.svx_cigar_scan_ws_bytes(1000, 0) == (1 << 30) // 32 + (1 << 30) // 128      # frame records + the map of the frames launch

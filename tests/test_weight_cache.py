@@ -20,8 +20,8 @@ def test_blob_round_trip_and_digest(tmp_path, monkeypatch):
     prefix = str(tmp_path / "m.ckpt")
     params = _weights(1)
     ck.write_checkpoint(prefix, params)
-    d1 = weight_cache.checkpoint_digest(prefix, abi=410)
-    assert d1 and d1 == weight_cache.checkpoint_digest(prefix, abi=410) and d1 != weight_cache.checkpoint_digest(prefix, abi=411)
+    d1 = weight_cache.checkpoint_digest(prefix, abi=420)
+    assert d1 and d1 == weight_cache.checkpoint_digest(prefix, abi=420) and d1 != weight_cache.checkpoint_digest(prefix, abi=421)
     net = AlexNet(params, device="cpu")
     path = weight_cache.cache_path(prefix, d1)
     assert os.path.dirname(path) == str(tmp_path) and d1[:16] in os.path.basename(path)
@@ -37,7 +37,7 @@ def test_blob_round_trip_and_digest(tmp_path, monkeypatch):
     # another checkpoint under the same name: another digest, so the old blob is never picked up
     params["fc8/biases"] = params["fc8/biases"] + np.float32(1)
     ck.write_checkpoint(prefix, params)
-    d2 = weight_cache.checkpoint_digest(prefix, abi=410)
+    d2 = weight_cache.checkpoint_digest(prefix, abi=420)
     assert d2 != d1 and weight_cache.load(weight_cache.cache_path(prefix, d2)) is None
     # foreign, short and other-format files are ignored
     with open(path, "r+b") as f:
@@ -46,7 +46,7 @@ def test_blob_round_trip_and_digest(tmp_path, monkeypatch):
     with open(path, "wb") as f:
         f.write(b"not a blob")
     assert weight_cache.load(path) is None
-    assert weight_cache.checkpoint_digest(str(tmp_path / "absent"), abi=410) is None
+    assert weight_cache.checkpoint_digest(str(tmp_path / "absent"), abi=420) is None
     monkeypatch.setenv("SVX_CACHE_DIR", str(tmp_path / "elsewhere"))
     assert os.path.dirname(weight_cache.cache_path(prefix, d1)) == str(tmp_path / "elsewhere")
     assert weight_cache.save(weight_cache.cache_path(prefix, d1), {"x": np.ones(3, np.float32)})      # the directory is created
