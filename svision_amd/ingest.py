@@ -283,6 +283,8 @@ class ChromosomeFeed:
                 if arrays is not None:                         # device engine: the host copy of the CIGAR words follows later
                     meta["lazy_cigar"] = int(table.cigar.size)
                     meta["spilled"] = threading.Event()
+                    if hasattr(table.cigar, "attach"):            # (LazyCigar: a reader in THIS process waits for the spill)
+                        table.cigar.event = meta["spilled"]
                     spill.put((table, meta["spilled"], sample))
                 else:
                     # host engine: the upload served the scan and nothing else (windows of a file-driven run are never scanned

@@ -72,6 +72,7 @@ class LazyCigar:
 
     def __init__(self, n_words, path=None, ready=None):
         self.size, self.nbytes, self.path, self.ready, self._arr = int(n_words), 4 * int(n_words), path, ready, None
+        self.event = None                    # owner process: set when the spill of this table is through (ingest.ChromosomeFeed)
 
     def attach(self, arr):
         self._arr = arr
@@ -80,6 +81,13 @@ class LazyCigar:
         if self._arr is None:
             import time
             if self.path is None:
+                # the owner process itself reads the words (-t 1: the by-value comparison of duplicated records): the spill runs
+                # right behind the hand-over on a thread of its own -- wait for it (round 6: with the hand-over 10 ms earlier the
+                # first window's collection could get here first, and the window was skipped as "failed")
+                if self.event is not None:
+                    self.event.wait(timeout=120)
+                if self._arr is not None:
+                    return self._arr
                 raise RuntimeError("the CIGAR words of this table are on the device only")
             t0 = time.time()
             while not os.path.exists(self.ready):              # the owner spills them right after the hand-over

@@ -247,6 +247,12 @@ def test_command_line_with_device_ingest_equals_host_ingest(tmp_path):
                                env=dict(os.environ, PYTHONPATH=root, SVX_INGEST=engine, SVX_TIMING="1"))
             assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
             assert ("'engine': '%s'" % engine) in r.stdout
+            if os.environ.get("SVX_TEST_DUMP"):
+                with open(os.path.join(os.environ["SVX_TEST_DUMP"], "%s_%s_%s.log" % (name, engine, t)), "w") as f_:
+                    f_.write(r.stdout[-20000:] + "\n---- stderr\n" + r.stderr[-20000:])
+                    for lf in os.listdir(out):
+                        if lf.endswith(".log"):
+                            f_.write("\n---- %s\n" % lf + open(os.path.join(out, lf)).read()[-20000:])
             outs[(engine, t)] = {rel: open(os.path.join(out, rel)).read() for rel in ["HGi.svision.s3.vcf"] +
                                  ["segments/" + f for f in sorted(os.listdir(os.path.join(out, "segments")))]}
         assert outs[("cpu", "1")] == outs[("gpu", "1")] == outs[("gpu", "3")]

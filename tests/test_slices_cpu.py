@@ -206,3 +206,29 @@ def test_a_record_spanning_a_whole_slice_is_not_an_empty_slice(tmp_path):
             assert sorted(t.pos[got].tolist()) == sorted(table.pos[want].tolist()), (u, a, b)
         served.append(u)
     assert sum(len(u.windows) for u in served) == len(windows) and replans >= 1
+
+
+def test_lazy_cigar_in_the_owner_process_waits_for_the_spill():
+    """Round 6: with the hand-over a few ms earlier, the first window's collection in a `-t 1` run could read a table's CIGAR
+    words (by-value comparison of duplicated records) before the spill thread had attached them -- RuntimeError, and the window
+    was skipped as failed.  A reader in the owner process waits for the spill's event now."""
+    import threading
+    import time
+    from svision_amd.ingest_gpu import LazyCigar
+    lazy = LazyCigar(5)
+    with pytest.raises(RuntimeError):
+        lazy[0]                                               # no event: the words are on the device only, said at once
+    lazy = LazyCigar(5)
+    lazy.event = threading.Event()
+
+    def spill():
+        time.sleep(0.05)
+        lazy.attach(np.arange(5, dtype=np.uint32))
+        lazy.event.set()
+    threading.Thread(target=spill).start()
+    assert lazy[3] == 3 and np.asarray(lazy).tolist() == [0, 1, 2, 3, 4]
+    failed = LazyCigar(5)
+    failed.event = threading.Event()
+    failed.event.set()                                        # a spill that failed sets the event without attaching anything
+    with pytest.raises(RuntimeError):
+        failed[0]
